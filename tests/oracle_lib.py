@@ -1,0 +1,270 @@
+"""ctypes bindings for the CPU oracle (oracle/liboscen_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: nothing under oscen_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboscen_oracle.so")
+
+OO_MAX_EVENTS = 32
+OO_NUM_HARMONICS = 32
+
+
+class Event(C.Structure):
+    _fields_ = [("frame_offset", C.c_uint32), ("scalar", C.c_float), ("is_object", C.c_int32)]
+
+
+class Queue(C.Structure):
+    _fields_ = [("ev", Event * OO_MAX_EVENTS), ("len", C.c_uint32)]
+
+
+class Ramp(C.Structure):
+    _fields_ = [("current", C.c_float), ("target", C.c_float), ("increment", C.c_float),
+                ("frames_remaining", C.c_uint32)]
+
+
+class RampedInput(C.Structure):
+    _fields_ = [("r", Ramp), ("default_frames", C.c_uint32)]
+
+
+class Oscillator(C.Structure):
+    _fields_ = [("phase", C.c_float), ("frequency", C.c_float), ("frequency_mod", C.c_float),
+                ("amplitude", C.c_float), ("output", C.c_float), ("waveform", C.c_int32),
+                ("sample_rate", C.c_float)]
+
+
+class PolyBlep(C.Structure):
+    _fields_ = [("phase", C.c_float), ("phase_mod", C.c_float), ("frequency", C.c_float),
+                ("frequency_mod", C.c_float), ("amplitude", C.c_float), ("pulse_width", C.c_float),
+                ("output", C.c_float), ("waveform", C.c_int32), ("sample_rate", C.c_float)]
+
+
+class Tpt(C.Structure):
+    _fields_ = [("input", C.c_float * 2), ("cutoff", C.c_float), ("q", C.c_float), ("f_mod", C.c_float),
+                ("output", C.c_float * 2), ("current_cutoff", C.c_float), ("current_q", C.c_float),
+                ("z", (C.c_float * 2) * 2), ("h", C.c_float), ("g", C.c_float), ("r", C.c_float),
+                ("k", C.c_float), ("sample_rate", C.c_float), ("channels", C.c_int32)]
+
+
+class Adsr(C.Structure):
+    _fields_ = [("gate", Queue), ("attack", C.c_float), ("decay", C.c_float), ("sustain", C.c_float),
+                ("release", C.c_float), ("output", C.c_float), ("stage", C.c_int32),
+                ("attack_samples", C.c_uint32), ("decay_samples", C.c_uint32),
+                ("release_samples", C.c_uint32), ("samples_remaining", C.c_uint32),
+                ("attack_coeff", C.c_float), ("decay_coeff", C.c_float), ("release_increment", C.c_float),
+                ("level", C.c_float), ("target_level", C.c_float), ("sustain_level", C.c_float),
+                ("velocity", C.c_float), ("sample_rate", C.c_float)]
+
+
+class Gain(C.Structure):
+    _fields_ = [("input", C.c_float), ("gain", C.c_float), ("output", C.c_float)]
+
+
+class FmOperator(C.Structure):
+    _fields_ = [("phase", C.c_float), ("prev_output", C.c_float), ("sample_rate", C.c_float),
+                ("base_freq", C.c_float), ("ratio", C.c_float), ("phase_mod", C.c_float),
+                ("feedback", C.c_float), ("envelope", C.c_float), ("level", C.c_float),
+                ("output", C.c_float)]
+
+
+class HbDownStage(C.Structure):
+    _fields_ = [("history", C.c_float * 24), ("head", C.c_uint32)]
+
+
+class HbUpStage(C.Structure):
+    _fields_ = [("history", C.c_float * 12), ("head", C.c_uint32)]
+
+
+class SincDown(C.Structure):
+    _fields_ = [("st", HbDownStage * 3), ("n_stages", C.c_uint32), ("factor", C.c_uint32)]
+
+
+class SincUp(C.Structure):
+    _fields_ = [("st", HbUpStage * 3), ("n_stages", C.c_uint32), ("factor", C.c_uint32)]
+
+
+class Allpass1(C.Structure):
+    _fields_ = [("a", C.c_float), ("x_prev", C.c_float), ("y_prev", C.c_float)]
+
+
+class IirHb2x(C.Structure):
+    _fields_ = [("a", Allpass1 * 2), ("b", Allpass1 * 2), ("prev_odd_in", C.c_float)]
+
+
+class IirResampler(C.Structure):
+    _fields_ = [("st", IirHb2x * 3), ("n_stages", C.c_uint32), ("factor", C.c_uint32)]
+
+
+class LinearUp(C.Structure):
+    _fields_ = [("prev", C.c_float), ("factor", C.c_uint32)]
+
+
+class StaticSimple(C.Structure):
+    _fields_ = [("osc", Oscillator), ("filter", Tpt), ("gain", Gain)]
+
+
+class StaticComplex(C.Structure):
+    _fields_ = [("osc1", PolyBlep), ("osc2", PolyBlep), ("osc3", PolyBlep),
+                ("mix1", Gain), ("mix2", Gain), ("mix3", Gain), ("mixer", Gain), ("env_amount", Gain),
+                ("vca", Gain), ("filter_env", Adsr), ("amp_env", Adsr), ("filter", Tpt)]
+
+
+class NotePlan(C.Structure):
+    _fields_ = [("note", C.c_uint8), ("velocity", C.c_uint8), ("on_frame", C.c_uint32),
+                ("off_frame", C.c_uint32), ("retrig_frame", C.c_uint32), ("frequency", C.c_float)]
+
+
+BANK_FM, BANK_SUB, BANK_EPIANO, BANK_SAT4X, BANK_SAT1X = range(5)
+EV_GATE, EV_FREQ = 0, 1
+PB_SINE, PB_SAW, PB_SQUARE, PB_TRIANGLE = range(4)
+WAVE_SINE, WAVE_SQUARE, WAVE_SAW = range(3)
+
+FM_PARAMS = [
+    "op3_ratio", "op3_level", "op3_feedback", "op3_attack", "op3_decay", "op3_sustain", "op3_release",
+    "op2_ratio", "op2_level", "op2_feedback", "op2_attack", "op2_decay", "op2_sustain", "op2_release",
+    "op1_ratio", "op1_attack", "op1_decay", "op1_sustain", "op1_release",
+    "route",
+    "filter_cutoff", "filter_resonance", "filter_attack", "filter_decay", "filter_sustain",
+    "filter_release", "filter_env_amount",
+]
+SUB_PARAMS = ["cutoff", "q"]
+EPIANO_PARAMS = ["brightness", "velocity_scaling", "decay_rate", "harmonic_decay", "key_scaling",
+                 "release_rate", "vibrato_intensity", "vibrato_speed"]
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
+
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oscen_oracle.c", "oracle_bench.c", "oscen_oracle.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        build()
+    lib = C.CDLL(LIB_PATH)
+    f32p = C.POINTER(C.c_float)
+    u32p = C.POINTER(C.c_uint32)
+    lib.oo_bank_create.restype = C.c_void_p
+    lib.oo_bank_create.argtypes = [C.c_int, C.c_uint32]
+    lib.oo_bank_destroy.argtypes = [C.c_void_p]
+    lib.oo_bank_init.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_bank_num_params.argtypes = [C.c_void_p]
+    lib.oo_bank_num_params.restype = C.c_uint32
+    lib.oo_bank_channels.argtypes = [C.c_void_p]
+    lib.oo_bank_channels.restype = C.c_uint32
+    lib.oo_bank_set_value.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+    lib.oo_bank_set_value_with_ramp.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]
+    lib.oo_bank_set_value_immediate.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+    lib.oo_bank_set_voice_frequency.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+    lib.oo_bank_push_event.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_float]
+    lib.oo_bank_process_block.argtypes = [C.c_void_p, C.c_uint32, f32p, u32p, C.c_uint32, f32p]
+    lib.oo_bank_process_per_sample.argtypes = [C.c_void_p, C.c_uint32, f32p, u32p, C.c_uint32, f32p]
+    lib.oo_bank_last_bus_f64.argtypes = [C.c_void_p]
+    lib.oo_bank_last_bus_f64.restype = C.POINTER(C.c_double)
+    lib.oo_bank_bench.restype = C.c_double
+    lib.oo_bank_bench.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                  C.POINTER(C.c_double)]
+    lib.oo_midi_note_to_freq.restype = C.c_float
+    lib.oo_midi_note_to_freq.argtypes = [C.c_uint8]
+    lib.oo_midi_velocity_to_gate.restype = C.c_float
+    lib.oo_midi_velocity_to_gate.argtypes = [C.c_uint8]
+    lib.oo_sinc_down_process.restype = C.c_float
+    lib.oo_iir_down_process.restype = C.c_float
+    lib.oo_linear_down_process.restype = C.c_float
+    lib.oo_linear_down_process.argtypes = [C.c_uint32, f32p]
+    lib.oo_latch_down_process.restype = C.c_float
+    lib.oo_latch_down_process.argtypes = [C.c_uint32, f32p]
+    lib.oo_latch_up_process.argtypes = [C.c_uint32, C.c_float, f32p]
+    lib.oo_sinc_down_latency.restype = C.c_uint32
+    lib.oo_sinc_up_latency.restype = C.c_uint32
+    lib.oo_iir_latency.restype = C.c_uint32
+    lib.oo_polyblep_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.oo_oscillator_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.oo_tpt_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.oo_adsr_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    lib.oo_ramp_new.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_ramp_set_immediate.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_ramp_set_with_ramp.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    lib.oo_sinc_up_process.argtypes = [C.c_void_p, C.c_float, f32p]
+    lib.oo_iir_up_process.argtypes = [C.c_void_p, C.c_float, f32p]
+    lib.oo_linear_up_process.argtypes = [C.c_void_p, C.c_float, f32p]
+    lib.oo_static_simple_init.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_static_complex_init.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_fm_compute_waveform.argtypes = [C.c_float] * 8 + [C.c_uint32, f32p]
+    lib.oo_note_plan_for_voice.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(NotePlan)]
+    _LIB = lib
+    return lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def uptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Bank:
+    """Thin OO wrapper over oo_bank_* (the poly-wrapper graph of the reference)."""
+
+    def __init__(self, kind, n_voices, sample_rate=48000.0):
+        self.lib = load()
+        self.kind = kind
+        self.n = n_voices
+        self.h = self.lib.oo_bank_create(kind, n_voices)
+        self.lib.oo_bank_init(self.h, sample_rate)
+        self.channels = self.lib.oo_bank_channels(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oo_bank_destroy(self.h)
+            self.h = None
+
+    def set_value(self, p, v):
+        assert self.lib.oo_bank_set_value(self.h, p, v) == 0
+
+    def set_value_with_ramp(self, p, v, frames):
+        assert self.lib.oo_bank_set_value_with_ramp(self.h, p, v, frames) == 0
+
+    def set_value_immediate(self, p, v):
+        assert self.lib.oo_bank_set_value_immediate(self.h, p, v) == 0
+
+    def set_voice_frequency(self, voice, hz):
+        self.lib.oo_bank_set_voice_frequency(self.h, voice, hz)
+
+    def push_event(self, voice, frame_offset, kind, value):
+        assert self.lib.oo_bank_push_event(self.h, voice, frame_offset, kind, value) == 0
+
+    def process_block(self, frames, taps=None, per_sample=False):
+        out = np.zeros(frames * self.channels, dtype=np.float32)
+        fn = self.lib.oo_bank_process_per_sample if per_sample else self.lib.oo_bank_process_block
+        if taps is None or len(taps) == 0:
+            fn(self.h, frames, fptr(out), None, 0, None)
+            return out.reshape(frames, self.channels), None
+        tv = np.asarray(taps, dtype=np.uint32)
+        tb = np.zeros((len(tv), frames), dtype=np.float32)
+        fn(self.h, frames, fptr(out), uptr(tv), len(tv), fptr(tb))
+        return out.reshape(frames, self.channels), tb
+
+    def last_bus_f64(self, frames):
+        p = self.lib.oo_bank_last_bus_f64(self.h)
+        return np.array([p[i] for i in range(frames)], dtype=np.float64)
+
+
+def note_plan(seed, voice):
+    p = NotePlan()
+    load().oo_note_plan_for_voice(seed, voice, C.byref(p))
+    return p
