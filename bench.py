@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: voices*samples/sec of the fm-synth voice bank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one 256-frame block of the fm_voice graph over this rank's voice
+shard (BASELINE.json configs[1]: 65 536 voices per GPU, 48 kHz, f32, synthetic
+note streams already resident in HBM).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(block, seed):
+    """Time the CPU oracle (scalar C port of the reference path) on the host cores, bounded sample."""
+    import ctypes as C
+
+    from tests import oracle_lib as ol
+
+    lib = ol.load()
+    cores = os.cpu_count() or 1
+    cs = C.c_double()
+    # calibrate on a tiny bank, then size the sample for ~12 s of CPU work on all cores
+    probe_v, probe_f = 64 * min(cores, 8), 2048
+    t = lib.oo_bank_bench(ol.BANK_FM, probe_v, probe_f, block, cores, seed, C.byref(cs))
+    rate = probe_v * probe_f / max(t, 1e-6)
+    frames = 12000  # first 0.25 s of the note streams (attack/decay + first note-offs)
+    voices = int(max(cores, min(65536, rate * 12.0 / frames)))
+    voices = max(cores, (voices // cores) * cores)
+    t = lib.oo_bank_bench(ol.BANK_FM, voices, frames, block, cores, seed, C.byref(cs))
+    return {
+        "value": voices * frames / t,
+        "unit": "voices*samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d voices x %d frames (block %d) of the same synthetic fm-synth note streams, "
+                  "C oracle, %d threads, %.1f s" % (voices, frames, block, cores, t),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=188)   # 188 x 256 frames = 1 s of audio
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--voices-per-gpu", type=int, default=65536)
+    ap.add_argument("--block", type=int, default=256)
+    ap.add_argument("--graph", default="fm_voice")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import oscen_amd
+    from oscen_amd import distributed as ogd
+
+    rank, local_rank, world_size = ogd.world()
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size)
+
+    V = args.voices_per_gpu
+    total_voices = V * world_size
+    lo, hi = ogd.shard_range(rank, world_size, total_voices)
+    block, K, W = args.block, args.steps, args.warmup
+    total_frames = (K + W) * block
+
+    eng = oscen_amd.Engine(args.graph, hi - lo, device=local_rank, sample_rate=48000.0)
+    plans = oscen_amd.note_plans(hi - lo, first_voice=lo)  # global voice ids keep their note streams
+    oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    bus = torch.zeros((K + W, block), dtype=torch.float32, device="cuda")
+    base = bus.data_ptr()
+
+    def step(i):
+        eng.process_block_async(block, base + i * block * 4)
+
+    for i in range(W):
+        step(i)
+    if W and dist is not None:
+        ogd.reduce_bus(bus[:W])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    if dist is not None:
+        ogd.reduce_bus(bus[W:])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms, n_launch = eng.kernel_time_ms()
+    eng.enable_kernel_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        mix = bus[W:].float().cpu().numpy()
+        assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
+        value = total_voices * K * block / elapsed
+        words = eng.state_words_per_voice
+        n_wg = (V + 63) // 64
+        # algorithmic HBM bytes of one launch: state planes read once + written once,
+        # the two event-cursor words read per voice, one partial-bus row written per workgroup
+        bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        line = {
+            "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
+            "value": value,
+            "unit": "voices*samples/s",
+            "n_gpus": world_size,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "fm-synth voice bank (FMVoice graph), %d voices/GPU, block=%d frames, 48 kHz, f32; "
+                            "synthetic note streams splitmix64(0x05CE2026 ^ voice) resident in HBM; "
+                            "mix bus reduced once per run over RCCL" % (V, block),
+                "graph": args.graph,
+                "voices_per_gpu": V,
+                "total_voices": total_voices,
+                "block": block,
+                "sample_rate": 48000,
+                "parallelism": "voice-shard x%d" % world_size,
+            },
+            "realtime_voices_at_48k": value / 48000.0,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_avg": kern_ms,
+                "kernel_launches": n_launch,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bytes_per_voice_sample": bytes_per_launch / float(V * block),
+                "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block",
+            },
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * oscen_gpu.h -- C ABI of the MI355X voice-parallel synthesis engine.
+ *
+ * The reference (reedrosenbluth/oscen) has no FFI boundary on this path: node
+ * bodies are inlined into the struct that the `graph!` proc-macro generates.
+ * The boundary this library sits behind is therefore the PUBLIC SURFACE OF A
+ * GENERATED GRAPH STRUCT (oscen-graph-compiler/src/codegen/mod.rs:1292-1392);
+ * every entry point below cites the generated item it replaces.  A Rust shim
+ * implementing the same-named inherent methods over this ABI is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative OG_E_* code and never throws across the ABI;
+ * og_last_error() gives the message for the calling thread.  An engine is not
+ * thread-safe (the reference's graph is `&mut self`, one audio thread).
+ * There is no CPU fallback: creating an engine without a usable HIP device
+ * fails with OG_E_DEVICE.
+ */
+#ifndef OSCEN_GPU_H
+#define OSCEN_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OG_OK 0
+#define OG_E_INVALID (-1)     /* bad argument / unknown name            */
+#define OG_E_UNSUPPORTED (-2) /* graph uses a feature this build lacks  */
+#define OG_E_DEVICE (-3)      /* HIP error or no device                 */
+#define OG_E_STATE (-4)       /* call order (e.g. process before init)  */
+#define OG_E_OVERFLOW (-5)    /* event queue capacity (event dropped)   */
+
+#define OG_MAX_BLOCK_SIZE 512u /* MAX_BLOCK_SIZE, oscen-lib/src/graph/types.rs:12 */
+#define OG_MAX_EVENTS_PER_BLOCK 32u /* per voice per endpoint per block, types.rs:18 */
+
+/* endpoint kinds of `input name: kind` (oscen-graph-compiler/src/parse.rs:387-443) */
+#define OG_KIND_VALUE 0
+#define OG_KIND_EVENT 1
+#define OG_KIND_STREAM 2
+
+/* input flags */
+#define OG_IN_PER_VOICE 1u /* value fed per voice (MidiVoiceHandler.frequency, oscen-lib/src/midi.rs:49) */
+
+typedef struct og_graph_desc og_graph_desc; /* a `graph! { ... }` body, builder form */
+typedef struct og_engine og_engine;         /* N voices of one voice graph + the mix bus */
+
+/* ---- graph description: the `graph!` DSL surface ----------------------------
+ * name: X;                                  -> og_graph_new("X")
+ * input n: value = d [ramp: N];             -> og_graph_add_input(g,"n",OG_KIND_VALUE,d,N,flags)
+ * input n: event;                           -> og_graph_add_input(g,"n",OG_KIND_EVENT,0,0,0)
+ * output n: stream;                         -> og_graph_add_output(g,"n",OG_KIND_STREAM)
+ * nodes { n = Type::ctor(a, b) [* N]; }     -> og_graph_add_node(g,"n","Type::ctor",args,nargs,N)
+ * connections { [policy] src_expr -> dst; } -> og_graph_connect(g,"src_expr","dst","policy")
+ * (oscen-graph-compiler/src/parse.rs:195-979)                                            */
+int og_graph_new(const char* name, og_graph_desc** out);
+int og_graph_builtin(const char* name, og_graph_desc** out); /* "fm_voice", "sub_voice", ... */
+int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float default_value,
+                       uint32_t ramp_frames, uint32_t flags);
+int og_graph_add_output(og_graph_desc* g, const char* name, int kind);
+int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
+                      uint32_t n_args, uint32_t rate_factor);
+int og_graph_connect(og_graph_desc* g, const char* src_expr, const char* dst, const char* policy);
+void og_graph_free(og_graph_desc* g);
+/* The HIP source of the fused voice kernel this description lowers to (for
+ * inspection / ahead-of-time builds).  Returns the length; copies at most cap-1 bytes. */
+int64_t og_graph_kernel_source(const og_graph_desc* g, char* buf, size_t cap);
+
+/* ---- engine ------------------------------------------------------------------- */
+/* Graph::new()  codegen/mod.rs:1309-1328: n_voices copies of the voice graph,
+ * sample rate 44100 until og_init. */
+int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engine** out);
+void og_destroy(og_engine* e);
+/* init(sample_rate) = set_sample_rate + prepare  codegen/mod.rs:1335-1350, 1374-1382 */
+int og_init(og_engine* e, float sample_rate);
+
+/* name -> index of a graph input (value or event), or OG_E_INVALID */
+int og_input_index(const og_engine* e, const char* name);
+uint32_t og_num_inputs(const og_engine* e);
+
+/* Generated value setters  codegen/mod.rs:917-976.  For an input declared with
+ * [ramp: N]: og_set_value = set_<n>(v) (default ramp, no-op if v == target),
+ * og_set_value_ramp = set_<n>_with_ramp(v, frames), og_set_value_immediate =
+ * set_<n>_immediate(v).  For a plain value input all three store the value. */
+int og_set_value(og_engine* e, uint32_t input, float v);
+int og_set_value_ramp(og_engine* e, uint32_t input, float v, uint32_t frames);
+int og_set_value_immediate(og_engine* e, uint32_t input, float v);
+int og_get_value(const og_engine* e, uint32_t input, float* out);
+
+/* Per-voice value input (the `voice_handlers.frequency -> voices.frequency`
+ * edge, examples/fm-synth/src/lib.rs:88): takes effect at the next block. */
+int og_set_voice_value(og_engine* e, uint32_t input, uint32_t voice, float v);
+int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first_voice, uint32_t count, const float* v);
+
+/* <event_input>.try_push(EventInstance{frame_offset, Scalar(v)}) for one voice
+ * (oscen-lib/src/graph/types.rs:137-241).  frame_offset is relative to the
+ * next og_process_block; events at frame_offset >= frames of that block are
+ * dropped exactly like the reference does (codegen/mod.rs:782-871).
+ * OG_E_OVERFLOW (event dropped) past 32 events per voice per input per block. */
+int og_push_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint32_t frame_offset, float scalar);
+/* The note-on frame also changes MidiVoiceHandler.frequency (midi.rs:91-105):
+ * set a per-voice value input exactly on frame_offset of the next block. */
+int og_push_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint32_t frame_offset, float v);
+/* Extension for bulk rendering: schedule on the absolute timeline (frames since
+ * og_init); consumed by whichever block contains that frame. */
+int og_schedule_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float scalar);
+int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float v);
+
+/* process_block(frames)  codegen/mod.rs:755-873, frames <= 512, then copies
+ * <out>_block[..frames] (the sum over voices, `voices.out -> out`) to host
+ * memory: out_bus[frames * channels].  Blocking. */
+int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
+/* Same, but the bus stays in device memory (d_out_bus[frames*channels], may be
+ * NULL to keep it in the engine's own buffer) and the call only enqueues work
+ * on the engine's stream. */
+int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus);
+int og_synchronize(og_engine* e);
+int og_set_stream(og_engine* e, void* hip_stream);
+/* BlockRender::render  oscen-lib/src/graph/offline.rs:46-90: total_frames in
+ * chunks of `block` (<= 512); out_bus[total_frames*channels] (host). */
+int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bus);
+
+/* Introspection of `graph.voices[i].<out>` (tests poke node fields in the
+ * reference): record the per-voice output of the listed voices during the
+ * following blocks.  og_read_voice_taps copies the last block: out[n*frames]. */
+int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n);
+int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames);
+
+uint32_t og_channels(const og_engine* e);
+uint32_t og_num_voices(const og_engine* e);
+uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
+uint64_t og_frames_processed(const og_engine* e);
+/* layout facts used by the roofline accounting */
+uint32_t og_state_words_per_voice(const og_engine* e);
+uint64_t og_events_dropped(const og_engine* e);
+/* average device time of the voice kernel over the launches since the last
+ * call (HIP events on the engine's stream); returns <0 if timing is off */
+int og_enable_kernel_timing(og_engine* e, int on);
+double og_kernel_time_ms(og_engine* e, uint32_t* n_launches);
+
+/* state snapshot (flat SoA blob) */
+size_t og_state_bytes(const og_engine* e);
+int og_save_state(og_engine* e, void* dst, size_t cap);
+int og_load_state(og_engine* e, const void* src, size_t len);
+
+const char* og_last_error(void);
+const char* og_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

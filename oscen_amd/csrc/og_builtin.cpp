@@ -1,0 +1,155 @@
+// og_builtin.cpp -- builder-form descriptions of the reference graphs in scope.
+// These are the graphs whose kernels are compiled ahead of time into the
+// library; any other description goes through the same compiler at og_create().
+#include <stdexcept>
+
+#include "og_graph.h"
+
+namespace ogc {
+namespace {
+
+GInput value_in(const char* name, float def, uint32_t ramp = 0)
+{
+    GInput i;
+    i.name = name;
+    i.kind = Kind::Value;
+    i.def = def;
+    i.ramp_frames = ramp;
+    return i;
+}
+GInput voice_in(const char* name, float def)
+{
+    GInput i = value_in(name, def);
+    i.per_voice = true;
+    return i;
+}
+GInput event_in(const char* name)
+{
+    GInput i;
+    i.name = name;
+    i.kind = Kind::Event;
+    return i;
+}
+
+// FMVoice (examples/fm-synth/src/fm_voice.rs:6-156) as driven by the FMGraph
+// wrapper (examples/fm-synth/src/lib.rs:22-131): `frequency`/`gate` arrive per
+// voice, every other input is broadcast, and the wrapper's [ramp: 2205]
+// inputs are ramped.
+GraphDesc fm_voice()
+{
+    GraphDesc g;
+    g.name = "fm_voice";
+    const uint32_t R = 2205;
+    g.inputs.push_back(voice_in("frequency", 440.0f));
+    g.inputs.push_back(event_in("gate"));
+    struct Op {
+        const char* n;
+        float ratio, level, a, d, s, r;
+        bool has_level;
+    } ops[3] = {{"op3", 3.0f, 0.5f, 0.01f, 0.1f, 0.7f, 0.3f, true},
+                {"op2", 2.0f, 0.5f, 0.01f, 0.1f, 0.7f, 0.3f, true},
+                {"op1", 1.0f, 0.0f, 0.01f, 0.2f, 0.8f, 0.5f, false}};
+    for (const Op& o : ops) {
+        std::string p = o.n;
+        g.inputs.push_back(value_in((p + "_ratio").c_str(), o.ratio));
+        if (o.has_level) {
+            g.inputs.push_back(value_in((p + "_level").c_str(), o.level, R));
+            g.inputs.push_back(value_in((p + "_feedback").c_str(), 0.0f, R));
+        }
+        g.inputs.push_back(value_in((p + "_attack").c_str(), o.a));
+        g.inputs.push_back(value_in((p + "_decay").c_str(), o.d));
+        g.inputs.push_back(value_in((p + "_sustain").c_str(), o.s));
+        g.inputs.push_back(value_in((p + "_release").c_str(), o.r));
+    }
+    g.inputs.push_back(value_in("route", 0.0f, R));
+    g.inputs.push_back(value_in("filter_cutoff", 2000.0f, R));
+    g.inputs.push_back(value_in("filter_resonance", 0.707f, R));
+    g.inputs.push_back(value_in("filter_attack", 0.01f));
+    g.inputs.push_back(value_in("filter_decay", 0.2f));
+    g.inputs.push_back(value_in("filter_sustain", 0.5f));
+    g.inputs.push_back(value_in("filter_release", 0.3f));
+    g.inputs.push_back(value_in("filter_env_amount", 0.0f, R));
+    g.outputs.push_back({"audio_out", Kind::Stream});
+
+    g.nodes.push_back({"env3", "AdsrEnvelope::new", {0.01f, 0.1f, 0.7f, 0.3f}, 1});
+    g.nodes.push_back({"env2", "AdsrEnvelope::new", {0.01f, 0.1f, 0.7f, 0.3f}, 1});
+    g.nodes.push_back({"env1", "AdsrEnvelope::new", {0.01f, 0.2f, 0.8f, 0.5f}, 1});
+    g.nodes.push_back({"env_filter", "AdsrEnvelope::new", {0.01f, 0.2f, 0.5f, 0.3f}, 1});
+    g.nodes.push_back({"filter_env_gain", "Gain::new", {0.0f}, 1});
+    g.nodes.push_back({"cutoff_mod", "AddValue::new", {2000.0f}, 1});
+    g.nodes.push_back({"op3_osc", "FmOperator::new", {}, 1});
+    g.nodes.push_back({"op2_osc", "FmOperator::new", {}, 1});
+    g.nodes.push_back({"op1_osc", "FmOperator::new", {}, 1});
+    g.nodes.push_back({"op3_route", "Crossfade::new", {}, 1});
+    g.nodes.push_back({"op1_mod_mixer", "Mixer::new", {}, 1});
+    g.nodes.push_back({"filter", "TptFilter::new", {2000.0f, 0.707f}, 1});
+    g.nodes.push_back({"output_gain", "Gain::new", {0.3f}, 1});
+
+    auto c = [&](const std::string& s, const std::string& d) { g.edges.push_back({s, d, ""}); };
+    const char* envs[4][2] = {{"env3", "op3"}, {"env2", "op2"}, {"env1", "op1"}, {"env_filter", "filter"}};
+    for (auto& e : envs) c("gate", std::string(e[0]) + ".gate");
+    for (auto& e : envs)
+        for (const char* prm : {"attack", "decay", "sustain", "release"})
+            c(std::string(e[1]) + "_" + prm, std::string(e[0]) + "." + prm);
+    c("env_filter.output", "filter_env_gain.input");
+    c("filter_env_amount", "filter_env_gain.gain");
+    c("filter_env_gain.output", "cutoff_mod.input");
+    c("filter_cutoff", "cutoff_mod.value");
+    c("cutoff_mod.output", "filter.cutoff");
+    for (const char* op : {"op3", "op2", "op1"}) {
+        std::string o = op;
+        c("frequency", o + "_osc.base_freq");
+        c(o + "_ratio", o + "_osc.ratio");
+        if (o != "op1") {
+            c(o + "_feedback", o + "_osc.feedback");
+            c(o + "_level", o + "_osc.level");
+        }
+        c("env" + o.substr(2) + ".output", o + "_osc.envelope");
+    }
+    c("op3_osc.output", "op3_route.input");
+    c("route", "op3_route.mix");
+    c("op3_route.output_a", "op2_osc.phase_mod");
+    c("op2_osc.output", "op1_mod_mixer.input_a");
+    c("op3_route.output_b", "op1_mod_mixer.input_b");
+    c("op1_mod_mixer.output", "op1_osc.phase_mod");
+    c("op1_osc.output", "filter.input");
+    c("filter_resonance", "filter.q");
+    c("filter.output", "output_gain.input");
+    c("output_gain.output", "audio_out");
+    return g;
+}
+
+// "osc+env+TptFilter" voice (oscen-lib/perf/profile_graph.rs:12-37)
+GraphDesc sub_voice()
+{
+    GraphDesc g;
+    g.name = "sub_voice";
+    g.inputs.push_back(voice_in("frequency", 440.0f));
+    g.inputs.push_back(event_in("gate"));
+    g.inputs.push_back(value_in("cutoff", 3000.0f));
+    g.inputs.push_back(value_in("q", 0.707f));
+    g.outputs.push_back({"audio", Kind::Stream});
+    g.nodes.push_back({"osc", "PolyBlepOscillator::saw", {440.0f, 0.6f}, 1});
+    g.nodes.push_back({"filter", "TptFilter::new", {3000.0f, 0.707f}, 1});
+    g.nodes.push_back({"envelope", "AdsrEnvelope::new", {0.01f, 0.1f, 0.7f, 0.2f}, 1});
+    g.edges.push_back({"frequency", "osc.frequency", ""});
+    g.edges.push_back({"gate", "envelope.gate", ""});
+    g.edges.push_back({"cutoff", "filter.cutoff", ""});
+    g.edges.push_back({"q", "filter.q", ""});
+    g.edges.push_back({"osc.output", "filter.input", ""});
+    g.edges.push_back({"filter.output * envelope.output", "audio", ""});
+    return g;
+}
+
+} // namespace
+
+std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice"}; }
+
+GraphDesc builtin_graph(const std::string& name)
+{
+    if (name == "fm_voice") return fm_voice();
+    if (name == "sub_voice") return sub_voice();
+    throw std::runtime_error("unknown builtin graph '" + name + "'");
+}
+
+} // namespace ogc

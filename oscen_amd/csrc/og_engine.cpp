@@ -1,0 +1,815 @@
+// og_engine.cpp -- host runtime of the voice-bank engine + the C ABI of
+// include/oscen_gpu.h.  Compiled by hipcc (host side only; the kernels live in
+// csrc/gen/*.hip and in og_kernel_rt.hip.h).
+//
+// An engine is the MI355X form of the reference's poly wrapper graph
+// (examples/fm-synth/src/lib.rs:22-131): `voices = [Voice; N]`, every broadcast
+// value input fanned out to all voices (ramped where declared `[ramp: N]`),
+// per-voice `frequency`/`gate`, and `voices.out -> out` summed onto the bus.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/oscen_gpu.h"
+#include "og_graph.h"
+#include "og_jit.h"
+#include "og_registry.h"
+
+// Sum the per-workgroup partial rows in workgroup order (fixed association).
+// grid = ceil(frames/64), block = 64; each thread owns one frame and walks the
+// rows with 8 independent accumulators combined in a fixed order.
+__global__ void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows, uint32_t frames,
+                              float* __restrict__ bus)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t r = 0;
+    for (; r + 8 <= n_rows; r += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += partials[(size_t)(r + i) * frames + f];
+    }
+    for (int i = 0; r < n_rows; ++r, ++i) acc[i] += partials[(size_t)r * frames + f];
+    bus[f] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+// ---- registry ---------------------------------------------------------------
+OgKernelEntry*& og_kernel_registry_head()
+{
+    static OgKernelEntry* head = nullptr;
+    return head;
+}
+OgLaunchFn og_find_kernel(uint64_t hash)
+{
+    for (OgKernelEntry* e = og_kernel_registry_head(); e; e = e->next)
+        if (e->hash == hash) return e->launch;
+    return nullptr;
+}
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const std::string& m)
+{
+    g_err = m;
+    return code;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define HIPCK(expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                         \
+    } while (0)
+
+struct Ramp { // ValueRampState  oscen-lib/src/graph/types.rs:300-373
+    float current = 0, target = 0, increment = 0;
+    uint32_t frames_remaining = 0;
+    uint32_t default_frames = 0;
+    bool ramping() const { return frames_remaining > 0; }
+    void set_immediate(float v)
+    {
+        current = target = v;
+        increment = 0.0f;
+        frames_remaining = 0;
+    }
+    void set_with_ramp(float t, uint32_t frames)
+    {
+        if (frames == 0) {
+            set_immediate(t);
+        } else {
+            target = t;
+            increment = (t - current) / (float)frames;
+            frames_remaining = frames;
+        }
+    }
+    bool tick()
+    {
+        if (frames_remaining > 0) {
+            frames_remaining -= 1;
+            if (frames_remaining == 0) {
+                current = target;
+                increment = 0.0f;
+                return true;
+            }
+            current += increment;
+        }
+        return false;
+    }
+};
+
+struct HostEvent {
+    uint32_t voice;
+    uint64_t frame;
+    uint32_t target;
+    float value;
+    uint64_t seq;
+    bool block_local; // pushed relative to the next block (reference try_push semantics)
+    bool uploaded;
+};
+
+constexpr int RAMP_RING = 8;
+
+} // namespace
+
+struct og_graph_desc {
+    ogc::GraphDesc g;
+};
+
+struct og_engine {
+    std::unique_ptr<ogc::CompiledGraph> cg;
+    OgLaunchFn launch = nullptr;
+    std::unique_ptr<OgJitKernel> jit;
+    uint32_t V = 0;
+    int device = 0;
+    float sr = 44100.0f;
+    bool inited = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    std::vector<float> values; // per input: plain value, or mirror of ramp.current
+    std::vector<Ramp> ramps;   // per input (only meaningful when ramp_row >= 0)
+    uint32_t active_ramps = 0;
+
+    uint32_t n_wg = 0;
+    uint32_t* d_state = nullptr;
+    OgEvent* d_events = nullptr;
+    size_t ev_cap = 0;
+    uint32_t* d_ev_end = nullptr;
+    uint32_t* d_ev_cursor = nullptr;
+    float* d_partials = nullptr;
+    float* d_bus = nullptr;
+    float* d_ramp[RAMP_RING] = {};
+    float* h_ramp[RAMP_RING] = {};
+    hipEvent_t ramp_ev[RAMP_RING] = {};
+    bool ramp_ev_used[RAMP_RING] = {};
+    int ramp_head = 0;
+    float* d_taps = nullptr;
+    int32_t* d_tap_slot = nullptr;
+    uint32_t n_taps = 0;
+    uint32_t last_frames = 0;
+
+    std::vector<HostEvent> pending;
+    bool ev_dirty = true;
+    uint64_t seq = 0;
+    uint64_t frame_now = 0;
+    uint64_t dropped = 0;
+
+    bool timing = false;
+    std::vector<hipEvent_t> t_start, t_stop;
+    size_t t_used = 0;
+
+    ~og_engine()
+    {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        hipFree(d_state);
+        hipFree(d_events);
+        hipFree(d_ev_end);
+        hipFree(d_ev_cursor);
+        hipFree(d_partials);
+        hipFree(d_bus);
+        hipFree(d_taps);
+        hipFree(d_tap_slot);
+        for (int i = 0; i < RAMP_RING; ++i) {
+            hipFree(d_ramp[i]);
+            if (h_ramp[i]) hipHostFree(h_ramp[i]);
+            if (ramp_ev[i]) hipEventDestroy(ramp_ev[i]);
+        }
+        for (auto ev : t_start) hipEventDestroy(ev);
+        for (auto ev : t_stop) hipEventDestroy(ev);
+        if (own_stream && stream) hipStreamDestroy(stream);
+    }
+
+    ogc::UEnv env() const { return ogc::UEnv{sr, values.data()}; }
+
+    void upload_initial_state()
+    {
+        const size_t nw = cg->state.size();
+        std::vector<uint32_t> img(nw * (size_t)V);
+        ogc::UEnv e = env();
+        for (size_t w = 0; w < nw; ++w) {
+            const uint32_t bits = cg->state[w].init(e);
+            std::fill(img.begin() + w * V, img.begin() + (w + 1) * V, bits);
+        }
+        HIPCK(hipMemcpyAsync(d_state, img.data(), img.size() * 4, hipMemcpyHostToDevice, stream));
+        HIPCK(hipStreamSynchronize(stream));
+    }
+
+    void rebuild_events()
+    {
+        // drop what earlier blocks already consumed
+        pending.erase(std::remove_if(pending.begin(), pending.end(),
+                                     [&](const HostEvent& h) { return h.uploaded && h.frame < frame_now; }),
+                      pending.end());
+        std::stable_sort(pending.begin(), pending.end(), [](const HostEvent& a, const HostEvent& b) {
+            if (a.voice != b.voice) return a.voice < b.voice;
+            if (a.frame != b.frame) return a.frame < b.frame;
+            return a.seq < b.seq;
+        });
+        const size_t n = pending.size();
+        if (n > ev_cap) {
+            if (d_events) HIPCK(hipFree(d_events));
+            ev_cap = std::max<size_t>(n * 2, 1024);
+            HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
+        }
+        std::vector<OgEvent> evs(n);
+        std::vector<uint32_t> cursor(V), end(V);
+        size_t i = 0;
+        for (uint32_t v = 0; v < V; ++v) {
+            cursor[v] = (uint32_t)i;
+            while (i < n && pending[i].voice == v) {
+                evs[i] = OgEvent{pending[i].frame, pending[i].target, pending[i].value};
+                pending[i].uploaded = true;
+                ++i;
+            }
+            end[v] = (uint32_t)i;
+        }
+        if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
+        HIPCK(hipMemcpyAsync(d_ev_cursor, cursor.data(), V * 4, hipMemcpyHostToDevice, stream));
+        HIPCK(hipMemcpyAsync(d_ev_end, end.data(), V * 4, hipMemcpyHostToDevice, stream));
+        HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
+        ev_dirty = false;
+    }
+
+    void process_async(uint32_t frames, float* d_out)
+    {
+        HIPCK(hipSetDevice(device));
+        // reference: a try_push'ed event whose frame_offset >= frames is never delivered
+        bool any_local = false;
+        for (auto& h : pending) any_local |= h.block_local;
+        if (any_local) {
+            const uint64_t lim = frame_now + frames;
+            size_t before = pending.size();
+            pending.erase(std::remove_if(pending.begin(), pending.end(),
+                                         [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
+                          pending.end());
+            dropped += before - pending.size();
+            for (auto& h : pending) h.block_local = false;
+        }
+        if (ev_dirty) rebuild_events();
+
+        OgBlockArgs A;
+        memset(&A, 0, sizeof A);
+        A.n_voices = V;
+        A.frames = frames;
+        A.frame0 = frame_now;
+        A.state = d_state;
+        A.events = d_events;
+        A.ev_end = d_ev_end;
+        A.ev_cursor = d_ev_cursor;
+        A.partials = d_partials;
+        A.taps = d_taps;
+        A.tap_slot = d_tap_slot;
+
+        // block-uniform slots from the values at block start (ramped: `.current`)
+        {
+            ogc::UEnv e = env();
+            for (const auto& up : cg->uprogs) A.slots[up.dst] = up.fn(e);
+        }
+        // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks
+        const bool ramps_on = active_ramps > 0 && cg->n_ramps > 0;
+        if (ramps_on) {
+            const int r = ramp_head;
+            ramp_head = (ramp_head + 1) % RAMP_RING;
+            if (ramp_ev_used[r]) HIPCK(hipEventSynchronize(ramp_ev[r]));
+            float* tab = h_ramp[r];
+            for (uint32_t f = 0; f < frames; ++f) {
+                for (size_t i = 0; i < cg->inputs.size(); ++i) {
+                    const int row = cg->inputs[i].ramp_row;
+                    if (row < 0) continue;
+                    if (active_ramps > 0 && ramps[i].tick()) active_ramps -= 1;
+                    tab[(size_t)row * frames + f] = ramps[i].current;
+                }
+            }
+            for (size_t i = 0; i < cg->inputs.size(); ++i)
+                if (cg->inputs[i].ramp_row >= 0) values[i] = ramps[i].current;
+            HIPCK(hipMemcpyAsync(d_ramp[r], tab, (size_t)cg->n_ramps * frames * 4, hipMemcpyHostToDevice, stream));
+            HIPCK(hipEventRecord(ramp_ev[r], stream));
+            ramp_ev_used[r] = true;
+            A.ramp_table = d_ramp[r];
+        }
+        const bool taps_on = n_taps > 0;
+        if (timing) {
+            if (t_used == t_start.size()) {
+                hipEvent_t a, b;
+                HIPCK(hipEventCreate(&a));
+                HIPCK(hipEventCreate(&b));
+                t_start.push_back(a);
+                t_stop.push_back(b);
+            }
+            HIPCK(hipEventRecord(t_start[t_used], stream));
+        }
+        if (launch)
+            launch(A, ramps_on, taps_on, stream);
+        else
+            jit->launch(A, ramps_on, taps_on, stream);
+        if (timing) {
+            HIPCK(hipEventRecord(t_stop[t_used], stream));
+            ++t_used;
+        }
+        HIPCK(hipGetLastError());
+        float* bus = d_out ? d_out : d_bus;
+        hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64), dim3(64), 0, stream, d_partials, n_wg, frames,
+                           bus);
+        HIPCK(hipGetLastError());
+        frame_now += frames;
+        last_frames = frames;
+    }
+};
+
+namespace {
+
+template <class F>
+int guard(F&& f)
+{
+    try {
+        return f();
+    } catch (const HipError& e) {
+        return set_err(OG_E_DEVICE, e.what());
+    } catch (const std::exception& e) {
+        const std::string m = e.what();
+        const bool unsup = m.find("not supported") != std::string::npos || m.find("unsupported") != std::string::npos ||
+                           m.find("in this version") != std::string::npos;
+        return set_err(unsup ? OG_E_UNSUPPORTED : OG_E_INVALID, m);
+    }
+}
+
+int check_value_input(const og_engine* e, uint32_t input, bool per_voice)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (input >= e->cg->inputs.size()) return set_err(OG_E_INVALID, "input index out of range");
+    const auto& in = e->cg->inputs[input];
+    if (in.decl.kind != ogc::Kind::Value) return set_err(OG_E_INVALID, "'" + in.decl.name + "' is not a value input");
+    if (in.decl.per_voice != per_voice)
+        return set_err(OG_E_INVALID, "'" + in.decl.name + (per_voice ? "' is a broadcast input" : "' is a per-voice input"));
+    return OG_OK;
+}
+
+int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, float value, bool local, bool setvalue)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (input >= e->cg->inputs.size()) return set_err(OG_E_INVALID, "input index out of range");
+    if (voice >= e->V) return set_err(OG_E_INVALID, "voice index out of range");
+    const auto& in = e->cg->inputs[input];
+    uint32_t target;
+    if (setvalue) {
+        if (in.decl.kind != ogc::Kind::Value || !in.decl.per_voice)
+            return set_err(OG_E_INVALID, "'" + in.decl.name + "' is not a per-voice value input");
+        target = OG_EV_SETVALUE | input;
+    } else {
+        if (in.decl.kind != ogc::Kind::Event) return set_err(OG_E_INVALID, "'" + in.decl.name + "' is not an event input");
+        target = (uint32_t)in.event_index;
+    }
+    if (local && !setvalue) { // ArrayVec<EventInstance, 32> capacity per endpoint per block
+        uint32_t cnt = 0;
+        for (const auto& h : e->pending)
+            if (h.block_local && h.voice == voice && h.target == target) ++cnt;
+        if (cnt >= OG_MAX_EVENTS_PER_BLOCK) {
+            e->dropped += 1;
+            return set_err(OG_E_OVERFLOW, "event queue full (32 per voice per input per block): event dropped");
+        }
+    }
+    e->pending.push_back(HostEvent{voice, frame, target, value, e->seq++, local, false});
+    e->ev_dirty = true;
+    return OG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* og_last_error(void) { return g_err.c_str(); }
+const char* og_version(void) { return "oscen_amd 0.1 (gfx950)"; }
+
+int og_graph_new(const char* name, og_graph_desc** out)
+{
+    if (!name || !out) return set_err(OG_E_INVALID, "null argument");
+    auto* g = new og_graph_desc;
+    g->g.name = name;
+    *out = g;
+    return OG_OK;
+}
+
+int og_graph_builtin(const char* name, og_graph_desc** out)
+{
+    if (!name || !out) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        auto* g = new og_graph_desc;
+        try {
+            g->g = ogc::builtin_graph(name);
+        } catch (...) {
+            delete g;
+            throw;
+        }
+        *out = g;
+        return OG_OK;
+    });
+}
+
+int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float def, uint32_t ramp_frames, uint32_t flags)
+{
+    if (!g || !name) return set_err(OG_E_INVALID, "null argument");
+    if (kind < 0 || kind > 2) return set_err(OG_E_INVALID, "bad endpoint kind");
+    ogc::GInput in;
+    in.name = name;
+    in.kind = (ogc::Kind)kind;
+    in.def = def;
+    in.ramp_frames = ramp_frames;
+    in.per_voice = (flags & OG_IN_PER_VOICE) != 0;
+    g->g.inputs.push_back(in);
+    return (int)g->g.inputs.size() - 1;
+}
+
+int og_graph_add_output(og_graph_desc* g, const char* name, int kind)
+{
+    if (!g || !name) return set_err(OG_E_INVALID, "null argument");
+    if (kind < 0 || kind > 2) return set_err(OG_E_INVALID, "bad endpoint kind");
+    g->g.outputs.push_back({name, (ogc::Kind)kind});
+    return (int)g->g.outputs.size() - 1;
+}
+
+int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args,
+                      uint32_t rate_factor)
+{
+    if (!g || !name || !type_ctor || (n_args && !args)) return set_err(OG_E_INVALID, "null argument");
+    ogc::GNode n;
+    n.name = name;
+    n.type = type_ctor;
+    n.args.assign(args, args + n_args);
+    n.rate_factor = rate_factor ? rate_factor : 1;
+    g->g.nodes.push_back(n);
+    return (int)g->g.nodes.size() - 1;
+}
+
+int og_graph_connect(og_graph_desc* g, const char* src, const char* dst, const char* policy)
+{
+    if (!g || !src || !dst) return set_err(OG_E_INVALID, "null argument");
+    g->g.edges.push_back({src, dst, policy ? policy : ""});
+    return OG_OK;
+}
+
+void og_graph_free(og_graph_desc* g) { delete g; }
+
+int64_t og_graph_kernel_source(const og_graph_desc* g, char* buf, size_t cap)
+{
+    if (!g) return set_err(OG_E_INVALID, "null graph");
+    int64_t len = -1;
+    int rc = guard([&] {
+        auto cg = ogc::compile(g->g);
+        len = (int64_t)cg->source.size();
+        if (buf && cap) {
+            size_t n = std::min(cap - 1, cg->source.size());
+            memcpy(buf, cg->source.data(), n);
+            buf[n] = 0;
+        }
+        return OG_OK;
+    });
+    return rc == OG_OK ? len : rc;
+}
+
+int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engine** out)
+{
+    if (!g || !out) return set_err(OG_E_INVALID, "null argument");
+    if (n_voices == 0) return set_err(OG_E_INVALID, "n_voices must be > 0");
+    return guard([&] {
+        std::unique_ptr<og_engine> e(new og_engine);
+        e->cg = ogc::compile(g->g);
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+            throw HipError("no HIP device available (this engine has no CPU fallback)");
+        if (device_id < 0 || device_id >= n_dev) throw HipError("device id out of range");
+        e->device = device_id;
+        HIPCK(hipSetDevice(device_id));
+        e->launch = og_find_kernel(e->cg->hash);
+        if (!e->launch) e->jit = og_jit_compile(*e->cg); // throws if hiprtc is unavailable or fails
+        e->V = n_voices;
+        e->n_wg = (n_voices + OG_WAVE - 1) / OG_WAVE;
+        HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+        const auto& cg = *e->cg;
+        e->values.resize(cg.inputs.size());
+        e->ramps.resize(cg.inputs.size());
+        for (size_t i = 0; i < cg.inputs.size(); ++i) {
+            e->values[i] = cg.inputs[i].decl.def;
+            e->ramps[i].set_immediate(cg.inputs[i].decl.def); // ValueRampState::new(default)
+            e->ramps[i].default_frames = cg.inputs[i].decl.ramp_frames;
+        }
+        HIPCK(hipMalloc(&e->d_state, std::max<size_t>(1, cg.state.size()) * (size_t)n_voices * 4));
+        HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
+        HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
+        HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
+        HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
+        HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
+        HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
+        if (cg.n_ramps) {
+            for (int i = 0; i < RAMP_RING; ++i) {
+                HIPCK(hipMalloc(&e->d_ramp[i], (size_t)cg.n_ramps * OG_MAX_BLOCK * 4));
+                HIPCK(hipHostMalloc((void**)&e->h_ramp[i], (size_t)cg.n_ramps * OG_MAX_BLOCK * 4, hipHostMallocDefault));
+                HIPCK(hipEventCreateWithFlags(&e->ramp_ev[i], hipEventDisableTiming));
+            }
+        }
+        e->upload_initial_state(); // Graph::new(): 44.1 kHz until init()
+        *out = e.release();
+        return OG_OK;
+    });
+}
+
+void og_destroy(og_engine* e) { delete e; }
+
+int og_init(og_engine* e, float sample_rate)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (!(sample_rate > 0.0f)) return set_err(OG_E_INVALID, "sample rate must be positive");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->sr = sample_rate;
+        e->upload_initial_state();
+        e->pending.clear();
+        e->ev_dirty = true;
+        e->frame_now = 0;
+        e->inited = true;
+        return OG_OK;
+    });
+}
+
+int og_input_index(const og_engine* e, const char* name)
+{
+    if (!e || !name) return set_err(OG_E_INVALID, "null argument");
+    int i = e->cg->find_input(name);
+    return i >= 0 ? i : set_err(OG_E_INVALID, std::string("no input named '") + name + "'");
+}
+uint32_t og_num_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->inputs.size() : 0; }
+
+int og_set_value(og_engine* e, uint32_t input, float v)
+{
+    int rc = check_value_input(e, input, false);
+    if (rc) return rc;
+    if (e->cg->inputs[input].ramp_row < 0) {
+        e->values[input] = v;
+        return OG_OK;
+    }
+    Ramp& r = e->ramps[input]; // set_<name>  codegen/mod.rs:931-940
+    if (v != r.target) {
+        if (!r.ramping()) e->active_ramps += 1;
+        r.set_with_ramp(v, r.default_frames);
+        e->values[input] = r.current;
+    }
+    return OG_OK;
+}
+
+int og_set_value_ramp(og_engine* e, uint32_t input, float v, uint32_t frames)
+{
+    int rc = check_value_input(e, input, false);
+    if (rc) return rc;
+    if (e->cg->inputs[input].ramp_row < 0) {
+        e->values[input] = v;
+        return OG_OK;
+    }
+    Ramp& r = e->ramps[input]; // set_<name>_with_ramp  codegen/mod.rs:944-953
+    if (v != r.target) {
+        if (frames > 0 && !r.ramping()) e->active_ramps += 1;
+        // (the reference leaves active_ramps untouched when a running ramp is cut by
+        //  frames == 0; the counter only gates ticking, so results are unaffected)
+        if (frames == 0 && r.ramping()) e->active_ramps -= 1;
+        r.set_with_ramp(v, frames);
+        e->values[input] = r.current;
+    }
+    return OG_OK;
+}
+
+int og_set_value_immediate(og_engine* e, uint32_t input, float v)
+{
+    int rc = check_value_input(e, input, false);
+    if (rc) return rc;
+    if (e->cg->inputs[input].ramp_row >= 0) { // set_<name>_immediate  codegen/mod.rs:957-963
+        Ramp& r = e->ramps[input];
+        if (r.ramping()) e->active_ramps -= 1;
+        r.set_immediate(v);
+    }
+    e->values[input] = v;
+    return OG_OK;
+}
+
+int og_get_value(const og_engine* e, uint32_t input, float* out)
+{
+    int rc = check_value_input(e, input, false);
+    if (rc) return rc;
+    if (!out) return set_err(OG_E_INVALID, "null argument");
+    *out = e->values[input];
+    return OG_OK;
+}
+
+int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t count, const float* v)
+{
+    int rc = check_value_input(e, input, true);
+    if (rc) return rc;
+    if (!v || (uint64_t)first + count > e->V) return set_err(OG_E_INVALID, "voice range out of bounds");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        const size_t w = (size_t)e->cg->inputs[input].state_word;
+        HIPCK(hipMemcpyAsync(e->d_state + w * e->V + first, v, (size_t)count * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+int og_set_voice_value(og_engine* e, uint32_t input, uint32_t voice, float v)
+{
+    return og_set_voice_values(e, input, voice, 1, &v);
+}
+
+int og_push_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint32_t frame_offset, float scalar)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return push_event(e, input, voice, e->frame_now + frame_offset, scalar, true, false);
+}
+int og_push_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint32_t frame_offset, float v)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return push_event(e, input, voice, e->frame_now + frame_offset, v, true, true);
+}
+int og_schedule_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float scalar)
+{
+    return push_event(e, input, voice, abs_frame, scalar, false, false);
+}
+int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float v)
+{
+    return push_event(e, input, voice, abs_frame, v, false, true);
+}
+
+int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
+    if (frames == 0 || frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 1..512");
+    return guard([&] {
+        e->process_async(frames, d_out_bus);
+        return OG_OK;
+    });
+}
+
+int og_synchronize(og_engine* e)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
+{
+    int rc = og_process_block_async(e, frames, nullptr);
+    if (rc) return rc;
+    return guard([&] {
+        if (out_bus)
+            HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+int og_set_stream(og_engine* e, void* s)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipStreamSynchronize(e->stream));
+        if (e->own_stream) HIPCK(hipStreamDestroy(e->stream));
+        e->own_stream = false;
+        e->stream = (hipStream_t)s;
+        return OG_OK;
+    });
+}
+
+int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bus)
+{
+    if (!e || !out_bus) return set_err(OG_E_INVALID, "null argument");
+    if (block == 0 || block > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "block must be in 1..512");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        const uint32_t ch = e->cg->channels;
+        float* d_all = nullptr;
+        HIPCK(hipMalloc(&d_all, (size_t)total_frames * ch * 4));
+        try {
+            for (uint64_t f0 = 0; f0 < total_frames; f0 += block) {
+                const uint32_t frames = (uint32_t)std::min<uint64_t>(block, total_frames - f0);
+                e->process_async(frames, d_all + f0 * ch);
+            }
+            HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total_frames * ch * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(hipStreamSynchronize(e->stream));
+        } catch (...) {
+            hipFree(d_all);
+            throw;
+        }
+        HIPCK(hipFree(d_all));
+        return OG_OK;
+    });
+}
+
+int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
+{
+    if (!e || (n && !voices)) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipStreamSynchronize(e->stream));
+        std::vector<int32_t> slot(e->V, -1);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (voices[i] >= e->V) throw std::runtime_error("tap voice out of range");
+            slot[voices[i]] = (int32_t)i;
+        }
+        HIPCK(hipMemcpy(e->d_tap_slot, slot.data(), (size_t)e->V * 4, hipMemcpyHostToDevice));
+        if (e->d_taps) HIPCK(hipFree(e->d_taps));
+        e->d_taps = nullptr;
+        if (n) {
+            HIPCK(hipMalloc(&e->d_taps, (size_t)n * OG_MAX_BLOCK * 4));
+            HIPCK(hipMemset(e->d_taps, 0, (size_t)n * OG_MAX_BLOCK * 4));
+        }
+        e->n_taps = n;
+        return OG_OK;
+    });
+}
+
+int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames)
+{
+    if (!e || !out) return set_err(OG_E_INVALID, "null argument");
+    if (n > e->n_taps || frames != e->last_frames) return set_err(OG_E_INVALID, "taps: n/frames do not match the last block");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipMemcpyAsync(out, e->d_taps, (size_t)n * frames * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+uint32_t og_channels(const og_engine* e) { return e ? e->cg->channels : 0; }
+uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
+uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
+uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }
+uint32_t og_state_words_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->state.size() : 0; }
+uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
+
+int og_enable_kernel_timing(og_engine* e, int on)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    e->timing = on != 0;
+    e->t_used = 0;
+    return OG_OK;
+}
+
+double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
+{
+    if (!e || !e->timing) return -1.0;
+    double total = 0.0;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    for (size_t i = 0; i < e->t_used; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->t_start[i], e->t_stop[i]) == hipSuccess) total += ms;
+    }
+    if (n_launches) *n_launches = (uint32_t)e->t_used;
+    const double avg = e->t_used ? total / (double)e->t_used : 0.0;
+    e->t_used = 0;
+    return avg;
+}
+
+size_t og_state_bytes(const og_engine* e) { return e ? e->cg->state.size() * (size_t)e->V * 4 : 0; }
+
+int og_save_state(og_engine* e, void* dst, size_t cap)
+{
+    if (!e || !dst) return set_err(OG_E_INVALID, "null argument");
+    if (cap < og_state_bytes(e)) return set_err(OG_E_INVALID, "buffer too small");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipMemcpyAsync(dst, e->d_state, og_state_bytes(e), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+int og_load_state(og_engine* e, const void* src, size_t len)
+{
+    if (!e || !src) return set_err(OG_E_INVALID, "null argument");
+    if (len != og_state_bytes(e)) return set_err(OG_E_INVALID, "state blob size mismatch");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipMemcpyAsync(e->d_state, src, len, hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+} // extern "C"

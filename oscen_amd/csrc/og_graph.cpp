@@ -1,0 +1,905 @@
+// og_graph.cpp -- graph lowering + HIP code generation (see og_graph.h).
+#include "og_graph.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+namespace ogc {
+
+uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+int CompiledGraph::find_input(const std::string& n) const
+{
+    for (size_t i = 0; i < inputs.size(); ++i)
+        if (inputs[i].decl.name == n) return (int)i;
+    return -1;
+}
+
+namespace {
+
+[[noreturn]] void fail(const std::string& m) { throw std::runtime_error("oscen graph: " + m); }
+
+std::string flit(float v)
+{ // exact float literal
+    if (std::isinf(v)) return v > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%af", (double)v);
+    return buf;
+}
+uint32_t fbits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+Rate join(Rate a, Rate b)
+{
+    if (a == Rate::Vary || b == Rate::Vary) return Rate::Vary;
+    const bool voice = (a == Rate::VBlock || b == Rate::VBlock);
+    const bool frame = (a == Rate::UFrame || b == Rate::UFrame);
+    if (voice && frame) return Rate::Vary;
+    if (voice) return Rate::VBlock;
+    if (frame) return Rate::UFrame;
+    if (a == Rate::UBlock || b == Rate::UBlock) return Rate::UBlock;
+    return Rate::Const;
+}
+
+struct Val {
+    std::string e;
+    Rate rate = Rate::Const;
+    HostFn host;                  // available when rate <= UBlock
+    std::set<int> voice_inputs;   // per-voice value inputs this depends on (rate VBlock)
+};
+
+Val vconst(float c)
+{
+    Val v;
+    v.e = flit(c);
+    v.rate = Rate::Const;
+    v.host = [c](const UEnv&) { return c; };
+    return v;
+}
+
+// ---- expression parsing ------------------------------------------------------
+struct Expr {
+    enum T { Num, Ref, Bin, Neg } t = Num;
+    float num = 0;
+    std::string node, port; // Ref: port empty => bare identifier
+    char op = 0;
+    std::shared_ptr<Expr> a, b;
+};
+using ExprP = std::shared_ptr<Expr>;
+
+struct Parser {
+    const std::string& s;
+    size_t i = 0;
+    explicit Parser(const std::string& str) : s(str) {}
+    void ws()
+    {
+        while (i < s.size() && isspace((unsigned char)s[i])) ++i;
+    }
+    bool eat(char c)
+    {
+        ws();
+        if (i < s.size() && s[i] == c) {
+            ++i;
+            return true;
+        }
+        return false;
+    }
+    std::string ident()
+    {
+        ws();
+        size_t b = i;
+        while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_')) ++i;
+        return s.substr(b, i - b);
+    }
+    ExprP primary()
+    {
+        ws();
+        if (i >= s.size()) fail("unexpected end of expression '" + s + "'");
+        if (eat('(')) {
+            ExprP e = sum();
+            if (!eat(')')) fail("missing ')' in '" + s + "'");
+            return e;
+        }
+        if (eat('-')) {
+            auto e = std::make_shared<Expr>();
+            e->t = Expr::Neg;
+            e->a = primary();
+            return e;
+        }
+        if (isdigit((unsigned char)s[i]) || s[i] == '.') {
+            std::string num;
+            while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '.' || s[i] == '_' ||
+                                    ((s[i] == '+' || s[i] == '-') && i > 0 && (s[i - 1] == 'e' || s[i - 1] == 'E')))) {
+                if (s[i] != '_') num.push_back(s[i]);
+                ++i;
+            }
+            // strip rust suffixes
+            for (const char* suf : {"f32", "f64"}) {
+                size_t p = num.rfind(suf);
+                if (p != std::string::npos && p + 3 == num.size()) num.erase(p);
+            }
+            auto e = std::make_shared<Expr>();
+            e->t = Expr::Num;
+            e->num = strtof(num.c_str(), nullptr);
+            return e;
+        }
+        std::string id = ident();
+        if (id.empty()) fail("bad expression '" + s + "'");
+        auto e = std::make_shared<Expr>();
+        e->t = Expr::Ref;
+        e->node = id;
+        ws();
+        if (i < s.size() && s[i] == '.') {
+            ++i;
+            e->port = ident();
+            if (eat('(')) { // legacy `osc.output()` accessor syntax
+                if (!eat(')')) fail("bad accessor in '" + s + "'");
+            }
+        }
+        return e;
+    }
+    ExprP product()
+    {
+        ExprP l = primary();
+        for (;;) {
+            ws();
+            if (i < s.size() && (s[i] == '*' || s[i] == '/')) {
+                char op = s[i++];
+                auto e = std::make_shared<Expr>();
+                e->t = Expr::Bin;
+                e->op = op;
+                e->a = l;
+                e->b = primary();
+                l = e;
+            } else
+                return l;
+        }
+    }
+    ExprP sum()
+    {
+        ExprP l = product();
+        for (;;) {
+            ws();
+            if (i < s.size() && (s[i] == '+' || s[i] == '-')) {
+                char op = s[i++];
+                auto e = std::make_shared<Expr>();
+                e->t = Expr::Bin;
+                e->op = op;
+                e->a = l;
+                e->b = product();
+                l = e;
+            } else
+                return l;
+        }
+    }
+    ExprP parse()
+    {
+        ExprP e = sum();
+        ws();
+        if (i != s.size()) fail("trailing characters in '" + s + "'");
+        return e;
+    }
+};
+
+void collect_refs(const ExprP& e, std::vector<const Expr*>& out)
+{
+    if (!e) return;
+    if (e->t == Expr::Ref) out.push_back(e.get());
+    collect_refs(e->a, out);
+    collect_refs(e->b, out);
+}
+
+// ---- node type registry ------------------------------------------------------
+struct PortSpec {
+    const char* name;
+    Kind kind;
+    float def;
+    int arg; // ctor argument that overrides the default, or -1
+};
+
+struct Codegen;
+struct NodeCtx;
+using Emitter = void (*)(NodeCtx&);
+
+struct NodeTypeInfo {
+    std::vector<PortSpec> inputs;
+    std::vector<const char*> outputs;
+    Emitter emit;
+    int variant;
+    size_t nargs;
+};
+
+struct NodeInst {
+    const GNode* decl = nullptr;
+    const NodeTypeInfo* type = nullptr;
+    int id = -1;
+    bool live = true;
+    std::map<std::string, std::vector<ExprP>> in_edges; // stream/value port -> sources in edge order
+    std::map<std::string, std::vector<int>> ev_edges;   // event port -> graph event-input indices
+};
+
+struct Codegen {
+    const GraphDesc& g;
+    CompiledGraph& out;
+    std::vector<NodeInst> nodes;
+    std::map<std::string, int> node_by_name, input_by_name, output_by_name;
+    std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
+
+    // emitted code sections
+    std::ostringstream decl, load, derive, pre, tick, store;
+    std::map<int, std::ostringstream> ev_handlers; // per graph event input
+    bool any_derive = false;
+
+    Codegen(const GraphDesc& gd, CompiledGraph& cg) : g(gd), out(cg) {}
+
+    int new_slot(std::function<uint32_t(const UEnv&)> fn)
+    {
+        int s = out.n_slots++;
+        out.uprogs.push_back({s, std::move(fn)});
+        return s;
+    }
+    int new_state(const std::string& name, bool is_float, std::function<uint32_t(const UEnv&)> init)
+    {
+        out.state.push_back({name, is_float, std::move(init)});
+        return (int)out.state.size() - 1;
+    }
+
+    Val input_val(int idx)
+    {
+        const InputInfo& in = out.inputs[idx];
+        Val v;
+        if (in.decl.kind != Kind::Value) fail("input '" + in.decl.name + "' is not a value input");
+        if (in.decl.per_voice) {
+            v.e = "vin_" + std::to_string(idx);
+            v.rate = Rate::VBlock;
+            v.voice_inputs.insert(idx);
+        } else if (in.ramp_row >= 0) {
+            v.e = "RV(" + std::to_string(in.ramp_row) + ", " + std::to_string(in.slot) + ")";
+            v.rate = Rate::UFrame;
+        } else {
+            v.e = "SF(" + std::to_string(in.slot) + ")";
+            v.rate = Rate::UBlock;
+            v.host = [idx](const UEnv& e) { return e.input_values[idx]; };
+        }
+        return v;
+    }
+
+    Val eval(const ExprP& e)
+    {
+        switch (e->t) {
+        case Expr::Num: return vconst(e->num);
+        case Expr::Neg: {
+            Val a = eval(e->a);
+            Val r;
+            r.e = "(-" + a.e + ")";
+            r.rate = a.rate;
+            r.voice_inputs = a.voice_inputs;
+            if (a.host) {
+                HostFn h = a.host;
+                r.host = [h](const UEnv& env) { return -h(env); };
+            }
+            return r;
+        }
+        case Expr::Ref: {
+            if (e->port.empty()) {
+                auto it = input_by_name.find(e->node);
+                if (it == input_by_name.end()) fail("unknown source '" + e->node + "'");
+                return input_val(it->second);
+            }
+            auto nit = node_by_name.find(e->node);
+            if (nit == node_by_name.end()) fail("unknown node '" + e->node + "'");
+            auto vit = node_outputs.find("n" + std::to_string(nit->second) + "." + e->port);
+            if (vit == node_outputs.end())
+                fail("node '" + e->node + "' has no output '" + e->port + "' (or it is read before it runs)");
+            return vit->second;
+        }
+        default: {
+            Val a = eval(e->a), b = eval(e->b);
+            Val r;
+            r.e = "(" + a.e + " " + e->op + " " + b.e + ")";
+            r.rate = join(a.rate, b.rate);
+            r.voice_inputs = a.voice_inputs;
+            r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
+            if (a.host && b.host && r.rate <= Rate::UBlock) {
+                HostFn ha = a.host, hb = b.host;
+                char op = e->op;
+                r.host = [ha, hb, op](const UEnv& env) {
+                    float x = ha(env), y = hb(env);
+                    switch (op) {
+                    case '+': return x + y;
+                    case '-': return x - y;
+                    case '*': return x * y;
+                    default: return x / y;
+                    }
+                };
+            }
+            return r;
+        }
+        }
+    }
+};
+
+struct NodeCtx {
+    Codegen& cg;
+    NodeInst& n;
+    std::string p; // local-name prefix "n<id>_"
+
+    const PortSpec& port(const std::string& name) const
+    {
+        for (const auto& ps : n.type->inputs)
+            if (name == ps.name) return ps;
+        fail("node '" + n.decl->name + "' has no input '" + name + "'");
+    }
+    float def(const std::string& name) const
+    {
+        const PortSpec& ps = port(name);
+        if (ps.arg >= 0 && (size_t)ps.arg < n.decl->args.size()) return n.decl->args[ps.arg];
+        return ps.def;
+    }
+    bool connected(const std::string& name) const { return n.in_edges.count(name) > 0; }
+    // resolved value of a stream/value input: constant default, one source, or the sum of sources
+    Val in(const std::string& name)
+    {
+        auto it = n.in_edges.find(name);
+        if (it == n.in_edges.end()) return vconst(def(name));
+        Val acc = cg.eval(it->second[0]);
+        for (size_t i = 1; i < it->second.size(); ++i) { // connect, then accumulate in edge order
+            Val b = cg.eval(it->second[i]);
+            Val r;
+            r.e = "(" + acc.e + " + " + b.e + ")";
+            r.rate = join(acc.rate, b.rate);
+            r.voice_inputs = acc.voice_inputs;
+            r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
+            if (acc.host && b.host && r.rate <= Rate::UBlock) {
+                HostFn ha = acc.host, hb = b.host;
+                r.host = [ha, hb](const UEnv& env) { return ha(env) + hb(env); };
+            }
+            acc = r;
+        }
+        return acc;
+    }
+    Val in_uniform(const std::string& name)
+    {
+        Val v = in(name);
+        if (v.rate > Rate::UBlock || !v.host)
+            fail("node '" + n.decl->name + "': input '" + name +
+                 "' must be a block-uniform value (constant or non-ramped broadcast input) in this version");
+        return v;
+    }
+    std::string sf(int slot) const { return "SF(" + std::to_string(slot) + ")"; }
+    std::string su(int slot) const { return "SU(" + std::to_string(slot) + ")"; }
+    int slot_f(std::function<float(const UEnv&)> fn)
+    {
+        return cg.new_slot([fn](const UEnv& e) { return fbits(fn(e)); });
+    }
+    int slot_u(std::function<uint32_t(const UEnv&)> fn) { return cg.new_slot(std::move(fn)); }
+    float rate_sr_factor() const { return (float)n.decl->rate_factor; }
+    int sr_slot()
+    {
+        float k = rate_sr_factor();
+        return slot_f([k](const UEnv& e) { return e.sample_rate * k; });
+    }
+    // declare a state word held in a register named <prefix><name>
+    std::string state_f(const std::string& name, std::function<float(const UEnv&)> init)
+    {
+        std::string var = p + name;
+        int w = cg.new_state(n.decl->name + "." + name, true, [init](const UEnv& e) { return fbits(init(e)); });
+        cg.decl << "    float " << var << " = 0.0f;\n";
+        cg.load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
+        cg.store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
+        return var;
+    }
+    std::string state_u(const std::string& name, uint32_t init)
+    {
+        std::string var = p + name;
+        int w = cg.new_state(n.decl->name + "." + name, false, [init](const UEnv&) { return init; });
+        cg.decl << "    uint32_t " << var << " = 0u;\n";
+        cg.load << "        " << var << " = og::ld_u(A, c, " << w << ");\n";
+        cg.store << "        og::st_u(A, c, " << w << ", " << var << ");\n";
+        return var;
+    }
+    void set_out(const std::string& port, const std::string& expr)
+    {
+        std::string var = p + port;
+        cg.tick << "        const float " << var << " = " << expr << ";\n";
+        Val v;
+        v.e = var;
+        v.rate = Rate::Vary;
+        cg.node_outputs["n" + std::to_string(n.id) + "." + port] = v;
+    }
+    // a value that is constant over the block per voice: computed in derive()
+    std::string hoist(const std::string& name, const std::string& expr)
+    {
+        std::string var = p + name;
+        cg.decl << "    float " << var << " = 0.0f;\n";
+        cg.derive << "        " << var << " = " << expr << ";\n";
+        cg.any_derive = true;
+        return var;
+    }
+};
+
+// ---- emitters ---------------------------------------------------------------
+
+constexpr float ADSR_MIN_TIME = 1.0e-5f;
+constexpr float ADSR_CURVE_K = 4.6051702f;
+
+uint32_t rs_as_u32(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+// adsr.rs:117-134 on the host: same libm the reference's f32::exp binds to
+uint32_t adsr_samples(float t, float sr)
+{
+    uint32_t n = rs_as_u32(fmaxf(fmaxf(t, 0.0f), ADSR_MIN_TIME) * fmaxf(sr, 1.0f));
+    return n < 1 ? 1 : n;
+}
+float adsr_coeff(uint32_t n) { return 1.0f - expf(-ADSR_CURVE_K / (float)n); }
+
+void emit_adsr(NodeCtx& x)
+{
+    Val a = x.in_uniform("attack"), d = x.in_uniform("decay"), s = x.in_uniform("sustain"),
+        r = x.in_uniform("release");
+    const float k = x.rate_sr_factor();
+    HostFn ha = a.host, hd = d.host, hs = s.host, hr = r.host;
+    int s_an = x.slot_u([ha, k](const UEnv& e) { return adsr_samples(ha(e), e.sample_rate * k); });
+    int s_dn = x.slot_u([hd, k](const UEnv& e) { return adsr_samples(hd(e), e.sample_rate * k); });
+    int s_rn = x.slot_u([hr, k](const UEnv& e) { return adsr_samples(hr(e), e.sample_rate * k); });
+    int s_ac = x.slot_f([ha, k](const UEnv& e) { return adsr_coeff(adsr_samples(ha(e), e.sample_rate * k)); });
+    int s_dc = x.slot_f([hd, k](const UEnv& e) { return adsr_coeff(adsr_samples(hd(e), e.sample_rate * k)); });
+    int s_su = x.slot_f([hs](const UEnv& e) {
+        float v = hs(e);
+        return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    });
+    int s_ai = x.slot_u([ha](const UEnv& e) { return (uint32_t)(ha(e) <= ADSR_MIN_TIME); });
+    int s_ri = x.slot_u([hr](const UEnv& e) { return (uint32_t)(fmaxf(hr(e), 0.0f) <= ADSR_MIN_TIME); });
+    (void)s_dn; (void)s_rn; (void)s_su; (void)s_ai; (void)s_ri; // eight consecutive slots, see og_nodes.hip.h
+    const std::string K = "A, " + std::to_string(s_an);
+    std::string stage = x.state_u("stage", 0), rem = x.state_u("rem", 0);
+    std::string level = x.state_f("level", [](const UEnv&) { return 0.0f; });
+    std::string vel = x.state_f("velocity", [](const UEnv&) { return 1.0f; });
+    std::string sus = x.p + "sus";
+    x.cg.decl << "    float " << sus << " = 0.0f;\n";
+    x.cg.pre << "        og::adsr_block_begin(" << stage << ", " << rem << ", " << vel << ", " << sus << ", " << K
+             << ");\n";
+    auto ev = x.n.ev_edges.find("gate");
+    if (ev != x.n.ev_edges.end())
+        for (int ei : ev->second)
+            x.cg.ev_handlers[ei] << "                og::adsr_gate(" << stage << ", " << rem << ", " << level << ", "
+                                 << vel << ", " << sus << ", ev.value, " << K << ");\n";
+    x.set_out("output", "og::adsr_tick(" + stage + ", " + rem + ", " + level + ", " + sus + ", " + x.sf(s_ac) + ", " +
+                            x.sf(s_dc) + ", " + x.su(s_dn) + ")");
+}
+
+void emit_fm_operator(NodeCtx& x)
+{
+    Val bf = x.in("base_freq"), ratio = x.in("ratio"), pm = x.in("phase_mod"), fb = x.in("feedback"),
+        env = x.in("envelope"), lvl = x.in("level");
+    int s_sr = x.sr_slot();
+    std::string phase = x.state_f("phase", [](const UEnv&) { return 0.0f; });
+    std::string prev = x.state_f("prev_output", [](const UEnv&) { return 0.0f; });
+    std::string inc_expr = "(" + bf.e + " * " + ratio.e + ") / " + x.sf(s_sr);
+    std::string inc;
+    Rate rr = join(bf.rate, ratio.rate);
+    if (rr <= Rate::VBlock && rr != Rate::UFrame) {
+        inc = x.hoist("inc", inc_expr);
+    } else {
+        inc = x.p + "inc";
+        x.cg.tick << "        const float " << inc << " = " << inc_expr << ";\n";
+    }
+    x.set_out("output", "og::fm_operator_tick(" + phase + ", " + prev + ", " + inc + ", " + pm.e + ", " + fb.e + ", " +
+                            env.e + ", " + lvl.e + ")");
+}
+
+void emit_tpt(NodeCtx& x)
+{
+    Val in = x.in("input"), cutoff = x.in("cutoff"), q = x.in("q"), fmod = x.in("f_mod");
+    const float k = x.rate_sr_factor();
+    const float c0 = x.def("cutoff"), q0 = x.def("q");
+    int s_two_sr = x.slot_f([k](const UEnv& e) { return 2.0f * (e.sample_rate * k); });
+    int s_period = x.slot_f([k](const UEnv& e) { return 0.5f / (e.sample_rate * k); });
+    int s_nyq = x.slot_f([k](const UEnv& e) { return (e.sample_rate * k) * 0.5f - 1.1920929e-7f; });
+    int s_maxc = x.slot_f([k](const UEnv& e) { return fminf((e.sample_rate * k) * 0.5f - 1.1920929e-7f, 20000.0f); });
+    // prepare(): update_coefficients(sr, self.cutoff, self.q) with the ctor fields (tpt/mod.rs:129-131, 69-82)
+    auto coef = [c0, q0, k](const UEnv& e, int which) {
+        const float sr = e.sample_rate * k;
+        const float nyquist = sr * 0.5f - 1.1920929e-7f;
+        float freq = c0 < 20.0f ? 20.0f : c0;
+        freq = freq > nyquist ? nyquist : freq;
+        const float period = 0.5f / sr;
+        const float f = (2.0f * sr) * tanf(2.0f * 3.14159274101257324f * freq * period) * period;
+        const float inv_q = 1.0f / q0;
+        const float h = 1.0f / (1.0f + inv_q * f + f * f);
+        return which == 0 ? h : (which == 1 ? f : f + inv_q);
+    };
+    std::string z0 = x.state_f("z0", [](const UEnv&) { return 0.0f; });
+    std::string z1 = x.state_f("z1", [](const UEnv&) { return 0.0f; });
+    std::string cc = x.state_f("current_cutoff", [c0](const UEnv&) { return c0; });
+    std::string cq = x.state_f("current_q", [q0](const UEnv&) { return q0; });
+    std::string h = x.state_f("h", [coef](const UEnv& e) { return coef(e, 0); });
+    std::string g = x.state_f("g", [coef](const UEnv& e) { return coef(e, 1); });
+    std::string kk = x.state_f("k", [coef](const UEnv& e) { return coef(e, 2); });
+    const bool nomod = (fmod.rate == Rate::Const) && !x.connected("f_mod") && x.def("f_mod") == 0.0f;
+    if (nomod)
+        x.cg.tick << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << x.sf(s_maxc) << ", "
+                  << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", " << cq
+                  << ", " << h << ", " << g << ", " << kk << ");\n";
+    else
+        x.cg.tick << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << x.sf(s_maxc)
+                  << ", " << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", "
+                  << cq << ", " << h << ", " << g << ", " << kk << ");\n";
+    x.set_out("output", "og::tpt_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + h + ", " + g + ", " + kk + ")");
+}
+
+void emit_polyblep(NodeCtx& x)
+{
+    Val pm = x.in("phase_mod"), fr = x.in("frequency"), fm = x.in("frequency_mod"), amp = x.in("amplitude"),
+        pw = x.in("pulse_width");
+    int s_sr = x.sr_slot();
+    std::string phase = x.state_f("phase", [](const UEnv&) { return 0.0f; });
+    x.set_out("output", "og::polyblep_tick<" + std::to_string(x.n.type->variant) + "u>(" + phase + ", " + fr.e + ", " +
+                            fm.e + ", " + pm.e + ", " + amp.e + ", " + pw.e + ", " + x.sf(s_sr) + ")");
+}
+
+void emit_oscillator(NodeCtx& x)
+{
+    Val fr = x.in("frequency"), fm = x.in("frequency_mod"), amp = x.in("amplitude");
+    int s_sr = x.sr_slot();
+    std::string phase = x.state_f("phase", [](const UEnv&) { return 0.0f; });
+    x.set_out("output", "og::oscillator_tick<" + std::to_string(x.n.type->variant) + "u>(" + phase + ", " + fr.e +
+                            ", " + fm.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
+}
+
+void emit_gain(NodeCtx& x) { x.set_out("output", x.in("input").e + " * " + x.in("gain").e); }
+void emit_vca(NodeCtx& x) { x.set_out("output", x.in("input").e + " * " + x.in("control").e); }
+void emit_add_value(NodeCtx& x) { x.set_out("output", x.in("input").e + " + " + x.in("value").e); }
+void emit_mixer(NodeCtx& x) { x.set_out("output", x.in("input_a").e + " + " + x.in("input_b").e); }
+void emit_hardclip(NodeCtx& x) { x.set_out("output", "og::hardclip(" + x.in("input").e + ")"); }
+void emit_crossfade(NodeCtx& x)
+{
+    Val in = x.in("input"), mix = x.in("mix");
+    std::string m = x.p + "mix";
+    x.cg.tick << "        const float " << m << " = og::clamp01(" << mix.e << ");\n";
+    x.set_out("output_a", in.e + " * (1.0f - " + m + ")");
+    x.set_out("output_b", in.e + " * " + m);
+}
+
+const std::map<std::string, NodeTypeInfo>& registry()
+{
+    static const std::map<std::string, NodeTypeInfo> R = [] {
+        std::map<std::string, NodeTypeInfo> r;
+        const Kind V = Kind::Value, S = Kind::Stream, E = Kind::Event;
+        r["AdsrEnvelope::new"] = {{{"gate", E, 0, -1}, {"attack", V, 0, 0}, {"decay", V, 0, 1}, {"sustain", V, 0, 2},
+                                   {"release", V, 0, 3}},
+                                  {"output"}, emit_adsr, 0, 4};
+        r["FmOperator::new"] = {{{"base_freq", V, 440.0f, -1}, {"ratio", V, 1.0f, -1}, {"phase_mod", S, 0, -1},
+                                 {"feedback", V, 0, -1}, {"envelope", S, 1.0f, -1}, {"level", V, 1.0f, -1}},
+                                {"output"}, emit_fm_operator, 0, 0};
+        r["TptFilter::new"] = {{{"input", S, 0, -1}, {"cutoff", S, 0, 0}, {"q", V, 0, 1}, {"f_mod", S, 0, -1}},
+                               {"output"}, emit_tpt, 0, 2};
+        const char* pbn[4] = {"sine", "saw", "square", "triangle"};
+        for (int w = 0; w < 4; ++w)
+            r[std::string("PolyBlepOscillator::") + pbn[w]] = {
+                {{"phase_mod", S, 0, -1}, {"frequency", V, 0, 0}, {"frequency_mod", S, 0, -1}, {"amplitude", V, 0, 1},
+                 {"pulse_width", V, 0.5f, -1}},
+                {"output"}, emit_polyblep, w, 2};
+        const char* on[3] = {"sine", "square", "saw"};
+        for (int w = 0; w < 3; ++w)
+            r[std::string("Oscillator::") + on[w]] = {
+                {{"frequency", V, 0, 0}, {"frequency_mod", S, 0, -1}, {"amplitude", V, 0, 1}},
+                {"output"}, emit_oscillator, w, 2};
+        r["Gain::new"] = {{{"input", S, 0, -1}, {"gain", S, 1.0f, 0}}, {"output"}, emit_gain, 0, 1};
+        r["Vca::new"] = {{{"input", S, 0, -1}, {"control", S, 1.0f, -1}}, {"output"}, emit_vca, 0, 0};
+        r["AddValue::new"] = {{{"input", S, 0, -1}, {"value", V, 0, 0}}, {"output"}, emit_add_value, 0, 1};
+        r["Mixer::new"] = {{{"input_a", S, 0, -1}, {"input_b", S, 0, -1}}, {"output"}, emit_mixer, 0, 0};
+        r["Crossfade::new"] = {{{"input", S, 0, -1}, {"mix", V, 0, -1}}, {"output_a", "output_b"}, emit_crossfade, 0, 0};
+        r["HardClip::new"] = {{{"input", S, 0, -1}}, {"output"}, emit_hardclip, 0, 0};
+        return r;
+    }();
+    return R;
+}
+
+} // namespace
+
+std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
+{
+    auto cgp = std::make_unique<CompiledGraph>();
+    CompiledGraph& out = *cgp;
+    out.name = g.name;
+    Codegen cg(g, out);
+
+    // ---- inputs / outputs ----------------------------------------------------
+    for (size_t i = 0; i < g.inputs.size(); ++i) {
+        const GInput& in = g.inputs[i];
+        if (cg.input_by_name.count(in.name)) fail("duplicate input '" + in.name + "'");
+        cg.input_by_name[in.name] = (int)i;
+        InputInfo info;
+        info.decl = in;
+        if (in.kind == Kind::Event) {
+            info.event_index = out.n_event_inputs++;
+        } else if (in.kind == Kind::Value) {
+            if (in.per_voice) {
+                if (in.ramp_frames) fail("per-voice input '" + in.name + "' cannot be ramped");
+                const float d = in.def;
+                info.state_word = cg.new_state("in." + in.name, true, [d](const UEnv&) { return fbits(d); });
+                cg.decl << "    float vin_" << i << " = 0.0f;\n";
+                cg.load << "        vin_" << i << " = og::ld_f(A, c, " << info.state_word << ");\n";
+            } else {
+                const int idx = (int)i;
+                info.slot = cg.new_slot([idx](const UEnv& e) { return fbits(e.input_values[idx]); });
+                if (in.ramp_frames) info.ramp_row = out.n_ramps++;
+            }
+        } else {
+            fail("stream graph inputs are not supported by the voice-bank engine (input '" + in.name + "')");
+        }
+        out.inputs.push_back(info);
+    }
+    for (size_t i = 0; i < g.outputs.size(); ++i) cg.output_by_name[g.outputs[i].name] = (int)i;
+
+    // ---- nodes ------------------------------------------------------------------
+    cg.nodes.resize(g.nodes.size());
+    for (size_t i = 0; i < g.nodes.size(); ++i) {
+        const GNode& nd = g.nodes[i];
+        if (cg.node_by_name.count(nd.name) || cg.input_by_name.count(nd.name))
+            fail("duplicate name '" + nd.name + "'");
+        auto it = registry().find(nd.type);
+        if (it == registry().end()) fail("unknown node type '" + nd.type + "' (node '" + nd.name + "')");
+        if (nd.args.size() != it->second.nargs)
+            fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(it->second.nargs) + " arguments");
+        if (nd.rate_factor != 1)
+            fail("node '" + nd.name + "': oversampled (`* N`) nodes are not supported by this version");
+        cg.node_by_name[nd.name] = (int)i;
+        cg.nodes[i].decl = &nd;
+        cg.nodes[i].type = &it->second;
+        cg.nodes[i].id = (int)i;
+    }
+
+    // ---- edges ------------------------------------------------------------------
+    struct OutEdge {
+        ExprP src;
+        std::string policy;
+    };
+    std::map<int, std::vector<OutEdge>> out_edges; // graph output index -> sources
+    std::vector<std::set<int>> deps(g.nodes.size()); // node -> nodes it reads
+    std::vector<std::set<int>> out_deps(g.outputs.size());
+    for (const GEdge& e : g.edges) {
+        ExprP src = Parser(e.src).parse();
+        std::vector<const Expr*> refs;
+        collect_refs(src, refs);
+        std::set<int> src_nodes;
+        bool src_is_event_input = false;
+        int src_event_input = -1;
+        for (const Expr* r : refs) {
+            if (r->port.empty()) {
+                auto it = cg.input_by_name.find(r->node);
+                if (it == cg.input_by_name.end()) fail("unknown source '" + r->node + "' in '" + e.src + "'");
+                if (g.inputs[it->second].kind == Kind::Event) {
+                    src_is_event_input = true;
+                    src_event_input = out.inputs[it->second].event_index;
+                }
+            } else {
+                auto it = cg.node_by_name.find(r->node);
+                if (it == cg.node_by_name.end()) fail("unknown node '" + r->node + "' in '" + e.src + "'");
+                src_nodes.insert(it->second);
+            }
+        }
+        // destination
+        std::string dn = e.dst, dp;
+        size_t dot = dn.find('.');
+        if (dot != std::string::npos) {
+            dp = dn.substr(dot + 1);
+            dn = dn.substr(0, dot);
+            size_t par = dp.find('(');
+            if (par != std::string::npos) dp = dp.substr(0, par);
+        }
+        auto trim = [](std::string& s) {
+            while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+            while (!s.empty() && isspace((unsigned char)s.front())) s.erase(s.begin());
+        };
+        trim(dn);
+        trim(dp);
+        if (dp.empty()) {
+            auto oit = cg.output_by_name.find(dn);
+            if (oit == cg.output_by_name.end()) fail("unknown destination '" + e.dst + "'");
+            if (src_is_event_input) fail("event outputs are not supported ('" + e.dst + "')");
+            if (!e.policy.empty()) fail("cross-rate policies need oversampled nodes, unsupported in this version");
+            out_edges[oit->second].push_back({src, e.policy});
+            out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
+            continue;
+        }
+        auto nit = cg.node_by_name.find(dn);
+        if (nit == cg.node_by_name.end()) fail("unknown destination node '" + dn + "'");
+        NodeInst& dst = cg.nodes[nit->second];
+        const PortSpec* ps = nullptr;
+        for (const auto& p : dst.type->inputs)
+            if (dp == p.name) ps = &p;
+        if (!ps) fail("node '" + dn + "' (" + dst.decl->type + ") has no input '" + dp + "'");
+        if (!e.policy.empty()) fail("cross-rate policies need oversampled nodes, unsupported in this version");
+        if (ps->kind == Kind::Event) {
+            if (!src_is_event_input || src->t != Expr::Ref)
+                fail("event input '" + e.dst + "' must be fed by a graph event input");
+            dst.ev_edges[dp].push_back(src_event_input);
+        } else {
+            if (src_is_event_input) fail("event source '" + e.src + "' cannot feed '" + e.dst + "'");
+            dst.in_edges[dp].push_back(src);
+            deps[nit->second].insert(src_nodes.begin(), src_nodes.end());
+        }
+    }
+
+    // ---- dead-node removal (ir/passes/dead_nodes.rs:11-62) ------------------------
+    if (!g.outputs.empty()) {
+        std::vector<char> live(g.nodes.size(), 0);
+        std::deque<int> q;
+        for (auto& od : out_deps)
+            for (int n : od) q.push_back(n);
+        while (!q.empty()) {
+            int n = q.front();
+            q.pop_front();
+            if (live[n]) continue;
+            live[n] = 1;
+            for (int d : deps[n]) q.push_back(d);
+        }
+        for (size_t i = 0; i < g.nodes.size(); ++i) cg.nodes[i].live = live[i];
+    }
+
+    // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
+    std::vector<int> order;
+    {
+        std::vector<int> indeg(g.nodes.size(), 0);
+        std::vector<std::vector<int>> users(g.nodes.size());
+        for (size_t i = 0; i < g.nodes.size(); ++i) {
+            if (!cg.nodes[i].live) continue;
+            for (int d : deps[i]) {
+                if (d == (int)i) fail("node '" + g.nodes[i].name + "' feeds itself without a delay");
+                indeg[i]++;
+                users[d].push_back((int)i);
+            }
+        }
+        std::deque<int> ready;
+        size_t n_live = 0;
+        for (size_t i = 0; i < g.nodes.size(); ++i)
+            if (cg.nodes[i].live) {
+                ++n_live;
+                if (indeg[i] == 0) ready.push_back((int)i);
+            }
+        while (!ready.empty()) {
+            int n = ready.front();
+            ready.pop_front();
+            order.push_back(n);
+            for (int u : users[n])
+                if (--indeg[u] == 0) ready.push_back(u);
+        }
+        if (order.size() != n_live)
+            fail("graph contains a non-feedback cycle (feedback edges are not supported by this version)");
+    }
+
+    // ---- emit nodes ----------------------------------------------------------------
+    for (int ni : order) {
+        NodeInst& n = cg.nodes[ni];
+        NodeCtx x{cg, n, "n" + std::to_string(n.id) + "_"};
+        cg.tick << "        // " << n.decl->name << " = " << n.decl->type << "\n";
+        n.type->emit(x);
+        out.node_order.push_back(n.decl->name);
+    }
+
+    // ---- graph output -----------------------------------------------------------------
+    std::string bus_expr = "0.0f";
+    {
+        int n_stream = 0;
+        for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
+            if (g.outputs[oi].kind == Kind::Event) fail("event outputs are not supported");
+            auto it = out_edges.find((int)oi);
+            if (it == out_edges.end()) continue;
+            if (++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
+            std::string acc;
+            for (size_t k = 0; k < it->second.size(); ++k) {
+                Val v = cg.eval(it->second[k].src);
+                acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
+            }
+            cg.tick << "        const float g_out = " << acc << ";\n";
+            bus_expr = "g_out";
+        }
+    }
+
+    if (out.n_slots > 160) fail("graph needs more than 160 uniform slots");
+
+    // ---- assemble the translation unit ----------------------------------------------------
+    std::ostringstream body;
+    body << "template <bool RAMPS, bool TAPS>\n"
+         << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
+         << "    __shared__ og::BusLds bus;\n"
+         << "    og::VoiceCtx c;\n"
+         << "    og::voice_begin<TAPS>(A, c);\n"
+         << cg.decl.str() << "    if (c.valid) {\n"
+         << cg.load.str() << "    }\n";
+    body << "    auto derive = [&]() {\n" << cg.derive.str() << "    };\n";
+    body << "    {\n" << cg.pre.str() << "    derive();\n";
+    body << "    for (uint32_t f = 0; f < A.frames; ++f) {\n";
+    body << "        if (f == c.next_ev) {\n"
+         << "            do {\n"
+         << "                const OgEvent ev = A.events[c.ev_cur];\n";
+    bool first = true;
+    for (size_t i = 0; i < out.inputs.size(); ++i) {
+        const InputInfo& in = out.inputs[i];
+        if (in.decl.kind == Kind::Value && in.decl.per_voice) {
+            body << "                " << (first ? "" : "else ") << "if (ev.target == (OG_EV_SETVALUE | " << i
+                 << "u)) { vin_" << i << " = ev.value; derive(); }\n";
+            first = false;
+        }
+    }
+    for (auto& kv : cg.ev_handlers) {
+        body << "                " << (first ? "" : "else ") << "if (ev.target == " << kv.first << "u) {\n"
+             << kv.second.str() << "                }\n";
+        first = false;
+    }
+    body << "                og::ev_advance(A, c);\n"
+         << "            } while (c.next_ev <= f);\n"
+         << "        }\n";
+    body << cg.tick.str();
+    body << "        og::bus_push<TAPS>(A, c, bus, f, " << bus_expr << ");\n"
+         << "    }\n    }\n";
+    body << "    og::bus_flush(A, c, bus);\n"
+         << "    if (c.valid) {\n"
+         << cg.store.str();
+    for (size_t i = 0; i < out.inputs.size(); ++i) {
+        const InputInfo& in = out.inputs[i];
+        if (in.decl.kind == Kind::Value && in.decl.per_voice)
+            body << "        if (c.ev_cur != c.ev_cur0) og::st_f(A, c, " << in.state_word << ", vin_" << i << ");\n";
+    }
+    body << "    }\n    og::voice_end(A, c);\n}\n";
+
+    const std::string body_s = body.str();
+    out.hash = fnv1a(body_s);
+    char hs[32];
+    snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
+
+    std::ostringstream src;
+    src << "// GENERATED by oscen_amd/csrc/og_graph.cpp from graph '" << g.name << "' -- do not edit.\n"
+        << "// One fused voice kernel: " << out.state.size() << " state words/voice, " << out.n_slots
+        << " uniform slots, " << out.n_ramps << " ramped inputs, " << out.n_event_inputs << " event inputs.\n"
+        << "// Node order: ";
+    for (auto& nn : out.node_order) src << nn << " ";
+    src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
+        << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
+        << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.frames + f] : og::slot_f(A, (slot)))\n\n"
+        << "namespace og_gen_" << hs << " {\n"
+        << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n\n";
+    const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
+                                  {"11", "true", "true"}};
+    for (auto& v : variants)
+        src << "extern \"C\" __global__ __launch_bounds__(64) void og_k_" << hs << "_" << v[0]
+            << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
+    src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
+        << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
+        << "    const dim3 grid((A.n_voices + OG_WAVE - 1) / OG_WAVE), block(OG_WAVE);\n"
+        << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
+        << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"
+        << "    else if (!ramps && taps) hipLaunchKernelGGL(og_k_" << hs << "_01, grid, block, 0, s, A);\n"
+        << "    else hipLaunchKernelGGL(og_k_" << hs << "_11, grid, block, 0, s, A);\n}\n"
+        << "static const OgKernelRegistrar og_reg_" << hs << "(0x" << hs << "ull, \"" << g.name << "\", &og_launch_"
+        << hs << ");\n#endif\n";
+    out.source = src.str();
+    return cgp;
+}
+
+} // namespace ogc

@@ -1,0 +1,118 @@
+// og_graph.h -- host-side graph description, lowering and HIP code generation.
+//
+// This is the MI355X engine's counterpart of the reference's compile-time
+// layer (oscen-macros `graph!` -> oscen-graph-compiler: parse -> IR -> passes
+// -> codegen).  The reference decides the schedule when rustc expands the
+// macro; here the same decisions are taken when a graph description is
+// flattened on the host:
+//   * Kahn topological order over non-feedback edges   (ir/lower.rs:1015-1085)
+//   * dead-node removal by reverse BFS from the outputs (ir/passes/dead_nodes.rs:11-62)
+//   * >= 2 stream sources into one input = sum in edge order
+//                                                       (codegen/emit_node.rs:35-111,153-174)
+//   * compound sources (`a.x * b.y -> dst`) evaluated as f32 expressions
+//                                                       (codegen/emit_node.rs:241-286)
+//   * event inputs dispatched to the node handlers on their exact frame
+//                                                       (codegen/mod.rs:755-873)
+// and the result is one fused voice kernel (HIP source) whose per-voice state
+// is laid out as [word][voice] planes.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace ogc {
+
+enum class Kind { Value = 0, Event = 1, Stream = 2 };
+
+// How fast a value changes, which decides where it is computed.
+enum class Rate {
+    Const = 0,   // literal
+    UBlock = 1,  // voice-uniform, constant over the block (plain broadcast value input)
+    UFrame = 2,  // voice-uniform, per-frame (ramped broadcast value input)
+    VBlock = 3,  // per-voice, changes only through set-value events
+    Vary = 4,    // per-voice per-sample
+};
+
+struct UEnv { // host-side evaluation environment for block-uniform expressions
+    float sample_rate;
+    const float* input_values; // by graph-input index (ramped inputs: `.current`)
+};
+using HostFn = std::function<float(const UEnv&)>;
+
+struct GInput {
+    std::string name;
+    Kind kind = Kind::Value;
+    float def = 0.0f;
+    uint32_t ramp_frames = 0; // [ramp: N] (value inputs only)
+    bool per_voice = false;   // value input fed per voice (MidiVoiceHandler.frequency)
+};
+struct GOutput {
+    std::string name;
+    Kind kind = Kind::Stream;
+};
+struct GNode {
+    std::string name;
+    std::string type; // "AdsrEnvelope::new", "PolyBlepOscillator::saw", ...
+    std::vector<float> args;
+    uint32_t rate_factor = 1; // `* N`
+};
+struct GEdge {
+    std::string src; // endpoint or compound expression: "env.output", "a.x * b.y", "gate"
+    std::string dst; // "node.port" or graph output name
+    std::string policy; // "", "sinc", "sinc_iir", "linear", "latch"
+};
+
+struct GraphDesc {
+    std::string name;
+    std::vector<GInput> inputs;
+    std::vector<GOutput> outputs;
+    std::vector<GNode> nodes;
+    std::vector<GEdge> edges;
+};
+
+// ---- compiled form ---------------------------------------------------------
+struct InputInfo {
+    GInput decl;
+    int slot = -1;       // broadcast value inputs: block-uniform slot with the current value
+    int ramp_row = -1;   // ramped inputs: row in the per-frame ramp table
+    int state_word = -1; // per-voice value inputs: state plane
+    int event_index = -1;
+};
+struct StateWord {
+    std::string name;
+    bool is_float = true;
+    std::function<uint32_t(const UEnv&)> init; // initial bits
+};
+struct UniformProg {
+    int dst;
+    std::function<uint32_t(const UEnv&)> fn;
+};
+struct CompiledGraph {
+    std::string name;
+    std::string source; // complete HIP translation unit for this graph
+    uint64_t hash = 0;  // FNV-1a of the kernel body: AOT registry / JIT cache key
+    std::vector<InputInfo> inputs;
+    std::vector<StateWord> state;
+    std::vector<UniformProg> uprogs;
+    int n_slots = 0;
+    int n_ramps = 0;
+    int n_event_inputs = 0;
+    uint32_t channels = 1;
+    uint32_t latency_samples = 0;
+    std::vector<std::string> node_order; // topological order actually emitted (introspection/tests)
+    int find_input(const std::string& n) const;
+};
+
+// Throws std::runtime_error with a diagnostic on malformed/unsupported graphs.
+std::unique_ptr<CompiledGraph> compile(const GraphDesc& g);
+
+uint64_t fnv1a(const std::string& s);
+
+// Built-in graph descriptions (builder form of the reference graphs in scope).
+GraphDesc builtin_graph(const std::string& name);
+std::vector<std::string> builtin_graph_names();
+
+} // namespace ogc

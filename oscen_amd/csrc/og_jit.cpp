@@ -1,0 +1,112 @@
+// og_jit.cpp -- see og_jit.h
+#include "og_jit.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string csrc_dir()
+{
+    Dl_info info;
+    if (dladdr((void*)&csrc_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/csrc";
+    }
+    return "csrc";
+}
+
+std::string slurp(const std::string& path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("oscen jit: cannot read " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+std::vector<char> compile_to_code(const ogc::CompiledGraph& cg, const char* arch)
+{
+    const std::string dir = csrc_dir();
+    const char* names[3] = {"og_kernel_rt.hip.h", "og_nodes.hip.h", "og_math.h"};
+    std::string bodies[3];
+    const char* srcs[3];
+    for (int i = 0; i < 3; ++i) {
+        bodies[i] = slurp(dir + "/" + names[i]);
+        srcs[i] = bodies[i].c_str();
+    }
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, cg.source.c_str(), (cg.name + ".hip").c_str(), 3, srcs, names) != HIPRTC_SUCCESS)
+        throw std::runtime_error("oscen jit: hiprtcCreateProgram failed");
+    std::string archopt = std::string("--offload-arch=") + arch;
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-DOG_JIT=1"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        throw std::runtime_error("oscen jit: compile failed for graph '" + cg.name + "':\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    std::vector<char> code(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return code;
+}
+
+struct JitImpl : OgJitKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[4] = {};
+    ~JitImpl() override
+    {
+        if (mod) hipModuleUnload(mod);
+    }
+    void launch(const OgBlockArgs& args, bool ramps, bool taps, hipStream_t stream) override
+    {
+        OgBlockArgs a = args;
+        size_t sz = sizeof a;
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        const unsigned grid = (a.n_voices + OG_WAVE - 1) / OG_WAVE;
+        hipError_t e = hipModuleLaunchKernel(fn[(ramps ? 1 : 0) + (taps ? 2 : 0)], grid, 1, 1, OG_WAVE, 1, 1, 0, stream,
+                                             nullptr, cfg);
+        if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));
+    }
+};
+
+} // namespace
+
+size_t og_jit_compile_only(const ogc::CompiledGraph& cg, const char* arch) { return compile_to_code(cg, arch).size(); }
+
+std::unique_ptr<OgJitKernel> og_jit_compile(const ogc::CompiledGraph& cg)
+{
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        throw std::runtime_error("oscen jit: no device");
+    std::string arch = prop.gcnArchName;
+    size_t colon = arch.find(':');
+    if (colon != std::string::npos) arch = arch.substr(0, colon);
+    std::vector<char> code = compile_to_code(cg, arch.c_str());
+    std::unique_ptr<JitImpl> k(new JitImpl);
+    if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess) throw std::runtime_error("oscen jit: hipModuleLoadData failed");
+    char hs[32];
+    snprintf(hs, sizeof hs, "%016llx", (unsigned long long)cg.hash);
+    const char* var[4] = {"00", "10", "01", "11"};
+    for (int i = 0; i < 4; ++i) {
+        std::string name = std::string("og_k_") + hs + "_" + var[i];
+        if (hipModuleGetFunction(&k->fn[i], k->mod, name.c_str()) != hipSuccess)
+            throw std::runtime_error("oscen jit: kernel " + name + " not found in module");
+    }
+    return k;
+}

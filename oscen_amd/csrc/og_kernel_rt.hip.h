@@ -1,0 +1,165 @@
+// og_kernel_rt.hip.h -- hand-written device runtime shared by every generated
+// voice kernel: the block-argument ABI between the host engine and a kernel,
+// SoA state access, per-voice event cursors, and the mix-bus reduction.
+//
+// Execution model (gfx950): one workgroup = one wave64, one lane = one voice.
+// A launch covers ceil(n_voices/64) workgroups (1024 for 65 536 voices, i.e.
+// one wave per SIMD on 256 CUs; 4 per SIMD at 262 144).  Per-voice state is
+// loaded once from the [word][voice] planes (coalesced: lane i reads word w at
+// address w*n_voices + v, 256 B per wave-instruction), lives in VGPRs for the
+// whole block of <= 512 frames, and is stored once.
+//
+// Mix bus (reference: `voices.audio_out -> audio_out` = sequential f32 sum in
+// voice order, oscen-graph-compiler/src/codegen/emit_node.rs:463-466): each
+// frame every lane drops its sample into an LDS tile [16 frames][64+1 lanes];
+// every 16 frames the wave transposes: lane (q*16+j) adds voices q*16..q*16+15
+// of frame j in voice order, two cross-lane adds combine the quarters, and 16
+// lanes append the wave's partial for those frames.  One partial row per
+// workgroup goes to HBM; og_bus_reduce sums the rows in workgroup order.  No
+// atomics: the result is deterministic and differs from the reference's left
+// fold only by this fixed re-association.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OG_WAVE 64
+#define OG_MAX_BLOCK 512
+#define OG_MAX_SLOTS 160
+#define OG_BUS_CHUNK 16
+#define OG_NO_EVENT 0xFFFFFFFFu
+#define OG_EV_SETVALUE 0x80000000u
+
+struct OgEvent {
+    uint64_t frame;  // absolute frame since og_init
+    uint32_t target; // event-input index, or OG_EV_SETVALUE | per-voice value index
+    float value;     // scalar payload (gate velocity) or the new value
+};
+
+struct OgBlockArgs {
+    uint32_t n_voices;
+    uint32_t frames;
+    uint64_t frame0;
+    uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
+    const OgEvent* events;     // sorted by (voice, frame, push order)
+    const uint32_t* ev_end;    // [n_voices] one past the voice's last event
+    uint32_t* ev_cursor;       // [n_voices] next unconsumed event
+    float* partials;           // [n_workgroups][frames]
+    const float* ramp_table;   // [n_ramps][frames] per-frame values of ramped inputs
+    float* taps;               // [n_taps][frames] per-voice output taps (or null)
+    const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
+    uint32_t slots[OG_MAX_SLOTS]; // block-uniform values (f32 or u32 bits)
+};
+
+namespace og {
+
+__device__ __forceinline__ float slot_f(const OgBlockArgs& a, int i) { return __uint_as_float(a.slots[i]); }
+__device__ __forceinline__ uint32_t slot_u(const OgBlockArgs& a, int i) { return a.slots[i]; }
+// a slot pinned to an SGPR value (opaque to the optimizer, see og_nodes.hip.h)
+__device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)a.slots[i]);
+}
+
+struct VoiceCtx {
+    uint32_t v;     // voice index
+    bool valid;     // v < n_voices
+    uint32_t lane;
+    // events
+    uint32_t ev_cur, ev_cur0, ev_end;
+    uint32_t next_ev; // frame offset inside this block of the next event, or OG_NO_EVENT
+    // taps
+    int32_t tap;
+};
+
+__device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t idx)
+{
+    const uint64_t fr = a.events[idx].frame;
+    const uint64_t rel = (fr > a.frame0) ? (fr - a.frame0) : 0ull; // late events fire on frame 0
+    return (rel < (uint64_t)a.frames) ? (uint32_t)rel : OG_NO_EVENT;
+}
+
+template <bool TAPS>
+__device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
+{
+    c.lane = threadIdx.x;
+    c.v = blockIdx.x * OG_WAVE + threadIdx.x;
+    c.valid = c.v < a.n_voices;
+    c.ev_cur = c.ev_end = 0;
+    c.next_ev = OG_NO_EVENT;
+    c.tap = -1;
+    if (c.valid) {
+        c.ev_cur = a.ev_cursor[c.v];
+        c.ev_end = a.ev_end[c.v];
+        if (c.ev_cur < c.ev_end) c.next_ev = ev_rel_frame(a, c.ev_cur);
+        if (TAPS) c.tap = a.tap_slot[c.v];
+    }
+    c.ev_cur0 = c.ev_cur;
+}
+
+__device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
+{
+    if (c.valid && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
+}
+
+// pop the current event and arm the next one
+__device__ __forceinline__ void ev_advance(const OgBlockArgs& a, VoiceCtx& c)
+{
+    c.ev_cur += 1;
+    c.next_ev = (c.ev_cur < c.ev_end) ? ev_rel_frame(a, c.ev_cur) : OG_NO_EVENT;
+}
+
+__device__ __forceinline__ float ld_f(const OgBlockArgs& a, const VoiceCtx& c, int w)
+{
+    return __uint_as_float(a.state[(size_t)w * a.n_voices + c.v]);
+}
+__device__ __forceinline__ uint32_t ld_u(const OgBlockArgs& a, const VoiceCtx& c, int w)
+{
+    return a.state[(size_t)w * a.n_voices + c.v];
+}
+__device__ __forceinline__ void st_f(const OgBlockArgs& a, const VoiceCtx& c, int w, float x)
+{
+    a.state[(size_t)w * a.n_voices + c.v] = __float_as_uint(x);
+}
+__device__ __forceinline__ void st_u(const OgBlockArgs& a, const VoiceCtx& c, int w, uint32_t x)
+{
+    a.state[(size_t)w * a.n_voices + c.v] = x;
+}
+
+// ---- mix bus ---------------------------------------------------------------
+struct BusLds {
+    float tile[OG_BUS_CHUNK][OG_WAVE + 1]; // +1 pad: conflict-free transposed read
+    float part[OG_MAX_BLOCK];              // this wave's partial sum per frame
+};
+
+template <bool TAPS>
+__device__ __forceinline__ void bus_push(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, float out)
+{
+    const float y = c.valid ? out : 0.0f;
+    lds.tile[f % OG_BUS_CHUNK][c.lane] = y;
+    if (TAPS) {
+        if (c.tap >= 0) a.taps[(size_t)c.tap * a.frames + f] = y;
+    }
+    if ((f % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || f + 1 == a.frames) {
+        __syncthreads(); // one-wave workgroup: orders the LDS writes before the transposed reads
+        const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
+        const uint32_t q = c.lane / OG_BUS_CHUNK;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.tile[j][q * (OG_WAVE / 4) + i];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const uint32_t base = f - (f % OG_BUS_CHUNK);
+        if (c.lane < OG_BUS_CHUNK && base + j < a.frames) lds.part[base + j] = s;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void bus_flush(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds)
+{
+    __syncthreads();
+    for (uint32_t f = c.lane; f < a.frames; f += OG_WAVE)
+        a.partials[(size_t)blockIdx.x * a.frames + f] = lds.part[f];
+}
+
+} // namespace og
+

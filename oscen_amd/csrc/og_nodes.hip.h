@@ -1,0 +1,353 @@
+// og_nodes.hip.h -- hand-written gfx950 device bodies of the Oscen DSP nodes.
+//
+// One lane = one voice.  Every function works on scalar references so that a
+// generated voice kernel keeps all per-voice state in VGPRs across the block.
+// Arithmetic follows the reference's f32 operation order (the translation
+// unit is compiled with -ffp-contract=off; the only fused ops are the explicit
+// fmaf() inside og_math.h).  Parameter-derived coefficients that depend only
+// on block-uniform values (ADSR step counts / one-pole coefficients, filter
+// limits) are computed once per block by the host library and arrive as
+// kernel-argument constants; what remains here is the per-sample, per-voice
+// recurrence.  Each function cites the reference lines it implements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "og_kernel_rt.hip.h"
+#include "og_math.h"
+
+namespace og {
+
+#define OG_DEV __device__ __forceinline__
+
+constexpr float F32_EPSILON = 1.1920929e-7f;
+constexpr float F32_TAU = 6.28318548202514648f;
+
+// Rust f32::clamp (NaN passes through): used where the reference clamps.
+OG_DEV float clampf(float x, float lo, float hi)
+{
+    x = (x < lo) ? lo : x;
+    x = (x > hi) ? hi : x;
+    return x;
+}
+OG_DEV float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
+
+// ---------------------------------------------------------------------------
+// AdsrEnvelope  oscen-lib/src/envelope/adsr.rs
+// ---------------------------------------------------------------------------
+enum : uint32_t { ST_IDLE = 0, ST_ATTACK = 1, ST_DECAY = 2, ST_SUSTAIN = 3, ST_RELEASE = 4 };
+
+// Block-uniform, host-derived (adsr.rs:84-90, 117-134), eight consecutive
+// uniform slots per envelope: stage lengths in samples, one-pole coefficients
+// 1 - exp(-4.6051702/n), sustain clamped to [0,1], and the two
+// "time <= MIN_TIME_SECONDS" flags (adsr.rs:259, 265).  Only d_n/a_c/d_c are
+// needed every sample; the rest is read from the kernel arguments where it is
+// used (block start, gate events) so it does not pin SGPRs across the loop.
+enum : int { ADSR_A_N = 0, ADSR_D_N, ADSR_R_N, ADSR_A_C, ADSR_D_C, ADSR_SUSTAIN, ADSR_A_INST, ADSR_R_INST };
+
+// Once per block (and nowhere else is it observable): the part of
+// apply_parameters()/update_sustain_level() that only changes when a parameter
+// or the velocity changed -- sustain_level (adsr.rs:93) and the
+// samples_remaining clamp against the re-derived stage length (adsr.rs:95-106).
+OG_DEV void adsr_block_begin(uint32_t stage, uint32_t& rem, float vel, float& sus_lvl, const OgBlockArgs& A, int k)
+{
+    sus_lvl = clamp01(slot_f(A, k + ADSR_SUSTAIN) * vel);
+    // scalar_u(): keep the three kernel-argument reads scalar; a lane-varying
+    // select between them must select values, not addresses
+    const uint32_t a_n = scalar_u(A, k + ADSR_A_N), d_n = scalar_u(A, k + ADSR_D_N), r_n = scalar_u(A, k + ADSR_R_N);
+    uint32_t lim = (stage == ST_ATTACK) ? a_n : (stage == ST_DECAY) ? d_n : r_n;
+    bool moving = (stage == ST_ATTACK) | (stage == ST_DECAY) | (stage == ST_RELEASE);
+    if (moving && rem > 0) rem = max(min(rem, lim), 1u);
+}
+
+// handle_gate_event  adsr.rs:250-273 (scalar payload)
+OG_DEV void adsr_gate(uint32_t& stage, uint32_t& rem, float& level, float& vel, float& sus_lvl, float v,
+                      const OgBlockArgs& A, int k)
+{
+    const uint32_t a_n = scalar_u(A, k + ADSR_A_N), d_n = scalar_u(A, k + ADSR_D_N), r_n = scalar_u(A, k + ADSR_R_N);
+    const uint32_t a_inst = scalar_u(A, k + ADSR_A_INST), r_inst = scalar_u(A, k + ADSR_R_INST);
+    const float sustain = __uint_as_float(scalar_u(A, k + ADSR_SUSTAIN));
+    if (v > 0.0f) {
+        vel = clamp01(v);
+        sus_lvl = clamp01(sustain * vel); // update_sustain_level :93
+        if (a_inst) {                     // attack <= MIN_TIME_SECONDS
+            level = 1.0f;
+            stage = ST_DECAY; // set_stage(Decay, sustain_level): d_n >= 1
+            rem = d_n;
+        } else {
+            stage = ST_ATTACK; // set_stage(Attack, 1.0): a_n >= 1
+            rem = a_n;
+        }
+    } else if (r_inst) {
+        stage = ST_IDLE;
+        level = 0.0f;
+        rem = 0;
+    } else {
+        stage = ST_RELEASE; // release_increment is re-derived every sample (adsr.rs:112-114)
+        rem = r_n;
+    }
+}
+
+// process_stage  adsr.rs:206-248 with complete_stage :175-204 folded in.
+// Written as selects: the lanes of a wave sit in different stages.
+OG_DEV float adsr_tick(uint32_t& stage, uint32_t& rem, float& level, float sus_lvl, float a_c, float d_c,
+                       uint32_t d_n)
+{
+    const uint32_t st = stage;
+    const bool att = st == ST_ATTACK, dec = st == ST_DECAY, rel = st == ST_RELEASE;
+    const bool moving = att | dec | rel;
+    float lv = level;
+    uint32_t r = rem;
+    // one-pole approach (attack toward 1, decay toward sustain_level)
+    const float tgt = att ? 1.0f : sus_lvl;
+    const float cf = att ? a_c : d_c;
+    const float lv_ad = lv + (tgt - lv) * cf;
+    // linear release: update_release_increment adsr.rs:162-173, every sample
+    const float cur = clamp01(lv);
+    const float inc = (cur <= 0.0f) ? 0.0f : (-cur / (float)r);
+    const float lv_r = lv + inc;
+    const bool step = moving & (r > 0u);
+    float nl = rel ? lv_r : lv_ad;
+    nl = clamp01(nl);
+    lv = step ? nl : lv;
+    r = step ? r - 1u : r;
+    const bool done = moving & (r == 0u);
+    // stage end: Attack -> (level 1) Decay; Decay -> Sustain; Release -> Idle
+    const float end_lv = att ? 1.0f : (dec ? sus_lvl : 0.0f);
+    lv = done ? end_lv : lv;
+    const uint32_t end_st = att ? (uint32_t)ST_DECAY : (dec ? (uint32_t)ST_SUSTAIN : (uint32_t)ST_IDLE);
+    const uint32_t end_r = att ? d_n : 0u;
+    stage = done ? end_st : st;
+    r = done ? end_r : r;
+    // holding stages
+    lv = (st == ST_SUSTAIN) ? sus_lvl : lv;
+    lv = (st == ST_IDLE) ? 0.0f : lv;
+    level = lv;
+    rem = r;
+    return lv;
+}
+
+// ---------------------------------------------------------------------------
+// FmOperator  examples/fm-synth/src/nodes/fm_operator.rs:58-76
+// `inc` = (base_freq * ratio) / sample_rate, hoisted by the caller when both
+// factors are constant over the block (bit-identical: same IEEE ops).
+// ---------------------------------------------------------------------------
+OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float phase_mod, float feedback,
+                              float envelope, float level)
+{
+    const float feedback_mod = prev_output * feedback;
+    const float total_phase_mod = phase_mod + feedback_mod;
+    const float phase_rad = (phase + total_phase_mod) * F32_TAU;
+    const float output = og_sinf(phase_rad) * envelope * level;
+    prev_output = output;
+    const float p = phase + inc;
+    phase = p - truncf(p); // f32::fract
+    return output;
+}
+
+// ---------------------------------------------------------------------------
+// TptFilter<f32>  oscen-lib/src/filters/tpt/mod.rs
+// ---------------------------------------------------------------------------
+// update_coefficients :69-82.  two_sr = 2*sr, period = 0.5/sr, nyquist =
+// sr*0.5 - EPSILON are block-uniform host slots.
+OG_DEV void tpt_update_coefficients(float cutoff, float q, float two_sr, float period, float nyquist, float& cur_c,
+                                    float& cur_q, float& h, float& g, float& k)
+{
+    const float freq = clampf(cutoff, 20.0f, nyquist);
+    const float f = two_sr * og_tanf_q1(F32_TAU * freq * period) * period;
+    const float inv_q = 1.0f / q;
+    h = 1.0f / (1.0f + inv_q * f + f * f);
+    g = f;
+    k = f + inv_q;
+    cur_c = cutoff;
+    cur_q = q;
+}
+
+// apply_parameter_updates :85-102, general form (f_mod connected)
+OG_DEV void tpt_params_mod(float cutoff_in, float q_in, float f_mod, float max_cutoff, float two_sr, float period,
+                           float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
+{
+    const float cutoff_base = clampf(cutoff_in, 20.0f, max_cutoff);
+    const float q = clampf(q_in, 0.1f, 10.0f);
+    const float modulation = clampf(f_mod, -1.0f, 1.0f);
+    const float min_factor = 20.0f / cutoff_base;
+    const float max_factor = max_cutoff / cutoff_base;
+    const float factor = clampf(1.0f + modulation, min_factor, max_factor);
+    const float cutoff = clampf(cutoff_base * factor, 20.0f, max_cutoff);
+    if (fabsf(cutoff - cur_c) > F32_EPSILON || fabsf(q - cur_q) > F32_EPSILON)
+        tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+}
+
+// Same with f_mod structurally 0.0 (input left unconnected, e.g. FMVoice):
+// factor = clamp(1.0, 20/cb, max/cb) == 1.0 exactly because correctly rounded
+// 20/cb <= 1 <= max/cb for cb in [20, max]; cb*1.0 == cb; the outer clamp is
+// then the identity.  Result-identical, two divides cheaper.
+OG_DEV void tpt_params_nomod(float cutoff_in, float q_in, float max_cutoff, float two_sr, float period,
+                             float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
+{
+    const float cutoff = clampf(cutoff_in, 20.0f, max_cutoff);
+    const float q = clampf(q_in, 0.1f, 10.0f);
+    if (fabsf(cutoff - cur_c) > F32_EPSILON || fabsf(q - cur_q) > F32_EPSILON)
+        tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+}
+
+// state-variable core :114-122
+OG_DEV float tpt_tick(float in, float& z0, float& z1, float h, float g, float k)
+{
+    const float high = (in - z0 * k - z1) * h;
+    const float hg = high * g;
+    const float band = hg + z0;
+    const float bg = band * g;
+    const float low = bg + z1;
+    z0 = hg + band;
+    z1 = bg + low;
+    return low;
+}
+
+// ---------------------------------------------------------------------------
+// PolyBlepOscillator  oscen-lib/src/oscillators/mod.rs:88-233
+// ---------------------------------------------------------------------------
+enum : uint32_t { PB_SINE = 0, PB_SAW = 1, PB_SQUARE = 2, PB_TRIANGLE = 3 };
+
+OG_DEV float wrap_phase(float p) // rem_euclid(1.0) :171-173
+{
+    float r = fmodf(p, 1.0f);
+    return (r < 0.0f) ? r + 1.0f : r;
+}
+
+OG_DEV float poly_blep(float t, float dt) // :139-153
+{
+    float res = 0.0f;
+    if (dt > F32_EPSILON) {
+        if (t < dt) {
+            const float x = t / dt;
+            res = x + x - x * x - 1.0f;
+        } else if (t > 1.0f - dt) {
+            const float x = (t - 1.0f) / dt;
+            res = x * x + x + x + 1.0f;
+        }
+    }
+    return res;
+}
+
+OG_DEV float poly_blamp(float t, float dt) // :155-169
+{
+    float res = 0.0f;
+    if (dt > F32_EPSILON) {
+        if (t < dt) {
+            const float x = t / dt - 1.0f;
+            res = -(x * x * x) / 3.0f;
+        } else if (t > 1.0f - dt) {
+            const float x = (t - 1.0f) / dt + 1.0f;
+            res = (x * x * x) / 3.0f;
+        }
+    }
+    return res;
+}
+
+template <uint32_t WAVE>
+OG_DEV float polyblep_tick(float& phase_state, float frequency_in, float frequency_mod, float phase_mod,
+                           float amplitude, float pulse_width_in, float sr)
+{
+    const float frequency = fmaxf(frequency_in * (1.0f + frequency_mod), 0.0f);
+    float pulse_width = clampf(pulse_width_in, 0.0001f, 0.9999f);
+    float phase = wrap_phase(phase_state + phase_mod);
+    const float freq_per_sample = frequency / fmaxf(sr, F32_EPSILON);
+    const float dt = fminf(freq_per_sample, 1.0f);
+    if (pulse_width <= 0.0f) pulse_width = 0.0001f;
+    float value;
+    if (frequency >= sr * 0.25f || WAVE == PB_SINE) {
+        value = og_sinf(phase * F32_TAU);
+    } else if (WAVE == PB_SAW) {
+        float y = 2.0f * phase - 1.0f;
+        y -= poly_blep(phase, dt);
+        value = y;
+    } else if (WAVE == PB_SQUARE) {
+        float y = (phase < pulse_width) ? 1.0f : -1.0f;
+        y += poly_blep(phase, dt);
+        const float t = wrap_phase(phase + 1.0f - pulse_width);
+        y -= poly_blep(t, dt);
+        value = y;
+    } else {
+        float y = 4.0f * phase;
+        if (y >= 3.0f) {
+            y -= 4.0f;
+        } else if (y > 1.0f) {
+            y = 2.0f - y;
+        }
+        const float t1 = wrap_phase(phase + 0.25f);
+        const float t2 = wrap_phase(phase + 0.75f);
+        value = y + 4.0f * dt * (poly_blamp(t1, dt) - poly_blamp(t2, dt));
+    }
+    value = value * amplitude;
+    phase_state = wrap_phase(phase_state + freq_per_sample);
+    return value;
+}
+
+// ---------------------------------------------------------------------------
+// Oscillator  oscen-lib/src/oscillators/mod.rs:7-76
+// ---------------------------------------------------------------------------
+enum : uint32_t { OSC_SINE = 0, OSC_SQUARE = 1, OSC_SAW = 2 };
+
+template <uint32_t WAVE>
+OG_DEV float oscillator_tick(float& phase, float frequency_in, float frequency_mod, float amplitude, float sr)
+{
+    const float frequency = frequency_in * (1.0f + frequency_mod);
+    const float p = fmodf(phase, 1.0f);
+    float w;
+    if (WAVE == OSC_SINE) {
+        w = og_sinf(p * 2.0f * 3.14159274101257324f); // (p * 2.0 * PI).sin()
+    } else if (WAVE == OSC_SQUARE) {
+        w = (p < 0.5f) ? 1.0f : -1.0f;
+    } else {
+        const float transition_width = 0.1f;
+        const float raw_saw = 2.0f * p - 1.0f;
+        if (p > (1.0f - transition_width / 2.0f)) {
+            const float t = (p - (1.0f - transition_width / 2.0f)) / (transition_width / 2.0f);
+            w = -1.0f + (1.0f - t * t) * (raw_saw + 1.0f);
+        } else {
+            w = raw_saw;
+        }
+    }
+    const float out = w * amplitude;
+    phase += frequency / sr;
+    phase = fmodf(phase, 1.0f);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Small nodes: gain/mod.rs:30-34, fm-synth nodes/{add_value,crossfade,mixer}.rs,
+// pivot vca.rs:31-35, oversampled-saturator main.rs:54-61
+// ---------------------------------------------------------------------------
+OG_DEV float hardclip(float in) { return clampf(in * 1.5f, -0.7f, 0.7f); }
+
+// ---------------------------------------------------------------------------
+// SincDownFir / Halfband2xDownStage  oscen-lib/src/resample/sinc_fir.rs:96-144
+// The 24-slot ring is kept unrotated in registers: `h[0]` is always the
+// newest sample (x[2m+1]); a push shifts by two.  `at(d)` of the reference
+// (x[2m-d]) is h[d+1].  Same taps, same summation order.
+// ---------------------------------------------------------------------------
+struct HbDown {
+    float h[24];
+};
+
+OG_DEV float hb_down_step(HbDown& s, float x0, float x1)
+{
+    const float HALF[6] = {-3.8558514e-5f, 1.2218465e-3f, -7.2854808e-3f,
+                           2.6409210e-2f,  -7.8128843e-2f, 3.0782697e-1f};
+    const float CENTER = 0.4999897f;
+#pragma unroll
+    for (int i = 23; i >= 2; --i) s.h[i] = s.h[i - 2];
+    s.h[1] = x0;
+    s.h[0] = x1;
+    float acc = s.h[11 + 1] * CENTER;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+        const float left = s.h[2 * kk + 1];
+        const float right = s.h[22 - 2 * kk + 1];
+        acc = acc + (left + right) * HALF[kk];
+    }
+    return acc;
+}
+
+} // namespace og

@@ -1,0 +1,127 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and
+exports every symbol include/oscen_gpu.h declares, the graph compiler lowers
+descriptions the way the reference's graph! macro does, and the synthetic input
+generator agrees with the oracle's.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from oscen_amd import build
+
+    build.build()
+    return oscen_amd.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "oscen_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(og_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 40
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export " + n
+    assert b"gfx950" in lib.og_version()
+
+
+def test_generated_sources_are_committed_and_current(lib):
+    # csrc/gen/*.hip must be exactly what the graph compiler emits today
+    for name in ("fm_voice", "sub_voice"):
+        src = oscen_amd.Graph(builtin=name).kernel_source()
+        path = os.path.join(ROOT, "oscen_amd", "csrc", "gen", name + ".hip")
+        assert open(path).read() == src
+
+
+def test_fm_voice_lowering(lib):
+    src = oscen_amd.Graph(builtin="fm_voice").kernel_source()
+    order = re.search(r"// Node order: (.*)", src).group(1).split()
+    assert len(order) == 13
+    pos = {n: i for i, n in enumerate(order)}
+    # topological constraints of fm_voice.rs:81-155
+    for a, b in [("env3", "op3_osc"), ("op3_osc", "op3_route"), ("op3_route", "op2_osc"),
+                 ("op2_osc", "op1_mod_mixer"), ("op1_mod_mixer", "op1_osc"), ("op1_osc", "filter"),
+                 ("env_filter", "filter_env_gain"), ("filter_env_gain", "cutoff_mod"), ("cutoff_mod", "filter"),
+                 ("filter", "output_gain")]:
+        assert pos[a] < pos[b]
+    assert "30 state words/voice" in src and "8 ramped inputs" in src
+
+
+def _simple(extra=None):
+    g = oscen_amd.Graph("t")
+    g.input_value("frequency", 440.0, per_voice=True)
+    g.input_value("cutoff", 1200.0)
+    g.output_stream("out")
+    g.node("osc", "PolyBlepOscillator::saw", 440.0, 0.5)
+    g.node("filter", "TptFilter::new", 1200.0, 0.707)
+    g.connect("frequency", "osc.frequency").connect("cutoff", "filter.cutoff")
+    g.connect("osc.output", "filter.input")
+    if extra:
+        extra(g)
+    return g
+
+
+def test_dead_node_removal_and_fanin_sum(lib):
+    def extra(g):
+        g.node("unused", "PolyBlepOscillator::sine", 5.0, 0.2)   # reaches no output -> pruned
+        g.node("osc2", "PolyBlepOscillator::square", 220.0, 0.25)
+        g.connect("osc2.output", "filter.input")                 # second source into one input = sum
+        g.connect("filter.output * 0.5 + osc2.output", "out")    # compound source
+    src = _simple(extra).kernel_source()
+    assert "unused" not in re.search(r"// Node order: (.*)", src).group(1)
+    assert re.search(r"tpt_tick\(\(n\d+_output \+ n\d+_output\)", src)
+    assert re.search(r"g_out = \(\(n\d+_output \* 0x1p-1f\) \+ n\d+_output\)", src)
+
+
+def test_compile_errors_are_reported(lib):
+    g = _simple()
+    g.connect("nosuch.output", "out")
+    with pytest.raises(oscen_amd.OscenError) as e:
+        g.kernel_source()
+    assert "unknown node" in str(e.value)
+    g = oscen_amd.Graph("cyc")
+    g.output_stream("out")
+    g.node("a", "Gain::new", 1.0)
+    g.node("b", "Gain::new", 1.0)
+    g.connect("a.output", "b.input").connect("b.output", "a.input").connect("b.output", "out")
+    with pytest.raises(oscen_amd.OscenError) as e:
+        g.kernel_source()
+    assert "cycle" in str(e.value)
+    g = oscen_amd.Graph("bad")
+    g.node("x", "NoSuchNode::new")
+    with pytest.raises(oscen_amd.OscenError):
+        g.kernel_source()
+
+
+def test_engine_needs_a_gpu_no_cpu_fallback(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Engine("fm_voice", 64)
+    assert e.value.code == oscen_amd.OG_E_DEVICE
+
+
+def test_note_plans_match_oracle_generator():
+    n = 300
+    plans = oscen_amd.note_plans(n)
+    for v in list(range(40)) + [n - 1]:
+        p = ol.note_plan(oscen_amd.SYNTH_SEED, v)
+        assert (p.note, p.velocity, p.on_frame, p.off_frame, p.retrig_frame) == oscen_amd.note_plan(v)
+        assert plans["note"][v] == p.note and plans["velocity"][v] == p.velocity
+        assert plans["on_frame"][v] == p.on_frame and plans["off_frame"][v] == p.off_frame
+        assert plans["retrig_frame"][v] == p.retrig_frame
+        assert abs(plans["frequency"][v] - p.frequency) <= 2e-6 * p.frequency
+    # midi contract known answers (oscen-lib/src/midi.rs:237-250)
+    assert oscen_amd.midi_note_to_freq(69) == 440.0
+    assert abs(oscen_amd.midi_note_to_freq(60) - 261.626) < 0.01
+    assert abs(oscen_amd.midi_velocity_to_gate(100) - 100 / 127) < 1e-7

@@ -1,0 +1,300 @@
+"""GPU parity tests: the HIP voice kernels (through the C ABI) against the CPU
+oracle on identical note events.  Tolerance per BASELINE.json north_star:
+|a - b| <= 1e-5 * max(1, |ref|) on every per-voice sample; the mix bus is
+judged against the oracle's f64 sum of the per-voice outputs (the reference's
+sequential f32 fold and the GPU's fixed tree differ only by re-association).
+"""
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+SR = 48000.0
+
+
+def rel_err(got, ref):
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+
+
+class Pair:
+    """An engine and an oracle bank driven by the same calls."""
+
+    def __init__(self, graph, kind, n, params, sr=SR):
+        self.eng = oscen_amd.Engine(graph, n, sample_rate=sr)
+        self.bank = ol.Bank(kind, n, sr)
+        self.params = params
+        self.n = n
+        self.taps = list(range(n))
+        self.eng.set_voice_taps(self.taps)
+
+    def set_value(self, name, v):
+        self.eng.set_value(name, v)
+        self.bank.set_value(self.params.index(name), v)
+
+    def set_value_with_ramp(self, name, v, frames):
+        self.eng.set_value_with_ramp(name, v, frames)
+        self.bank.set_value_with_ramp(self.params.index(name), v, frames)
+
+    def set_value_immediate(self, name, v):
+        self.eng.set_value_immediate(name, v)
+        self.bank.set_value_immediate(self.params.index(name), v)
+
+    def set_freqs(self, freqs):
+        self.eng.set_voice_values("frequency", np.asarray(freqs, dtype=np.float32))
+        for v, f in enumerate(freqs):
+            self.bank.set_voice_frequency(v, float(f))
+
+    def gate(self, voice, off, vel):
+        assert self.eng.push_voice_event("gate", voice, off, vel) == 0
+        self.bank.push_event(voice, off, ol.EV_GATE, vel)
+
+    def freq(self, voice, off, hz):
+        self.eng.push_voice_value("frequency", voice, off, hz)
+        self.bank.push_event(voice, off, ol.EV_FREQ, hz)
+
+    def block(self, frames):
+        bus = self.eng.process_block(frames)
+        taps = self.eng.read_voice_taps(frames)
+        ref_bus, ref_taps = self.bank.process_block(frames, taps=self.taps)
+        return bus, taps, ref_bus, ref_taps, self.bank.last_bus_f64(frames)
+
+
+def random_note_script(n, total, seed, span=(300, 1500)):
+    """per-voice (on, off, retrig) frames inside `total`, plus velocities"""
+    rng = np.random.default_rng(seed)
+    on = rng.integers(0, 256, n)
+    off = on + rng.integers(span[0], span[1], n)
+    re = off + rng.integers(100, 900, n)
+    vel = rng.integers(32, 128, n).astype(np.float32) / np.float32(127.0)
+    events = []
+    for v in range(n):
+        events += [(int(on[v]), v, float(vel[v])), (int(off[v]), v, 0.0)]
+        if re[v] < total:
+            events.append((int(re[v]), v, float(vel[v])))
+    return sorted(events)
+
+
+def run_script(pair, events, blocks, check_bus=True):
+    f0 = 0
+    worst = 0.0
+    all_taps, all_ref = [], []
+    for frames in blocks:
+        for fr, v, val in events:
+            if f0 <= fr < f0 + frames:
+                pair.gate(v, fr - f0, val)
+        bus, taps, ref_bus, ref_taps, ref64 = pair.block(frames)
+        worst = max(worst, rel_err(taps, ref_taps))
+        if check_bus:
+            # bus: f64 oracle sum, tolerance scaled by sum |x_i| (re-association error bound)
+            scale = max(1.0, float(np.max(np.sum(np.abs(ref_taps), axis=0))))
+            assert np.max(np.abs(bus[:, 0] - ref64)) <= TOL * scale
+        all_taps.append(taps)
+        all_ref.append(ref_taps)
+        f0 += frames
+    return worst, np.concatenate(all_taps, axis=1), np.concatenate(all_ref, axis=1)
+
+
+def midi_freqs(n, seed):
+    rng = np.random.default_rng(seed)
+    return oscen_amd.midi_note_to_freq(rng.integers(36, 97, n)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+def test_fm_voice_config1_one_voice_one_second():
+    # BASELINE.json configs[0]: 1 voice, 48 kHz, 1 s, note 69 on @0 vel 100/127, off @24000
+    p = Pair("fm_voice", ol.BANK_FM, 1, ol.FM_PARAMS)
+    p.set_freqs([oscen_amd.midi_note_to_freq(69)])
+    events = [(0, 0, float(oscen_amd.midi_velocity_to_gate(100))), (24000, 0, 0.0)]
+    worst, got, ref = run_script(p, events, [256] * 187 + [128])
+    assert got.shape == (1, 48000)
+    assert np.max(np.abs(ref)) > 0.05
+    assert worst <= TOL, worst
+
+
+def test_fm_bank_default_params_ragged_voice_count():
+    n = 150  # not a multiple of 64: exercises the masked tail wave
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    p.set_freqs(midi_freqs(n, 1))
+    events = random_note_script(n, 4096, 2)
+    worst, got, ref = run_script(p, events, [256] * 16)
+    assert np.max(np.abs(ref)) > 0.05
+    assert worst <= TOL, worst
+
+
+def test_fm_bank_fast_envelopes_all_stages():
+    # short A/D/R so attack, decay, sustain, release, idle and retrigger-from-release all occur
+    n = 128
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    for op in ("op3", "op2", "op1", "filter"):
+        p.set_value(op + "_attack", 0.002)
+        p.set_value(op + "_decay", 0.004)
+        p.set_value(op + "_release", 0.006)
+    p.set_freqs(midi_freqs(n, 3))
+    events = random_note_script(n, 3072, 4, span=(500, 1200))
+    worst, got, ref = run_script(p, events, [256] * 12)
+    assert worst <= TOL, worst
+
+
+def test_fm_bank_variant_feedback_route_envamount_and_ramps():
+    # SURVEY 8d config-2 variant: feedback, route, filter_env_amount (per-sample tan) and a cutoff ramp
+    n = 96
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    p.set_value_immediate("op3_feedback", 0.3)
+    p.set_value_immediate("op2_feedback", 0.2)
+    p.set_value_immediate("route", 0.5)
+    p.set_value_immediate("filter_env_amount", 2000.0)
+    p.set_freqs(midi_freqs(n, 5))
+    events = random_note_script(n, 4096, 6)
+    f0, worst = 0, 0.0
+    for b in range(16):
+        if b == 3:
+            p.set_value("filter_cutoff", 6000.0)          # default ramp 2205 frames
+            p.set_value_with_ramp("route", 0.1, 300)
+        if b == 9:
+            p.set_value_immediate("op3_level", 0.8)
+            p.set_value("filter_resonance", 2.5)
+        for fr, v, val in events:
+            if f0 <= fr < f0 + 256:
+                p.gate(v, fr - f0, val)
+        bus, taps, ref_bus, ref_taps, ref64 = p.block(256)
+        worst = max(worst, rel_err(taps, ref_taps))
+        f0 += 256
+    assert worst <= TOL, worst
+    assert abs(p.eng.get_value("filter_cutoff") - 6000.0) < 1e-3
+
+
+def test_block_size_does_not_change_results_bit_exact():
+    # block_processing_test.rs law on the GPU: 256 vs 512 vs ragged chunks, bit-exact
+    n = 70
+    outs = []
+    for blocks in ([256] * 8, [512] * 4, [100, 412, 1, 511, 256, 256, 512]):
+        eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+        eng.set_voice_values("frequency", midi_freqs(n, 7))
+        eng.set_voice_taps(list(range(n)))
+        eng.set_value_immediate("filter_env_amount", 1500.0)
+        events = random_note_script(n, 2048, 8, span=(200, 700))
+        f0, chunks, buses = 0, [], []
+        for frames in blocks:
+            for fr, v, val in events:
+                if f0 <= fr < f0 + frames:
+                    eng.push_voice_event("gate", v, fr - f0, val)
+            buses.append(eng.process_block(frames))
+            chunks.append(eng.read_voice_taps(frames))
+            f0 += frames
+        outs.append((np.concatenate(chunks, axis=1), np.concatenate(buses, axis=0)))
+    for taps, bus in outs[1:]:
+        assert np.array_equal(taps, outs[0][0])
+    assert np.any(outs[0][0] != 0.0)
+
+
+def test_event_edge_cases():
+    n = 64
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    p.set_freqs(midi_freqs(n, 9))
+    # same-frame off+on, event on the last frame, frequency change with the note-on
+    p.gate(0, 0, 1.0)
+    p.gate(1, 255, 0.7)
+    p.gate(2, 10, 0.9)
+    p.gate(2, 10, 0.0)
+    p.gate(2, 10, 0.5)
+    p.freq(3, 100, 523.25)
+    p.gate(3, 100, 0.8)
+    # an event beyond the block is dropped (codegen/mod.rs:782-871), in both implementations
+    p.eng.push_voice_event("gate", 4, 300, 1.0)
+    p.bank.push_event(4, 300, ol.EV_GATE, 1.0)
+    worst = 0.0
+    for _ in range(6):
+        bus, taps, ref_bus, ref_taps, _ = p.block(256)
+        worst = max(worst, rel_err(taps, ref_taps))
+        assert np.all(taps[4] == 0.0) and np.all(ref_taps[4] == 0.0)
+    assert worst <= TOL, worst
+    assert p.eng.events_dropped == 1
+    # 33rd event on one voice/input in one block overflows like ArrayVec<_, 32>
+    for i in range(32):
+        assert p.eng.push_voice_event("gate", 5, i, 0.5) == 0
+    assert p.eng.push_voice_event("gate", 5, 40, 0.5) == oscen_amd.OG_E_OVERFLOW
+    p.eng.process_block(64)
+
+
+def test_sub_voice_parity():
+    # "osc+env+TptFilter" voice (perf/profile_graph.rs:12-37): PolyBLEP saw, TPT, ADSR
+    n = 100
+    p = Pair("sub_voice", ol.BANK_SUB, n, ol.SUB_PARAMS)
+    p.set_freqs(midi_freqs(n, 11))
+    events = random_note_script(n, 4096, 12)
+    f0, worst = 0, 0.0
+    for b in range(16):
+        if b == 5:
+            p.set_value("cutoff", 900.0)
+            p.set_value("q", 3.0)
+        for fr, v, val in events:
+            if f0 <= fr < f0 + 256:
+                p.gate(v, fr - f0, val)
+        bus, taps, ref_bus, ref_taps, ref64 = p.block(256)
+        worst = max(worst, rel_err(taps, ref_taps))
+        f0 += 256
+    assert worst <= TOL, worst
+
+
+def test_state_snapshot_roundtrip():
+    n = 64
+    eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    eng.set_voice_values("frequency", midi_freqs(n, 13))
+    for v in range(n):
+        eng.push_voice_event("gate", v, v, 0.9)
+    eng.process_block(256)
+    blob = eng.save_state()
+    a = eng.process_block(256)
+    eng.load_state(blob)
+    b = eng.process_block(256)
+    assert np.array_equal(a, b)
+
+
+# --------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[1]: 65 536 voices, block 256)
+# --------------------------------------------------------------------------
+def test_full_size_properties():
+    n = 65536
+    total, block = 2048, 256
+    plans = oscen_amd.note_plans(n)
+    sample = np.unique(np.concatenate([np.arange(0, n, 997), [63, 64, n - 1]])).astype(np.uint32)
+
+    def run(blk):
+        eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+        eng.set_voice_values("frequency", plans["frequency"])
+        eng.set_voice_taps(sample)
+        for v in range(n):
+            eng.schedule_voice_event("gate", v, int(plans["on_frame"][v]), float(plans["gate"][v]))
+        silent = None
+        buses, taps = [], []
+        for f0 in range(0, total, blk):
+            buses.append(eng.process_block(blk))
+            taps.append(eng.read_voice_taps(blk))
+        return np.concatenate(buses, axis=0), np.concatenate(taps, axis=1)
+
+    bus_a, taps_a = run(block)
+    bus_b, taps_b = run(512)
+    # determinism + block-size independence at full size, bit-exact
+    assert np.array_equal(taps_a, taps_b)
+    assert np.array_equal(bus_a, bus_b)
+    # voices are independent: a sampled voice of the big bank == the same voice in the oracle
+    bank = ol.Bank(ol.BANK_FM, len(sample), SR)
+    for i, v in enumerate(sample):
+        bank.set_voice_frequency(i, float(plans["frequency"][v]))
+    worst = 0.0
+    for b, f0 in enumerate(range(0, total, block)):
+        for i, v in enumerate(sample):
+            on = int(plans["on_frame"][v])
+            if f0 <= on < f0 + block:
+                bank.push_event(i, on - f0, ol.EV_GATE, float(plans["gate"][v]))
+        _, ref = bank.process_block(block, taps=list(range(len(sample))))
+        worst = max(worst, rel_err(taps_a[:, f0:f0 + block], ref))
+    assert worst <= TOL, worst
+    # nothing sounds before the first note-on, and the bus is alive afterwards
+    first_on = int(plans["on_frame"].min())
+    assert np.all(bus_a[:first_on] == 0.0)
+    assert np.max(np.abs(bus_a[1024:])) > 1.0
