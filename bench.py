@@ -129,7 +129,8 @@ def main():
         assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
         value = total_voices * K * block / elapsed
         words = eng.state_words_per_voice
-        n_wg = (V + 63) // 64
+        lanes = eng.voices_per_wave
+        n_wg = (V + lanes - 1) // lanes
         # algorithmic HBM bytes of one launch: state planes read once + written once,
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
         bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
@@ -169,6 +170,7 @@ def main():
                 "kernel_ms_avg": kern_ms,
                 "kernel_launches": n_launch,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "voices_per_wave": lanes,
                 "bytes_per_voice_sample": bytes_per_launch / float(V * block),
                 "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block",
             },

@@ -67,6 +67,10 @@ void og_graph_free(og_graph_desc* g);
 /* The HIP source of the fused voice kernel this description lowers to (for
  * inspection / ahead-of-time builds).  Returns the length; copies at most cap-1 bytes. */
 int64_t og_graph_kernel_source(const og_graph_desc* g, char* buf, size_t cap);
+/* Compile that source with hiprtc for `arch` (e.g. "gfx950") without touching a
+ * device -- the path og_create() takes for graphs that were not compiled ahead
+ * of time.  Returns the code-object size in bytes, or a negative OG_E_* code. */
+int64_t og_graph_jit_check(const og_graph_desc* g, const char* arch);
 
 /* ---- engine ------------------------------------------------------------------- */
 /* Graph::new()  codegen/mod.rs:1309-1328: n_voices copies of the voice graph,
@@ -134,6 +138,7 @@ uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
 uint64_t og_frames_processed(const og_engine* e);
 /* layout facts used by the roofline accounting */
 uint32_t og_state_words_per_voice(const og_engine* e);
+uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
 uint64_t og_events_dropped(const og_engine* e);
 /* average device time of the voice kernel over the launches since the last
  * call (HIP events on the engine's stream); returns <0 if timing is off */

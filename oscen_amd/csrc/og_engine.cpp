@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -22,22 +23,37 @@
 #include "og_jit.h"
 #include "og_registry.h"
 
-// Sum the per-workgroup partial rows in workgroup order (fixed association).
-// grid = ceil(frames/64), block = 64; each thread owns one frame and walks the
-// rows with 8 independent accumulators combined in a fixed order.
-__global__ void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows, uint32_t frames,
-                              float* __restrict__ bus)
+// Sum the per-workgroup partial rows (fixed association, no atomics).
+// One workgroup per 64 frames, 16 row-slices x 64 frames = 1024 threads: thread
+// (slice s, frame f) adds rows s, s+16, s+32, ... in order with four
+// independent accumulators (64 independent loads in flight per row-slice keep
+// the HBM/L2 latency covered; the first version walked all rows from 4 waves
+// and took 40 us for 1024 rows), then slice 0 adds the 16 slice sums in order.
+#define OG_RED_SLICES 16
+__global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
+                                                      uint32_t frames, float* __restrict__ bus)
 {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= frames) return;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t r = 0;
-    for (; r + 8 <= n_rows; r += 8) {
+    __shared__ float part[OG_RED_SLICES][64];
+    const uint32_t fx = threadIdx.x & 63u;
+    const uint32_t slice = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 64u + fx;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (f < frames) {
+        uint32_t r = slice;
+        for (; r + 3 * OG_RED_SLICES < n_rows; r += 4 * OG_RED_SLICES) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += partials[(size_t)(r + i) * frames + f];
+            for (int i = 0; i < 4; ++i) acc[i] += partials[(size_t)(r + i * OG_RED_SLICES) * frames + f];
+        }
+        for (int i = 0; r < n_rows; r += OG_RED_SLICES, ++i) acc[i] += partials[(size_t)r * frames + f];
     }
-    for (int i = 0; r < n_rows; ++r, ++i) acc[i] += partials[(size_t)r * frames + f];
-    bus[f] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    part[slice][fx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (slice == 0 && f < frames) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < OG_RED_SLICES; ++i) s += part[i][fx];
+        bus[f] = s;
+    }
 }
 
 // ---- registry ---------------------------------------------------------------
@@ -142,6 +158,7 @@ struct og_engine {
     uint32_t active_ramps = 0;
 
     uint32_t n_wg = 0;
+    uint32_t lanes = OG_WAVE;
     uint32_t* d_state = nullptr;
     OgEvent* d_events = nullptr;
     size_t ev_cap = 0;
@@ -263,6 +280,7 @@ struct og_engine {
         memset(&A, 0, sizeof A);
         A.n_voices = V;
         A.frames = frames;
+        A.lanes = lanes;
         A.frame0 = frame_now;
         A.state = d_state;
         A.events = d_events;
@@ -320,7 +338,7 @@ struct og_engine {
         }
         HIPCK(hipGetLastError());
         float* bus = d_out ? d_out : d_bus;
-        hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64), dim3(64), 0, stream, d_partials, n_wg, frames,
+        hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64), dim3(1024), 0, stream, d_partials, n_wg, frames,
                            bus);
         HIPCK(hipGetLastError());
         frame_now += frames;
@@ -478,6 +496,18 @@ int64_t og_graph_kernel_source(const og_graph_desc* g, char* buf, size_t cap)
     return rc == OG_OK ? len : rc;
 }
 
+int64_t og_graph_jit_check(const og_graph_desc* g, const char* arch)
+{
+    if (!g || !arch) return set_err(OG_E_INVALID, "null argument");
+    int64_t len = -1;
+    int rc = guard([&] {
+        auto cg = ogc::compile(g->g);
+        len = (int64_t)og_jit_compile_only(*cg, arch);
+        return OG_OK;
+    });
+    return rc == OG_OK ? len : rc;
+}
+
 int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engine** out)
 {
     if (!g || !out) return set_err(OG_E_INVALID, "null argument");
@@ -494,7 +524,23 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         e->launch = og_find_kernel(e->cg->hash);
         if (!e->launch) e->jit = og_jit_compile(*e->cg); // throws if hiprtc is unavailable or fails
         e->V = n_voices;
-        e->n_wg = (n_voices + OG_WAVE - 1) / OG_WAVE;
+        // voices per wave: narrow the wave until every SIMD holds two (og_kernel_rt.hip.h)
+        {
+            hipDeviceProp_t prop;
+            HIPCK(hipGetDeviceProperties(&prop, device_id));
+            const uint32_t simds = 4u * (uint32_t)prop.multiProcessorCount;
+            // Measured on MI355X (65 536 fm voices): 64 lanes 0.129 ms, 32 lanes 0.185 ms, 16 lanes
+            // 0.325 ms per block -- the SIMD retires ~one wave-instruction per 4 cycles however the
+            // waves are shaped, so narrowing only multiplies instructions.  Kept as an experiment knob.
+            (void)simds;
+            uint32_t lanes = OG_WAVE;
+            if (const char* ev = getenv("OSCEN_GPU_LANES")) {
+                const int l = atoi(ev);
+                if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
+            }
+            e->lanes = lanes;
+        }
+        e->n_wg = (n_voices + e->lanes - 1) / e->lanes;
         HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
         const auto& cg = *e->cg;
@@ -760,6 +806,7 @@ uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }
 uint32_t og_state_words_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->state.size() : 0; }
+uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes : 0; }
 uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
 
 int og_enable_kernel_timing(og_engine* e, int on)

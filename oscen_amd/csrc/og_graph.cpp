@@ -5,6 +5,7 @@
 #include <cctype>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <set>
@@ -245,7 +246,8 @@ struct Codegen {
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
 
     // emitted code sections
-    std::ostringstream decl, load, derive, pre, tick, store;
+    std::ostringstream decl, load, derive, pre, tick, post, store;
+    std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
     std::map<int, std::ostringstream> ev_handlers; // per graph event input
     bool any_derive = false;
 
@@ -473,22 +475,30 @@ void emit_adsr(NodeCtx& x)
     });
     int s_ai = x.slot_u([ha](const UEnv& e) { return (uint32_t)(ha(e) <= ADSR_MIN_TIME); });
     int s_ri = x.slot_u([hr](const UEnv& e) { return (uint32_t)(fmaxf(hr(e), 0.0f) <= ADSR_MIN_TIME); });
-    (void)s_dn; (void)s_rn; (void)s_su; (void)s_ai; (void)s_ri; // eight consecutive slots, see og_nodes.hip.h
+    (void)s_rn; (void)s_su; (void)s_ai; (void)s_ri; // eight consecutive slots, see og_nodes.hip.h
     const std::string K = "A, " + std::to_string(s_an);
-    std::string stage = x.state_u("stage", 0), rem = x.state_u("rem", 0);
-    std::string level = x.state_f("level", [](const UEnv&) { return 0.0f; });
-    std::string vel = x.state_f("velocity", [](const UEnv&) { return 1.0f; });
-    std::string sus = x.p + "sus";
-    x.cg.decl << "    float " << sus << " = 0.0f;\n";
-    x.cg.pre << "        og::adsr_block_begin(" << stage << ", " << rem << ", " << vel << ", " << sus << ", " << K
-             << ");\n";
+    const std::string E = x.p + "e";
+    // state planes keep the reference's fields; the kernel works on the register form og::Adsr
+    int w_stage = x.cg.new_state(x.n.decl->name + ".stage", false, [](const UEnv&) { return 0u; });
+    int w_rem = x.cg.new_state(x.n.decl->name + ".samples_remaining", false, [](const UEnv&) { return 0u; });
+    int w_level = x.cg.new_state(x.n.decl->name + ".level", true, [](const UEnv&) { return fbits(0.0f); });
+    int w_vel = x.cg.new_state(x.n.decl->name + ".velocity", true, [](const UEnv&) { return fbits(1.0f); });
+    x.cg.decl << "    og::Adsr " << E << " = {0u, og::ADSR_HOLD, 0.0f, 1.0f, 0.0f};\n";
+    x.cg.load << "        og::adsr_block_begin(" << E << ", og::ld_u(A, c, " << w_stage << "), og::ld_u(A, c, " << w_rem
+              << "), og::ld_f(A, c, " << w_level << "), og::ld_f(A, c, " << w_vel << "), " << K << ");\n";
+    x.cg.store << "        og::st_u(A, c, " << w_stage << ", " << E << ".stage);\n"
+               << "        og::st_u(A, c, " << w_rem << ", og::adsr_rem(" << E << "));\n"
+               << "        og::st_f(A, c, " << w_level << ", " << E << ".lv);\n"
+               << "        og::st_f(A, c, " << w_vel << ", " << E << ".vel);\n";
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
-            x.cg.ev_handlers[ei] << "                og::adsr_gate(" << stage << ", " << rem << ", " << level << ", "
-                                 << vel << ", " << sus << ", ev.value, " << K << ");\n";
-    x.set_out("output", "og::adsr_tick(" + stage + ", " + rem + ", " + level + ", " + sus + ", " + x.sf(s_ac) + ", " +
-                            x.sf(s_dc) + ", " + x.su(s_dn) + ")");
+            x.cg.ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
+    x.set_out("output", "og::adsr_tick(" + E + ")");
+    // the non-output half of a stage end is handled once per frame for all envelopes of the voice
+    x.cg.post_zero.push_back(E + ".cnt");
+    x.cg.post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", " << x.su(s_dn)
+              << ");\n";
 }
 
 void emit_fm_operator(NodeCtx& x)
@@ -507,8 +517,10 @@ void emit_fm_operator(NodeCtx& x)
         inc = x.p + "inc";
         x.cg.tick << "        const float " << inc << " = " << inc_expr << ";\n";
     }
-    x.set_out("output", "og::fm_operator_tick(" + phase + ", " + prev + ", " + inc + ", " + pm.e + ", " + fb.e + ", " +
-                            env.e + ", " + lvl.e + ")");
+    // unconnected feedback (0.0) contributes prev*0 + pm = pm for every finite prev: drop the two ops
+    const bool no_fb = fb.rate == Rate::Const && !x.connected("feedback") && x.def("feedback") == 0.0f;
+    x.set_out("output", std::string(no_fb ? "og::fm_operator_tick_nofb(" : "og::fm_operator_tick(") + phase + ", " + prev +
+                            ", " + inc + ", " + pm.e + ", " + (no_fb ? "" : fb.e + ", ") + env.e + ", " + lvl.e + ")");
 }
 
 void emit_tpt(NodeCtx& x)
@@ -833,9 +845,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << cg.decl.str() << "    if (c.valid) {\n"
          << cg.load.str() << "    }\n";
     body << "    auto derive = [&]() {\n" << cg.derive.str() << "    };\n";
-    body << "    {\n" << cg.pre.str() << "    derive();\n";
-    body << "    for (uint32_t f = 0; f < A.frames; ++f) {\n";
-    body << "        if (f == c.next_ev) {\n"
+    body << cg.pre.str() << "    derive();\n";
+    // one frame of the voice graph (nodes in topological order); returns the voice's output sample
+    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << cg.tick.str();
+    if (!cg.post_zero.empty()) {
+        std::string m = cg.post_zero[0];
+        for (size_t i = 1; i < cg.post_zero.size(); ++i) m = "min(" + m + ", " + cg.post_zero[i] + ")";
+        body << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n"
+             << cg.post.str() << "        }\n";
+    }
+    body << "        return " << bus_expr << ";\n    };\n";
+    // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
+    body << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
+         << "        if (f == c.next_ev) {\n"
          << "            do {\n"
          << "                const OgEvent ev = A.events[c.ev_cur];\n";
     bool first = true;
@@ -854,10 +876,23 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     }
     body << "                og::ev_advance(A, c);\n"
          << "            } while (c.next_ev <= f);\n"
-         << "        }\n";
-    body << cg.tick.str();
-    body << "        og::bus_push<TAPS>(A, c, bus, f, " << bus_expr << ");\n"
-         << "    }\n    }\n";
+         << "        }\n    };\n";
+    int unroll = 2; // frames per straight-line scheduling region of the quiet-chunk loop
+    if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
+    body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
+         << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
+         << "        if (n == OG_BUS_CHUNK && __all((int)(c.next_ev >= base + OG_BUS_CHUNK))) {\n"
+         << "            // no lane of this wave has an event in the chunk: straight-line body\n"
+         << "#pragma unroll " << unroll << "\n"
+         << "            for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j));\n"
+         << "        } else {\n"
+         << "            for (uint32_t j = 0; j < n; ++j) {\n"
+         << "                events(base + j);\n"
+         << "                og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j));\n"
+         << "            }\n"
+         << "        }\n"
+         << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"
+         << "    }\n";
     body << "    og::bus_flush(A, c, bus);\n"
          << "    if (c.valid) {\n"
          << cg.store.str();
@@ -891,7 +926,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
-        << "    const dim3 grid((A.n_voices + OG_WAVE - 1) / OG_WAVE), block(OG_WAVE);\n"
+        << "    const dim3 grid((A.n_voices + A.lanes - 1) / A.lanes), block(OG_WAVE);\n"
         << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
         << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"
         << "    else if (!ramps && taps) hipLaunchKernelGGL(og_k_" << hs << "_01, grid, block, 0, s, A);\n"

@@ -5,6 +5,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -13,13 +14,19 @@
 
 namespace {
 
+bool readable(const std::string& path) { return std::ifstream(path).good(); }
+
+// the kernel headers ship next to the library: <libdir>/csrc (or one level up for build variants)
 std::string csrc_dir()
 {
+    if (const char* e = getenv("OSCEN_GPU_CSRC")) return e;
     Dl_info info;
     if (dladdr((void*)&csrc_dir, &info) && info.dli_fname) {
         std::string p = info.dli_fname;
         size_t s = p.rfind('/');
-        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/csrc";
+        const std::string dir = (s == std::string::npos ? std::string(".") : p.substr(0, s));
+        for (const char* rel : {"/csrc", "/../csrc"})
+            if (readable(dir + rel + "/og_kernel_rt.hip.h")) return dir + rel;
     }
     return "csrc";
 }
@@ -77,7 +84,7 @@ struct JitImpl : OgJitKernel {
         OgBlockArgs a = args;
         size_t sz = sizeof a;
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        const unsigned grid = (a.n_voices + OG_WAVE - 1) / OG_WAVE;
+        const unsigned grid = (a.n_voices + a.lanes - 1) / a.lanes;
         hipError_t e = hipModuleLaunchKernel(fn[(ramps ? 1 : 0) + (taps ? 2 : 0)], grid, 1, 1, OG_WAVE, 1, 1, 0, stream,
                                              nullptr, cfg);
         if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));

@@ -9,18 +9,35 @@
 // address w*n_voices + v, 256 B per wave-instruction), lives in VGPRs for the
 // whole block of <= 512 frames, and is stored once.
 //
+// Voices per wave (OgBlockArgs::lanes) is 64.  Narrower waves (32/16 voices, to
+// put two waves on every SIMD at 65 536 voices) were measured and are slower:
+// the path is bound by VALU issue (~one wave-instruction per 4 cycles per SIMD
+// at any occupancy), so what counts is the number of wave-instructions.
+//
 // Mix bus (reference: `voices.audio_out -> audio_out` = sequential f32 sum in
 // voice order, oscen-graph-compiler/src/codegen/emit_node.rs:463-466): each
 // frame every lane drops its sample into an LDS tile [16 frames][64+1 lanes];
 // every 16 frames the wave transposes: lane (q*16+j) adds voices q*16..q*16+15
 // of frame j in voice order, two cross-lane adds combine the quarters, and 16
-// lanes append the wave's partial for those frames.  One partial row per
+// lanes append the wave's partial for those frames.  The same 16-frame chunk
+// is the unit of the frame loop: a chunk in which no lane of the wave has an
+// event runs as one straight-line, unrolled body (no per-frame branches, so
+// the scheduler can overlap frame f+1's envelopes with frame f's operator
+// chain -- with one wave per SIMD at 65 536 voices there is no other wave to
+// hide VALU latency behind).  One partial row per
 // workgroup goes to HBM; og_bus_reduce sums the rows in workgroup order.  No
 // atomics: the result is deterministic and differs from the reference's left
 // fold only by this fixed re-association.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else // hiprtc pre-includes the HIP runtime; its fixed-width types live in __hip_internal
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 #define OG_WAVE 64
 #define OG_MAX_BLOCK 512
@@ -38,6 +55,8 @@ struct OgEvent {
 struct OgBlockArgs {
     uint32_t n_voices;
     uint32_t frames;
+    uint32_t lanes;            // voices per wave: 64, or 32/16 to put >= 2 waves on every SIMD (see below)
+    uint32_t pad0;
     uint64_t frame0;
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
     const OgEvent* events;     // sorted by (voice, frame, push order)
@@ -82,8 +101,8 @@ template <bool TAPS>
 __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.lane = threadIdx.x;
-    c.v = blockIdx.x * OG_WAVE + threadIdx.x;
-    c.valid = c.v < a.n_voices;
+    c.v = blockIdx.x * a.lanes + threadIdx.x;
+    c.valid = (threadIdx.x < a.lanes) && (c.v < a.n_voices);
     c.ev_cur = c.ev_end = 0;
     c.next_ev = OG_NO_EVENT;
     c.tap = -1;
@@ -131,27 +150,32 @@ struct BusLds {
     float part[OG_MAX_BLOCK];              // this wave's partial sum per frame
 };
 
+// one sample of one voice into the wave's transpose tile (row j = frame within the chunk)
 template <bool TAPS>
-__device__ __forceinline__ void bus_push(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, float out)
+__device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, uint32_t j,
+                                        float out)
 {
     const float y = c.valid ? out : 0.0f;
-    lds.tile[f % OG_BUS_CHUNK][c.lane] = y;
+    lds.tile[j][c.lane] = y;
     if (TAPS) {
         if (c.tap >= 0) a.taps[(size_t)c.tap * a.frames + f] = y;
     }
-    if ((f % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || f + 1 == a.frames) {
-        __syncthreads(); // one-wave workgroup: orders the LDS writes before the transposed reads
-        const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
-        const uint32_t q = c.lane / OG_BUS_CHUNK;
-        float s = 0.0f;
+}
+
+// after n <= OG_BUS_CHUNK frames starting at `base`: transpose-sum the tile into part[base..base+n)
+__device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t base,
+                                                 uint32_t n)
+{
+    __syncthreads(); // one-wave workgroup: orders the LDS writes before the transposed reads
+    const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
+    const uint32_t q = c.lane / OG_BUS_CHUNK;
+    float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.tile[j][q * (OG_WAVE / 4) + i];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const uint32_t base = f - (f % OG_BUS_CHUNK);
-        if (c.lane < OG_BUS_CHUNK && base + j < a.frames) lds.part[base + j] = s;
-        __syncthreads();
-    }
+    for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.tile[j][q * (OG_WAVE / 4) + i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (c.lane < OG_BUS_CHUNK && j < n) lds.part[base + j] = s;
+    __syncthreads();
 }
 
 __device__ __forceinline__ void bus_flush(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds)

@@ -11,8 +11,13 @@
 // budget.  The hardware v_sin_f32 is deliberately not used: its absolute error
 // is too large once amplified through two modulation stages.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <math.h>
 #include <stdint.h>
+#else
+using __hip_internal::int32_t;
+using __hip_internal::uint32_t;
+#endif
 
 #if defined(__HIPCC__)
 #define OG_HD __host__ __device__ __forceinline__
@@ -52,7 +57,11 @@ OG_HD float og_sinf(float x)
     float k = rintf(x * INV_PI);
     float r = fmaf(-k, PI_A, x);
     r = fmaf(-k, PI_B, r);
+#ifdef OG_SIN_3TERM
     r = fmaf(-k, PI_C, r);
+#else
+    (void)PI_C; // |k| * 3.4e-15: below half an ulp of r for |x| < 1e5
+#endif
     // (-1)^k: flip the sign of r (odd polynomial) when k is odd
     int32_t ki = (int32_t)k;
     union { float f; uint32_t u; } b;

@@ -10,8 +10,10 @@
 // kernel-argument constants; what remains here is the per-sample, per-voice
 // recurrence.  Each function cites the reference lines it implements.
 #pragma once
+#ifndef __HIPCC_RTC__ // hiprtc pre-includes the HIP runtime and the fixed-width types
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "og_kernel_rt.hip.h"
 #include "og_math.h"
@@ -23,19 +25,32 @@ namespace og {
 constexpr float F32_EPSILON = 1.1920929e-7f;
 constexpr float F32_TAU = 6.28318548202514648f;
 
-// Rust f32::clamp (NaN passes through): used where the reference clamps.
-OG_DEV float clampf(float x, float lo, float hi)
+// f32::clamp(lo, hi) with lo <= hi as ONE v_med3_f32 (the compare/select form
+// costs two VALU ops plus VCC wait states).  Identical for every non-NaN x;
+// the signal path never carries NaN (a NaN input clamps to lo here instead of
+// propagating as Rust's clamp would).
+OG_DEV float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+OG_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
+// a / b for finite a and b >= 1: v_rcp_f32 plus one Newton step on the
+// quotient (q' = q + (a - q*b) * rcp(b)).  Correctly rounded except for rare
+// 1-ulp misses; 5 VALU ops instead of the 12 of the IEEE expansion.  Only
+// used where the reference's quotient feeds a contracting recurrence (the
+// ADSR release slope), never for phase increments.
+OG_DEV float div_near(float a, float b)
 {
-    x = (x < lo) ? lo : x;
-    x = (x > hi) ? hi : x;
-    return x;
+    const float rb = __builtin_amdgcn_rcpf(b);
+    const float q = a * rb;
+    const float r = fmaf(-q, b, a);
+    return fmaf(r, rb, q);
 }
-OG_DEV float clamp01(float x) { return clampf(x, 0.0f, 1.0f); }
 
 // ---------------------------------------------------------------------------
 // AdsrEnvelope  oscen-lib/src/envelope/adsr.rs
 // ---------------------------------------------------------------------------
-enum : uint32_t { ST_IDLE = 0, ST_ATTACK = 1, ST_DECAY = 2, ST_SUSTAIN = 3, ST_RELEASE = 4 };
+// Stage codes chosen so that the successor at a stage end is (stage + 1) & 7:
+// Attack -> Decay -> Sustain, Release -> Idle.
+enum : uint32_t { ST_IDLE = 0, ST_ATTACK = 1, ST_DECAY = 2, ST_SUSTAIN = 3, ST_RELEASE = 7 };
 
 // Block-uniform, host-derived (adsr.rs:84-90, 117-134), eight consecutive
 // uniform slots per envelope: stage lengths in samples, one-pole coefficients
@@ -45,86 +60,116 @@ enum : uint32_t { ST_IDLE = 0, ST_ATTACK = 1, ST_DECAY = 2, ST_SUSTAIN = 3, ST_R
 // used (block start, gate events) so it does not pin SGPRs across the loop.
 enum : int { ADSR_A_N = 0, ADSR_D_N, ADSR_R_N, ADSR_A_C, ADSR_D_C, ADSR_SUSTAIN, ADSR_A_INST, ADSR_R_INST };
 
-// Once per block (and nowhere else is it observable): the part of
-// apply_parameters()/update_sustain_level() that only changes when a parameter
-// or the velocity changed -- sustain_level (adsr.rs:93) and the
-// samples_remaining clamp against the re-derived stage length (adsr.rs:95-106).
-OG_DEV void adsr_block_begin(uint32_t stage, uint32_t& rem, float vel, float& sus_lvl, const OgBlockArgs& A, int k)
+// Register form of one envelope.  (stage, cnt, lv) mirror the reference's
+// (stage, samples_remaining, level); (tgt, cf) are the one-pole target and
+// coefficient of the current stage, refreshed only when the stage changes, so
+// the per-sample update is `lv += (tgt - lv) * cf` for every stage: holding
+// stages and Release run it with cf = 0, which leaves lv bit-unchanged.  tgt
+// is also the level a stage ends on (1 after Attack, sustain_level after
+// Decay, 0 after Release).  vel/sus are only touched at block start and by
+// gate events.  Holding stages keep cnt at ADSR_HOLD so the per-sample
+// countdown never reaches the stage-end test for them.
+//
+// The voice kernels are VALU-issue-bound (one wave-instruction per ~4 cycles
+// per SIMD, measured), so every instruction here is paid in full:
+//  * the reference's per-sample clamps of `level` are provable no-ops for
+//    lv, tgt in [0,1] and cf in [0,1] (round-to-nearest cannot carry
+//    lv + (tgt-lv)*cf past tgt's side of [0,1], nor lv - lv/n below 0) and are
+//    not re-executed;
+//  * `if current <= 0 {0} else {-current/n}` is -current/n for current >= 0
+//    (-0/n = -0, and x + -0 = x);
+//  * the Release divide runs only when some lane of the wave is in Release;
+//  * a stage end changes this frame's output only through `lv = tgt`; the
+//    rest of complete_stage() is deferred to one check per frame for all of a
+//    voice's envelopes (adsr_complete, called at the end of the frame).
+constexpr uint32_t ADSR_HOLD = 0xFFFFFFFFu;
+
+struct Adsr {
+    uint32_t stage, cnt;
+    float lv, tgt, cf, vel, sus;
+};
+
+OG_DEV void adsr_enter(Adsr& e, uint32_t stage, uint32_t n, float a_c, float d_c)
 {
-    sus_lvl = clamp01(slot_f(A, k + ADSR_SUSTAIN) * vel);
-    // scalar_u(): keep the three kernel-argument reads scalar; a lane-varying
-    // select between them must select values, not addresses
-    const uint32_t a_n = scalar_u(A, k + ADSR_A_N), d_n = scalar_u(A, k + ADSR_D_N), r_n = scalar_u(A, k + ADSR_R_N);
-    uint32_t lim = (stage == ST_ATTACK) ? a_n : (stage == ST_DECAY) ? d_n : r_n;
-    bool moving = (stage == ST_ATTACK) | (stage == ST_DECAY) | (stage == ST_RELEASE);
-    if (moving && rem > 0) rem = max(min(rem, lim), 1u);
+    const bool att = stage == ST_ATTACK, dec = stage == ST_DECAY;
+    e.stage = stage;
+    e.cnt = (stage == ST_SUSTAIN || stage == ST_IDLE) ? ADSR_HOLD : n;
+    e.tgt = att ? 1.0f : (dec ? e.sus : 0.0f);
+    e.cf = att ? a_c : (dec ? d_c : 0.0f);
 }
 
+// Once per block: load + the part of apply_parameters()/update_sustain_level()
+// that only changes when a parameter or the velocity changed -- sustain_level
+// (adsr.rs:93), the samples_remaining clamp against the re-derived stage
+// length (adsr.rs:95-106), and Sustain/Idle pinning the level (adsr.rs:241-246).
+OG_DEV void adsr_block_begin(Adsr& e, uint32_t stage, uint32_t rem, float level, float vel, const OgBlockArgs& A, int k)
+{
+    // scalar_u(): keep the kernel-argument reads scalar; a lane-varying select
+    // between them must select values, not addresses
+    const uint32_t a_n = scalar_u(A, k + ADSR_A_N), d_n = scalar_u(A, k + ADSR_D_N), r_n = scalar_u(A, k + ADSR_R_N);
+    const float a_c = __uint_as_float(scalar_u(A, k + ADSR_A_C)), d_c = __uint_as_float(scalar_u(A, k + ADSR_D_C));
+    e.vel = vel;
+    e.sus = clamp01(__uint_as_float(scalar_u(A, k + ADSR_SUSTAIN)) * vel);
+    const uint32_t lim = (stage == ST_ATTACK) ? a_n : (stage == ST_DECAY) ? d_n : r_n;
+    const bool moving = (stage == ST_ATTACK) | (stage == ST_DECAY) | (stage == ST_RELEASE);
+    if (moving && rem > 0) rem = max(min(rem, lim), 1u);
+    e.lv = (stage == ST_SUSTAIN) ? e.sus : ((stage == ST_IDLE) ? 0.0f : clamp01(level));
+    adsr_enter(e, stage, rem, a_c, d_c);
+}
+
+// what the state planes hold at block end
+OG_DEV uint32_t adsr_rem(const Adsr& e) { return (e.stage == ST_SUSTAIN || e.stage == ST_IDLE) ? 0u : e.cnt; }
+
 // handle_gate_event  adsr.rs:250-273 (scalar payload)
-OG_DEV void adsr_gate(uint32_t& stage, uint32_t& rem, float& level, float& vel, float& sus_lvl, float v,
-                      const OgBlockArgs& A, int k)
+OG_DEV void adsr_gate(Adsr& e, float v, const OgBlockArgs& A, int k)
 {
     const uint32_t a_n = scalar_u(A, k + ADSR_A_N), d_n = scalar_u(A, k + ADSR_D_N), r_n = scalar_u(A, k + ADSR_R_N);
     const uint32_t a_inst = scalar_u(A, k + ADSR_A_INST), r_inst = scalar_u(A, k + ADSR_R_INST);
+    const float a_c = __uint_as_float(scalar_u(A, k + ADSR_A_C)), d_c = __uint_as_float(scalar_u(A, k + ADSR_D_C));
     const float sustain = __uint_as_float(scalar_u(A, k + ADSR_SUSTAIN));
     if (v > 0.0f) {
-        vel = clamp01(v);
-        sus_lvl = clamp01(sustain * vel); // update_sustain_level :93
+        e.vel = clamp01(v);
+        e.sus = clamp01(sustain * e.vel); // update_sustain_level :93
         if (a_inst) {                     // attack <= MIN_TIME_SECONDS
-            level = 1.0f;
-            stage = ST_DECAY; // set_stage(Decay, sustain_level): d_n >= 1
-            rem = d_n;
+            e.lv = 1.0f;
+            adsr_enter(e, ST_DECAY, d_n, a_c, d_c); // set_stage(Decay, sustain_level): d_n >= 1
         } else {
-            stage = ST_ATTACK; // set_stage(Attack, 1.0): a_n >= 1
-            rem = a_n;
+            adsr_enter(e, ST_ATTACK, a_n, a_c, d_c); // set_stage(Attack, 1.0): a_n >= 1
         }
     } else if (r_inst) {
-        stage = ST_IDLE;
-        level = 0.0f;
-        rem = 0;
+        e.lv = 0.0f;
+        adsr_enter(e, ST_IDLE, 0, a_c, d_c);
     } else {
-        stage = ST_RELEASE; // release_increment is re-derived every sample (adsr.rs:112-114)
-        rem = r_n;
+        adsr_enter(e, ST_RELEASE, r_n, a_c, d_c); // release_increment is re-derived every sample (adsr.rs:112-114)
     }
 }
 
-// process_stage  adsr.rs:206-248 with complete_stage :175-204 folded in.
-// Written as selects: the lanes of a wave sit in different stages.
-OG_DEV float adsr_tick(uint32_t& stage, uint32_t& rem, float& level, float sus_lvl, float a_c, float d_c,
-                       uint32_t d_n)
+// process_stage  adsr.rs:206-248, the per-sample part
+OG_DEV float adsr_tick(Adsr& e)
 {
-    const uint32_t st = stage;
-    const bool att = st == ST_ATTACK, dec = st == ST_DECAY, rel = st == ST_RELEASE;
-    const bool moving = att | dec | rel;
-    float lv = level;
-    uint32_t r = rem;
-    // one-pole approach (attack toward 1, decay toward sustain_level)
-    const float tgt = att ? 1.0f : sus_lvl;
-    const float cf = att ? a_c : d_c;
-    const float lv_ad = lv + (tgt - lv) * cf;
-    // linear release: update_release_increment adsr.rs:162-173, every sample
-    const float cur = clamp01(lv);
-    const float inc = (cur <= 0.0f) ? 0.0f : (-cur / (float)r);
-    const float lv_r = lv + inc;
-    const bool step = moving & (r > 0u);
-    float nl = rel ? lv_r : lv_ad;
-    nl = clamp01(nl);
-    lv = step ? nl : lv;
-    r = step ? r - 1u : r;
-    const bool done = moving & (r == 0u);
-    // stage end: Attack -> (level 1) Decay; Decay -> Sustain; Release -> Idle
-    const float end_lv = att ? 1.0f : (dec ? sus_lvl : 0.0f);
-    lv = done ? end_lv : lv;
-    const uint32_t end_st = att ? (uint32_t)ST_DECAY : (dec ? (uint32_t)ST_SUSTAIN : (uint32_t)ST_IDLE);
-    const uint32_t end_r = att ? d_n : 0u;
-    stage = done ? end_st : st;
-    r = done ? end_r : r;
-    // holding stages
-    lv = (st == ST_SUSTAIN) ? sus_lvl : lv;
-    lv = (st == ST_IDLE) ? 0.0f : lv;
-    level = lv;
-    rem = r;
+    // Attack: lv += (1 - lv) * attack_coeff; Decay: lv += (sustain_level - lv) * decay_coeff; else cf == 0
+    float lv = e.lv + (e.tgt - e.lv) * e.cf;
+    // Release: lv += -lv / samples_remaining, increment re-derived every sample (adsr.rs:162-173)
+    const bool rel = e.stage == ST_RELEASE;
+    if (__any((int)rel)) {
+        const float lv_r = lv + div_near(-lv, (float)e.cnt);
+        lv = rel ? lv_r : lv;
+    }
+    // samples_remaining -= 1; at 0 the stage ends on its target level
+    const uint32_t c = e.cnt - 1u;
+    lv = (c == 0u) ? e.tgt : lv;
+    e.cnt = c;
+    e.lv = lv;
     return lv;
+}
+
+// complete_stage  adsr.rs:175-204 for an envelope whose countdown hit 0 this frame
+OG_DEV void adsr_complete(Adsr& e, float a_c, float d_c, uint32_t d_n)
+{
+    if (e.cnt == 0u) {
+        const uint32_t next = (e.stage + 1u) & 7u; // Attack -> Decay -> Sustain, Release -> Idle
+        adsr_enter(e, next, d_n, a_c, d_c);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -142,6 +187,19 @@ OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float
     prev_output = output;
     const float p = phase + inc;
     phase = p - truncf(p); // f32::fract
+    return output;
+}
+
+// feedback input left at its constructor value 0.0 (FMVoice op1): prev*0 + pm == pm
+// for finite prev (and a -0/+0 difference cannot reach the output: it is added to phase >= 0)
+OG_DEV float fm_operator_tick_nofb(float& phase, float& prev_output, float inc, float phase_mod, float envelope,
+                                   float level)
+{
+    const float phase_rad = (phase + phase_mod) * F32_TAU;
+    const float output = og_sinf(phase_rad) * envelope * level;
+    prev_output = output;
+    const float p = phase + inc;
+    phase = p - truncf(p);
     return output;
 }
 

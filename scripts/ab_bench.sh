@@ -1,0 +1,17 @@
+#!/bin/bash
+# interleaved A/B of library variants: scripts/ab_bench.sh "<tag> <tag> ..." [rounds] [bench args]
+TAGS=${1:-"base"}; ROUNDS=${2:-3}; shift; shift
+for r in $(seq 1 $ROUNDS); do
+  for t in $TAGS; do
+    unset OGC_UNROLL
+    if [ "$t" = "base" ]; then unset OSCEN_GPU_LIB; else export OSCEN_GPU_LIB=$PWD/oscen_amd/_build/liboscen_gpu_$t.so; fi
+    case $t in u[0-9]*) export OGC_UNROLL=${t#u};; esac
+    python bench.py --steps 94 --warmup 4 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: continue
+    print('$t', 'round $r', 'value %.4g' % d['value'], 'kernel_ms %.4f' % d['roofline']['kernel_ms_avg'], 'ms_per_step %.4f' % d['ms_per_step'])
+"
+  done
+done

@@ -125,3 +125,13 @@ def test_note_plans_match_oracle_generator():
     assert oscen_amd.midi_note_to_freq(69) == 440.0
     assert abs(oscen_amd.midi_note_to_freq(60) - 261.626) < 0.01
     assert abs(oscen_amd.midi_velocity_to_gate(100) - 100 / 127) < 1e-7
+
+
+def test_unregistered_graph_compiles_with_hiprtc_for_gfx950(lib):
+    # the og_create() path of a graph that has no ahead-of-time kernel; compile only, no device
+    def extra(g):
+        g.node("osc2", "Oscillator::sine", 3.0, 0.1)
+        g.connect("osc2.output", "osc.frequency_mod")
+        g.connect("filter.output", "out")
+    size = _simple(extra).jit_check("gfx950")
+    assert size > 4096

@@ -155,7 +155,10 @@ def test_fm_bank_variant_feedback_route_envamount_and_ramps():
             p.set_value("filter_cutoff", 6000.0)          # default ramp 2205 frames
             p.set_value_with_ramp("route", 0.1, 300)
         if b == 9:
-            p.set_value_immediate("op3_level", 0.8)
+            # keep the operator self-feedback loop gain 2*pi*feedback*level*env below 1:
+            # beyond it phase-feedback FM is chaotic and ulp-level libm differences grow
+            # without bound in ANY two implementations (not a parity regime)
+            p.set_value_immediate("op3_level", 0.4)
             p.set_value("filter_resonance", 2.5)
         for fr, v, val in events:
             if f0 <= fr < f0 + 256:
