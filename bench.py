@@ -21,6 +21,25 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(voices, block):
+    """HBM bytes per launch of the voice kernel from the committed rocprofv3 PMC passes
+    (profiles/*_summary.json, written by scripts/prof_summary.py): FETCH_SIZE and WRITE_SIZE are
+    collected in separate --pmc runs of this same command, so they cannot be measured in-process."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("voices") == voices and d.get("frames") == block and "hbm_traffic" in d:
+            best = (path, d)
+    if not best:
+        return None, None
+    return best[1]["hbm_traffic"]["total_bytes_corrected"], os.path.relpath(best[0], ROOT)
+
+
 def cpu_baseline(block, seed):
     """Time the CPU oracle (scalar C port of the reference path) on the host cores, bounded sample."""
     import ctypes as C
@@ -135,6 +154,8 @@ def main():
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
         bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        pmc_bytes, pmc_src = pmc_traffic(V, block)
+        traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
         line = {
             "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
             "value": value,
@@ -166,7 +187,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_bytes_per_launch": pmc_bytes,
+                "traffic_source": pmc_src,
                 "kernel_ms_avg": kern_ms,
                 "kernel_launches": n_launch,
                 "algorithmic_bytes_per_launch": bytes_per_launch,

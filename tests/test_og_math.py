@@ -1,0 +1,57 @@
+"""The device math header compiles for the host too: check og_sinf / og_tanf_q1 against glibc
+(the libm the reference's f32::sin / f32::tan bind to on Linux).  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = r'''
+#include "og_math.h"
+extern "C" void og_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sinf(x[i]); }
+extern "C" void og_tan_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_tanf_q1(x[i]); }
+extern "C" void ref_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = sinf(x[i]); }
+extern "C" void ref_tan_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = tanf(x[i]); }
+'''
+
+
+@pytest.fixture(scope="module")
+def mlib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ogmath")
+    src = d / "m.cpp"
+    src.write_text(SRC)
+    so = d / "libm_test.so"
+    flags = ["-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "oscen_amd", "csrc")]
+    if "fma" in open("/proc/cpuinfo").read():
+        flags.append("-mfma")
+    subprocess.run(["g++"] + flags + [str(src), "-o", str(so), "-lm"], check=True)
+    return C.CDLL(str(so))
+
+
+def _apply(lib, name, x):
+    y = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    getattr(lib, name)(x.ctypes.data_as(fp), y.ctypes.data_as(fp), C.c_long(len(x)))
+    return y
+
+
+def test_sin_matches_glibc_over_fm_range(mlib):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-64, 64, 2_000_001), rng.uniform(-8192, 8192, 500_000),
+                        rng.uniform(-1e5, 1e5, 200_000), np.array([0.0, -0.0, 1e-30, np.pi, -np.pi])]).astype(np.float32)
+    got, ref = _apply(mlib, "og_sin_array", x), _apply(mlib, "ref_sin_array", x)
+    assert np.max(np.abs(got.astype(np.float64) - ref)) <= 2.4e-7
+    small = np.abs(x) <= 64
+    assert np.max(np.abs(got[small].astype(np.float64) - ref[small])) <= 1.2e-7
+    assert np.mean(got[small] == ref[small]) > 0.70  # the rest differ by 1 ulp
+    true = np.sin(x[small].astype(np.float64))
+    assert np.max(np.abs(got[small] - true)) <= 1.3e-7
+
+
+def test_tan_matches_glibc_on_first_quadrant(mlib):
+    x = np.linspace(1e-4, 1.5707, 2_000_001).astype(np.float32)
+    got, ref = _apply(mlib, "og_tan_array", x), _apply(mlib, "ref_tan_array", x)
+    rel = np.abs(got.astype(np.float64) - ref) / np.abs(ref)
+    assert rel.max() <= 2.5e-7
