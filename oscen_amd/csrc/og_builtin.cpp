@@ -141,14 +141,33 @@ GraphDesc sub_voice()
     return g;
 }
 
+// SatGraph_{1,4}x (examples/oversampled-saturator/src/main.rs:64-80): saw -> HardClip, both `* N`,
+// `[sinc] clip.output -> audio_out`.  The oscillator frequency is a per-voice input here (the
+// reference fixes 2000 Hz) so that a bank of voices is not N copies of one signal.
+GraphDesc sat_voice(uint32_t factor)
+{
+    GraphDesc g;
+    g.name = factor > 1 ? "sat4x_voice" : "sat1x_voice";
+    g.inputs.push_back(voice_in("frequency", 2000.0f));
+    g.outputs.push_back({"audio_out", Kind::Stream});
+    g.nodes.push_back({"osc", "PolyBlepOscillator::saw", {2000.0f, 0.6f}, factor});
+    g.nodes.push_back({"clip", "HardClip::new", {}, factor});
+    g.edges.push_back({"frequency", "osc.frequency", ""});
+    g.edges.push_back({"osc.output", "clip.input", ""});
+    g.edges.push_back({"clip.output", "audio_out", factor > 1 ? "sinc" : ""});
+    return g;
+}
+
 } // namespace
 
-std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice"}; }
+std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice"}; }
 
 GraphDesc builtin_graph(const std::string& name)
 {
     if (name == "fm_voice") return fm_voice();
     if (name == "sub_voice") return sub_voice();
+    if (name == "sat4x_voice") return sat_voice(4);
+    if (name == "sat1x_voice") return sat_voice(1);
     throw std::runtime_error("unknown builtin graph '" + name + "'");
 }
 

@@ -66,6 +66,7 @@ struct Val {
     Rate rate = Rate::Const;
     HostFn host;                  // available when rate <= UBlock
     std::set<int> voice_inputs;   // per-voice value inputs this depends on (rate VBlock)
+    bool inner = false;           // defined inside the oversampled (x N) inner loop
 };
 
 Val vconst(float c)
@@ -234,7 +235,12 @@ struct NodeInst {
     const NodeTypeInfo* type = nullptr;
     int id = -1;
     bool live = true;
-    std::map<std::string, std::vector<ExprP>> in_edges; // stream/value port -> sources in edge order
+    struct Src {
+        ExprP e;
+        std::string policy;
+    };
+    std::map<std::string, std::vector<Src>> in_edges; // stream/value port -> sources in edge order
+    int domain = 0; // 0 = outer before the inner loop, 1 = oversampled inner loop, 2 = outer after it
     std::map<std::string, std::vector<int>> ev_edges;   // event port -> graph event-input indices
 };
 
@@ -246,7 +252,14 @@ struct Codegen {
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
 
     // emitted code sections
-    std::ostringstream decl, load, derive, pre, tick, post, store;
+    std::ostringstream decl, load, derive, pre, post, store;
+    // per-frame code, multirate layout of emit_frame.rs:114-176:
+    //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
+    std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
+    std::ostringstream* cur = &s_pre;
+    std::ostringstream& os() { return *cur; }
+    int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
+    int n_cross = 0;  // cross-rate edges emitted so far
     std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
     std::map<int, std::ostringstream> ev_handlers; // per graph event input
     bool any_derive = false;
@@ -285,6 +298,81 @@ struct Codegen {
         return v;
     }
 
+    // Bring a source value into the destination's rate domain (ir/lower.rs:824-906 kernel
+    // selection; dispatch/stream.rs:94-104): same rate -> as is; value-kind or voice-uniform
+    // source into an oversampled node -> Latch (the value is simply visible in the inner loop);
+    // stream outer -> inner = Up{N, policy}; inner -> outer = Down{N, policy}; default policy Sinc.
+    Val cross(Val v, const std::string& policy, bool dst_inner, bool value_port)
+    {
+        if (N <= 1 || v.inner == dst_inner) {
+            if (!policy.empty() && v.rate == Rate::Vary && N <= 1)
+                fail("connection policy [" + policy + "] needs an oversampled (`* N`) node on one side");
+            return v;
+        }
+        const std::string pol = policy.empty() ? "sinc" : policy;
+        if (pol != "sinc" && pol != "sinc_iir" && pol != "linear" && pol != "latch")
+            fail("unknown connection policy [" + policy + "]");
+        const std::string id = std::to_string(n_cross++);
+        const std::string NN = std::to_string(N);
+        const int stages = N >= 8 ? 3 : (N >= 4 ? 2 : 1);
+        auto state_arr = [&](const std::string& var, int rows, int cols) {
+            decl << "    float " << var << "[" << rows << "][" << cols << "] = {};\n";
+            for (int r = 0; r < rows; ++r)
+                for (int c2 = 0; c2 < cols; ++c2) {
+                    int w = new_state("edge" + id + "." + var + "[" + std::to_string(r) + "][" + std::to_string(c2) + "]",
+                                      true, [](const UEnv&) { return 0u; });
+                    load << "        " << var << "[" << r << "][" << c2 << "] = og::ld_f(A, c, " << w << ");\n";
+                    store << "        og::st_f(A, c, " << w << ", " << var << "[" << r << "][" << c2 << "]);\n";
+                }
+        };
+        Val r;
+        r.rate = Rate::Vary;
+        if (dst_inner) { // Up edge (emit_frame.rs:254-307): upsample once per outer frame into a [N] buffer
+            if (v.rate != Rate::Vary || value_port || pol == "latch") { // Latch: every inner tick sees the outer value
+                v.inner = true;
+                return v;
+            }
+            const std::string buf = "up" + id, st = "up" + id + "_st";
+            s_up << "        float " << buf << "[" << NN << "];\n";
+            if (pol == "sinc") {
+                state_arr(st, stages, 12);
+                s_up << "        og::sinc_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
+            } else if (pol == "sinc_iir") {
+                state_arr(st, stages, 9);
+                s_up << "        og::iir_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
+            } else {
+                state_arr(st, 1, 1);
+                s_up << "        og::linear_up<" << NN << ">(" << st << "[0][0], " << v.e << ", " << buf << ");\n";
+            }
+            r.e = buf + "[j]";
+            r.inner = true;
+            return r;
+        }
+        // Down edge (emit_frame.rs:474-514): capture every inner tick, downsample once per outer frame
+        const std::string buf = "dn" + id, st = "dn" + id + "_st";
+        s_up << "        float " << buf << "[" << NN << "];\n";
+        s_cap << "            " << buf << "[j] = " << v.e << ";\n";
+        int lat = 0;
+        if (pol == "sinc") {
+            state_arr(st, stages, 24);
+            s_down << "        const float " << buf << "_o = og::sinc_down<" << NN << ">(" << st << ", " << buf << ");\n";
+            lat = 11 * (N - 1);
+        } else if (pol == "sinc_iir") {
+            state_arr(st, stages, 9);
+            s_down << "        const float " << buf << "_o = og::iir_down<" << NN << ">(" << st << ", " << buf << ");\n";
+            lat = 2 * (N - 1);
+        } else if (pol == "linear") {
+            s_down << "        const float " << buf << "_o = og::linear_down<" << NN << ">(" << buf << ");\n";
+            lat = (N - 1) / 2;
+        } else {
+            s_down << "        const float " << buf << "_o = " << buf << "[0];\n";
+        }
+        out.latency_samples += (uint32_t)(lat / N); // emit_struct.rs:534-570
+        r.e = buf + "_o";
+        r.inner = false;
+        return r;
+    }
+
     Val eval(const ExprP& e)
     {
         switch (e->t) {
@@ -294,6 +382,7 @@ struct Codegen {
             Val r;
             r.e = "(-" + a.e + ")";
             r.rate = a.rate;
+            r.inner = a.inner;
             r.voice_inputs = a.voice_inputs;
             if (a.host) {
                 HostFn h = a.host;
@@ -319,6 +408,9 @@ struct Codegen {
             Val r;
             r.e = "(" + a.e + " " + e->op + " " + b.e + ")";
             r.rate = join(a.rate, b.rate);
+            if (a.inner != b.inner && a.rate == Rate::Vary && b.rate == Rate::Vary)
+                fail("expression mixes outer-rate and oversampled node outputs; connect them through a cross-rate edge");
+            r.inner = a.inner || b.inner;
             r.voice_inputs = a.voice_inputs;
             r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
             if (a.host && b.host && r.rate <= Rate::UBlock) {
@@ -363,12 +455,20 @@ struct NodeCtx {
     {
         auto it = n.in_edges.find(name);
         if (it == n.in_edges.end()) return vconst(def(name));
-        Val acc = cg.eval(it->second[0]);
+        const bool dst_inner = n.domain == 1;
+        const bool value_port = port(name).kind == Kind::Value;
+        if (it->second.size() > 1) // fan-in sum: same-rate simple sources only (emit_node.rs:35-111)
+            for (auto& src : it->second)
+                if (!src.policy.empty()) fail("fan-in summing supports only same-rate sources (input '" + name + "')");
+        Val acc = cg.cross(cg.eval(it->second[0].e), it->second[0].policy, dst_inner, value_port);
         for (size_t i = 1; i < it->second.size(); ++i) { // connect, then accumulate in edge order
-            Val b = cg.eval(it->second[i]);
+            Val b = cg.eval(it->second[i].e);
+            if (b.inner != dst_inner && b.rate == Rate::Vary)
+                fail("fan-in summing supports only same-rate sources (input '" + name + "')");
             Val r;
             r.e = "(" + acc.e + " + " + b.e + ")";
             r.rate = join(acc.rate, b.rate);
+            r.inner = acc.inner || b.inner;
             r.voice_inputs = acc.voice_inputs;
             r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
             if (acc.host && b.host && r.rate <= Rate::UBlock) {
@@ -422,10 +522,11 @@ struct NodeCtx {
     void set_out(const std::string& port, const std::string& expr)
     {
         std::string var = p + port;
-        cg.tick << "        const float " << var << " = " << expr << ";\n";
+        cg.os() << "        const float " << var << " = " << expr << ";\n";
         Val v;
         v.e = var;
         v.rate = Rate::Vary;
+        v.inner = n.domain == 1;
         cg.node_outputs["n" + std::to_string(n.id) + "." + port] = v;
     }
     // a value that is constant over the block per voice: computed in derive()
@@ -495,10 +596,14 @@ void emit_adsr(NodeCtx& x)
         for (int ei : ev->second)
             x.cg.ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
     x.set_out("output", "og::adsr_tick(" + E + ")");
-    // the non-output half of a stage end is handled once per frame for all envelopes of the voice
-    x.cg.post_zero.push_back(E + ".cnt");
-    x.cg.post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", " << x.su(s_dn)
-              << ");\n";
+    if (x.n.domain == 1) { // oversampled: N ticks per frame, finish a stage end right away
+        x.cg.os() << "        og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", " << x.su(s_dn)
+                   << ");\n";
+    } else { // the non-output half of a stage end is handled once per frame for all envelopes of the voice
+        x.cg.post_zero.push_back(E + ".cnt");
+        x.cg.post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", "
+                  << x.su(s_dn) << ");\n";
+    }
 }
 
 void emit_fm_operator(NodeCtx& x)
@@ -515,7 +620,7 @@ void emit_fm_operator(NodeCtx& x)
         inc = x.hoist("inc", inc_expr);
     } else {
         inc = x.p + "inc";
-        x.cg.tick << "        const float " << inc << " = " << inc_expr << ";\n";
+        x.cg.os() << "        const float " << inc << " = " << inc_expr << ";\n";
     }
     // unconnected feedback (0.0) contributes prev*0 + pm = pm for every finite prev: drop the two ops
     const bool no_fb = fb.rate == Rate::Const && !x.connected("feedback") && x.def("feedback") == 0.0f;
@@ -553,11 +658,11 @@ void emit_tpt(NodeCtx& x)
     std::string kk = x.state_f("k", [coef](const UEnv& e) { return coef(e, 2); });
     const bool nomod = (fmod.rate == Rate::Const) && !x.connected("f_mod") && x.def("f_mod") == 0.0f;
     if (nomod)
-        x.cg.tick << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << x.sf(s_maxc) << ", "
+        x.cg.os() << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << x.sf(s_maxc) << ", "
                   << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", " << cq
                   << ", " << h << ", " << g << ", " << kk << ");\n";
     else
-        x.cg.tick << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << x.sf(s_maxc)
+        x.cg.os() << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << x.sf(s_maxc)
                   << ", " << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", "
                   << cq << ", " << h << ", " << g << ", " << kk << ");\n";
     x.set_out("output", "og::tpt_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + h + ", " + g + ", " + kk + ")");
@@ -591,7 +696,7 @@ void emit_crossfade(NodeCtx& x)
 {
     Val in = x.in("input"), mix = x.in("mix");
     std::string m = x.p + "mix";
-    x.cg.tick << "        const float " << m << " = og::clamp01(" << mix.e << ");\n";
+    x.cg.os() << "        const float " << m << " = og::clamp01(" << mix.e << ");\n";
     x.set_out("output_a", in.e + " * (1.0f - " + m + ")");
     x.set_out("output_b", in.e + " * " + m);
 }
@@ -678,8 +783,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         if (it == registry().end()) fail("unknown node type '" + nd.type + "' (node '" + nd.name + "')");
         if (nd.args.size() != it->second.nargs)
             fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(it->second.nargs) + " arguments");
-        if (nd.rate_factor != 1)
-            fail("node '" + nd.name + "': oversampled (`* N`) nodes are not supported by this version");
+        if (nd.rate_factor != 1) { // `* N`, N in {2,4,8} (parse.rs:460-488)
+            if (nd.rate_factor != 2 && nd.rate_factor != 4 && nd.rate_factor != 8)
+                fail("node '" + nd.name + "': oversampling factor must be 1, 2, 4 or 8");
+            if (cg.N != 1 && cg.N != (int)nd.rate_factor)
+                fail("all oversampled nodes of a graph must share one factor in this version (node '" + nd.name + "')");
+            cg.N = (int)nd.rate_factor;
+        }
         cg.node_by_name[nd.name] = (int)i;
         cg.nodes[i].decl = &nd;
         cg.nodes[i].type = &it->second;
@@ -734,7 +844,6 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             auto oit = cg.output_by_name.find(dn);
             if (oit == cg.output_by_name.end()) fail("unknown destination '" + e.dst + "'");
             if (src_is_event_input) fail("event outputs are not supported ('" + e.dst + "')");
-            if (!e.policy.empty()) fail("cross-rate policies need oversampled nodes, unsupported in this version");
             out_edges[oit->second].push_back({src, e.policy});
             out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
             continue;
@@ -746,14 +855,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         for (const auto& p : dst.type->inputs)
             if (dp == p.name) ps = &p;
         if (!ps) fail("node '" + dn + "' (" + dst.decl->type + ") has no input '" + dp + "'");
-        if (!e.policy.empty()) fail("cross-rate policies need oversampled nodes, unsupported in this version");
         if (ps->kind == Kind::Event) {
             if (!src_is_event_input || src->t != Expr::Ref)
                 fail("event input '" + e.dst + "' must be fed by a graph event input");
             dst.ev_edges[dp].push_back(src_event_input);
         } else {
             if (src_is_event_input) fail("event source '" + e.src + "' cannot feed '" + e.dst + "'");
-            dst.in_edges[dp].push_back(src);
+            dst.in_edges[dp].push_back({src, e.policy});
             deps[nit->second].insert(src_nodes.begin(), src_nodes.end());
         }
     }
@@ -805,17 +913,40 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             fail("graph contains a non-feedback cycle (feedback edges are not supported by this version)");
     }
 
-    // ---- emit nodes ----------------------------------------------------------------
+    // ---- rate domains (emit_frame.rs:183-215; taint analysis emit_node.rs:516-584) ------------
+    // 1 = oversampled inner loop; outer nodes downstream of an inner node run after the loop (2)
     for (int ni : order) {
         NodeInst& n = cg.nodes[ni];
-        NodeCtx x{cg, n, "n" + std::to_string(n.id) + "_"};
-        cg.tick << "        // " << n.decl->name << " = " << n.decl->type << "\n";
-        n.type->emit(x);
-        out.node_order.push_back(n.decl->name);
+        if (n.decl->rate_factor > 1) {
+            n.domain = 1;
+            for (int d : deps[ni])
+                if (cg.nodes[d].domain == 2)
+                    fail("oversampled node '" + n.decl->name + "' depends on '" + cg.nodes[d].decl->name +
+                         "', which itself depends on the oversampled region");
+        } else {
+            n.domain = 0;
+            for (int d : deps[ni])
+                if (cg.nodes[d].domain >= 1) n.domain = 2;
+        }
     }
 
-    // ---- graph output -----------------------------------------------------------------
+    // ---- emit nodes: outer (pre), inner, outer (post), each in topological order -------------
+    for (int dom = 0; dom < 3; ++dom) {
+        cg.cur = dom == 0 ? &cg.s_pre : (dom == 1 ? &cg.s_inner : &cg.s_post);
+        for (int ni : order) {
+            NodeInst& n = cg.nodes[ni];
+            if (n.domain != dom) continue;
+            NodeCtx x{cg, n, "n" + std::to_string(n.id) + "_"};
+            cg.os() << "        // " << n.decl->name << " = " << n.decl->type
+                     << (dom == 1 ? " * " + std::to_string(cg.N) : std::string()) << "\n";
+            n.type->emit(x);
+            out.node_order.push_back(n.decl->name);
+        }
+    }
+
+    // ---- graph output (outer rate) ---------------------------------------------------------
     std::string bus_expr = "0.0f";
+    cg.cur = &cg.s_post;
     {
         int n_stream = 0;
         for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
@@ -825,13 +956,23 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             if (++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
             std::string acc;
             for (size_t k = 0; k < it->second.size(); ++k) {
-                Val v = cg.eval(it->second[k].src);
+                if (it->second.size() > 1 && !it->second[k].policy.empty())
+                    fail("fan-in summing supports only same-rate sources (graph output)");
+                Val v = cg.cross(cg.eval(it->second[k].src), it->second[k].policy, false, false);
+                if (it->second.size() > 1 && v.inner) fail("fan-in summing supports only same-rate sources (graph output)");
                 acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
             }
-            cg.tick << "        const float g_out = " << acc << ";\n";
+            cg.os() << "        const float g_out = " << acc << ";\n";
             bus_expr = "g_out";
         }
     }
+    std::ostringstream tick_all;
+    tick_all << cg.s_pre.str() << cg.s_up.str();
+    if (cg.N > 1) {
+        tick_all << "#pragma unroll\n        for (int j = 0; j < " << cg.N << "; ++j) { // oversampled inner loop\n"
+                 << cg.s_inner.str() << cg.s_cap.str() << "        }\n";
+    }
+    tick_all << cg.s_down.str() << cg.s_post.str();
 
     if (out.n_slots > 160) fail("graph needs more than 160 uniform slots");
 
@@ -847,7 +988,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     body << "    auto derive = [&]() {\n" << cg.derive.str() << "    };\n";
     body << cg.pre.str() << "    derive();\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
-    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << cg.tick.str();
+    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << tick_all.str();
     if (!cg.post_zero.empty()) {
         std::string m = cg.post_zero[0];
         for (size_t i = 1; i < cg.post_zero.size(); ++i) m = "min(" + m + ", " + cg.post_zero[i] + ")";

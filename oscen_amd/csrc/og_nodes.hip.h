@@ -380,32 +380,180 @@ OG_DEV float oscillator_tick(float& phase, float frequency_in, float frequency_m
 OG_DEV float hardclip(float in) { return clampf(in * 1.5f, -0.7f, 0.7f); }
 
 // ---------------------------------------------------------------------------
-// SincDownFir / Halfband2xDownStage  oscen-lib/src/resample/sinc_fir.rs:96-144
-// The 24-slot ring is kept unrotated in registers: `h[0]` is always the
-// newest sample (x[2m+1]); a push shifts by two.  `at(d)` of the reference
-// (x[2m-d]) is h[d+1].  Same taps, same summation order.
+// Cross-rate kernels  oscen-lib/src/resample/{sinc_fir,halfband_iir,linear,latch}.rs
+// Histories are kept UNROTATED in registers: index 0 is always the newest
+// sample, a push shifts the array (the reference's ring + head gives the same
+// taps: its at(d) is h[d] for the up stage and h[d+1] for the down stage).
+// Same taps, same summation order, bit-identical results.
 // ---------------------------------------------------------------------------
-struct HbDown {
-    float h[24];
+template <int N>
+struct Log2 {
+    static constexpr int v = (N >= 8) ? 3 : (N >= 4) ? 2 : (N >= 2) ? 1 : 0;
 };
 
-OG_DEV float hb_down_step(HbDown& s, float x0, float x1)
+// Halfband2xDownStage::step  sinc_fir.rs:115-138 (taps coeffs.rs:17-27)
+OG_DEV float hb_down_step(float (&h)[24], float x0, float x1)
 {
     const float HALF[6] = {-3.8558514e-5f, 1.2218465e-3f, -7.2854808e-3f,
                            2.6409210e-2f,  -7.8128843e-2f, 3.0782697e-1f};
     const float CENTER = 0.4999897f;
 #pragma unroll
-    for (int i = 23; i >= 2; --i) s.h[i] = s.h[i - 2];
-    s.h[1] = x0;
-    s.h[0] = x1;
-    float acc = s.h[11 + 1] * CENTER;
+    for (int i = 23; i >= 2; --i) h[i] = h[i - 2];
+    h[1] = x0;
+    h[0] = x1;
+    float acc = h[11 + 1] * CENTER;
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
-        const float left = s.h[2 * kk + 1];
-        const float right = s.h[22 - 2 * kk + 1];
+        const float left = h[2 * kk + 1];
+        const float right = h[22 - 2 * kk + 1];
         acc = acc + (left + right) * HALF[kk];
     }
     return acc;
+}
+
+// SincDownFir<N>::downsample  sinc_fir.rs:232-247
+template <int N>
+OG_DEV float sinc_down(float (&h)[Log2<N>::v][24], const float (&xs)[N])
+{
+    float buf[8];
+#pragma unroll
+    for (int i = 0; i < N; ++i) buf[i] = xs[i];
+    int len = N;
+#pragma unroll
+    for (int s = 0; s < Log2<N>::v; ++s) {
+        const int half = len / 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < half) buf[i] = hb_down_step(h[s], buf[2 * i], buf[2 * i + 1]);
+        len = half;
+    }
+    return buf[0];
+}
+
+// Halfband2xUpStage::step  sinc_fir.rs:50-76
+OG_DEV void hb_up_step(float (&h)[12], float x, float& y0, float& y1)
+{
+    const float HALF[6] = {-3.8558514e-5f, 1.2218465e-3f, -7.2854808e-3f,
+                           2.6409210e-2f,  -7.8128843e-2f, 3.0782697e-1f};
+    const float CENTER2 = 2.0f * 0.4999897f;
+#pragma unroll
+    for (int i = 11; i >= 1; --i) h[i] = h[i - 1];
+    h[0] = x;
+    y1 = h[5] * CENTER2;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) acc = acc + (h[kk] + h[11 - kk]) * HALF[kk];
+    y0 = acc * 2.0f;
+}
+
+// SincUpFir<N>::upsample  sinc_fir.rs:170-190
+template <int N>
+OG_DEV void sinc_up(float (&h)[Log2<N>::v][12], float x, float (&out)[N])
+{
+    float buf[8], next[8];
+    buf[0] = x;
+    int len = 1;
+#pragma unroll
+    for (int s = 0; s < Log2<N>::v; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < len) hb_up_step(h[s], buf[i], next[2 * i], next[2 * i + 1]);
+        len *= 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < len) buf[i] = next[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = buf[i];
+}
+
+// IirHalfband2x  halfband_iir.rs:30-136; state per stage: a0{x,y} a1{x,y} b0{x,y} b1{x,y} prev_odd_in
+OG_DEV float flush_denormal(float x) { return (fabsf(x) < 1e-15f) ? 0.0f : x; }
+OG_DEV float allpass1_step(float a, float& xp, float& yp, float x)
+{
+    const float y = (x - yp) * a + xp;
+    xp = flush_denormal(x);
+    yp = flush_denormal(y);
+    return y;
+}
+OG_DEV void iir_step_up(float (&st)[9], float x, float& y0, float& y1)
+{
+    float a = allpass1_step(0.1355741f, st[0], st[1], x);
+    a = allpass1_step(0.6975849f, st[2], st[3], a);
+    float b = allpass1_step(0.4253804f, st[4], st[5], x);
+    b = allpass1_step(0.9055601f, st[6], st[7], b);
+    y0 = a;
+    y1 = b;
+}
+OG_DEV float iir_step_down(float (&st)[9], float x0, float x1)
+{
+    float a = allpass1_step(0.1355741f, st[0], st[1], x0);
+    a = allpass1_step(0.6975849f, st[2], st[3], a);
+    float b = allpass1_step(0.4253804f, st[4], st[5], st[8]);
+    b = allpass1_step(0.9055601f, st[6], st[7], b);
+    st[8] = x1;
+    return (a + b) * 0.5f;
+}
+template <int N>
+OG_DEV void iir_up(float (&st)[Log2<N>::v][9], float x, float (&out)[N])
+{
+    float buf[8], next[8];
+    buf[0] = x;
+    int len = 1;
+#pragma unroll
+    for (int s = 0; s < Log2<N>::v; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < len) iir_step_up(st[s], buf[i], next[2 * i], next[2 * i + 1]);
+        len *= 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < len) buf[i] = next[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = buf[i];
+}
+template <int N>
+OG_DEV float iir_down(float (&st)[Log2<N>::v][9], const float (&xs)[N])
+{
+    float buf[8];
+#pragma unroll
+    for (int i = 0; i < N; ++i) buf[i] = xs[i];
+    int len = N;
+#pragma unroll
+    for (int s = 0; s < Log2<N>::v; ++s) {
+        const int half = len / 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < half) buf[i] = iir_step_down(st[s], buf[2 * i], buf[2 * i + 1]);
+        len = half;
+    }
+    return buf[0];
+}
+
+// LinearUp / LinearDown  linear.rs:26-35, 62-69;  LatchUp / LatchDown  latch.rs
+template <int N>
+OG_DEV void linear_up(float& prev, float x, float (&out)[N])
+{
+    const float n_inv = 1.0f / (float)N;
+    const float delta = x - prev;
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = prev + delta * ((float)i * n_inv);
+    prev = x;
+}
+template <int N>
+OG_DEV float linear_down(const float (&xs)[N])
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc = acc + xs[i];
+    return acc * (1.0f / (float)N);
+}
+template <int N>
+OG_DEV void latch_up(float x, float (&out)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = x;
 }
 
 } // namespace og

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_generated_sources_are_committed_and_current(lib):
     # csrc/gen/*.hip must be exactly what the graph compiler emits today
-    for name in ("fm_voice", "sub_voice"):
+    for name in ("fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice"):
         src = oscen_amd.Graph(builtin=name).kernel_source()
         path = os.path.join(ROOT, "oscen_amd", "csrc", "gen", name + ".hip")
         assert open(path).read() == src
@@ -135,3 +135,26 @@ def test_unregistered_graph_compiles_with_hiprtc_for_gfx950(lib):
         g.connect("filter.output", "out")
     size = _simple(extra).jit_check("gfx950")
     assert size > 4096
+
+
+def test_multirate_lowering(lib):
+    src = oscen_amd.Graph(builtin="sat4x_voice").kernel_source()
+    assert "for (int j = 0; j < 4; ++j)" in src and "og::sinc_down<4>" in src
+    assert "polyblep_tick<1u>" in src.split("for (int j")[1].split("sinc_down")[0]  # osc runs inside the x4 loop
+    # an oversampled node may not depend on an outer node that is downstream of the oversampled region
+    g = oscen_amd.Graph("bad_rates")
+    g.output_stream("out")
+    g.node("a", "PolyBlepOscillator::saw", 100.0, 0.5, rate=4)
+    g.node("b", "Gain::new", 1.0)
+    g.node("c", "HardClip::new", rate=4)
+    g.connect("a.output", "b.input").connect("b.output", "c.input").connect("c.output", "out")
+    with pytest.raises(oscen_amd.OscenError) as e:
+        g.kernel_source()
+    assert "depends on the oversampled region" in str(e.value)
+    g = oscen_amd.Graph("two_factors")
+    g.output_stream("out")
+    g.node("a", "PolyBlepOscillator::saw", 100.0, 0.5, rate=4)
+    g.node("c", "HardClip::new", rate=2)
+    g.connect("a.output", "c.input").connect("c.output", "out")
+    with pytest.raises(oscen_amd.OscenError):
+        g.kernel_source()
