@@ -59,3 +59,139 @@ def test_custom_graph_is_jit_compiled_and_matches_oracle_nodes():
                 ref[v, i] = f.output[0]
         worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
     assert worst <= 1e-5, worst
+
+
+def _run_nodes(engine_graph, per_voice_setup, ref_fn, n=24, frames=256, blocks=3, sr=48000.0):
+    eng = oscen_amd.Engine(engine_graph, n, sample_rate=sr)
+    per_voice_setup(eng)
+    eng.set_voice_taps(list(range(n)))
+    got = []
+    for _ in range(blocks):
+        eng.process_block(frames)
+        got.append(eng.read_voice_taps(frames))
+    got = np.concatenate(got, axis=1)
+    ref = np.stack([ref_fn(v, frames * blocks) for v in range(n)])
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))), ref
+
+
+@pytest.mark.parametrize("wave,ctor", [(ol.PB_SQUARE, "square"), (ol.PB_TRIANGLE, "triangle"),
+                                       (ol.PB_SAW, "saw"), (ol.PB_SINE, "sine")])
+def test_polyblep_waveforms(wave, ctor):
+    # PolyBlepOscillator (oscillators/mod.rs:88-233): all four waveforms, incl. the >= sr/4 sine fallback
+    import ctypes as C
+    lib = ol.load()
+    n = 24
+    freqs = np.concatenate([np.geomspace(27.5, 11000.0, n - 2), [12000.0, 15000.0]]).astype(np.float32)
+    g = oscen_amd.Graph("pb_" + ctor)
+    g.input_value("frequency", 440.0, per_voice=True)
+    g.input_value("pw", 0.5)
+    g.output_stream("out")
+    g.node("osc", "PolyBlepOscillator::" + ctor, 440.0, 0.8)
+    g.connect("frequency", "osc.frequency").connect("pw", "osc.pulse_width").connect("osc.output", "out")
+
+    def setup(eng):
+        eng.set_voice_values("frequency", freqs)
+        eng.set_value("pw", 0.3)
+
+    def ref(v, total):
+        o = ol.PolyBlep()
+        lib.oo_polyblep_new(C.byref(o), 440.0, 0.8, wave)
+        o.sample_rate = 48000.0
+        o.frequency = float(freqs[v])
+        o.pulse_width = 0.3
+        out = np.zeros(total, dtype=np.float32)
+        for i in range(total):
+            lib.oo_polyblep_process(C.byref(o))
+            out[i] = o.output
+        return out
+
+    worst, r = _run_nodes(g, setup, ref, n=n)
+    assert np.max(np.abs(r)) > 0.5
+    assert worst <= 1e-5, worst
+
+
+def test_static_simple_graph_shape():
+    # benches/static_vs_runtime.rs:5-18 with an explicit output: Oscillator::sine -> TptFilter -> Gain
+    import ctypes as C
+    lib = ol.load()
+    n = 16
+    freqs = np.geomspace(55.0, 7040.0, n).astype(np.float32)
+    for wave, ctor in ((ol.WAVE_SINE, "sine"), (ol.WAVE_SQUARE, "square"), (ol.WAVE_SAW, "saw")):
+        g = oscen_amd.Graph("static_simple_" + ctor)
+        g.input_value("frequency", 440.0, per_voice=True)
+        g.output_stream("out")
+        g.node("osc", "Oscillator::" + ctor, 440.0, 1.0)
+        g.node("filter", "TptFilter::new", 1000.0, 0.7)
+        g.node("gain", "Gain::new", 0.5)
+        g.connect("frequency", "osc.frequency").connect("osc.output", "filter.input")
+        g.connect("filter.output", "gain.input").connect("gain.output", "out")
+
+        def ref(v, total):
+            s = ol.StaticSimple()
+            lib.oo_static_simple_new(C.byref(s))
+            s.osc.waveform = wave
+            lib.oo_static_simple_init(C.byref(s), 44100.0)
+            s.osc.frequency = float(freqs[v])
+            out = np.zeros(total, dtype=np.float32)
+            for i in range(total):
+                lib.oo_static_simple_process(C.byref(s))
+                out[i] = s.gain.output
+            return out
+
+        worst, r = _run_nodes(g, lambda e: e.set_voice_values("frequency", freqs), ref, n=n, sr=44100.0, blocks=2)
+        assert worst <= 1e-5, (ctor, worst)
+
+
+def test_static_complex_graph_shape():
+    # benches/static_vs_runtime.rs:21-66 (wired path osc1->mix1->mixer->filter->vca, env -> f_mod), gated here
+    import ctypes as C
+    lib = ol.load()
+    n = 16
+    g = oscen_amd.Graph("static_complex")
+    g.input_event("gate")
+    g.output_stream("out")
+    g.node("osc1", "PolyBlepOscillator::saw", 440.0, 0.33)
+    g.node("mix1", "Gain::new", 1.0)
+    g.node("mixer", "Gain::new", 1.0)
+    g.node("filter_env", "AdsrEnvelope::new", 0.01, 0.3, 0.5, 0.2)
+    g.node("env_amount", "Gain::new", 2000.0)
+    g.node("filter", "TptFilter::new", 800.0, 0.7)
+    g.node("amp_env", "AdsrEnvelope::new", 0.01, 0.2, 0.7, 0.3)
+    g.node("vca", "Gain::new", 1.0)
+    for s, d in [("gate", "filter_env.gate"), ("gate", "amp_env.gate"), ("osc1.output", "mix1.input"),
+                 ("mix1.output", "mixer.input"), ("mixer.output", "filter.input"),
+                 ("filter_env.output", "env_amount.input"), ("env_amount.output", "filter.f_mod"),
+                 ("filter.output", "vca.input"), ("amp_env.output", "vca.gain"), ("vca.output", "out")]:
+        g.connect(s, d)
+    eng = oscen_amd.Engine(g, n, sample_rate=44100.0)
+    eng.set_voice_taps(list(range(n)))
+    refs = []
+    for v in range(n):
+        c = ol.StaticComplex()
+        lib.oo_static_complex_new(C.byref(c))
+        lib.oo_static_complex_init(C.byref(c), 44100.0)
+        refs.append(c)
+    worst = 0.0
+    for b in range(4):
+        frames = 256
+        gates = {}
+        if b == 0:
+            gates = {v: (v * 3, 0.5 + 0.03 * v) for v in range(n)}
+        if b == 2:
+            gates = {v: (100 + v, 0.0) for v in range(n)}
+        for v, (fr, val) in gates.items():
+            eng.push_voice_event("gate", v, fr, val)
+        eng.process_block(frames)
+        got = eng.read_voice_taps(frames)
+        ref = np.zeros((n, frames), dtype=np.float32)
+        for v in range(n):
+            c = refs[v]
+            for i in range(frames):
+                if v in gates and gates[v][0] == i:
+                    ev = ol.Event(i, gates[v][1], 0)
+                    lib.oo_adsr_handle_gate_event(C.byref(c.filter_env), C.byref(ev))
+                    lib.oo_adsr_handle_gate_event(C.byref(c.amp_env), C.byref(ev))
+                lib.oo_static_complex_process(C.byref(c))
+                ref[v, i] = c.vca.output
+        worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+    assert worst <= 1e-5, worst
