@@ -62,6 +62,13 @@ int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float defau
 int og_graph_add_output(og_graph_desc* g, const char* name, int kind);
 int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
                       uint32_t n_args, uint32_t rate_factor);
+/* A node of the poly WRAPPER graph that runs once on the summed voices (e.g.
+ * `tremolo = Tremolo::new()` with `voices.output -> tremolo.input; tremolo.output -> out`,
+ * examples/electric-piano/src/main.rs:56,88-96).  Wire it with og_graph_connect:
+ * "<voice output name>" -> "node.input", value inputs -> "node.rate"/"node.depth",
+ * "node.output" -> "<second graph output>" (Frame<2>: the engine then has 2 channels). */
+int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
+                          uint32_t n_args);
 int og_graph_connect(og_graph_desc* g, const char* src_expr, const char* dst, const char* policy);
 void og_graph_free(og_graph_desc* g);
 /* The HIP source of the fused voice kernel this description lowers to (for

@@ -158,9 +158,45 @@ GraphDesc sat_voice(uint32_t factor)
     return g;
 }
 
+// ElectricPianoVoiceNode (examples/electric-piano/src/electric_piano_voice.rs:362-402) inside the
+// ElectricPianoGraph wrapper (examples/electric-piano/src/main.rs:33-97): per-voice frequency/gate,
+// six broadcast voice parameters, `voices.output -> tremolo.input` (sum), Tremolo -> Frame<2> out.
+GraphDesc epiano_voice()
+{
+    GraphDesc g;
+    g.name = "epiano_voice";
+    g.inputs.push_back(voice_in("frequency", 440.0f));
+    g.inputs.push_back(event_in("gate"));
+    const char* prm[6] = {"brightness", "velocity_scaling", "decay_rate", "harmonic_decay", "key_scaling", "release_rate"};
+    const float def[6] = {30.0f, 50.0f, 90.0f, 70.0f, 50.0f, 40.0f};
+    for (int i = 0; i < 6; ++i) g.inputs.push_back(value_in(prm[i], def[i]));
+    g.inputs.push_back(value_in("vibrato_intensity", 0.3f));
+    g.inputs.push_back(value_in("vibrato_speed", 5.0f));
+    g.outputs.push_back({"output", Kind::Stream});
+    g.outputs.push_back({"out", Kind::Stream});
+    g.nodes.push_back({"amplitude_source", "AmplitudeSource::new", {}, 1});
+    g.nodes.push_back({"oscillator_bank", "OscillatorBank::new", {}, 1});
+    GNode trem{"tremolo", "Tremolo::new", {}, 1};
+    trem.bus = true;
+    g.nodes.push_back(trem);
+    auto c = [&](const std::string& s, const std::string& d) { g.edges.push_back({s, d, ""}); };
+    c("frequency", "amplitude_source.frequency");
+    c("gate", "amplitude_source.gate");
+    for (int i = 0; i < 6; ++i) c(prm[i], std::string("amplitude_source.") + prm[i]);
+    c("frequency", "oscillator_bank.frequency");
+    c("gate", "oscillator_bank.gate");
+    c("amplitude_source.amplitudes", "oscillator_bank.amplitudes");
+    c("oscillator_bank.output", "output");
+    c("output", "tremolo.input");
+    c("vibrato_intensity", "tremolo.depth");
+    c("vibrato_speed", "tremolo.rate");
+    c("tremolo.output", "out");
+    return g;
+}
+
 } // namespace
 
-std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice"}; }
+std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice", "epiano_voice"}; }
 
 GraphDesc builtin_graph(const std::string& name)
 {
@@ -168,6 +204,7 @@ GraphDesc builtin_graph(const std::string& name)
     if (name == "sub_voice") return sub_voice();
     if (name == "sat4x_voice") return sat_voice(4);
     if (name == "sat1x_voice") return sat_voice(1);
+    if (name == "epiano_voice") return epiano_voice();
     throw std::runtime_error("unknown builtin graph '" + name + "'");
 }
 

@@ -21,6 +21,7 @@
 #include "../../include/oscen_gpu.h"
 #include "og_graph.h"
 #include "og_jit.h"
+#include "og_math.h"
 #include "og_registry.h"
 
 // Sum the per-workgroup partial rows (fixed association, no atomics).
@@ -53,6 +54,35 @@ __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < OG_RED_SLICES; ++i) s += part[i][fx];
         bus[f] = s;
+    }
+}
+
+// Post-mix Tremolo (examples/electric-piano/src/tremolo.rs:40-62) on the summed bus -> Frame<2>.
+// The LFO phase recurrence `phase = fract(phase + rate/sr)` is serial but two ops per frame: lane 0
+// runs it into LDS, then every frame computes its sine (bit-exact libm restatement) in parallel.
+__global__ __launch_bounds__(512) void og_bus_tremolo(const float* __restrict__ mono, uint32_t frames, float rate,
+                                                      float depth, float sr, float* __restrict__ phase_state,
+                                                      float* __restrict__ out)
+{
+    __shared__ float ph[OG_MAX_BLOCK];
+    if (threadIdx.x == 0) {
+        float p = *phase_state;
+        const float phase_increment = rate / sr;
+        for (uint32_t f = 0; f < frames; ++f) {
+            ph[f] = p;
+            const float q = p + phase_increment;
+            p = q - truncf(q);
+        }
+        *phase_state = p;
+    }
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < frames; f += blockDim.x) {
+        const float input = mono[f];
+        const float lfo = og_sinf_exact(ph[f] * 2.0f * 3.14159274101257324f);
+        const float scaled_depth = depth / 3.0f;
+        const float pan = 0.5f + lfo * scaled_depth;
+        out[2 * f] = input * pan;
+        out[2 * f + 1] = input * (1.0f - pan);
     }
 }
 
@@ -160,6 +190,9 @@ struct og_engine {
     uint32_t n_wg = 0;
     uint32_t lanes = OG_WAVE;
     uint32_t* d_state = nullptr;
+    uint32_t* d_lane_state = nullptr;
+    float* d_mono = nullptr;      // summed voices before the post-mix stage
+    float* d_bus_phase = nullptr; // Tremolo.phase
     OgEvent* d_events = nullptr;
     size_t ev_cap = 0;
     uint32_t* d_ev_end = nullptr;
@@ -191,6 +224,9 @@ struct og_engine {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         hipFree(d_state);
+        hipFree(d_lane_state);
+        hipFree(d_mono);
+        hipFree(d_bus_phase);
         hipFree(d_events);
         hipFree(d_ev_end);
         hipFree(d_ev_cursor);
@@ -220,6 +256,15 @@ struct og_engine {
             std::fill(img.begin() + w * V, img.begin() + (w + 1) * V, bits);
         }
         HIPCK(hipMemcpyAsync(d_state, img.data(), img.size() * 4, hipMemcpyHostToDevice, stream));
+        std::vector<uint32_t> limg;
+        if (!cg->lane_state.empty()) {
+            const size_t per = (size_t)V * cg->lpv;
+            limg.resize(cg->lane_state.size() * per);
+            for (size_t k = 0; k < cg->lane_state.size(); ++k)
+                std::fill(limg.begin() + k * per, limg.begin() + (k + 1) * per, cg->lane_state[k].init(e));
+            HIPCK(hipMemcpyAsync(d_lane_state, limg.data(), limg.size() * 4, hipMemcpyHostToDevice, stream));
+        }
+        if (d_bus_phase) HIPCK(hipMemsetAsync(d_bus_phase, 0, 4, stream));
         HIPCK(hipStreamSynchronize(stream));
     }
 
@@ -283,6 +328,7 @@ struct og_engine {
         A.lanes = lanes;
         A.frame0 = frame_now;
         A.state = d_state;
+        A.lane_state = d_lane_state;
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
@@ -338,9 +384,16 @@ struct og_engine {
         }
         HIPCK(hipGetLastError());
         float* bus = d_out ? d_out : d_bus;
+        float* sum_dst = cg->bus_tremolo ? d_mono : bus;
         hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64), dim3(1024), 0, stream, d_partials, n_wg, frames,
-                           bus);
+                           sum_dst);
         HIPCK(hipGetLastError());
+        if (cg->bus_tremolo) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
+            ogc::UEnv e = env();
+            hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, d_mono, frames, cg->tremolo_rate(e),
+                               cg->tremolo_depth(e), sr, d_bus_phase, bus);
+            HIPCK(hipGetLastError());
+        }
         frame_now += frames;
         last_frames = frames;
     }
@@ -470,6 +523,13 @@ int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor,
     return (int)g->g.nodes.size() - 1;
 }
 
+int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args)
+{
+    int rc = og_graph_add_node(g, name, type_ctor, args, n_args, 1);
+    if (rc >= 0) g->g.nodes.back().bus = true;
+    return rc;
+}
+
 int og_graph_connect(og_graph_desc* g, const char* src, const char* dst, const char* policy)
 {
     if (!g || !src || !dst) return set_err(OG_E_INVALID, "null argument");
@@ -540,7 +600,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             }
             e->lanes = lanes;
         }
-        e->n_wg = (n_voices + e->lanes - 1) / e->lanes;
+        e->n_wg = (uint32_t)(((size_t)n_voices * e->cg->lpv + e->lanes - 1) / e->lanes);
         HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
         const auto& cg = *e->cg;
@@ -552,6 +612,12 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             e->ramps[i].default_frames = cg.inputs[i].decl.ramp_frames;
         }
         HIPCK(hipMalloc(&e->d_state, std::max<size_t>(1, cg.state.size()) * (size_t)n_voices * 4));
+        if (!cg.lane_state.empty())
+            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * 4));
+        if (cg.bus_tremolo) {
+            HIPCK(hipMalloc(&e->d_mono, (size_t)OG_MAX_BLOCK * 4));
+            HIPCK(hipMalloc(&e->d_bus_phase, 4));
+        }
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
@@ -805,7 +871,10 @@ uint32_t og_channels(const og_engine* e) { return e ? e->cg->channels : 0; }
 uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }
-uint32_t og_state_words_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->state.size() : 0; }
+uint32_t og_state_words_per_voice(const og_engine* e)
+{
+    return e ? (uint32_t)(e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) : 0;
+}
 uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes : 0; }
 uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
 
@@ -833,7 +902,10 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
     return avg;
 }
 
-size_t og_state_bytes(const og_engine* e) { return e ? e->cg->state.size() * (size_t)e->V * 4 : 0; }
+size_t og_state_bytes(const og_engine* e)
+{
+    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) : 0;
+}
 
 int og_save_state(og_engine* e, void* dst, size_t cap)
 {
@@ -841,7 +913,10 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
     if (cap < og_state_bytes(e)) return set_err(OG_E_INVALID, "buffer too small");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
-        HIPCK(hipMemcpyAsync(dst, e->d_state, og_state_bytes(e), hipMemcpyDeviceToHost, e->stream));
+        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * 4;
+        HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
+        if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
+        if (e->d_bus_phase) HIPCK(hipMemcpyAsync((char*)dst + a + b, e->d_bus_phase, 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -853,7 +928,10 @@ int og_load_state(og_engine* e, const void* src, size_t len)
     if (len != og_state_bytes(e)) return set_err(OG_E_INVALID, "state blob size mismatch");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
-        HIPCK(hipMemcpyAsync(e->d_state, src, len, hipMemcpyHostToDevice, e->stream));
+        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * 4;
+        HIPCK(hipMemcpyAsync(e->d_state, src, a, hipMemcpyHostToDevice, e->stream));
+        if (b) HIPCK(hipMemcpyAsync(e->d_lane_state, (const char*)src + a, b, hipMemcpyHostToDevice, e->stream));
+        if (e->d_bus_phase) HIPCK(hipMemcpyAsync(e->d_bus_phase, (const char*)src + a + b, 4, hipMemcpyHostToDevice, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });

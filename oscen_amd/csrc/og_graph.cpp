@@ -67,6 +67,7 @@ struct Val {
     HostFn host;                  // available when rate <= UBlock
     std::set<int> voice_inputs;   // per-voice value inputs this depends on (rate VBlock)
     bool inner = false;           // defined inside the oversampled (x N) inner loop
+    bool lane = false;            // one value per lane of an LPV > 1 voice (an `[f32; 32]` endpoint)
 };
 
 Val vconst(float c)
@@ -228,6 +229,7 @@ struct NodeTypeInfo {
     Emitter emit;
     int variant;
     size_t nargs;
+    int lpv = 1; // lanes per voice this node type needs (32: per-harmonic arrays)
 };
 
 struct NodeInst {
@@ -252,7 +254,7 @@ struct Codegen {
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
 
     // emitted code sections
-    std::ostringstream decl, load, derive, pre, post, store;
+    std::ostringstream decl, load, derive, pre, post, pre_store, store;
     // per-frame code, multirate layout of emit_frame.rs:114-176:
     //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
     std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
@@ -451,6 +453,14 @@ struct NodeCtx {
     }
     bool connected(const std::string& name) const { return n.in_edges.count(name) > 0; }
     // resolved value of a stream/value input: constant default, one source, or the sum of sources
+    bool lane_ok = false;
+    Val in_lane(const std::string& name)
+    {
+        lane_ok = true;
+        Val v = in(name);
+        lane_ok = false;
+        return v;
+    }
     Val in(const std::string& name)
     {
         auto it = n.in_edges.find(name);
@@ -461,6 +471,8 @@ struct NodeCtx {
             for (auto& src : it->second)
                 if (!src.policy.empty()) fail("fan-in summing supports only same-rate sources (input '" + name + "')");
         Val acc = cg.cross(cg.eval(it->second[0].e), it->second[0].policy, dst_inner, value_port);
+        if (acc.lane && !lane_ok)
+            fail("node '" + n.decl->name + "': input '" + name + "' cannot take an array-valued ([f32; 32]) source");
         for (size_t i = 1; i < it->second.size(); ++i) { // connect, then accumulate in edge order
             Val b = cg.eval(it->second[i].e);
             if (b.inner != dst_inner && b.rate == Rate::Vary)
@@ -508,6 +520,17 @@ struct NodeCtx {
         cg.decl << "    float " << var << " = 0.0f;\n";
         cg.load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
         cg.store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
+        return var;
+    }
+    // a word per (voice, lane) of an LPV > 1 graph
+    std::string state_lane_f(const std::string& name, float init)
+    {
+        std::string var = p + name;
+        cg.out.lane_state.push_back({n.decl->name + "." + name + "[h]", true, [init](const UEnv&) { return fbits(init); }});
+        int k = (int)cg.out.lane_state.size() - 1;
+        cg.decl << "    float " << var << " = " << flit(init) << ";\n";
+        cg.load << "        " << var << " = og::ldl_f<LPV>(A, c, " << k << ");\n";
+        cg.store << "        og::stl_f<LPV>(A, c, " << k << ", " << var << ");\n";
         return var;
     }
     std::string state_u(const std::string& name, uint32_t init)
@@ -701,6 +724,52 @@ void emit_crossfade(NodeCtx& x)
     x.set_out("output_b", in.e + " * " + m);
 }
 
+// electric piano (examples/electric-piano/src/electric_piano_voice.rs), one voice = 32 lanes
+void emit_ep_amp(NodeCtx& x)
+{
+    Val br = x.in("brightness"), vs = x.in("velocity_scaling"), dr = x.in("decay_rate"), hd = x.in("harmonic_decay"),
+        ks = x.in("key_scaling"), rr = x.in("release_rate");
+    (void)x.in("frequency"); // routed to the node but never read by its process()
+    const std::string A = x.p + "a";
+    std::string cur = x.state_lane_f("current_value", 0.0f), tgt = x.state_lane_f("target_value", 0.0f),
+                dec = x.state_lane_f("decay", 0.0f), rel = x.state_lane_f("release", 0.0f);
+    std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
+    std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
+    x.cg.decl << "    og::EpAmp " << A << " = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 64u, 0.0f};\n";
+    x.cg.load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", " << released
+              << ", " << step << ", " << vel << "};\n";
+    // stores run before the generic store section reads the mirrors back
+    x.cg.pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
+                   << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
+                   << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
+    auto ev = x.n.ev_edges.find("gate");
+    if (ev != x.n.ev_edges.end())
+        for (int ei : ev->second)
+            x.cg.ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h, ev.value, " << br.e << ", " << vs.e
+                                 << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
+    x.set_out("amplitudes", "og::ep_amp_tick(" + A + ")");
+    x.cg.node_outputs["n" + std::to_string(x.n.id) + ".amplitudes"].lane = true;
+}
+
+void emit_ep_bank(NodeCtx& x)
+{
+    Val fr = x.in("frequency"), amp = x.in_lane("amplitudes");
+    if (!amp.lane) fail("node '" + x.n.decl->name + "': 'amplitudes' needs an array-valued source (AmplitudeSource.amplitudes)");
+    int s_sr = x.sr_slot();
+    const std::string B = x.p + "b";
+    std::string re = x.state_lane_f("osc_re", 1.0f), im = x.state_lane_f("osc_im", 0.0f),
+                mre = x.state_lane_f("mul_re", 1.0f), mim = x.state_lane_f("mul_im", 0.0f);
+    std::string lf = x.state_f("last_frequency", [](const UEnv&) { return 0.0f; });
+    x.cg.decl << "    og::EpBank " << B << " = {1.0f, 0.0f, 1.0f, 0.0f, 0.0f};\n";
+    x.cg.load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << "};\n";
+    x.cg.pre_store << "        " << re << " = " << B << ".re; " << im << " = " << B << ".im; " << mre << " = " << B << ".mre; "
+                   << mim << " = " << B << ".mim; " << lf << " = " << B << ".last_frequency;\n";
+    auto ev = x.n.ev_edges.find("gate");
+    if (ev != x.n.ev_edges.end())
+        for (int ei : ev->second) x.cg.ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
+    x.set_out("output", "og::ep_bank_tick(" + B + ", c.h, " + fr.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
+}
+
 const std::map<std::string, NodeTypeInfo>& registry()
 {
     static const std::map<std::string, NodeTypeInfo> R = [] {
@@ -731,6 +800,15 @@ const std::map<std::string, NodeTypeInfo>& registry()
         r["Mixer::new"] = {{{"input_a", S, 0, -1}, {"input_b", S, 0, -1}}, {"output"}, emit_mixer, 0, 0};
         r["Crossfade::new"] = {{{"input", S, 0, -1}, {"mix", V, 0, -1}}, {"output_a", "output_b"}, emit_crossfade, 0, 0};
         r["HardClip::new"] = {{{"input", S, 0, -1}}, {"output"}, emit_hardclip, 0, 0};
+        r["AmplitudeSource::new"] = {{{"frequency", V, 440.0f, -1}, {"gate", E, 0, -1}, {"brightness", V, 30.0f, -1},
+                                      {"velocity_scaling", V, 50.0f, -1}, {"decay_rate", V, 90.0f, -1},
+                                      {"harmonic_decay", V, 70.0f, -1}, {"key_scaling", V, 50.0f, -1},
+                                      {"release_rate", V, 40.0f, -1}},
+                                     {"amplitudes"}, emit_ep_amp, 0, 0, 32};
+        r["OscillatorBank::new"] = {{{"frequency", V, 440.0f, -1}, {"gate", E, 0, -1}, {"amplitudes", S, 0, -1}},
+                                    {"output"}, emit_ep_bank, 0, 0, 32};
+        // post-mix only (og_graph_add_bus_node): examples/electric-piano/src/tremolo.rs
+        r["Tremolo::new"] = {{{"input", S, 0, -1}, {"rate", V, 5.0f, -1}, {"depth", V, 0.5f, -1}}, {"output"}, nullptr, 0, 0};
         return r;
     }();
     return R;
@@ -794,6 +872,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         cg.nodes[i].decl = &nd;
         cg.nodes[i].type = &it->second;
         cg.nodes[i].id = (int)i;
+        if (nd.bus) {
+            if (nd.type != "Tremolo::new") fail("only Tremolo::new is available as a post-mix (bus) node in this version");
+            if (out.bus_tremolo) fail("only one post-mix (bus) node is supported in this version");
+            out.bus_tremolo = true;
+            out.channels = 2; // Frame<2>
+            out.tremolo_rate = [](const UEnv&) { return 5.0f; };  // Tremolo::new() defaults, tremolo.rs:27-37
+            out.tremolo_depth = [](const UEnv&) { return 0.5f; };
+        } else if (!it->second.emit) {
+            fail("node type '" + nd.type + "' can only be used as a post-mix (bus) node");
+        }
     }
 
     // ---- edges ------------------------------------------------------------------
@@ -804,7 +892,39 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     std::map<int, std::vector<OutEdge>> out_edges; // graph output index -> sources
     std::vector<std::set<int>> deps(g.nodes.size()); // node -> nodes it reads
     std::vector<std::set<int>> out_deps(g.outputs.size());
+    auto bus_node_of = [&](const std::string& endpoint) -> int {
+        std::string nm = endpoint.substr(0, endpoint.find('.'));
+        while (!nm.empty() && isspace((unsigned char)nm.back())) nm.pop_back();
+        while (!nm.empty() && isspace((unsigned char)nm.front())) nm.erase(nm.begin());
+        auto it = cg.node_by_name.find(nm);
+        return (it != cg.node_by_name.end() && g.nodes[it->second].bus) ? it->second : -1;
+    };
+    int bus_src_output = -1, bus_final_output = -1;
     for (const GEdge& e : g.edges) {
+        // ---- post-mix (bus) stage: `voices.output -> tremolo.input; v -> tremolo.depth; tremolo.output -> out`
+        const int bdst = bus_node_of(e.dst), bsrc = bus_node_of(e.src);
+        if (bdst >= 0 || bsrc >= 0) {
+            if (bsrc >= 0) {
+                auto oit = cg.output_by_name.find(e.dst);
+                if (oit == cg.output_by_name.end()) fail("a bus node can only feed a graph output ('" + e.dst + "')");
+                bus_final_output = oit->second;
+                continue;
+            }
+            const std::string port = e.dst.substr(e.dst.find('.') + 1);
+            if (port == "input") {
+                auto oit = cg.output_by_name.find(e.src);
+                if (oit == cg.output_by_name.end())
+                    fail("bus node input must be fed by the voice graph's output name (the summed voices), got '" + e.src + "'");
+                bus_src_output = oit->second;
+            } else if (port == "rate" || port == "depth") {
+                Val v = cg.eval(Parser(e.src).parse());
+                if (!v.host) fail("bus node parameter '" + e.dst + "' must be a block-uniform value");
+                (port == "rate" ? out.tremolo_rate : out.tremolo_depth) = v.host;
+            } else {
+                fail("bus node has no input '" + port + "'");
+            }
+            continue;
+        }
         ExprP src = Parser(e.src).parse();
         std::vector<const Expr*> refs;
         collect_refs(src, refs);
@@ -881,6 +1001,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         for (size_t i = 0; i < g.nodes.size(); ++i) cg.nodes[i].live = live[i];
     }
+    for (size_t i = 0; i < g.nodes.size(); ++i)
+        if (g.nodes[i].bus) cg.nodes[i].live = false;
+    if (out.bus_tremolo && (bus_src_output < 0 || bus_final_output < 0))
+        fail("the post-mix node must be wired `<voice output> -> node.input` and `node.output -> <graph output>`");
+    for (size_t i = 0; i < g.nodes.size(); ++i)
+        if (cg.nodes[i].live) out.lpv = std::max(out.lpv, cg.nodes[i].type->lpv);
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
     std::vector<int> order;
@@ -953,6 +1079,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             if (g.outputs[oi].kind == Kind::Event) fail("event outputs are not supported");
             auto it = out_edges.find((int)oi);
             if (it == out_edges.end()) continue;
+            if ((int)oi == bus_final_output) fail("graph output fed by the post-mix node cannot have other sources");
             if (++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
             std::string acc;
             for (size_t k = 0; k < it->second.size(); ++k) {
@@ -982,7 +1109,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
          << "    __shared__ og::BusLds bus;\n"
          << "    og::VoiceCtx c;\n"
-         << "    og::voice_begin<TAPS>(A, c);\n"
+         << "    og::voice_begin<TAPS, LPV>(A, c);\n"
          << cg.decl.str() << "    if (c.valid) {\n"
          << cg.load.str() << "    }\n";
     body << "    auto derive = [&]() {\n" << cg.derive.str() << "    };\n";
@@ -1035,7 +1162,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"
          << "    }\n";
     body << "    og::bus_flush(A, c, bus);\n"
-         << "    if (c.valid) {\n"
+         << cg.pre_store.str() << "    if (c.valid) {\n"
          << cg.store.str();
     for (size_t i = 0; i < out.inputs.size(); ++i) {
         const InputInfo& in = out.inputs[i];
@@ -1045,20 +1172,23 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     body << "    }\n    og::voice_end(A, c);\n}\n";
 
     const std::string body_s = body.str();
-    out.hash = fnv1a(body_s);
+    out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
 
     std::ostringstream src;
     src << "// GENERATED by oscen_amd/csrc/og_graph.cpp from graph '" << g.name << "' -- do not edit.\n"
         << "// One fused voice kernel: " << out.state.size() << " state words/voice, " << out.n_slots
-        << " uniform slots, " << out.n_ramps << " ramped inputs, " << out.n_event_inputs << " event inputs.\n"
+        << " uniform slots, " << out.n_ramps << " ramped inputs, " << out.n_event_inputs << " event inputs"
+        << (out.lpv > 1 ? ", " + std::to_string(out.lane_state.size()) + " x " + std::to_string(out.lpv) + " lane words/voice" : std::string())
+        << ".\n"
         << "// Node order: ";
     for (auto& nn : out.node_order) src << nn << " ";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
         << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.frames + f] : og::slot_f(A, (slot)))\n\n"
         << "namespace og_gen_" << hs << " {\n"
+        << "constexpr int LPV = " << out.lpv << "; // lanes per voice\n"
         << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n\n";
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
@@ -1067,7 +1197,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
-        << "    const dim3 grid((A.n_voices + A.lanes - 1) / A.lanes), block(OG_WAVE);\n"
+        << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n"
         << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
         << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"
         << "    else if (!ramps && taps) hipLaunchKernelGGL(og_k_" << hs << "_01, grid, block, 0, s, A);\n"

@@ -58,6 +58,7 @@ struct GNode {
     std::string type; // "AdsrEnvelope::new", "PolyBlepOscillator::saw", ...
     std::vector<float> args;
     uint32_t rate_factor = 1; // `* N`
+    bool bus = false;         // post-mix node of the wrapper graph (runs once on the summed bus, e.g. Tremolo)
 };
 struct GEdge {
     std::string src; // endpoint or compound expression: "env.output", "a.x * b.y", "gate"
@@ -95,7 +96,12 @@ struct CompiledGraph {
     std::string source; // complete HIP translation unit for this graph
     uint64_t hash = 0;  // FNV-1a of the kernel body: AOT registry / JIT cache key
     std::vector<InputInfo> inputs;
-    std::vector<StateWord> state;
+    std::vector<StateWord> state;      // per-voice words
+    std::vector<StateWord> lane_state; // per-(voice, lane) words of LPV > 1 graphs
+    int lpv = 1;                       // lanes per voice (32 for the electric-piano voice)
+    // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>
+    bool bus_tremolo = false;
+    HostFn tremolo_rate, tremolo_depth;
     std::vector<UniformProg> uprogs;
     int n_slots = 0;
     int n_ramps = 0;

@@ -75,6 +75,7 @@ std::vector<char> compile_to_code(const ogc::CompiledGraph& cg, const char* arch
 struct JitImpl : OgJitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn[4] = {};
+    unsigned lpv = 1;
     ~JitImpl() override
     {
         if (mod) hipModuleUnload(mod);
@@ -84,7 +85,7 @@ struct JitImpl : OgJitKernel {
         OgBlockArgs a = args;
         size_t sz = sizeof a;
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        const unsigned grid = (a.n_voices + a.lanes - 1) / a.lanes;
+        const unsigned grid = (unsigned)(((size_t)a.n_voices * lpv + a.lanes - 1) / a.lanes);
         hipError_t e = hipModuleLaunchKernel(fn[(ramps ? 1 : 0) + (taps ? 2 : 0)], grid, 1, 1, OG_WAVE, 1, 1, 0, stream,
                                              nullptr, cfg);
         if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));
@@ -106,6 +107,7 @@ std::unique_ptr<OgJitKernel> og_jit_compile(const ogc::CompiledGraph& cg)
     if (colon != std::string::npos) arch = arch.substr(0, colon);
     std::vector<char> code = compile_to_code(cg, arch.c_str());
     std::unique_ptr<JitImpl> k(new JitImpl);
+    k->lpv = (unsigned)cg.lpv;
     if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess) throw std::runtime_error("oscen jit: hipModuleLoadData failed");
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)cg.hash);

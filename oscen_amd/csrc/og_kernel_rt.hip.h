@@ -59,6 +59,7 @@ struct OgBlockArgs {
     uint32_t pad0;
     uint64_t frame0;
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
+    uint32_t* lane_state;      // [n_lane_words][n_voices][LPV]: words of voices that span LPV lanes
     const OgEvent* events;     // sorted by (voice, frame, push order)
     const uint32_t* ev_end;    // [n_voices] one past the voice's last event
     uint32_t* ev_cursor;       // [n_voices] next unconsumed event
@@ -82,6 +83,8 @@ __device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
 struct VoiceCtx {
     uint32_t v;     // voice index
     bool valid;     // v < n_voices
+    bool lead;      // first lane of the voice (the only one that reports / stores per-voice things)
+    uint32_t h;     // lane within the voice: 0 for ordinary graphs, the harmonic for LPV = 32 graphs
     uint32_t lane;
     // events
     uint32_t ev_cur, ev_cur0, ev_end;
@@ -97,11 +100,17 @@ __device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t 
     return (rel < (uint64_t)a.frames) ? (uint32_t)rel : OG_NO_EVENT;
 }
 
-template <bool TAPS>
+// LPV = lanes per voice: 1 for ordinary graphs (64 voices per wave).  Graphs whose nodes carry
+// per-harmonic arrays (the electric-piano voice: 32 partials, ~260 state words) spread one voice
+// over 32 lanes instead of 260 VGPRs: lane h owns harmonic h, per-voice scalars are replicated.
+template <bool TAPS, int LPV = 1>
 __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.lane = threadIdx.x;
-    c.v = blockIdx.x * a.lanes + threadIdx.x;
+    const uint32_t gl = blockIdx.x * a.lanes + threadIdx.x;
+    c.v = gl / LPV;
+    c.h = gl % LPV;
+    c.lead = c.h == 0;
     c.valid = (threadIdx.x < a.lanes) && (c.v < a.n_voices);
     c.ev_cur = c.ev_end = 0;
     c.next_ev = OG_NO_EVENT;
@@ -117,7 +126,7 @@ __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
 
 __device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
 {
-    if (c.valid && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
+    if (c.valid && c.lead && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
 }
 
 // pop the current event and arm the next one
@@ -144,6 +153,17 @@ __device__ __forceinline__ void st_u(const OgBlockArgs& a, const VoiceCtx& c, in
     a.state[(size_t)w * a.n_voices + c.v] = x;
 }
 
+template <int LPV>
+__device__ __forceinline__ float ldl_f(const OgBlockArgs& a, const VoiceCtx& c, int k)
+{
+    return __uint_as_float(a.lane_state[((size_t)k * a.n_voices + c.v) * LPV + c.h]);
+}
+template <int LPV>
+__device__ __forceinline__ void stl_f(const OgBlockArgs& a, const VoiceCtx& c, int k, float x)
+{
+    a.lane_state[((size_t)k * a.n_voices + c.v) * LPV + c.h] = __float_as_uint(x);
+}
+
 // ---- mix bus ---------------------------------------------------------------
 struct BusLds {
     float tile[OG_BUS_CHUNK][OG_WAVE + 1]; // +1 pad: conflict-free transposed read
@@ -155,10 +175,10 @@ template <bool TAPS>
 __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, uint32_t j,
                                         float out)
 {
-    const float y = c.valid ? out : 0.0f;
+    const float y = (c.valid && c.lead) ? out : 0.0f;
     lds.tile[j][c.lane] = y;
     if (TAPS) {
-        if (c.tap >= 0) a.taps[(size_t)c.tap * a.frames + f] = y;
+        if (c.tap >= 0 && c.lead) a.taps[(size_t)c.tap * a.frames + f] = y;
     }
 }
 

@@ -102,3 +102,75 @@ OG_HD float og_tanf_q1(float x)
     float y = (PIO2_HI - x) + PIO2_LO;
     return 1.0f / og_tan_poly(y);
 }
+
+// ---------------------------------------------------------------------------
+// Bit-exact sinf / cosf of glibc >= 2.28 (= ARM optimized-routines sincosf,
+// the libm the reference's Rust `f32::sin/cos` bind to on Linux): double
+// precision reduction by pi/2 (hpi_inv pre-scaled by 2^24 so the quadrant lands
+// in bits 24..31) + degree-7/8 polynomials in double, rounded once to f32.
+// Needed where a 1-ulp difference is NOT harmless: the electric-piano
+// OscillatorBank turns cos/sin of the per-harmonic angle into a rotation that
+// is applied 48 000 times a second (electric_piano_voice.rs:127-150), so an ulp
+// in the multiplier becomes a phase drift of ~1e-3 rad per second.  Verified
+// bit-identical to the host libm on 3.6e7 arguments (tests/test_og_math.py).
+// |x| >= 120 falls back to libm (never reached: the angle is < pi).
+// ---------------------------------------------------------------------------
+struct OgSincosTab {
+    double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+
+// The fused operations below are the ones GCC forms when it builds glibc's x86-64
+// FMA ifunc variant (__sinf_fma / __cosf_fma, selected on every AVX2+FMA host, i.e.
+// also on the EPYC hosts of the MI355X boxes): with them the restatement matched the
+// host libm on 6e7 arguments, without them it misses ~1 result in 4e6 by one ulp.
+OG_HD float og_sincos_poly(double x, double x2, bool neg_c, int n)
+{
+    const double sgn = neg_c ? -1.0 : 1.0; // second table of the reference negates the cosine coefficients
+    const double c0 = sgn * 0x1p0, c1 = sgn * -0x1.ffffffd0c621cp-2, c2 = sgn * 0x1.55553e1068f19p-5,
+                 c3 = sgn * -0x1.6c087e89a359dp-10, c4 = sgn * 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double t1 = fma(x2, s3, s2);
+        const double x7 = x3 * x2;
+        const double s = fma(x3, s1, x);
+        return (float)fma(x7, t1, s);
+    } else {
+        const double x4 = x2 * x2;
+        const double t2 = fma(x2, c4, c3);
+        const double t1 = fma(x2, c1, c0);
+        const double x6 = x4 * x2;
+        const double c = fma(x4, c2, t1);
+        return (float)fma(x6, t2, c);
+    }
+}
+
+OG_HD uint32_t og_abstop12(float x)
+{
+    union { float f; uint32_t u; } b;
+    b.f = x;
+    return (b.u >> 20) & 0x7ffu;
+}
+
+// which = 0: sinf(y), which = 1: cosf(y)
+OG_HD float og_sincosf_exact(float y, int which)
+{
+    const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;
+    const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    double x = (double)y;
+    if (og_abstop12(y) < og_abstop12(0x1.921FB6p-1f)) { // |y| < pi/4
+        if (og_abstop12(y) < og_abstop12(0x1p-12f)) return which ? 1.0f : y;
+        return og_sincos_poly(x, x * x, false, which);
+    }
+    if (og_abstop12(y) < og_abstop12(120.0f)) {
+        const double r = x * HPI_INV;
+        const int n = ((int32_t)r + 0x800000) >> 24;
+        x = fma(-(double)n, HPI, x);
+        const int q = n + which; // cosf uses sign[(n + 1) & 3] and the polynomial of quadrant n ^ 1
+        const double s = sign[q & 3];
+        return og_sincos_poly(x * s, x * x, (q & 2) != 0, which ? (n ^ 1) : n);
+    }
+    return which ? cosf(y) : sinf(y);
+}
+OG_HD float og_sinf_exact(float y) { return og_sincosf_exact(y, 0); }
+OG_HD float og_cosf_exact(float y) { return og_sincosf_exact(y, 1); }

@@ -556,4 +556,119 @@ OG_DEV void latch_up(float x, float (&out)[N])
     for (int i = 0; i < N; ++i) out[i] = x;
 }
 
+// ---------------------------------------------------------------------------
+// Electric piano voice  examples/electric-piano/src/electric_piano_voice.rs
+// One voice spans 32 lanes (LPV = 32): lane h owns harmonic h of AmplitudeSource
+// (current/target/decay/release) and of OscillatorBank (complex phasor +
+// rotation multiplier); per-voice scalars are replicated on the 32 lanes.
+// ---------------------------------------------------------------------------
+constexpr int EP_HARMONICS = 32;
+constexpr uint32_t EP_INTERP_STEPS = 64;
+
+// reference spectra :10-48
+__device__ const float EP_VEL0[EP_HARMONICS] = {0.02f, 0.05f};
+__device__ const float EP_VEL127[EP_HARMONICS] = {
+    0.150869f,   0.385766f,   0.215543f,   0.117811f,   0.100411f,    0.0128637f,  0.0288844f,  0.00243388f,
+    0.00963092f, 0.0035634f,  0.00256945f, 0.00184799f, 0.000399878f, 0.000660576f, 3.00995e-05f, 0.00021866f,
+    9.33705e-05f, 0.000177973f, 0.0002545f, 0.000323602f, 0.000779045f, 0.000116569f, 0.000772873f, 0.000364486f,
+    0.000248027f, 0.00018236f, 3.27292e-05f, 6.64988e-05f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+struct EpAmp {
+    float cur, tgt, decay, release; // this lane's harmonic
+    uint32_t released, step;        // per voice
+    float velocity;
+};
+
+// on_gate :308-318 -> trigger_note :292-299 (get_decay :244-268, get_release :270-274,
+// get_initial_amplitudes :276-290; note_pitch stays 60.0) or release_note :301-304
+OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h, float v, float brightness, float velocity_scaling, float decay_rate,
+                        float harmonic_decay, float key_scaling, float release_rate)
+{
+    if (v > 0.0f) {
+        a.velocity = v;
+        const float note = 60.0f;
+        const float base_decay_rate = (100.0f - decay_rate) / 40000.0f;
+        const float harmonic_scaling = 1.0f - ((100.0f - harmonic_decay) / 200000.0f);
+        const float scaling_multiplier = (48.0f - note) / 12.0f;
+        const float key_scaling_factor = scaling_multiplier * (key_scaling * 0.02f);
+        const float adjusted_decay = (key_scaling_factor > 0.0f) ? 1.0f - (base_decay_rate / (1.0f + key_scaling_factor))
+                                                                  : 1.0f - (base_decay_rate * (1.0f - key_scaling_factor));
+        float scaling = 1.0f; // scaling_h = ((1 * hs) * hs) ... h sequentially rounded products
+        for (uint32_t i = 0; i < h; ++i) scaling *= harmonic_scaling;
+        a.decay = adjusted_decay * scaling;
+        a.release = 0.999f - ((100.0f - release_rate) / 1000.0f);
+        float amp = (EP_VEL127[h] * v) + (EP_VEL0[h] * (1.0f - v));
+        float brightness_scaling = -0.2f + (0.8f * (brightness * 0.01f));
+        brightness_scaling += v * velocity_scaling * 0.01f * 0.5f;
+        amp *= 1.0f + brightness_scaling * (float)h;
+        a.cur = amp;
+        a.released = 0u;
+        a.step = 0u;
+    } else {
+        a.released = 1u;
+        a.step = 0u;
+    }
+}
+
+// AmplitudeSource::process :321-351, one harmonic
+OG_DEV float ep_amp_tick(EpAmp& a)
+{
+    if (a.step == 0u) a.tgt = a.cur * (a.released ? a.release : a.decay);
+    if (a.step < EP_INTERP_STEPS) {
+        const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
+        a.cur = a.cur * (1.0f - t) + a.tgt * t;
+        a.step += 1u;
+    } else {
+        a.cur = a.tgt;
+        a.step = 0u;
+    }
+    return a.cur;
+}
+
+struct EpBank {
+    float re, im, mre, mim; // this lane's harmonic
+    float last_frequency;   // per voice
+};
+
+OG_DEV void ep_bank_gate(EpBank& b, float v) // on_gate :115-122
+{
+    if (v > 0.0f) {
+        b.re = 1.0f;
+        b.im = 0.0f;
+    }
+}
+
+// OscillatorBank::process :154-169 (update_multipliers :126-150); returns the voice output on every lane
+OG_DEV float ep_bank_tick(EpBank& b, uint32_t h, float frequency, float amp, float sr)
+{
+    if (frequency > 0.0f && !(fabsf(b.last_frequency - frequency) < 0.01f)) {
+        b.last_frequency = frequency;
+        const float nyquist = sr * 0.5f;
+        const float harmonic_freq = frequency * (float)(h + 1u);
+        if (harmonic_freq < nyquist) {
+            const float angle = 2.0f * 3.14159274101257324f * harmonic_freq / sr;
+            b.mre = og_cosf_exact(angle); // bit-exact libm: the rotation is applied every sample
+            b.mim = og_sinf_exact(angle);
+        } else {
+            b.mre = 1.0f;
+            b.mim = 0.0f;
+        }
+        b.re = 1.0f;
+        b.im = 0.0f;
+    }
+    const float new_re = b.re * b.mre - b.im * b.mim; // Complex::mul :66-72
+    const float new_im = b.re * b.mim + b.im * b.mre;
+    b.re = new_re;
+    b.im = new_im;
+    // sum over the 32 harmonics of the voice (reference: sequential f32 fold; here a butterfly
+    // inside the 32-lane half of the wave -- re-association only)
+    float s = new_im * amp;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 16);
+    return s * 3.0f;
+}
+
 } // namespace og

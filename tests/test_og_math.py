@@ -12,6 +12,9 @@ SRC = r'''
 #include "og_math.h"
 extern "C" void og_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sinf(x[i]); }
 extern "C" void og_tan_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_tanf_q1(x[i]); }
+extern "C" void ex_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sinf_exact(x[i]); }
+extern "C" void ex_cos_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_cosf_exact(x[i]); }
+extern "C" void ref_cos_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = cosf(x[i]); }
 extern "C" void ref_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = sinf(x[i]); }
 extern "C" void ref_tan_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = tanf(x[i]); }
 '''
@@ -55,3 +58,15 @@ def test_tan_matches_glibc_on_first_quadrant(mlib):
     got, ref = _apply(mlib, "og_tan_array", x), _apply(mlib, "ref_tan_array", x)
     rel = np.abs(got.astype(np.float64) - ref) / np.abs(ref)
     assert rel.max() <= 2.5e-7
+
+
+def test_exact_sincos_is_bit_identical_to_glibc(mlib):
+    # the restated glibc/ARM sincosf algorithm must reproduce the host libm bit for bit
+    # (glibc picks its FMA build on AVX2+FMA CPUs; the restatement follows that variant)
+    if "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("host CPU without FMA: glibc uses its non-FMA sincosf build")
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.linspace(0.0, np.pi, 3_000_001), rng.uniform(-100.0, 100.0, 20_000_000),
+                        np.geomspace(1e-8, 119.0, 500_000), np.array([0.0, -0.0, np.pi / 4, -np.pi / 4])]).astype(np.float32)
+    assert np.array_equal(_apply(mlib, "ex_sin_array", x), _apply(mlib, "ref_sin_array", x))
+    assert np.array_equal(_apply(mlib, "ex_cos_array", x), _apply(mlib, "ref_cos_array", x))
