@@ -110,11 +110,12 @@ def main():
     oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    bus = torch.zeros((K + W, block), dtype=torch.float32, device="cuda")
+    ch = eng.channels
+    bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
     base = bus.data_ptr()
 
     def step(i):
-        eng.process_block_async(block, base + i * block * 4)
+        eng.process_block_async(block, base + i * block * ch * 4)
 
     for i in range(W):
         step(i)
@@ -148,10 +149,10 @@ def main():
         assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
         value = total_voices * K * block / elapsed
         words = eng.state_words_per_voice
-        lanes = eng.voices_per_wave
-        n_wg = (V + lanes - 1) // lanes
+        lanes = eng.voices_per_wave * eng.lanes_per_voice
         # algorithmic HBM bytes of one launch: state planes read once + written once,
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
+        n_wg = (V * eng.lanes_per_voice + lanes - 1) // lanes
         bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         pmc_bytes, pmc_src = pmc_traffic(V, block)

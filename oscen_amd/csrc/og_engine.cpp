@@ -31,21 +31,24 @@
 // the HBM/L2 latency covered; the first version walked all rows from 4 waves
 // and took 40 us for 1024 rows), then slice 0 adds the 16 slice sums in order.
 #define OG_RED_SLICES 16
+#define OG_RED_GROUP 1024 // rows per workgroup; larger banks take a second pass over the group sums
 __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
-                                                      uint32_t frames, float* __restrict__ bus)
+                                                      uint32_t frames, float* __restrict__ out)
 {
     __shared__ float part[OG_RED_SLICES][64];
     const uint32_t fx = threadIdx.x & 63u;
     const uint32_t slice = threadIdx.x >> 6;
     const uint32_t f = blockIdx.x * 64u + fx;
+    const uint32_t row0 = blockIdx.y * OG_RED_GROUP;
+    const uint32_t row1 = min(n_rows, row0 + OG_RED_GROUP);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (f < frames) {
-        uint32_t r = slice;
-        for (; r + 3 * OG_RED_SLICES < n_rows; r += 4 * OG_RED_SLICES) {
+        uint32_t r = row0 + slice;
+        for (; r + 3 * OG_RED_SLICES < row1; r += 4 * OG_RED_SLICES) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] += partials[(size_t)(r + i * OG_RED_SLICES) * frames + f];
         }
-        for (int i = 0; r < n_rows; r += OG_RED_SLICES, ++i) acc[i] += partials[(size_t)r * frames + f];
+        for (int i = 0; r < row1; r += OG_RED_SLICES, ++i) acc[i] += partials[(size_t)r * frames + f];
     }
     part[slice][fx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ 
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < OG_RED_SLICES; ++i) s += part[i][fx];
-        bus[f] = s;
+        out[(size_t)blockIdx.y * frames + f] = s;
     }
 }
 
@@ -198,6 +201,7 @@ struct og_engine {
     uint32_t* d_ev_end = nullptr;
     uint32_t* d_ev_cursor = nullptr;
     float* d_partials = nullptr;
+    float* d_partials2 = nullptr; // group sums of the multi-pass bus reduce
     float* d_bus = nullptr;
     float* d_ramp[RAMP_RING] = {};
     float* h_ramp[RAMP_RING] = {};
@@ -231,6 +235,7 @@ struct og_engine {
         hipFree(d_ev_end);
         hipFree(d_ev_cursor);
         hipFree(d_partials);
+        hipFree(d_partials2);
         hipFree(d_bus);
         hipFree(d_taps);
         hipFree(d_tap_slot);
@@ -385,8 +390,22 @@ struct og_engine {
         HIPCK(hipGetLastError());
         float* bus = d_out ? d_out : d_bus;
         float* sum_dst = cg->bus_tremolo ? d_mono : bus;
-        hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64), dim3(1024), 0, stream, d_partials, n_wg, frames,
-                           sum_dst);
+        {
+            // fixed-association tree: groups of 1024 rows, then (for > 1024 waves) the group sums
+            const float* src = d_partials;
+            uint32_t rows = n_wg;
+            float* tmp = d_partials2;
+            while (rows > OG_RED_GROUP) {
+                const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
+                hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64, groups), dim3(1024), 0, stream, src, rows,
+                                   frames, tmp);
+                src = tmp;
+                rows = groups;
+                tmp = tmp + (size_t)groups * OG_MAX_BLOCK; // next level writes behind this one
+            }
+            hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64, 1), dim3(1024), 0, stream, src, rows, frames,
+                               sum_dst);
+        }
         HIPCK(hipGetLastError());
         if (cg->bus_tremolo) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
             ogc::UEnv e = env();
@@ -621,6 +640,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
+        HIPCK(hipMalloc(&e->d_partials2, ((size_t)e->n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK * 4));
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
@@ -875,7 +895,8 @@ uint32_t og_state_words_per_voice(const og_engine* e)
 {
     return e ? (uint32_t)(e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) : 0;
 }
-uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes : 0; }
+uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lpv : 0; }
+uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes / (uint32_t)e->cg->lpv : 0; }
 uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
 
 int og_enable_kernel_timing(og_engine* e, int on)
