@@ -70,6 +70,14 @@ int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor,
 int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
                           uint32_t n_args);
 int og_graph_connect(og_graph_desc* g, const char* src_expr, const char* dst, const char* policy);
+/* The same description from the TEXT of a `graph! { ... }` body (the reference DSL,
+ * oscen-graph-compiler/src/parse.rs:195-979): name / input / output / nodes{} /
+ * connections{} with [policy] prefixes, `* N` rates and compound sources.
+ * per_voice_inputs: comma-separated value inputs the poly wrapper feeds per voice
+ * (e.g. "frequency"); may be NULL. */
+int og_graph_parse(const char* dsl_text, const char* per_voice_inputs, og_graph_desc** out);
+/* Print a description back as DSL text; returns the length, copies at most cap-1 bytes. */
+int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap);
 void og_graph_free(og_graph_desc* g);
 /* The HIP source of the fused voice kernel this description lowers to (for
  * inspection / ahead-of-time builds).  Returns the length; copies at most cap-1 bytes. */

@@ -556,6 +556,44 @@ int og_graph_connect(og_graph_desc* g, const char* src, const char* dst, const c
     return OG_OK;
 }
 
+int og_graph_parse(const char* dsl_text, const char* per_voice_inputs, og_graph_desc** out)
+{
+    if (!dsl_text || !out) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        std::vector<std::string> pv;
+        if (per_voice_inputs) {
+            std::string cur;
+            for (const char* p = per_voice_inputs;; ++p) {
+                if (*p == ',' || *p == 0) {
+                    while (!cur.empty() && isspace((unsigned char)cur.back())) cur.pop_back();
+                    while (!cur.empty() && isspace((unsigned char)cur.front())) cur.erase(cur.begin());
+                    if (!cur.empty()) pv.push_back(cur);
+                    cur.clear();
+                    if (*p == 0) break;
+                } else {
+                    cur.push_back(*p);
+                }
+            }
+        }
+        std::unique_ptr<og_graph_desc> g(new og_graph_desc);
+        g->g = ogc::parse_dsl(dsl_text, pv);
+        *out = g.release();
+        return OG_OK;
+    });
+}
+
+int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap)
+{
+    if (!g) return set_err(OG_E_INVALID, "null graph");
+    const std::string t = ogc::to_dsl(g->g);
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)t.size();
+}
+
 void og_graph_free(og_graph_desc* g) { delete g; }
 
 int64_t og_graph_kernel_source(const og_graph_desc* g, char* buf, size_t cap)

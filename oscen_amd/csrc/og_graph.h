@@ -117,6 +117,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g);
 
 uint64_t fnv1a(const std::string& s);
 
+// `graph! { ... }` body text -> description (og_dsl.cpp).  `per_voice` names the value inputs the
+// poly wrapper feeds per voice (e.g. "frequency").  to_dsl() prints a description back as DSL text.
+GraphDesc parse_dsl(const std::string& text, const std::vector<std::string>& per_voice);
+std::string to_dsl(const GraphDesc& g);
+
 // Built-in graph descriptions (builder form of the reference graphs in scope).
 GraphDesc builtin_graph(const std::string& name);
 std::vector<std::string> builtin_graph_names();

@@ -1,0 +1,103 @@
+"""Text front end for `graph! { ... }` bodies (oscen-graph-compiler/src/parse.rs grammar). CPU only."""
+import pytest
+
+import oscen_amd
+
+SYNTH = """
+graph! {
+    name: Synth;
+
+    // Control inputs with defaults
+    input carrier_freq: value = 440.0;
+    input mod_depth: value = 0.2 [0.0..1.0, ramp: 1_200];
+    input cutoff: value = 1_200.0 {range: 20.0..20000.0, unit: " Hz"};
+    input gate: event;
+    output audio_out: stream;
+
+    nodes {
+        modulator = PolyBlepOscillator::sine(5.0, 0.2);
+        carrier = oscen::PolyBlepOscillator::saw(440.0_f32, 0.5);
+        filter = TptFilter::new(1200.0, 0.707);
+        env = AdsrEnvelope::new(0.01, 0.1, 0.7, 0.2);
+    }
+
+    connections {
+        carrier_freq -> carrier.frequency;
+        mod_depth -> modulator.amplitude;
+        cutoff -> filter.cutoff;
+        gate -> env.gate;
+        modulator.output -> carrier.frequency_mod;
+        carrier.output -> filter.input;
+        filter.output * env.output -> audio_out;
+    }
+}
+"""
+
+
+def _builder_synth():
+    g = oscen_amd.Graph("Synth")
+    g.input_value("carrier_freq", 440.0, per_voice=True)
+    g.input_value("mod_depth", 0.2, ramp=1200)
+    g.input_value("cutoff", 1200.0)
+    g.input_event("gate")
+    g.output_stream("audio_out")
+    g.node("modulator", "PolyBlepOscillator::sine", 5.0, 0.2)
+    g.node("carrier", "PolyBlepOscillator::saw", 440.0, 0.5)
+    g.node("filter", "TptFilter::new", 1200.0, 0.707)
+    g.node("env", "AdsrEnvelope::new", 0.01, 0.1, 0.7, 0.2)
+    for s, d in [("carrier_freq", "carrier.frequency"), ("mod_depth", "modulator.amplitude"), ("cutoff", "filter.cutoff"),
+                 ("gate", "env.gate"), ("modulator.output", "carrier.frequency_mod"), ("carrier.output", "filter.input"),
+                 ("filter.output * env.output", "audio_out")]:
+        g.connect(s, d)
+    return g
+
+
+def test_dsl_text_lowers_to_the_same_kernel_as_the_builder():
+    parsed = oscen_amd.Graph(dsl=SYNTH, per_voice=["carrier_freq"])
+    a = parsed.kernel_source()
+    b = _builder_synth().kernel_source()
+    assert a == b
+    assert "input mod_depth: value = 0.200000003 [ramp: 1200];" in parsed.to_dsl()
+    assert "input carrier_freq: value = 440.0;  // per voice" in parsed.to_dsl()
+
+
+@pytest.mark.parametrize("name", ["fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice"])
+def test_builtin_graphs_roundtrip_through_the_dsl(name):
+    g = oscen_amd.Graph(builtin=name)
+    text = g.to_dsl()
+    assert text.startswith("name: " + name)
+    g2 = oscen_amd.Graph(dsl=text, per_voice=["frequency"])
+    assert g2.kernel_source() == g.kernel_source()
+
+
+def test_old_style_syntax_policies_and_rates():
+    text = """
+    name: ClipOversampled;
+    input value frequency = 220.0;
+    output stream out;
+    node {
+        osc = PolyBlepOscillator::sine(220.0, 0.9);
+        clip = HardClip::new() * 4;
+    }
+    connection {
+        frequency -> osc.frequency();
+        [sinc_iir] osc.output() -> clip.input();
+        [sinc_iir] clip.output() -> out;
+    }
+    """
+    src = oscen_amd.Graph(dsl=text, per_voice=["frequency"]).kernel_source()
+    assert "og::iir_up<4>" in src and "og::iir_down<4>" in src
+
+
+def test_dsl_diagnostics():
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Graph(dsl="name: X; nodes { voices = [FMVoice::new(); 8]; }")
+    assert "node arrays" in str(e.value)
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Graph(dsl="name: X;\ninput a: value = 1.0;\nbogus;")
+    assert "line 3" in str(e.value)
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.Graph(dsl="name: X; input a: value = 1.0;", per_voice=["nope"])
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Graph(dsl="name: X; output o: stream; nodes { d = Gain::new(1.0); } connections { d.output -> [4] -> d.input; }")
+    assert "inline delays" in str(e.value)
