@@ -166,6 +166,20 @@ size_t og_state_bytes(const og_engine* e);
 int og_save_state(og_engine* e, void* dst, size_t cap);
 int og_load_state(og_engine* e, const void* src, size_t len);
 
+/* ---- MIDI front end (host, control rate): MidiParser -> VoiceAllocator<N> -> MidiVoiceHandler
+ * (oscen-lib/src/midi.rs:40-225, voice_allocator.rs:46-136) with N = the engine's voice count.
+ * og_midi_send = `midi_in.try_push(raw_midi_event(bytes))` with frame_offset; messages are applied
+ * in frame order by og_midi_process_block (= flush + og_process_block).  With engine == NULL the
+ * object runs detached over n_voices and logs what the voices would receive (og_midi_pop_output). */
+typedef struct og_midi og_midi;
+int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input, const char* gate_input, og_midi** out);
+void og_midi_destroy(og_midi* m);
+int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_offset);
+int og_midi_flush(og_midi* m);
+int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus);
+int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age);
+int og_midi_pop_output(og_midi* m, uint32_t* voice, uint32_t* frame, float* frequency, int* has_frequency, float* gate);
+
 const char* og_last_error(void);
 const char* og_version(void);
 

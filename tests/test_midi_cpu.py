@@ -1,0 +1,69 @@
+"""Host-side MIDI front end (MidiParser -> VoiceAllocator -> MidiVoiceHandler): the reference's own
+unit tests restated against og_midi (oscen-lib/src/voice_allocator.rs:156-258, midi.rs:237-275). CPU only."""
+import oscen_amd
+
+
+def alloc(m, note):
+    m.note_on(note)
+    m.flush()
+    return m.pop_outputs()[-1][0]
+
+
+def test_voice_allocation_and_stealing():
+    m = oscen_amd.Midi(n_voices=4)
+    assert [alloc(m, n) for n in (60, 64, 67, 72)] == [0, 1, 2, 3]       # test_voice_allocation
+    assert all(m.voice_state(v)["active"] for v in range(4))
+    assert alloc(m, 76) == 0 and m.voice_state(0)["note"] == 76          # test_voice_stealing: oldest
+
+
+def test_find_and_release_voice():
+    m = oscen_amd.Midi(n_voices=4)
+    alloc(m, 60); alloc(m, 64)
+    m.note_off(64); m.flush()
+    out = m.pop_outputs()
+    assert out == [(1, 0, None, 0.0)]                                    # gate-off reaches voice 1
+    s = m.voice_state(1)
+    assert s["active"] and s["released"] and s["note"] is None
+    m.note_off(64); m.flush()
+    assert m.pop_outputs() == []                                         # not found any more
+
+
+def test_prefer_released_voices_for_stealing():
+    m = oscen_amd.Midi(n_voices=4)
+    for n in (60, 64, 67, 72):
+        alloc(m, n)
+    m.note_off(64); m.flush(); m.pop_outputs()
+    assert alloc(m, 76) == 1
+    assert m.voice_state(1)["note"] == 76 and not m.voice_state(1)["released"]
+
+
+def test_releasing_voice_continues_to_sound():
+    m = oscen_amd.Midi(n_voices=2)
+    assert alloc(m, 60) == 0
+    m.note_off(60); m.flush(); m.pop_outputs()
+    assert m.voice_state(0)["active"] and m.voice_state(0)["released"]
+    assert alloc(m, 64) == 1
+    assert alloc(m, 67) == 0                                             # steals the released voice
+
+
+def test_parser_and_handler_contract():
+    m = oscen_amd.Midi(n_voices=8)
+    m.send([0x90, 69, 100], frame_offset=17)      # note on A4 vel 100
+    m.send([0x90, 60, 0], frame_offset=5)         # note-on vel 0 == note off (nothing held: ignored)
+    m.send([0x91, 81, 127], frame_offset=3)       # channel nibble ignored
+    m.send([0xB0, 1, 2], frame_offset=0)          # CC: ignored
+    m.send([0x90, 60], frame_offset=0)            # short message: ignored
+    m.flush()
+    out = m.pop_outputs()
+    assert [(o[0], o[1]) for o in out] == [(0, 3), (1, 17)]              # applied in frame order
+    assert abs(out[0][2] - 880.0) < 0.01 and out[0][3] == 1.0
+    assert out[1][2] == 440.0 and abs(out[1][3] - 100.0 / 127.0) < 1e-7
+    m.send([0x80, 69, 0], frame_offset=9); m.flush()
+    assert m.pop_outputs() == [(1, 9, None, 0.0)]
+    # 65 536-voice allocator: first free voice, then LRU
+    big = oscen_amd.Midi(n_voices=65536)
+    for i in range(300):
+        big.note_on(30 + i % 60, frame_offset=i % 256)
+    big.flush()
+    voices = sorted(o[0] for o in big.pop_outputs())
+    assert voices == list(range(300))
