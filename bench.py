@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--single-device", action="store_true", help="map every rank onto GPU 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,6 +93,8 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
@@ -97,7 +102,7 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size)
+        dist.init_process_group(args.backend, rank=rank, world_size=world_size)
 
     V = args.voices_per_gpu
     total_voices = V * world_size
@@ -117,30 +122,44 @@ def main():
     def step(i):
         eng.process_block_async(block, base + i * block * ch * 4)
 
+    def reduce_bus(t):
+        if args.backend == "gloo":  # CPU collective (plumbing check only)
+            h = t.cpu()
+            ogd.reduce_bus(h)
+            t.copy_(h)
+        else:
+            ogd.reduce_bus(t)
+
+    def barrier():
+        if args.backend == "gloo":
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local_rank])
+
     for i in range(W):
         step(i)
     if W and dist is not None:
-        ogd.reduce_bus(bus[:W])
+        reduce_bus(bus[:W])
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
     if dist is not None:
-        ogd.reduce_bus(bus[W:])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
+        reduce_bus(bus[W:])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kern_ms, n_launch = eng.kernel_time_ms()
     eng.enable_kernel_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -205,7 +224,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
