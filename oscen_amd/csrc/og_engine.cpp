@@ -192,6 +192,7 @@ struct og_engine {
 
     uint32_t n_wg = 0;
     uint32_t lanes = OG_WAVE;
+    bool split = false;
     uint32_t* d_state = nullptr;
     uint32_t* d_lane_state = nullptr;
     float* d_mono = nullptr;      // summed voices before the post-mix stage
@@ -331,6 +332,7 @@ struct og_engine {
         A.n_voices = V;
         A.frames = frames;
         A.lanes = lanes;
+        A.split = split ? 1u : 0u;
         A.frame0 = frame_now;
         A.state = d_state;
         A.lane_state = d_lane_state;
@@ -656,6 +658,9 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
                 if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
             }
             e->lanes = lanes;
+            // two-wave pipeline variant: only when the bank cannot put two ordinary waves on every SIMD
+            e->split = e->cg->can_split && ((n_voices + OG_WAVE - 1) / OG_WAVE) < 2 * simds;
+            if (const char* ev = getenv("OSCEN_GPU_SPLIT")) e->split = e->cg->can_split && atoi(ev) != 0;
         }
         e->n_wg = (uint32_t)(((size_t)n_voices * e->cg->lpv + e->lanes - 1) / e->lanes);
         HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -934,6 +939,7 @@ uint32_t og_state_words_per_voice(const og_engine* e)
     return e ? (uint32_t)(e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) : 0;
 }
 uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lpv : 0; }
+int og_uses_split_kernel(const og_engine* e) { return e ? (int)e->split : 0; }
 uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes / (uint32_t)e->cg->lpv : 0; }
 uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
 

@@ -232,6 +232,19 @@ struct NodeTypeInfo {
     int lpv = 1; // lanes per voice this node type needs (32: per-harmonic arrays)
 };
 
+// rough VALU cost per tick of a node type (used to balance the two-stage split)
+int node_weight(const std::string& type)
+{
+    if (type.rfind("AdsrEnvelope", 0) == 0) return 12;
+    if (type.rfind("FmOperator", 0) == 0) return 23;
+    if (type.rfind("TptFilter", 0) == 0) return 17;
+    if (type.rfind("PolyBlepOscillator", 0) == 0) return 30;
+    if (type.rfind("Oscillator", 0) == 0) return 22;
+    if (type.rfind("Crossfade", 0) == 0) return 3;
+    if (type.rfind("HardClip", 0) == 0) return 2;
+    return 1;
+}
+
 struct NodeInst {
     const GNode* decl = nullptr;
     const NodeTypeInfo* type = nullptr;
@@ -253,18 +266,30 @@ struct Codegen {
     std::map<std::string, int> node_by_name, input_by_name, output_by_name;
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
 
-    // emitted code sections
-    std::ostringstream decl, load, derive, pre, post, pre_store, store;
-    // per-frame code, multirate layout of emit_frame.rs:114-176:
-    //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
-    std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
-    std::ostringstream* cur = &s_pre;
-    std::ostringstream& os() { return *cur; }
+    // Emitted code sections.  There are two sets: a graph may be cut into two pipeline stages
+    // (see "two-stage split" in compile()); nodes of stage 1 write into sec[1].  The ordinary
+    // kernel simply concatenates both sets.
+    struct Sect {
+        std::ostringstream decl, load, derive, pre, post, pre_store, store;
+        // per-frame code, multirate layout of emit_frame.rs:114-176:
+        //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
+        std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
+        std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
+        std::map<int, std::ostringstream> ev_handlers; // per graph event input
+    };
+    Sect sec[2];
+    int cs = 0;  // stage being emitted
+    int dom = 0; // rate domain being emitted: 0 pre, 1 inner, 2 post
+    Sect& S() { return sec[cs]; }
+    std::ostringstream& os() { return dom == 0 ? S().s_pre : (dom == 1 ? S().s_inner : S().s_post); }
+    std::ostringstream common_decl, common_load; // per-voice value inputs: visible to both stages
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
-    std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
-    std::map<int, std::ostringstream> ev_handlers; // per graph event input
     bool any_derive = false;
+    // two-stage split bookkeeping
+    bool split = false;
+    std::vector<int> stage_of;                   // per node
+    std::vector<std::pair<std::string, std::string>> xvals; // (stage-0 variable, stage-1 alias) crossing the cut
 
     Codegen(const GraphDesc& gd, CompiledGraph& cg) : g(gd), out(cg) {}
 
@@ -318,13 +343,13 @@ struct Codegen {
         const std::string NN = std::to_string(N);
         const int stages = N >= 8 ? 3 : (N >= 4 ? 2 : 1);
         auto state_arr = [&](const std::string& var, int rows, int cols) {
-            decl << "    float " << var << "[" << rows << "][" << cols << "] = {};\n";
+            S().decl << "    float " << var << "[" << rows << "][" << cols << "] = {};\n";
             for (int r = 0; r < rows; ++r)
                 for (int c2 = 0; c2 < cols; ++c2) {
                     int w = new_state("edge" + id + "." + var + "[" + std::to_string(r) + "][" + std::to_string(c2) + "]",
                                       true, [](const UEnv&) { return 0u; });
-                    load << "        " << var << "[" << r << "][" << c2 << "] = og::ld_f(A, c, " << w << ");\n";
-                    store << "        og::st_f(A, c, " << w << ", " << var << "[" << r << "][" << c2 << "]);\n";
+                    S().load << "        " << var << "[" << r << "][" << c2 << "] = og::ld_f(A, c, " << w << ");\n";
+                    S().store << "        og::st_f(A, c, " << w << ", " << var << "[" << r << "][" << c2 << "]);\n";
                 }
         };
         Val r;
@@ -335,16 +360,16 @@ struct Codegen {
                 return v;
             }
             const std::string buf = "up" + id, st = "up" + id + "_st";
-            s_up << "        float " << buf << "[" << NN << "];\n";
+            S().s_up << "        float " << buf << "[" << NN << "];\n";
             if (pol == "sinc") {
                 state_arr(st, stages, 12);
-                s_up << "        og::sinc_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
+                S().s_up << "        og::sinc_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
             } else if (pol == "sinc_iir") {
                 state_arr(st, stages, 9);
-                s_up << "        og::iir_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
+                S().s_up << "        og::iir_up<" << NN << ">(" << st << ", " << v.e << ", " << buf << ");\n";
             } else {
                 state_arr(st, 1, 1);
-                s_up << "        og::linear_up<" << NN << ">(" << st << "[0][0], " << v.e << ", " << buf << ");\n";
+                S().s_up << "        og::linear_up<" << NN << ">(" << st << "[0][0], " << v.e << ", " << buf << ");\n";
             }
             r.e = buf + "[j]";
             r.inner = true;
@@ -352,22 +377,22 @@ struct Codegen {
         }
         // Down edge (emit_frame.rs:474-514): capture every inner tick, downsample once per outer frame
         const std::string buf = "dn" + id, st = "dn" + id + "_st";
-        s_up << "        float " << buf << "[" << NN << "];\n";
-        s_cap << "            " << buf << "[j] = " << v.e << ";\n";
+        S().s_up << "        float " << buf << "[" << NN << "];\n";
+        S().s_cap << "            " << buf << "[j] = " << v.e << ";\n";
         int lat = 0;
         if (pol == "sinc") {
             state_arr(st, stages, 24);
-            s_down << "        const float " << buf << "_o = og::sinc_down<" << NN << ">(" << st << ", " << buf << ");\n";
+            S().s_down << "        const float " << buf << "_o = og::sinc_down<" << NN << ">(" << st << ", " << buf << ");\n";
             lat = 11 * (N - 1);
         } else if (pol == "sinc_iir") {
             state_arr(st, stages, 9);
-            s_down << "        const float " << buf << "_o = og::iir_down<" << NN << ">(" << st << ", " << buf << ");\n";
+            S().s_down << "        const float " << buf << "_o = og::iir_down<" << NN << ">(" << st << ", " << buf << ");\n";
             lat = 2 * (N - 1);
         } else if (pol == "linear") {
-            s_down << "        const float " << buf << "_o = og::linear_down<" << NN << ">(" << buf << ");\n";
+            S().s_down << "        const float " << buf << "_o = og::linear_down<" << NN << ">(" << buf << ");\n";
             lat = (N - 1) / 2;
         } else {
-            s_down << "        const float " << buf << "_o = " << buf << "[0];\n";
+            S().s_down << "        const float " << buf << "_o = " << buf << "[0];\n";
         }
         out.latency_samples += (uint32_t)(lat / N); // emit_struct.rs:534-570
         r.e = buf + "_o";
@@ -403,7 +428,18 @@ struct Codegen {
             auto vit = node_outputs.find("n" + std::to_string(nit->second) + "." + e->port);
             if (vit == node_outputs.end())
                 fail("node '" + e->node + "' has no output '" + e->port + "' (or it is read before it runs)");
-            return vit->second;
+            Val v = vit->second;
+            if (split && cs == 1 && stage_of[nit->second] == 0) { // value crosses the pipeline cut
+                std::string alias;
+                for (auto& xv : xvals)
+                    if (xv.first == v.e) alias = xv.second;
+                if (alias.empty()) {
+                    alias = "x" + std::to_string(xvals.size()) + "_" + v.e;
+                    xvals.push_back({v.e, alias});
+                }
+                v.e = alias;
+            }
+            return v;
         }
         default: {
             Val a = eval(e->a), b = eval(e->b);
@@ -517,9 +553,9 @@ struct NodeCtx {
     {
         std::string var = p + name;
         int w = cg.new_state(n.decl->name + "." + name, true, [init](const UEnv& e) { return fbits(init(e)); });
-        cg.decl << "    float " << var << " = 0.0f;\n";
-        cg.load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
-        cg.store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
+        cg.S().decl << "    float " << var << " = 0.0f;\n";
+        cg.S().load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
+        cg.S().store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
         return var;
     }
     // a word per (voice, lane) of an LPV > 1 graph
@@ -528,18 +564,18 @@ struct NodeCtx {
         std::string var = p + name;
         cg.out.lane_state.push_back({n.decl->name + "." + name + "[h]", true, [init](const UEnv&) { return fbits(init); }});
         int k = (int)cg.out.lane_state.size() - 1;
-        cg.decl << "    float " << var << " = " << flit(init) << ";\n";
-        cg.load << "        " << var << " = og::ldl_f<LPV>(A, c, " << k << ");\n";
-        cg.store << "        og::stl_f<LPV>(A, c, " << k << ", " << var << ");\n";
+        cg.S().decl << "    float " << var << " = " << flit(init) << ";\n";
+        cg.S().load << "        " << var << " = og::ldl_f<LPV>(A, c, " << k << ");\n";
+        cg.S().store << "        og::stl_f<LPV>(A, c, " << k << ", " << var << ");\n";
         return var;
     }
     std::string state_u(const std::string& name, uint32_t init)
     {
         std::string var = p + name;
         int w = cg.new_state(n.decl->name + "." + name, false, [init](const UEnv&) { return init; });
-        cg.decl << "    uint32_t " << var << " = 0u;\n";
-        cg.load << "        " << var << " = og::ld_u(A, c, " << w << ");\n";
-        cg.store << "        og::st_u(A, c, " << w << ", " << var << ");\n";
+        cg.S().decl << "    uint32_t " << var << " = 0u;\n";
+        cg.S().load << "        " << var << " = og::ld_u(A, c, " << w << ");\n";
+        cg.S().store << "        og::st_u(A, c, " << w << ", " << var << ");\n";
         return var;
     }
     void set_out(const std::string& port, const std::string& expr)
@@ -556,8 +592,8 @@ struct NodeCtx {
     std::string hoist(const std::string& name, const std::string& expr)
     {
         std::string var = p + name;
-        cg.decl << "    float " << var << " = 0.0f;\n";
-        cg.derive << "        " << var << " = " << expr << ";\n";
+        cg.S().decl << "    float " << var << " = 0.0f;\n";
+        cg.S().derive << "        " << var << " = " << expr << ";\n";
         cg.any_derive = true;
         return var;
     }
@@ -607,24 +643,24 @@ void emit_adsr(NodeCtx& x)
     int w_rem = x.cg.new_state(x.n.decl->name + ".samples_remaining", false, [](const UEnv&) { return 0u; });
     int w_level = x.cg.new_state(x.n.decl->name + ".level", true, [](const UEnv&) { return fbits(0.0f); });
     int w_vel = x.cg.new_state(x.n.decl->name + ".velocity", true, [](const UEnv&) { return fbits(1.0f); });
-    x.cg.decl << "    og::Adsr " << E << " = {0u, og::ADSR_HOLD, 0.0f, 1.0f, 0.0f};\n";
-    x.cg.load << "        og::adsr_block_begin(" << E << ", og::ld_u(A, c, " << w_stage << "), og::ld_u(A, c, " << w_rem
+    x.cg.S().decl << "    og::Adsr " << E << " = {0u, og::ADSR_HOLD, 0.0f, 1.0f, 0.0f};\n";
+    x.cg.S().load << "        og::adsr_block_begin(" << E << ", og::ld_u(A, c, " << w_stage << "), og::ld_u(A, c, " << w_rem
               << "), og::ld_f(A, c, " << w_level << "), og::ld_f(A, c, " << w_vel << "), " << K << ");\n";
-    x.cg.store << "        og::st_u(A, c, " << w_stage << ", " << E << ".stage);\n"
+    x.cg.S().store << "        og::st_u(A, c, " << w_stage << ", " << E << ".stage);\n"
                << "        og::st_u(A, c, " << w_rem << ", og::adsr_rem(" << E << "));\n"
                << "        og::st_f(A, c, " << w_level << ", " << E << ".lv);\n"
                << "        og::st_f(A, c, " << w_vel << ", " << E << ".vel);\n";
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
-            x.cg.ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
+            x.cg.S().ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
     x.set_out("output", "og::adsr_tick(" + E + ")");
     if (x.n.domain == 1) { // oversampled: N ticks per frame, finish a stage end right away
         x.cg.os() << "        og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", " << x.su(s_dn)
                    << ");\n";
     } else { // the non-output half of a stage end is handled once per frame for all envelopes of the voice
-        x.cg.post_zero.push_back(E + ".cnt");
-        x.cg.post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", "
+        x.cg.S().post_zero.push_back(E + ".cnt");
+        x.cg.S().post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", "
                   << x.su(s_dn) << ");\n";
     }
 }
@@ -710,10 +746,18 @@ void emit_oscillator(NodeCtx& x)
                             ", " + fm.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
 }
 
-void emit_gain(NodeCtx& x) { x.set_out("output", x.in("input").e + " * " + x.in("gain").e); }
-void emit_vca(NodeCtx& x) { x.set_out("output", x.in("input").e + " * " + x.in("control").e); }
-void emit_add_value(NodeCtx& x) { x.set_out("output", x.in("input").e + " + " + x.in("value").e); }
-void emit_mixer(NodeCtx& x) { x.set_out("output", x.in("input_a").e + " + " + x.in("input_b").e); }
+// (inputs are resolved in separate statements: operand evaluation order is unspecified in C++ and
+//  resolving an input can allocate cut-crossing channels, whose numbering must be deterministic)
+void emit_binary(NodeCtx& x, const char* a, const char* b, const char* op)
+{
+    const Val va = x.in(a);
+    const Val vb = x.in(b);
+    x.set_out("output", va.e + op + vb.e);
+}
+void emit_gain(NodeCtx& x) { emit_binary(x, "input", "gain", " * "); }
+void emit_vca(NodeCtx& x) { emit_binary(x, "input", "control", " * "); }
+void emit_add_value(NodeCtx& x) { emit_binary(x, "input", "value", " + "); }
+void emit_mixer(NodeCtx& x) { emit_binary(x, "input_a", "input_b", " + "); }
 void emit_hardclip(NodeCtx& x) { x.set_out("output", "og::hardclip(" + x.in("input").e + ")"); }
 void emit_crossfade(NodeCtx& x)
 {
@@ -735,17 +779,17 @@ void emit_ep_amp(NodeCtx& x)
                 dec = x.state_lane_f("decay", 0.0f), rel = x.state_lane_f("release", 0.0f);
     std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
     std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
-    x.cg.decl << "    og::EpAmp " << A << " = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 64u, 0.0f};\n";
-    x.cg.load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", " << released
+    x.cg.S().decl << "    og::EpAmp " << A << " = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 64u, 0.0f};\n";
+    x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", " << released
               << ", " << step << ", " << vel << "};\n";
     // stores run before the generic store section reads the mirrors back
-    x.cg.pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
+    x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
                    << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
                    << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
-            x.cg.ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h, ev.value, " << br.e << ", " << vs.e
+            x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h, ev.value, " << br.e << ", " << vs.e
                                  << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
     x.set_out("amplitudes", "og::ep_amp_tick(" + A + ")");
     x.cg.node_outputs["n" + std::to_string(x.n.id) + ".amplitudes"].lane = true;
@@ -760,13 +804,13 @@ void emit_ep_bank(NodeCtx& x)
     std::string re = x.state_lane_f("osc_re", 1.0f), im = x.state_lane_f("osc_im", 0.0f),
                 mre = x.state_lane_f("mul_re", 1.0f), mim = x.state_lane_f("mul_im", 0.0f);
     std::string lf = x.state_f("last_frequency", [](const UEnv&) { return 0.0f; });
-    x.cg.decl << "    og::EpBank " << B << " = {1.0f, 0.0f, 1.0f, 0.0f, 0.0f};\n";
-    x.cg.load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << "};\n";
-    x.cg.pre_store << "        " << re << " = " << B << ".re; " << im << " = " << B << ".im; " << mre << " = " << B << ".mre; "
+    x.cg.S().decl << "    og::EpBank " << B << " = {1.0f, 0.0f, 1.0f, 0.0f, 0.0f};\n";
+    x.cg.S().load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << "};\n";
+    x.cg.S().pre_store << "        " << re << " = " << B << ".re; " << im << " = " << B << ".im; " << mre << " = " << B << ".mre; "
                    << mim << " = " << B << ".mim; " << lf << " = " << B << ".last_frequency;\n";
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
-        for (int ei : ev->second) x.cg.ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
+        for (int ei : ev->second) x.cg.S().ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
     x.set_out("output", "og::ep_bank_tick(" + B + ", c.h, " + fr.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
 }
 
@@ -837,8 +881,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 if (in.ramp_frames) fail("per-voice input '" + in.name + "' cannot be ramped");
                 const float d = in.def;
                 info.state_word = cg.new_state("in." + in.name, true, [d](const UEnv&) { return fbits(d); });
-                cg.decl << "    float vin_" << i << " = 0.0f;\n";
-                cg.load << "        vin_" << i << " = og::ld_f(A, c, " << info.state_word << ");\n";
+                cg.common_decl << "    float vin_" << i << " = 0.0f;\n";
+                cg.common_load << "        vin_" << i << " = og::ld_f(A, c, " << info.state_word << ");\n";
             } else {
                 const int idx = (int)i;
                 info.slot = cg.new_slot([idx](const UEnv& e) { return fbits(e.input_values[idx]); });
@@ -1056,23 +1100,117 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
     }
 
+    // ---- two-stage split ---------------------------------------------------------------------
+    // With one wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave retires an instruction only
+    // every ~5.5 cycles, two co-resident waves every ~3.9 (measured).  The frame's node
+    // sequence is therefore also emitted as a 2-wave pipeline: wave 0 runs the first half of the
+    // nodes one 8-frame chunk ahead and hands the values that cross the cut to wave 1 through LDS.
+    // The cut is the position in the emission order that balances the estimated VALU cost.
+    cg.stage_of.assign(g.nodes.size(), 0);
+    {
+        const char* env_split = getenv("OGC_SPLIT");
+        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2;
+        const char* env_cut = getenv("OGC_CUT");
+        const bool depth_cut = env_cut && std::string(env_cut) == "depth";
+        if (want && !depth_cut) {
+            // Default: the prefix of the emission (topological) order that balances the estimated cost.
+            // Measured on MI355X for fm_voice: 0.094 ms per block against 0.105 ms for the
+            // depth-ordered partition below, although the latter balances the static estimate better
+            // and crosses fewer values.
+            int total = 0;
+            for (int ni : order) total += node_weight(cg.nodes[ni].decl->type);
+            int acc = 0, best = -1, best_diff = 1 << 30;
+            for (size_t k = 0; k + 1 < order.size(); ++k) {
+                acc += node_weight(cg.nodes[order[k]].decl->type);
+                const int diff = std::abs(2 * acc - total);
+                if (diff < best_diff) {
+                    best_diff = diff;
+                    best = (int)k;
+                }
+            }
+            if (best >= 0 && total >= 40) {
+                cg.split = true;
+                for (size_t k = 0; k < order.size(); ++k) cg.stage_of[order[k]] = (int)k > best ? 1 : 0;
+            }
+        } else if (want) {
+            // Stage 0 = the nodes farthest (longest path) from the graph output, up to half the
+            // estimated cost.  A node's sources are always strictly farther from the output than the
+            // node itself, so every prefix of the depth-descending order is closed under dependencies.
+            std::vector<int> depth(g.nodes.size(), 0), pos(g.nodes.size(), 0);
+            for (size_t k = 0; k < order.size(); ++k) pos[order[k]] = (int)k;
+            for (size_t k = order.size(); k-- > 0;) {
+                const int ni = order[k];
+                for (int d : deps[ni]) depth[d] = std::max(depth[d], depth[ni] + 1);
+            }
+            std::vector<int> by_depth(order);
+            std::stable_sort(by_depth.begin(), by_depth.end(), [&](int x, int y) {
+                if (depth[x] != depth[y]) return depth[x] > depth[y];
+                return pos[x] < pos[y];
+            });
+            int total = 0;
+            for (int ni : order) total += node_weight(cg.nodes[ni].decl->type);
+            // all nodes deeper than the level where the running cost crosses one half, plus the subset
+            // of that level which balances best (levels are small: brute force)
+            int acc = 0, level = -1;
+            for (int ni : by_depth) {
+                acc += node_weight(cg.nodes[ni].decl->type);
+                if (2 * acc >= total) {
+                    level = depth[ni];
+                    break;
+                }
+            }
+            std::vector<int> fixed, tie;
+            int w_fixed = 0;
+            for (int ni : by_depth) {
+                if (depth[ni] > level) {
+                    fixed.push_back(ni);
+                    w_fixed += node_weight(cg.nodes[ni].decl->type);
+                } else if (depth[ni] == level) {
+                    tie.push_back(ni);
+                }
+            }
+            if (tie.size() > 12) tie.resize(12);
+            uint32_t best_mask = 0;
+            int best_diff = 1 << 30;
+            for (uint32_t mask = 0; mask < (1u << tie.size()); ++mask) {
+                int w = w_fixed;
+                for (size_t i = 0; i < tie.size(); ++i)
+                    if (mask >> i & 1u) w += node_weight(cg.nodes[tie[i]].decl->type);
+                const int diff = std::abs(2 * w - total);
+                if (w > 0 && w < total && diff < best_diff) {
+                    best_diff = diff;
+                    best_mask = mask;
+                }
+            }
+            if (best_diff < (1 << 30) && total >= 40) {
+                cg.split = true;
+                for (int ni : order) cg.stage_of[ni] = 1;
+                for (int ni : fixed) cg.stage_of[ni] = 0;
+                for (size_t i = 0; i < tie.size(); ++i)
+                    if (best_mask >> i & 1u) cg.stage_of[tie[i]] = 0;
+            }
+        }
+    }
+
     // ---- emit nodes: outer (pre), inner, outer (post), each in topological order -------------
     for (int dom = 0; dom < 3; ++dom) {
-        cg.cur = dom == 0 ? &cg.s_pre : (dom == 1 ? &cg.s_inner : &cg.s_post);
+        cg.dom = dom;
         for (int ni : order) {
             NodeInst& n = cg.nodes[ni];
             if (n.domain != dom) continue;
+            cg.cs = cg.stage_of[ni];
             NodeCtx x{cg, n, "n" + std::to_string(n.id) + "_"};
             cg.os() << "        // " << n.decl->name << " = " << n.decl->type
-                     << (dom == 1 ? " * " + std::to_string(cg.N) : std::string()) << "\n";
+                    << (dom == 1 ? " * " + std::to_string(cg.N) : std::string()) << "\n";
             n.type->emit(x);
             out.node_order.push_back(n.decl->name);
         }
     }
 
-    // ---- graph output (outer rate) ---------------------------------------------------------
+    // ---- graph output (outer rate, last stage) -------------------------------------------------
     std::string bus_expr = "0.0f";
-    cg.cur = &cg.s_post;
+    cg.dom = 2;
+    cg.cs = cg.split ? 1 : 0;
     {
         int n_stream = 0;
         for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
@@ -1093,60 +1231,95 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             bus_expr = "g_out";
         }
     }
-    std::ostringstream tick_all;
-    tick_all << cg.s_pre.str() << cg.s_up.str();
-    if (cg.N > 1) {
-        tick_all << "#pragma unroll\n        for (int j = 0; j < " << cg.N << "; ++j) { // oversampled inner loop\n"
-                 << cg.s_inner.str() << cg.s_cap.str() << "        }\n";
-    }
-    tick_all << cg.s_down.str() << cg.s_post.str();
+    if (cg.split && cg.xvals.size() > 8) fail("internal: pipeline cut crosses more than 8 values"); // not reached by the built-ins
+    out.can_split = cg.split;
 
     if (out.n_slots > 160) fail("graph needs more than 160 uniform slots");
 
-    // ---- assemble the translation unit ----------------------------------------------------
+    // per-stage pieces of the kernel body
+    auto tick_code = [&](int st) {
+        Codegen::Sect& S = cg.sec[st];
+        std::ostringstream t;
+        t << S.s_pre.str() << S.s_up.str();
+        if (cg.N > 1)
+            t << "#pragma unroll\n        for (int j = 0; j < " << cg.N << "; ++j) { // oversampled inner loop\n"
+              << S.s_inner.str() << S.s_cap.str() << "        }\n";
+        t << S.s_down.str() << S.s_post.str();
+        return t.str();
+    };
+    auto post_code = [&](std::initializer_list<int> stages) {
+        std::vector<std::string> zeros;
+        std::string code;
+        for (int st : stages) {
+            zeros.insert(zeros.end(), cg.sec[st].post_zero.begin(), cg.sec[st].post_zero.end());
+            code += cg.sec[st].post.str();
+        }
+        std::ostringstream t;
+        if (!zeros.empty()) {
+            std::string m = zeros[0];
+            for (size_t i = 1; i < zeros.size(); ++i) m = "min(" + m + ", " + zeros[i] + ")";
+            t << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n" << code << "        }\n";
+        }
+        return t.str();
+    };
+    // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
+    auto events_code = [&](std::initializer_list<int> stages) {
+        std::ostringstream t;
+        t << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
+          << "        if (f == c.next_ev) {\n"
+          << "            do {\n"
+          << "                const OgEvent ev = A.events[c.ev_cur];\n";
+        bool first = true;
+        for (size_t i = 0; i < out.inputs.size(); ++i) {
+            const InputInfo& in = out.inputs[i];
+            if (in.decl.kind == Kind::Value && in.decl.per_voice) {
+                t << "                " << (first ? "" : "else ") << "if (ev.target == (OG_EV_SETVALUE | " << i
+                  << "u)) { vin_" << i << " = ev.value; derive(); }\n";
+                first = false;
+            }
+        }
+        std::map<int, std::string> handlers;
+        for (int st : stages)
+            for (auto& kv : cg.sec[st].ev_handlers) handlers[kv.first] += kv.second.str();
+        for (auto& kv : handlers) {
+            t << "                " << (first ? "" : "else ") << "if (ev.target == " << kv.first << "u) {\n" << kv.second
+              << "                }\n";
+            first = false;
+        }
+        t << "                og::ev_advance(A, c);\n"
+          << "            } while (c.next_ev <= f);\n"
+          << "        }\n    };\n";
+        return t.str();
+    };
+    auto vin_store = [&]() {
+        std::ostringstream t;
+        for (size_t i = 0; i < out.inputs.size(); ++i) {
+            const InputInfo& in = out.inputs[i];
+            if (in.decl.kind == Kind::Value && in.decl.per_voice)
+                t << "        if (c.ev_cur != c.ev_cur0) og::st_f(A, c, " << in.state_word << ", vin_" << i << ");\n";
+        }
+        return t.str();
+    };
+    int unroll = 2; // frames per straight-line scheduling region of the quiet-chunk loop
+    if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
+
+    // ---- ordinary kernel: one wave = 64 voices, the whole node sequence -------------------------
     std::ostringstream body;
     body << "template <bool RAMPS, bool TAPS>\n"
          << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
          << "    __shared__ og::BusLds bus;\n"
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
-         << cg.decl.str() << "    if (c.valid) {\n"
-         << cg.load.str() << "    }\n";
-    body << "    auto derive = [&]() {\n" << cg.derive.str() << "    };\n";
-    body << cg.pre.str() << "    derive();\n";
+         << cg.common_decl.str() << cg.sec[0].decl.str() << cg.sec[1].decl.str() << "    if (c.valid) {\n"
+         << cg.common_load.str() << cg.sec[0].load.str() << cg.sec[1].load.str() << "    }\n";
+    body << "    auto derive = [&]() {\n" << cg.sec[0].derive.str() << cg.sec[1].derive.str() << "    };\n";
+    body << cg.sec[0].pre.str() << cg.sec[1].pre.str() << "    derive();\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
-    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << tick_all.str();
-    if (!cg.post_zero.empty()) {
-        std::string m = cg.post_zero[0];
-        for (size_t i = 1; i < cg.post_zero.size(); ++i) m = "min(" + m + ", " + cg.post_zero[i] + ")";
-        body << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n"
-             << cg.post.str() << "        }\n";
-    }
+    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << tick_code(0);
+    for (auto& xv : cg.xvals) body << "        const float " << xv.second << " = " << xv.first << ";\n";
+    body << tick_code(1) << post_code({0, 1});
     body << "        return " << bus_expr << ";\n    };\n";
-    // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
-    body << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
-         << "        if (f == c.next_ev) {\n"
-         << "            do {\n"
-         << "                const OgEvent ev = A.events[c.ev_cur];\n";
-    bool first = true;
-    for (size_t i = 0; i < out.inputs.size(); ++i) {
-        const InputInfo& in = out.inputs[i];
-        if (in.decl.kind == Kind::Value && in.decl.per_voice) {
-            body << "                " << (first ? "" : "else ") << "if (ev.target == (OG_EV_SETVALUE | " << i
-                 << "u)) { vin_" << i << " = ev.value; derive(); }\n";
-            first = false;
-        }
-    }
-    for (auto& kv : cg.ev_handlers) {
-        body << "                " << (first ? "" : "else ") << "if (ev.target == " << kv.first << "u) {\n"
-             << kv.second.str() << "                }\n";
-        first = false;
-    }
-    body << "                og::ev_advance(A, c);\n"
-         << "            } while (c.next_ev <= f);\n"
-         << "        }\n    };\n";
-    int unroll = 2; // frames per straight-line scheduling region of the quiet-chunk loop
-    if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
+    body << events_code({0, 1});
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
          << "        if (n == OG_BUS_CHUNK && __all((int)(c.next_ev >= base + OG_BUS_CHUNK))) {\n"
@@ -1162,14 +1335,87 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"
          << "    }\n";
     body << "    og::bus_flush(A, c, bus);\n"
-         << cg.pre_store.str() << "    if (c.valid) {\n"
-         << cg.store.str();
-    for (size_t i = 0; i < out.inputs.size(); ++i) {
-        const InputInfo& in = out.inputs[i];
-        if (in.decl.kind == Kind::Value && in.decl.per_voice)
-            body << "        if (c.ev_cur != c.ev_cur0) og::st_f(A, c, " << in.state_word << ", vin_" << i << ");\n";
-    }
+         << cg.sec[0].pre_store.str() << cg.sec[1].pre_store.str() << "    if (c.valid) {\n"
+         << cg.sec[0].store.str() << cg.sec[1].store.str() << vin_store();
     body << "    }\n    og::voice_end(A, c);\n}\n";
+
+    // ---- two-stage kernel: workgroup = 2 waves over the same 64 voices -----------------------------
+    if (cg.split) {
+        const size_t nx = std::max<size_t>(1, cg.xvals.size());
+        body << "\n// Two-wave pipeline over the same 64 voices (used when the bank is too small to put two waves\n"
+             << "// on every SIMD): wave 0 = nodes";
+        for (int ni : order)
+            if (cg.stage_of[ni] == 0) body << " " << g.nodes[ni].name;
+        body << ";\n// wave 1 = the rest + the mix bus.  " << cg.xvals.size() << " values cross the cut through LDS, "
+             << "OG_XCH frames per hand-off.\n"
+             << "template <bool RAMPS, bool TAPS>\n"
+             << "__device__ __forceinline__ void voice_block_split(const OgBlockArgs& A)\n{\n"
+             << "    __shared__ og::BusLds bus;\n"
+             << "    __shared__ float chan[2][OG_XCH][" << nx << "][OG_WAVE];\n"
+             << "    const uint32_t stage = threadIdx.x / OG_WAVE;\n"
+             << "    og::VoiceCtx c;\n"
+             << "    og::voice_begin_split<TAPS>(A, c);\n"
+             << cg.common_decl.str() << "    if (c.valid) {\n" << cg.common_load.str() << "    }\n"
+             << "    const uint32_t n_chunks = (A.frames + OG_XCH - 1) / OG_XCH;\n";
+        for (int st = 0; st < 2; ++st) {
+            Codegen::Sect& S = cg.sec[st];
+            body << (st == 0 ? "    if (stage == 0) {\n" : "    } else {\n");
+            body << S.decl.str() << "    if (c.valid) {\n" << S.load.str() << "    }\n";
+            body << "    auto derive = [&]() {\n" << S.derive.str() << "    };\n";
+            body << S.pre.str() << "    derive();\n";
+            if (st == 0) {
+                body << "    auto tick = [&](const uint32_t f, const uint32_t buf, const uint32_t j) __attribute__((always_inline)) {\n"
+                     << tick_code(0);
+                for (size_t k = 0; k < cg.xvals.size(); ++k)
+                    body << "        chan[buf][j][" << k << "][c.lane] = " << cg.xvals[k].first << ";\n";
+                body << post_code({0}) << "    };\n";
+            } else {
+                body << "    auto tick = [&](const uint32_t f, const uint32_t buf, const uint32_t j) __attribute__((always_inline)) -> float {\n";
+                for (size_t k = 0; k < cg.xvals.size(); ++k)
+                    body << "        const float " << cg.xvals[k].second << " = chan[buf][j][" << k << "][c.lane];\n";
+                body << tick_code(1) << post_code({1}) << "        return " << bus_expr << ";\n    };\n";
+            }
+            body << events_code({st});
+            if (st == 1) body << "    __syncthreads(); // chunk 0 has been produced\n";
+            // SALU instructions cost issue slots like VALU ones: the quiet chunk is a straight-line,
+            // fully unrolled body; per-frame tests only exist on the (rare) event path
+            const std::string call = st == 0 ? "tick(f, ch & 1u, j);"
+                                             : "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, tick(f, ch & 1u, j));";
+            body << "    for (uint32_t ch = 0; ch < n_chunks; ++ch) {\n"
+                 << "        const uint32_t base = ch * OG_XCH;\n"
+                 << "        const uint32_t n = min((uint32_t)OG_XCH, A.frames - base);\n"
+                 << "        if (n == OG_XCH && __all((int)(c.next_ev >= base + OG_XCH))) {\n"
+                 << "#pragma unroll\n"
+                 << "            for (uint32_t j = 0; j < OG_XCH; ++j) {\n"
+                 << "                const uint32_t f = base + j;\n"
+                 << "                " << call << "\n"
+                 << "            }\n"
+                 << "        } else {\n"
+                 << "            for (uint32_t j = 0; j < n; ++j) {\n"
+                 << "                const uint32_t f = base + j;\n"
+                 << "                events(f);\n"
+                 << "                " << call << "\n"
+                 << "            }\n"
+                 << "        }\n";
+            if (st == 1)
+                body << "        { // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / OG_XCH hand-offs\n"
+                     << "            const uint32_t last = base + n - 1;\n"
+                     << "            if ((last % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || last + 1 == A.frames)\n"
+                     << "                og::bus_chunk_reduce(A, c, bus, last - (last % OG_BUS_CHUNK), (last % OG_BUS_CHUNK) + 1);\n"
+                     << "        }\n";
+            body << "        __syncthreads(); // hand-off: wave 0 stays one chunk ahead of wave 1\n"
+                 << "    }\n";
+            if (st == 0) {
+                body << "    __syncthreads(); // wave 1 has consumed the last chunk\n"
+                     << S.pre_store.str() << "    if (c.valid) {\n" << S.store.str() << vin_store() << "    }\n"
+                     << "    og::voice_end(A, c);\n";
+            } else {
+                body << "    og::bus_flush(A, c, bus);\n"
+                     << S.pre_store.str() << "    if (c.valid) {\n" << S.store.str() << "    }\n";
+            }
+        }
+        body << "    }\n}\n";
+    }
 
     const std::string body_s = body.str();
     out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
@@ -1195,10 +1441,22 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     for (auto& v : variants)
         src << "extern \"C\" __global__ __launch_bounds__(64) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
+    if (cg.split)
+        for (auto& v : variants)
+            src << "extern \"C\" __global__ __launch_bounds__(128) void og_k2_" << hs << "_" << v[0]
+                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_split<" << v[1] << ", " << v[2] << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
-        << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n"
-        << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
+        << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n";
+    if (cg.split)
+        src << "    if (A.split) { // two waves per 64 voices\n"
+            << "        const dim3 g2((A.n_voices + OG_WAVE - 1) / OG_WAVE), b2(2 * OG_WAVE);\n"
+            << "        if (!ramps && !taps) hipLaunchKernelGGL(og_k2_" << hs << "_00, g2, b2, 0, s, A);\n"
+            << "        else if (ramps && !taps) hipLaunchKernelGGL(og_k2_" << hs << "_10, g2, b2, 0, s, A);\n"
+            << "        else if (!ramps && taps) hipLaunchKernelGGL(og_k2_" << hs << "_01, g2, b2, 0, s, A);\n"
+            << "        else hipLaunchKernelGGL(og_k2_" << hs << "_11, g2, b2, 0, s, A);\n"
+            << "        return;\n    }\n";
+    src << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
         << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"
         << "    else if (!ramps && taps) hipLaunchKernelGGL(og_k_" << hs << "_01, grid, block, 0, s, A);\n"
         << "    else hipLaunchKernelGGL(og_k_" << hs << "_11, grid, block, 0, s, A);\n}\n"

@@ -99,6 +99,7 @@ struct CompiledGraph {
     std::vector<StateWord> state;      // per-voice words
     std::vector<StateWord> lane_state; // per-(voice, lane) words of LPV > 1 graphs
     int lpv = 1;                       // lanes per voice (32 for the electric-piano voice)
+    bool can_split = false;            // a two-wave pipeline variant of the kernel exists (og_k2_*)
     // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>
     bool bus_tremolo = false;
     HostFn tremolo_rate, tremolo_depth;

@@ -43,6 +43,7 @@ using __hip_internal::uint64_t;
 #define OG_MAX_BLOCK 512
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16
+#define OG_XCH 8 // frames per hand-off between the two waves of the split kernel
 #define OG_NO_EVENT 0xFFFFFFFFu
 #define OG_EV_SETVALUE 0x80000000u
 
@@ -55,8 +56,8 @@ struct OgEvent {
 struct OgBlockArgs {
     uint32_t n_voices;
     uint32_t frames;
-    uint32_t lanes;            // voices per wave: 64, or 32/16 to put >= 2 waves on every SIMD (see below)
-    uint32_t pad0;
+    uint32_t lanes;            // active lanes per wave (64; experiment knob)
+    uint32_t split;            // launch the two-wave pipeline variant (small banks, see og_graph.cpp)
     uint64_t frame0;
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
     uint32_t* lane_state;      // [n_lane_words][n_voices][LPV]: words of voices that span LPV lanes
@@ -124,6 +125,27 @@ __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
     c.ev_cur0 = c.ev_cur;
 }
 
+// two-wave pipeline kernel: both waves of the workgroup see the same 64 voices
+template <bool TAPS>
+__device__ __forceinline__ void voice_begin_split(const OgBlockArgs& a, VoiceCtx& c)
+{
+    c.lane = threadIdx.x % OG_WAVE;
+    c.v = blockIdx.x * OG_WAVE + c.lane;
+    c.h = 0;
+    c.lead = true;
+    c.valid = c.v < a.n_voices;
+    c.ev_cur = c.ev_end = 0;
+    c.next_ev = OG_NO_EVENT;
+    c.tap = -1;
+    if (c.valid) {
+        c.ev_cur = a.ev_cursor[c.v];
+        c.ev_end = a.ev_end[c.v];
+        if (c.ev_cur < c.ev_end) c.next_ev = ev_rel_frame(a, c.ev_cur);
+        if (TAPS) c.tap = a.tap_slot[c.v];
+    }
+    c.ev_cur0 = c.ev_cur;
+}
+
 __device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
 {
     if (c.valid && c.lead && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
@@ -164,6 +186,16 @@ __device__ __forceinline__ void stl_f(const OgBlockArgs& a, const VoiceCtx& c, i
     a.lane_state[((size_t)k * a.n_voices + c.v) * LPV + c.h] = __float_as_uint(x);
 }
 
+// All LDS traffic of the mix bus stays inside one wave (DS operations of a wave execute in order),
+// so a wavefront-scope fence is the whole synchronisation; a workgroup barrier would also stall on
+// the other wave of the two-wave pipeline kernel.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- mix bus ---------------------------------------------------------------
 struct BusLds {
     float tile[OG_BUS_CHUNK][OG_WAVE + 1]; // +1 pad: conflict-free transposed read
@@ -186,7 +218,7 @@ __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c,
 __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t base,
                                                  uint32_t n)
 {
-    __syncthreads(); // one-wave workgroup: orders the LDS writes before the transposed reads
+    wave_sync(); // orders the wave's LDS writes before its transposed reads
     const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
     const uint32_t q = c.lane / OG_BUS_CHUNK;
     float s = 0.0f;
@@ -195,12 +227,12 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     if (c.lane < OG_BUS_CHUNK && j < n) lds.part[base + j] = s;
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ void bus_flush(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds)
 {
-    __syncthreads();
+    wave_sync();
     for (uint32_t f = c.lane; f < a.frames; f += OG_WAVE)
         a.partials[(size_t)blockIdx.x * a.frames + f] = lds.part[f];
 }
