@@ -54,7 +54,12 @@ OG_HD float og_sinf(float x)
     const float PI_A = 0x1.921fb6p+1f;     // fl(pi)
     const float PI_B = -0x1.777a5cp-24f;   // fl(pi - PI_A)
     const float PI_C = -0x1.ee59dap-49f;   // fl(pi - PI_A - PI_B)
-    float k = rintf(x * INV_PI);
+    // k = rint(x / pi) by the 1.5 * 2^23 trick: after the fma the integer sits in the low mantissa
+    // bits, so its parity (the sign of sin) is bit 0 -- no float->int conversion needed.
+    const float MAGIC = 12582912.0f;
+    union { float f; uint32_t u; } t, b;
+    t.f = fmaf(x, INV_PI, MAGIC);
+    const float k = t.f - MAGIC;
     float r = fmaf(-k, PI_A, x);
     r = fmaf(-k, PI_B, r);
 #ifdef OG_SIN_3TERM
@@ -63,10 +68,8 @@ OG_HD float og_sinf(float x)
     (void)PI_C; // |k| * 3.4e-15: below half an ulp of r for |x| < 1e5
 #endif
     // (-1)^k: flip the sign of r (odd polynomial) when k is odd
-    int32_t ki = (int32_t)k;
-    union { float f; uint32_t u; } b;
     b.f = r;
-    b.u ^= ((uint32_t)ki) << 31;
+    b.u ^= t.u << 31;
     return og_sin_reduced(b.f);
 }
 

@@ -78,7 +78,6 @@ enum : int { ADSR_A_N = 0, ADSR_D_N, ADSR_R_N, ADSR_A_C, ADSR_D_C, ADSR_SUSTAIN,
 //    not re-executed;
 //  * `if current <= 0 {0} else {-current/n}` is -current/n for current >= 0
 //    (-0/n = -0, and x + -0 = x);
-//  * the Release divide runs only when some lane of the wave is in Release;
 //  * a stage end changes this frame's output only through `lv = tgt`; the
 //    rest of complete_stage() is deferred to one check per frame for all of a
 //    voice's envelopes (adsr_complete, called at the end of the frame).
@@ -150,11 +149,10 @@ OG_DEV float adsr_tick(Adsr& e)
     // Attack: lv += (1 - lv) * attack_coeff; Decay: lv += (sustain_level - lv) * decay_coeff; else cf == 0
     float lv = e.lv + (e.tgt - e.lv) * e.cf;
     // Release: lv += -lv / samples_remaining, increment re-derived every sample (adsr.rs:162-173)
-    const bool rel = e.stage == ST_RELEASE;
-    if (__any((int)rel)) {
-        const float lv_r = lv + div_near(-lv, (float)e.cnt);
-        lv = rel ? lv_r : lv;
-    }
+    // (computed unconditionally: a wave-uniform "any lane releasing" test costs more issue slots
+    //  than it saves -- the compiler if-converts it into the same arithmetic plus scalar selects)
+    const float lv_r = lv + div_near(-lv, (float)e.cnt);
+    lv = (e.stage == ST_RELEASE) ? lv_r : lv;
     // samples_remaining -= 1; at 0 the stage ends on its target level
     const uint32_t c = e.cnt - 1u;
     lv = (c == 0u) ? e.tgt : lv;
