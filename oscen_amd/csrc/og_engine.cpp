@@ -16,6 +16,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/oscen_gpu.h"
@@ -215,6 +216,8 @@ struct og_engine {
     uint32_t last_frames = 0;
 
     std::vector<HostEvent> pending;
+    size_t n_block_local = 0; // events pushed with try_push semantics for the next block
+    std::unordered_map<uint64_t, uint32_t> local_count; // (voice, target) -> events queued for the next block
     bool ev_dirty = true;
     uint64_t seq = 0;
     uint64_t frame_now = 0;
@@ -314,9 +317,7 @@ struct og_engine {
     {
         HIPCK(hipSetDevice(device));
         // reference: a try_push'ed event whose frame_offset >= frames is never delivered
-        bool any_local = false;
-        for (auto& h : pending) any_local |= h.block_local;
-        if (any_local) {
+        if (n_block_local > 0) { // (a counter: scanning a resident 200 000-event timeline per block cost 30 us)
             const uint64_t lim = frame_now + frames;
             size_t before = pending.size();
             pending.erase(std::remove_if(pending.begin(), pending.end(),
@@ -324,6 +325,8 @@ struct og_engine {
                           pending.end());
             dropped += before - pending.size();
             for (auto& h : pending) h.block_local = false;
+            n_block_local = 0;
+            local_count.clear();
         }
         if (ev_dirty) rebuild_events();
 
@@ -464,15 +467,16 @@ int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, flo
         target = (uint32_t)in.event_index;
     }
     if (local && !setvalue) { // ArrayVec<EventInstance, 32> capacity per endpoint per block
-        uint32_t cnt = 0;
-        for (const auto& h : e->pending)
-            if (h.block_local && h.voice == voice && h.target == target) ++cnt;
-        if (cnt >= OG_MAX_EVENTS_PER_BLOCK) {
+        uint32_t& cnt = e->local_count[((uint64_t)voice << 32) | target];
+        if (cnt < OG_MAX_EVENTS_PER_BLOCK) {
+            cnt += 1;
+        } else {
             e->dropped += 1;
             return set_err(OG_E_OVERFLOW, "event queue full (32 per voice per input per block): event dropped");
         }
     }
     e->pending.push_back(HostEvent{voice, frame, target, value, e->seq++, local, false});
+    if (local) e->n_block_local += 1;
     e->ev_dirty = true;
     return OG_OK;
 }
@@ -711,6 +715,8 @@ int og_init(og_engine* e, float sample_rate)
         e->sr = sample_rate;
         e->upload_initial_state();
         e->pending.clear();
+        e->n_block_local = 0;
+        e->local_count.clear();
         e->ev_dirty = true;
         e->frame_now = 0;
         e->inited = true;
