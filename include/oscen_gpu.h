@@ -181,6 +181,11 @@ int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus);
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age);
 int og_midi_pop_output(og_midi* m, uint32_t* voice, uint32_t* frame, float* frequency, int* has_frequency, float* gate);
 
+/* Output step: interleaved bus -> RIFF/WAVE file, 16-bit PCM or 32-bit float (what the reference
+ * examples do with the `hound` crate after BlockRender::render). */
+int og_write_wav(const char* path, const float* interleaved, uint64_t frames, uint32_t channels,
+                 uint32_t sample_rate, uint32_t bits_per_sample);
+
 const char* og_last_error(void);
 const char* og_version(void);
 

@@ -565,6 +565,101 @@ void oo_adsr_process(oo_adsr *e) /* :281-291 */
     e->output = e->level;
 }
 
+/* ---- IirLowpass  filters/iir_lowpass/mod.rs ----------------------------- */
+
+static void iir_lowpass_update_coefficients(oo_iir_lowpass *f, float sample_rate) /* :84-101 */
+{
+    float nyquist = sample_rate * 0.5f - F32_EPSILON;
+    float freq = rs_clamp(f->cutoff, 20.0f, nyquist);
+    float q = rs_max(f->q, 0.01f);
+    float n = 1.0f / tanf(F32_PI * freq / sample_rate);
+    float n_squared = n * n;
+    float c1 = 1.0f / (1.0f + 1.0f / q * n + n_squared);
+    f->b0 = c1;
+    f->b1 = c1 * 2.0f;
+    f->b2 = c1;
+    f->a1 = c1 * 2.0f * (1.0f - n_squared);
+    f->a2 = c1 * (1.0f - 1.0f / q * n + n_squared);
+}
+
+void oo_iir_lowpass_new(oo_iir_lowpass *f, float cutoff, float q) /* :43-76 */
+{
+    memset(f, 0, sizeof *f);
+    f->cutoff = cutoff;
+    f->q = q;
+    f->b0 = 1.0f;
+    f->frames_per_update = 32;
+    f->sample_rate = OO_DEFAULT_SR;
+}
+
+void oo_iir_lowpass_prepare(oo_iir_lowpass *f) { iir_lowpass_update_coefficients(f, f->sample_rate); } /* :149-151 */
+
+float oo_iir_lowpass_process_sample(oo_iir_lowpass *f, float input) /* :109-134 */
+{
+    const float DENORMAL_THRESHOLD = 1e-15f;
+    if (fabsf(input) < DENORMAL_THRESHOLD) input = 0.0f;
+    float output = f->b0 * input + f->v1;
+    f->v1 = f->b1 * input - f->a1 * output + f->v2;
+    f->v2 = f->b2 * input - f->a2 * output;
+    if (fabsf(f->v1) < DENORMAL_THRESHOLD) f->v1 = 0.0f;
+    if (fabsf(f->v2) < DENORMAL_THRESHOLD) f->v2 = 0.0f;
+    return output;
+}
+
+void oo_iir_lowpass_process(oo_iir_lowpass *f) /* :137-143, 153-162 */
+{
+    if (f->frame_counter == 0) iir_lowpass_update_coefficients(f, f->sample_rate);
+    f->frame_counter = (f->frame_counter + 1) % f->frames_per_update;
+    f->output = oo_iir_lowpass_process_sample(f, f->input);
+}
+
+/* ---- LP18Filter  examples/nih-twin-peaks/src/lp18_filter.rs -------------- */
+
+static void lp18_update_cutoff(oo_lp18 *f) /* :63-67 */
+{
+    float modulated_cutoff = f->cutoff + f->fmod;
+    float fc = rs_clamp(modulated_cutoff / f->sample_rate, 0.001f, 0.33f);
+    f->g = tanf(F32_PI * fc);
+}
+
+void oo_lp18_new(oo_lp18 *f, float cutoff, float resonance) /* :45-61 */
+{
+    memset(f, 0, sizeof *f);
+    f->cutoff = cutoff;
+    f->resonance = rs_clamp(resonance, 0.0f, 0.99f);
+    f->last_cutoff = cutoff;
+    f->last_resonance = resonance;
+    f->sample_rate = OO_DEFAULT_SR;
+}
+
+void oo_lp18_prepare(oo_lp18 *f) /* :75-78 */
+{
+    lp18_update_cutoff(f);
+    f->h = 2.0f * f->resonance;
+}
+
+void oo_lp18_process(oo_lp18 *f) /* :80-107 */
+{
+    if (f->cutoff != f->last_cutoff || f->fmod != f->last_fmod) {
+        f->last_cutoff = f->cutoff;
+        f->last_fmod = f->fmod;
+        lp18_update_cutoff(f);
+    }
+    if (f->resonance != f->last_resonance) {
+        f->last_resonance = f->resonance;
+        f->resonance = rs_clamp(f->resonance, 0.0f, 0.99f);
+        f->h = 2.0f * f->resonance;
+    }
+    float hp = (f->input - f->h * f->z[0] - f->z[1] - f->z[2]) / (1.0f + f->g);
+    float bp1 = f->g * hp + f->z[0];
+    f->z[0] = tanhf(bp1);
+    float bp2 = f->g * bp1 + f->z[1];
+    f->z[1] = bp2;
+    float lp = f->g * bp2 + f->z[2];
+    f->z[2] = lp;
+    f->output = lp;
+}
+
 /* ---- small nodes ------------------------------------------------------- */
 
 void oo_gain_process(oo_gain *g) { g->output = g->input * g->gain; } /* gain/mod.rs:30-34 */

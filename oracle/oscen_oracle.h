@@ -141,6 +141,27 @@ void oo_crossfade_process(oo_crossfade *n);
 void oo_mixer_process(oo_mixer *n);
 void oo_hardclip_process(oo_hardclip *n);
 
+/* ---- IirLowpass  oscen-lib/src/filters/iir_lowpass/mod.rs:15-164 -------- */
+typedef struct {
+    float input, cutoff, q, output;
+    float b0, b1, b2, a1, a2, v1, v2;
+    float sample_rate;
+    uint32_t frame_counter, frames_per_update;
+} oo_iir_lowpass;
+void oo_iir_lowpass_new(oo_iir_lowpass *f, float cutoff, float q);
+void oo_iir_lowpass_prepare(oo_iir_lowpass *f);
+void oo_iir_lowpass_process(oo_iir_lowpass *f);
+float oo_iir_lowpass_process_sample(oo_iir_lowpass *f, float input);
+
+/* ---- LP18Filter  examples/nih-twin-peaks/src/lp18_filter.rs:1-108 ------- */
+typedef struct {
+    float input, cutoff, fmod, resonance, output;
+    float z[3], g, h, last_cutoff, last_fmod, last_resonance, sample_rate;
+} oo_lp18;
+void oo_lp18_new(oo_lp18 *f, float cutoff, float resonance);
+void oo_lp18_prepare(oo_lp18 *f);
+void oo_lp18_process(oo_lp18 *f);
+
 /* ---- FmOperator  examples/fm-synth/src/nodes/fm_operator.rs:12-76 ------ */
 typedef struct {
     float phase, prev_output, sample_rate;

@@ -22,7 +22,7 @@ LIB = os.path.join(PKG, "liboscen_gpu.so")
 BUILD = os.path.join(PKG, "_build")
 ARCH = "gfx950"
 
-HOST_SRCS = ["og_engine.cpp", "og_graph.cpp", "og_builtin.cpp", "og_dsl.cpp", "og_midi.cpp", "og_jit.cpp"]
+HOST_SRCS = ["og_engine.cpp", "og_graph.cpp", "og_builtin.cpp", "og_dsl.cpp", "og_midi.cpp", "og_wav.cpp", "og_jit.cpp"]
 HEADERS = ["og_math.h", "og_nodes.hip.h", "og_kernel_rt.hip.h", "og_graph.h", "og_registry.h", "og_jit.h",
            os.path.join("..", "..", "include", "oscen_gpu.h")]
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + CSRC]

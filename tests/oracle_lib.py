@@ -62,6 +62,20 @@ class Adsr(C.Structure):
                 ("velocity", C.c_float), ("sample_rate", C.c_float)]
 
 
+class IirLowpass(C.Structure):
+    _fields_ = [("input", C.c_float), ("cutoff", C.c_float), ("q", C.c_float), ("output", C.c_float),
+                ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("a1", C.c_float), ("a2", C.c_float),
+                ("v1", C.c_float), ("v2", C.c_float), ("sample_rate", C.c_float),
+                ("frame_counter", C.c_uint32), ("frames_per_update", C.c_uint32)]
+
+
+class Lp18(C.Structure):
+    _fields_ = [("input", C.c_float), ("cutoff", C.c_float), ("fmod", C.c_float), ("resonance", C.c_float),
+                ("output", C.c_float), ("z", C.c_float * 3), ("g", C.c_float), ("h", C.c_float),
+                ("last_cutoff", C.c_float), ("last_fmod", C.c_float), ("last_resonance", C.c_float),
+                ("sample_rate", C.c_float)]
+
+
 class Gain(C.Structure):
     _fields_ = [("input", C.c_float), ("gain", C.c_float), ("output", C.c_float)]
 
@@ -194,6 +208,10 @@ def load():
     lib.oo_polyblep_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
     lib.oo_oscillator_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
     lib.oo_tpt_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.oo_iir_lowpass_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.oo_iir_lowpass_process_sample.argtypes = [C.c_void_p, C.c_float]
+    lib.oo_iir_lowpass_process_sample.restype = C.c_float
+    lib.oo_lp18_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_adsr_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.oo_ramp_new.argtypes = [C.c_void_p, C.c_float]
     lib.oo_ramp_set_immediate.argtypes = [C.c_void_p, C.c_float]

@@ -67,3 +67,22 @@ def test_parser_and_handler_contract():
     big.flush()
     voices = sorted(o[0] for o in big.pop_outputs())
     assert voices == list(range(300))
+
+
+def test_wav_writer_roundtrip(tmp_path):
+    import wave
+    import numpy as np
+
+    t = np.arange(4800, dtype=np.float32) / 48000.0
+    stereo = np.stack([0.5 * np.sin(2 * np.pi * 440 * t), -0.25 * np.sin(2 * np.pi * 220 * t)], axis=1).astype(np.float32)
+    p16 = tmp_path / "a.wav"
+    oscen_amd.write_wav(p16, stereo, 48000, 16)
+    with wave.open(str(p16)) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (2, 2, 48000, 4800)
+        pcm = np.frombuffer(w.readframes(4800), dtype="<i2").reshape(-1, 2)
+    assert np.max(np.abs(pcm / 32767.0 - stereo)) < 1.0 / 32767.0
+    p32 = tmp_path / "b.wav"
+    oscen_amd.write_wav(p32, stereo[:, 0], 48000, 32)
+    raw = open(p32, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and raw[20:22] == b"\x03\x00"
+    assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), stereo[:, 0])

@@ -562,3 +562,51 @@ def test_static_bench_graphs(lib):
         lib.oo_static_complex_process(C.byref(c))
     assert c.vca.output == 0.0  # envelopes never gated
     assert abs(c.filter.output[0]) > 0.0
+
+
+# --------------------------------------------------------------------------
+# IirLowpass  oscen-lib/src/filters/iir_lowpass/mod.rs:166-330 (N3 row)
+# --------------------------------------------------------------------------
+def _iir(lib, cutoff, q, fpu=None):
+    f = ol.IirLowpass()
+    lib.oo_iir_lowpass_new(C.byref(f), cutoff, q)
+    f.sample_rate = 48000.0
+    if fpu:
+        f.frames_per_update = fpu
+    lib.oo_iir_lowpass_prepare(C.byref(f))
+    return f
+
+
+def test_iir_lowpass_coefficients_match_juce_formula(lib):
+    q = f32(np.sqrt(0.5))
+    f = _iir(lib, 1000.0, float(q))
+    sr = f32(48000.0)
+    n = f32(1.0) / f32(math.tan(f32(np.pi) * f32(1000.0) / sr))
+    n2 = n * n
+    c1 = f32(1.0) / (f32(1.0) + f32(1.0) / q * n + n2)
+    for got, want in ((f.b0, c1), (f.b1, c1 * f32(2.0)), (f.b2, c1), (f.a1, c1 * f32(2.0) * (f32(1.0) - n2)),
+                      (f.a2, c1 * (f32(1.0) - f32(1.0) / q * n + n2))):
+        assert abs(got - float(want)) <= 1e-6
+
+
+def test_iir_lowpass_dc_gain_impulse_stability_denormal(lib):
+    q = float(np.sqrt(0.5))
+    f = _iir(lib, 1000.0, q, fpu=1)
+    for _ in range(1000):
+        f.input = 1.0
+        lib.oo_iir_lowpass_process(C.byref(f))
+    assert abs(f.output - 1.0) < 0.01
+    f = _iir(lib, 2000.0, q, fpu=1)
+    outs = []
+    for n in range(8):
+        f.input = 1.0 if n == 0 else 0.0
+        lib.oo_iir_lowpass_process(C.byref(f))
+        outs.append(f.output)
+    assert outs[0] > 0.0 and all(abs(o) < 2.0 for o in outs)
+    f = _iir(lib, 1000.0, 10.0, fpu=1)
+    for n in range(100):
+        f.input = 1.0 if n == 0 else 0.0
+        lib.oo_iir_lowpass_process(C.byref(f))
+        assert abs(f.output) < 10.0
+    f = _iir(lib, 100.0, q)
+    assert lib.oo_iir_lowpass_process_sample(C.byref(f), 1e-20) == 0.0
