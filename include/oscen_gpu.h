@@ -54,6 +54,7 @@ typedef struct og_engine og_engine;         /* N voices of one voice graph + the
  * output n: stream;                         -> og_graph_add_output(g,"n",OG_KIND_STREAM)
  * nodes { n = Type::ctor(a, b) [* N]; }     -> og_graph_add_node(g,"n","Type::ctor",args,nargs,N)
  * connections { [policy] src_expr -> dst; } -> og_graph_connect(g,"src_expr","dst","policy")
+ * connections { src -> [via] -> dst; }      -> og_graph_connect_via(g,"src","via","dst")
  * (oscen-graph-compiler/src/parse.rs:195-979)                                            */
 int og_graph_new(const char* name, og_graph_desc** out);
 int og_graph_builtin(const char* name, og_graph_desc** out); /* "fm_voice", "sub_voice", ... */
@@ -70,6 +71,11 @@ int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor,
 int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
                           uint32_t n_args);
 int og_graph_connect(og_graph_desc* g, const char* src_expr, const char* dst, const char* policy);
+/* `src -> [via] -> dst` (oscen-graph-compiler/src/ir/lower.rs:342-347): route through a declared
+ * Delay node, or, when `via` is a sample count ("64"), through an anonymous Delay::new(N, 0.0).
+ * Adds `src -> via.input` and the feedback edge `via.output -> dst`, which imposes no ordering:
+ * a consumer scheduled before the delay reads the sample the delay produced one frame earlier. */
+int og_graph_connect_via(og_graph_desc* g, const char* src_expr, const char* via, const char* dst);
 /* The same description from the TEXT of a `graph! { ... }` body (the reference DSL,
  * oscen-graph-compiler/src/parse.rs:195-979): name / input / output / nodes{} /
  * connections{} with [policy] prefixes, `* N` rates and compound sources.

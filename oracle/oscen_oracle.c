@@ -613,6 +613,130 @@ void oo_iir_lowpass_process(oo_iir_lowpass *f) /* :137-143, 153-162 */
     f->output = oo_iir_lowpass_process_sample(f, f->input);
 }
 
+/* ---- RingBuffer  ring_buffer/mod.rs --------------------------------------- */
+
+void oo_ring_new(oo_ring *r, size_t size, int mode) /* :35-54 */
+{
+    size_t capacity = size < 1 ? 1 : size;
+    if (mode == OO_RING_POW2) {
+        size_t p = 1;
+        while (p < capacity) p <<= 1;
+        capacity = p;
+    }
+    r->buffer = (float *)calloc(capacity, sizeof(float));
+    r->write_pos = 0;
+    r->capacity = capacity;
+    r->mask = capacity - 1;
+    r->mode = mode;
+}
+
+void oo_ring_free(oo_ring *r)
+{
+    free(r->buffer);
+    r->buffer = NULL;
+}
+
+static size_t ring_wrap(const oo_ring *r, size_t i) /* & mask  |  % capacity */
+{
+    return r->mode == OO_RING_POW2 ? (i & r->mask) : (i % r->capacity);
+}
+
+void oo_ring_push(oo_ring *r, float v) /* :57-77 */
+{
+    r->buffer[r->write_pos] = v;
+    r->write_pos = ring_wrap(r, r->write_pos + 1);
+}
+
+static float ring_read_pos(const oo_ring *r, float offset) /* :81-92 */
+{
+    float n = (float)r->capacity;
+    float rp = (float)r->write_pos - offset - 1.0f;
+    return fmodf(fmodf(rp, n) + n, n);
+}
+
+float oo_ring_get_linear(const oo_ring *r, float offset) /* :95-118 */
+{
+    float rp = ring_read_pos(r, offset);
+    size_t i = (size_t)rp;
+    float f = rp - truncf(rp);
+    float a = r->buffer[i];
+    float b = r->buffer[ring_wrap(r, i + 1)];
+    return fmaf(a, 1.0f - f, b * f); /* a.mul_add(1.0 - f, b * f) */
+}
+
+float oo_ring_get_cubic(const oo_ring *r, float offset) /* :121-164 */
+{
+    if (r->capacity < 4) return oo_ring_get_linear(r, offset);
+    float rp = ring_read_pos(r, offset);
+    size_t i = (size_t)rp;
+    float f = rp - truncf(rp);
+    size_t im1 = r->mode == OO_RING_POW2 ? ((i - 1) & r->mask) : ((i + r->capacity - 1) % r->capacity);
+    float v0 = r->buffer[im1];
+    float v1 = r->buffer[i];
+    float v2 = r->buffer[ring_wrap(r, i + 1)];
+    float v3 = r->buffer[ring_wrap(r, i + 2)];
+    float c0 = v1;
+    float c1 = 0.5f * (v2 - v0);
+    float c2 = v0 - 2.5f * v1 + 2.0f * v2 - 0.5f * v3;
+    float c3 = 0.5f * (v3 - v0) + 1.5f * (v1 - v2);
+    return c0 + f * (c1 + f * (c2 + f * c3));
+}
+
+static size_t f32_as_usize(float x) /* Rust `as usize`: saturating, NaN -> 0 */
+{
+    if (!(x > 0.0f)) return 0;
+    if (x >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)x;
+}
+
+float oo_ring_get(const oo_ring *r, float offset) /* :167-203 */
+{
+    float o = rs_max(offset, 0.0f);
+    float fr = o - truncf(o);
+    if (fr < 1e-6f || (1.0f - fr) < 1e-6f) {
+        size_t offset_samples = f32_as_usize(roundf(o));
+        size_t read_idx = ((r->write_pos + r->capacity) - (offset_samples % r->capacity) - 1) % r->capacity;
+        return r->buffer[read_idx];
+    }
+    if (r->capacity >= 4) return oo_ring_get_cubic(r, o);
+    return oo_ring_get_linear(r, o);
+}
+
+/* ---- Delay  delay/mod.rs --------------------------------------------------- */
+
+void oo_delay_new(oo_delay *d, float delay_samples, float feedback) /* :25-39 */
+{
+    memset(d, 0, sizeof *d);
+    d->delay_samples = delay_samples;
+    d->feedback = feedback;
+    oo_ring_new(&d->buffer, 1024, OO_RING_POW2);
+    d->sample_rate = OO_DEFAULT_SR;
+    d->frames_per_update = 32;
+}
+
+void oo_delay_prepare(oo_delay *d) /* :59-69 */
+{
+    size_t buffer_size = f32_as_usize(2.0f * d->sample_rate);
+    if (buffer_size > 88200) buffer_size = 88200;
+    oo_ring_free(&d->buffer);
+    oo_ring_new(&d->buffer, buffer_size, OO_RING_POW2);
+}
+
+void oo_delay_process(oo_delay *d) /* :47-56, 72-83 */
+{
+    if (d->frame_counter == 0) {
+        float max_delay = (float)d->buffer.capacity - 1.0f;
+        d->delay_samples = rs_clamp(d->delay_samples, 0.0f, max_delay);
+        d->feedback = rs_clamp(d->feedback, 0.0f, 0.99f);
+    }
+    d->frame_counter = (d->frame_counter + 1) % d->frames_per_update;
+    float delayed = oo_ring_get(&d->buffer, d->delay_samples);
+    oo_ring_push(&d->buffer, d->input + delayed * d->feedback);
+    d->output = delayed;
+}
+
+void oo_delay_free(oo_delay *d) { oo_ring_free(&d->buffer); }
+
 /* ---- LP18Filter  examples/nih-twin-peaks/src/lp18_filter.rs -------------- */
 
 static void lp18_update_cutoff(oo_lp18 *f) /* :63-67 */

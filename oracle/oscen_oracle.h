@@ -153,6 +153,32 @@ void oo_iir_lowpass_prepare(oo_iir_lowpass *f);
 void oo_iir_lowpass_process(oo_iir_lowpass *f);
 float oo_iir_lowpass_process_sample(oo_iir_lowpass *f, float input);
 
+/* ---- RingBuffer  oscen-lib/src/ring_buffer/mod.rs:14-208 ---------------- */
+enum { OO_RING_POW2 = 0, OO_RING_EXACT = 1 };
+typedef struct {
+    float *buffer; /* heap, `capacity` samples */
+    size_t write_pos, capacity, mask;
+    int32_t mode;
+} oo_ring;
+void oo_ring_new(oo_ring *r, size_t size, int mode); /* with_mode :35-54 */
+void oo_ring_free(oo_ring *r);
+void oo_ring_push(oo_ring *r, float v);
+float oo_ring_get(const oo_ring *r, float offset);
+float oo_ring_get_linear(const oo_ring *r, float offset);
+float oo_ring_get_cubic(const oo_ring *r, float offset);
+
+/* ---- Delay  oscen-lib/src/delay/mod.rs:5-86 ------------------------------ */
+typedef struct {
+    float input, delay_samples, feedback, output;
+    oo_ring buffer;
+    float sample_rate;
+    size_t frames_per_update, frame_counter;
+} oo_delay;
+void oo_delay_new(oo_delay *d, float delay_samples, float feedback);
+void oo_delay_prepare(oo_delay *d);
+void oo_delay_process(oo_delay *d);
+void oo_delay_free(oo_delay *d);
+
 /* ---- LP18Filter  examples/nih-twin-peaks/src/lp18_filter.rs:1-108 ------- */
 typedef struct {
     float input, cutoff, fmod, resonance, output;

@@ -9,7 +9,8 @@
 // KIND = value | event | stream; the only part of a [spec] the engine needs is `ramp: N`;
 // policy = latch | linear | sinc | sinc_iir; DST = node.port | node.port() | output name.
 // Not handled (diagnosed): node arrays `[V::new(); N]` (the poly wrapper is the engine itself),
-// `external`, inline delays `-> [N] ->`.
+// `external`.  `src -> [N] -> dst` and `src -> [delay_node] -> dst` expand into the two edges of
+// ir/lower.rs:342-347 (the second one a feedback edge).
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -278,12 +279,41 @@ void parse_connection(Lexer& lx, GraphDesc& g)
     }
     e.src = lx.until_arrow();
     if (!lx.eat_arrow()) dfail("expected `->` in connection", lx.line);
-    if (lx.peek() == '[') dfail("inline delays (`-> [N] ->`) are not supported by this version", lx.line);
+    std::string via;
+    if (lx.peek() == '[') { // `src -> [N] -> dst` / `src -> [delay_node] -> dst`  (ir/lower.rs:342-347)
+        lx.expect('[');
+        if (isdigit((unsigned char)lx.peek())) {
+            const float n = lx.number();
+            int k = 0;
+            for (const auto& nd : g.nodes)
+                if (nd.name.rfind("__inline_delay_", 0) == 0) ++k;
+            GNode d;
+            d.name = "__inline_delay_" + std::to_string(k);
+            d.type = "Delay::new";
+            d.args = {n, 0.0f};
+            g.nodes.push_back(d);
+            via = d.name;
+        } else {
+            via = lx.ident();
+        }
+        lx.expect(']');
+        if (!lx.eat_arrow()) dfail("expected `->` after the delay in `src -> [..] -> dst`", lx.line);
+    }
     e.dst = lx.until(";");
     size_t par = e.dst.find("()");
     if (par != std::string::npos) e.dst.erase(par, 2);
     lx.expect(';');
     if (e.src.empty() || e.dst.empty()) dfail("empty connection endpoint", lx.line);
+    if (!via.empty()) {
+        GEdge in_leg = e, out_leg = e;
+        in_leg.dst = via + ".input";
+        out_leg.src = via + ".output";
+        out_leg.policy.clear();
+        out_leg.feedback = true;
+        g.edges.push_back(in_leg);
+        g.edges.push_back(out_leg);
+        return;
+    }
     g.edges.push_back(e);
 }
 
@@ -387,6 +417,7 @@ std::string to_dsl(const GraphDesc& g)
             o << "    // post-mix (bus) node: " << n.name << " = " << n.type << "()\n";
             continue;
         }
+        if (n.name.rfind("__inline_delay_", 0) == 0) continue; // printed as `-> [N] ->`
         o << "    " << n.name << " = " << n.type << "(";
         for (size_t i = 0; i < n.args.size(); ++i) o << (i ? ", " : "") << num(n.args[i]);
         o << ")";
@@ -397,8 +428,24 @@ std::string to_dsl(const GraphDesc& g)
     std::set<std::string> bus;
     for (const auto& n : g.nodes)
         if (n.bus) bus.insert(n.name);
-    for (const auto& e : g.edges) {
+    for (size_t ei = 0; ei < g.edges.size(); ++ei) {
+        const GEdge& e = g.edges[ei];
         auto root = [](const std::string& s) { return s.substr(0, s.find('.')); };
+        if (ei + 1 < g.edges.size() && g.edges[ei + 1].feedback && !e.feedback) { // `src -> [via] -> dst`
+            const GEdge& f = g.edges[ei + 1];
+            const std::string via = root(f.src);
+            if (e.dst == via + ".input" && f.src == via + ".output") {
+                std::string label = via;
+                for (const auto& n : g.nodes)
+                    if (n.name == via && via.rfind("__inline_delay_", 0) == 0 && !n.args.empty())
+                        label = std::to_string((unsigned)n.args[0]);
+                o << "    " << (e.policy.empty() ? "" : "[" + e.policy + "] ") << e.src << " -> [" << label << "] -> " << f.dst
+                  << ";\n";
+                ++ei;
+                continue;
+            }
+        }
+        if (e.feedback) throw std::runtime_error("oscen graph dsl: unpaired feedback edge '" + e.src + " -> " + e.dst + "'");
         if (bus.count(root(e.src)) || bus.count(root(e.dst))) {
             o << "    // post-mix: " << e.src << " -> " << e.dst << ";\n";
             continue;

@@ -196,6 +196,8 @@ struct og_engine {
     bool split = false;
     uint32_t* d_state = nullptr;
     uint32_t* d_lane_state = nullptr;
+    float* d_ring[OG_MAX_RINGS] = {nullptr, nullptr, nullptr, nullptr}; // delay lines [capacity][V]
+    uint32_t ring_cap[OG_MAX_RINGS] = {0, 0, 0, 0};
     float* d_mono = nullptr;      // summed voices before the post-mix stage
     float* d_bus_phase = nullptr; // Tremolo.phase
     OgEvent* d_events = nullptr;
@@ -233,6 +235,7 @@ struct og_engine {
         if (stream) hipStreamSynchronize(stream);
         hipFree(d_state);
         hipFree(d_lane_state);
+        for (int k = 0; k < OG_MAX_RINGS; ++k) hipFree(d_ring[k]);
         hipFree(d_mono);
         hipFree(d_bus_phase);
         hipFree(d_events);
@@ -274,7 +277,25 @@ struct og_engine {
             HIPCK(hipMemcpyAsync(d_lane_state, limg.data(), limg.size() * 4, hipMemcpyHostToDevice, stream));
         }
         if (d_bus_phase) HIPCK(hipMemsetAsync(d_bus_phase, 0, 4, stream));
+        // prepare(): every Delay gets a fresh zeroed ring sized from the sample rate (delay/mod.rs:59-69)
+        for (size_t k = 0; k < cg->rings.size(); ++k) {
+            const uint32_t cap = cg->rings[k].capacity(sr);
+            if (cap != ring_cap[k]) {
+                if (d_ring[k]) HIPCK(hipFree(d_ring[k]));
+                d_ring[k] = nullptr;
+                ring_cap[k] = 0;
+                HIPCK(hipMalloc(&d_ring[k], (size_t)cap * V * 4));
+                ring_cap[k] = cap;
+            }
+            HIPCK(hipMemsetAsync(d_ring[k], 0, (size_t)cap * V * 4, stream));
+        }
         HIPCK(hipStreamSynchronize(stream));
+    }
+    size_t ring_bytes() const
+    {
+        size_t n = 0;
+        for (size_t k = 0; k < cg->rings.size(); ++k) n += (size_t)ring_cap[k] * V * 4;
+        return n;
     }
 
     void rebuild_events()
@@ -345,6 +366,10 @@ struct og_engine {
         A.partials = d_partials;
         A.taps = d_taps;
         A.tap_slot = d_tap_slot;
+        for (size_t k = 0; k < cg->rings.size(); ++k) {
+            A.rings[k] = d_ring[k];
+            A.ring_cap[k] = ring_cap[k];
+        }
 
         // block-uniform slots from the values at block start (ramped: `.current`)
         {
@@ -559,6 +584,30 @@ int og_graph_connect(og_graph_desc* g, const char* src, const char* dst, const c
 {
     if (!g || !src || !dst) return set_err(OG_E_INVALID, "null argument");
     g->g.edges.push_back({src, dst, policy ? policy : ""});
+    return OG_OK;
+}
+
+int og_graph_connect_via(og_graph_desc* g, const char* src, const char* via, const char* dst)
+{
+    if (!g || !src || !via || !dst) return set_err(OG_E_INVALID, "null argument");
+    std::string v = via;
+    bool numeric = !v.empty();
+    for (char ch : v) numeric = numeric && isdigit((unsigned char)ch);
+    if (numeric) { // `-> [N] ->`: an anonymous Delay::new(N, 0.0)  (ir/lower.rs:575-650)
+        int k = 0;
+        for (const auto& nd : g->g.nodes)
+            if (nd.name.rfind("__inline_delay_", 0) == 0) ++k;
+        ogc::GNode d;
+        d.name = "__inline_delay_" + std::to_string(k);
+        d.type = "Delay::new";
+        d.args = {(float)atof(via), 0.0f};
+        g->g.nodes.push_back(d);
+        v = d.name;
+    }
+    ogc::GEdge in_leg{src, v + ".input", ""}, out_leg{v + ".output", dst, ""};
+    out_leg.feedback = true;
+    g->g.edges.push_back(in_leg);
+    g->g.edges.push_back(out_leg);
     return OG_OK;
 }
 
@@ -975,7 +1024,10 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
 
 size_t og_state_bytes(const og_engine* e)
 {
-    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) : 0;
+    // (delay lines are part of the state: their size is known once og_init has sized them)
+    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) +
+                   e->ring_bytes()
+             : 0;
 }
 
 int og_save_state(og_engine* e, void* dst, size_t cap)
@@ -988,6 +1040,12 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
         HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
         if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync((char*)dst + a + b, e->d_bus_phase, 4, hipMemcpyDeviceToHost, e->stream));
+        size_t off = a + b + (e->d_bus_phase ? 4 : 0);
+        for (size_t k = 0; k < e->cg->rings.size(); ++k) {
+            const size_t n = (size_t)e->ring_cap[k] * e->V * 4;
+            if (n) HIPCK(hipMemcpyAsync((char*)dst + off, e->d_ring[k], n, hipMemcpyDeviceToHost, e->stream));
+            off += n;
+        }
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -1003,6 +1061,12 @@ int og_load_state(og_engine* e, const void* src, size_t len)
         HIPCK(hipMemcpyAsync(e->d_state, src, a, hipMemcpyHostToDevice, e->stream));
         if (b) HIPCK(hipMemcpyAsync(e->d_lane_state, (const char*)src + a, b, hipMemcpyHostToDevice, e->stream));
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync(e->d_bus_phase, (const char*)src + a + b, 4, hipMemcpyHostToDevice, e->stream));
+        size_t off = a + b + (e->d_bus_phase ? 4 : 0);
+        for (size_t k = 0; k < e->cg->rings.size(); ++k) {
+            const size_t n = (size_t)e->ring_cap[k] * e->V * 4;
+            if (n) HIPCK(hipMemcpyAsync(e->d_ring[k], (const char*)src + off, n, hipMemcpyHostToDevice, e->stream));
+            off += n;
+        }
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });

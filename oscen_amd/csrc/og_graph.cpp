@@ -240,6 +240,9 @@ int node_weight(const std::string& type)
     if (type.rfind("TptFilter", 0) == 0) return 17;
     if (type.rfind("PolyBlepOscillator", 0) == 0) return 30;
     if (type.rfind("Oscillator", 0) == 0) return 22;
+    if (type.rfind("IirLowpass", 0) == 0) return 14;
+    if (type.rfind("LP18Filter", 0) == 0) return 40;
+    if (type.rfind("Delay", 0) == 0) return 30;
     if (type.rfind("Crossfade", 0) == 0) return 3;
     if (type.rfind("HardClip", 0) == 0) return 2;
     return 1;
@@ -265,6 +268,9 @@ struct Codegen {
     std::vector<NodeInst> nodes;
     std::map<std::string, int> node_by_name, input_by_name, output_by_name;
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
+    std::set<std::string> fb_sources;            // "n<id>.<port>" fed into a feedback edge
+    std::map<std::string, std::string> fb_vars;  // ... -> state variable holding last frame's value
+    std::vector<char> emitted;                   // per node
 
     // Emitted code sections.  There are two sets: a graph may be cut into two pipeline stages
     // (see "two-stage split" in compile()); nodes of stage 1 write into sec[1].  The ordinary
@@ -425,7 +431,25 @@ struct Codegen {
             }
             auto nit = node_by_name.find(e->node);
             if (nit == node_by_name.end()) fail("unknown node '" + e->node + "'");
-            auto vit = node_outputs.find("n" + std::to_string(nit->second) + "." + e->port);
+            const std::string key = "n" + std::to_string(nit->second) + "." + e->port;
+            auto vit = node_outputs.find(key);
+            if (vit == node_outputs.end() && fb_sources.count(key) && !emitted[nit->second] && nodes[nit->second].live) {
+                // feedback edge whose producer runs later in the frame: the consumer sees the field the
+                // producer wrote on the previous frame (the struct field persists, codegen/emit_node.rs)
+                auto fit = fb_vars.find(key);
+                if (fit == fb_vars.end()) {
+                    const std::string var = "n" + std::to_string(nit->second) + "_" + e->port + "_z";
+                    int w = new_state(e->node + "." + e->port, true, [](const UEnv&) { return 0u; });
+                    S().decl << "    float " << var << " = 0.0f;\n";
+                    S().load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
+                    S().store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
+                    fit = fb_vars.emplace(key, var).first;
+                }
+                Val v;
+                v.e = fit->second;
+                v.rate = Rate::Vary;
+                return v;
+            }
             if (vit == node_outputs.end())
                 fail("node '" + e->node + "' has no output '" + e->port + "' (or it is read before it runs)");
             Val v = vit->second;
@@ -586,7 +610,10 @@ struct NodeCtx {
         v.e = var;
         v.rate = Rate::Vary;
         v.inner = n.domain == 1;
-        cg.node_outputs["n" + std::to_string(n.id) + "." + port] = v;
+        const std::string key = "n" + std::to_string(n.id) + "." + port;
+        cg.node_outputs[key] = v;
+        auto fit = cg.fb_vars.find(key); // an earlier node of the frame reads last frame's value
+        if (fit != cg.fb_vars.end()) cg.os() << "        " << fit->second << " = " << var << ";\n";
     }
     // a value that is constant over the block per voice: computed in derive()
     std::string hoist(const std::string& name, const std::string& expr)
@@ -746,6 +773,118 @@ void emit_oscillator(NodeCtx& x)
                             ", " + fm.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
 }
 
+// IirLowpass (filters/iir_lowpass/mod.rs): coefficients are refreshed when frame_counter == 0 (every
+// 32nd tick).  With block-uniform cutoff/q the five coefficients are host-derived slots (the host's
+// libm tanf is the one the reference's f32::tan binds to); otherwise they are computed on the device.
+struct IirCoef {
+    float b0, b1, b2, a1, a2;
+};
+IirCoef iir_lowpass_coef(float cutoff, float q_in, float sr)
+{
+    const float nyquist = sr * 0.5f - 1.1920929e-7f;
+    float freq = cutoff < 20.0f ? 20.0f : cutoff;
+    freq = freq > nyquist ? nyquist : freq;
+    const float q = fmaxf(q_in, 0.01f);
+    const float n = 1.0f / tanf(3.14159274101257324f * freq / sr);
+    const float n2 = n * n;
+    const float c1 = 1.0f / (1.0f + 1.0f / q * n + n2);
+    return {c1, c1 * 2.0f, c1, c1 * 2.0f * (1.0f - n2), c1 * (1.0f - 1.0f / q * n + n2)};
+}
+
+void emit_iir_lowpass(NodeCtx& x)
+{
+    const Val in = x.in("input");
+    const Val cutoff = x.in("cutoff");
+    const Val q = x.in("q");
+    const float k = x.rate_sr_factor();
+    const float c0 = x.def("cutoff"), q0 = x.def("q");
+    auto prep = [c0, q0, k](int which) {
+        return [c0, q0, k, which](const UEnv& e) {
+            const IirCoef c = iir_lowpass_coef(c0, q0, e.sample_rate * k);
+            const float v[5] = {c.b0, c.b1, c.b2, c.a1, c.a2};
+            return v[which];
+        };
+    };
+    std::string v1 = x.state_f("v1", [](const UEnv&) { return 0.0f; });
+    std::string v2 = x.state_f("v2", [](const UEnv&) { return 0.0f; });
+    std::string b0 = x.state_f("b0", prep(0)), b1 = x.state_f("b1", prep(1)), b2 = x.state_f("b2", prep(2)),
+                a1 = x.state_f("a1", prep(3)), a2 = x.state_f("a2", prep(4));
+    std::string fc = x.state_u("frame_counter", 0);
+    if (cutoff.rate <= Rate::UBlock && q.rate <= Rate::UBlock && cutoff.host && q.host) {
+        HostFn hc = cutoff.host, hq = q.host;
+        int s[5];
+        for (int w = 0; w < 5; ++w)
+            s[w] = x.slot_f([hc, hq, k, w](const UEnv& e) {
+                const IirCoef c = iir_lowpass_coef(hc(e), hq(e), e.sample_rate * k);
+                const float v[5] = {c.b0, c.b1, c.b2, c.a1, c.a2};
+                return v[w];
+            });
+        x.cg.os() << "        if (" << fc << " == 0u) { " << b0 << " = " << x.sf(s[0]) << "; " << b1 << " = " << x.sf(s[1]) << "; "
+                  << b2 << " = " << x.sf(s[2]) << "; " << a1 << " = " << x.sf(s[3]) << "; " << a2 << " = " << x.sf(s[4])
+                  << "; }\n";
+    } else {
+        int s_sr = x.sr_slot();
+        int s_nyq = x.slot_f([k](const UEnv& e) { return (e.sample_rate * k) * 0.5f - 1.1920929e-7f; });
+        x.cg.os() << "        if (" << fc << " == 0u) og::iir_lowpass_coeffs(" << cutoff.e << ", " << q.e << ", " << x.sf(s_sr)
+                  << ", " << x.sf(s_nyq) << ", " << b0 << ", " << b1 << ", " << b2 << ", " << a1 << ", " << a2 << ");\n";
+    }
+    x.cg.os() << "        " << fc << " = (" << fc << " + 1u) & 31u;\n";
+    x.set_out("output", "og::iir_lowpass_tick(" + in.e + ", " + v1 + ", " + v2 + ", " + b0 + ", " + b1 + ", " + b2 + ", " +
+                            a1 + ", " + a2 + ")");
+}
+
+// LP18Filter (examples/nih-twin-peaks/src/lp18_filter.rs)
+void emit_lp18(NodeCtx& x)
+{
+    const Val in = x.in("input");
+    const Val cutoff = x.in("cutoff");
+    const Val fmod = x.in("fmod");
+    Val res = x.in("resonance");
+    const float k = x.rate_sr_factor();
+    const float c0 = x.def("cutoff"), r0 = x.def("resonance");
+    auto clamp_res = [](float r) { return r < 0.0f ? 0.0f : (r > 0.99f ? 0.99f : r); };
+    if (!x.connected("resonance")) res = vconst(clamp_res(r0)); // new() stores the clamped value in the field :50
+    int s_sr = x.sr_slot();
+    std::string z0 = x.state_f("z0", [](const UEnv&) { return 0.0f; });
+    std::string z1 = x.state_f("z1", [](const UEnv&) { return 0.0f; });
+    std::string z2 = x.state_f("z2", [](const UEnv&) { return 0.0f; });
+    std::string g = x.state_f("g", [c0, k](const UEnv& e) { // prepare() :75-78
+        float fc = (c0 + 0.0f) / (e.sample_rate * k);
+        fc = fc < 0.001f ? 0.001f : (fc > 0.33f ? 0.33f : fc);
+        return tanf(3.14159274101257324f * fc);
+    });
+    std::string h = x.state_f("h", [r0, clamp_res](const UEnv&) { return 2.0f * clamp_res(r0); });
+    std::string lc = x.state_f("last_cutoff", [c0](const UEnv&) { return c0; });
+    std::string lf = x.state_f("last_fmod", [](const UEnv&) { return 0.0f; });
+    std::string lr = x.state_f("last_resonance", [r0](const UEnv&) { return r0; });
+    x.cg.os() << "        og::lp18_params(" << cutoff.e << ", " << fmod.e << ", " << res.e << ", " << x.sf(s_sr) << ", " << g
+              << ", " << h << ", " << lc << ", " << lf << ", " << lr << ");\n";
+    x.set_out("output", "og::lp18_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + z2 + ", " + g + ", " + h + ")");
+}
+
+// Delay (oscen-lib/src/delay/mod.rs): the line itself is an HBM ring per voice (CompiledGraph::rings)
+void emit_delay(NodeCtx& x)
+{
+    if (x.cg.out.lpv != 1) fail("Delay is not supported in array-valued (32 lanes per voice) graphs");
+    if (x.n.domain == 1) fail("Delay inside an oversampled (`* N`) region is not supported by this version");
+    if (x.cg.out.rings.size() >= 4) fail("at most 4 Delay nodes per graph");
+    const Val in = x.in("input");
+    const Val ds = x.in("delay_samples");
+    const Val fb = x.in("feedback");
+    const int k = (int)x.cg.out.rings.size();
+    x.cg.out.rings.push_back({x.n.decl->name, x.rate_sr_factor()});
+    const float d0 = x.def("delay_samples"), f0 = x.def("feedback");
+    std::string dsv = x.state_f("delay_samples", [d0](const UEnv&) { return d0; });
+    std::string fbv = x.state_f("feedback", [f0](const UEnv&) { return f0; });
+    std::string wp = x.state_u("write_pos", 0), fc = x.state_u("frame_counter", 0);
+    // connected value inputs overwrite the field every frame; the clamp of frame_counter == 0 then applies
+    // to that frame's value only (delay/mod.rs:47-56 after the generated edge copy)
+    if (x.connected("delay_samples")) x.cg.os() << "        " << dsv << " = " << ds.e << ";\n";
+    if (x.connected("feedback")) x.cg.os() << "        " << fbv << " = " << fb.e << ";\n";
+    x.set_out("output", "og::delay_tick(A.rings[" + std::to_string(k) + "], A.ring_cap[" + std::to_string(k) +
+                            "], A.n_voices, c.v, c.valid, " + in.e + ", " + dsv + ", " + fbv + ", " + wp + ", " + fc + ")");
+}
+
 // (inputs are resolved in separate statements: operand evaluation order is unspecified in C++ and
 //  resolving an input can allocate cut-crossing channels, whose numbering must be deterministic)
 void emit_binary(NodeCtx& x, const char* a, const char* b, const char* op)
@@ -843,6 +982,10 @@ const std::map<std::string, NodeTypeInfo>& registry()
         r["AddValue::new"] = {{{"input", S, 0, -1}, {"value", V, 0, 0}}, {"output"}, emit_add_value, 0, 1};
         r["Mixer::new"] = {{{"input_a", S, 0, -1}, {"input_b", S, 0, -1}}, {"output"}, emit_mixer, 0, 0};
         r["Crossfade::new"] = {{{"input", S, 0, -1}, {"mix", V, 0, -1}}, {"output_a", "output_b"}, emit_crossfade, 0, 0};
+        r["IirLowpass::new"] = {{{"input", S, 0, -1}, {"cutoff", V, 0, 0}, {"q", V, 0, 1}}, {"output"}, emit_iir_lowpass, 0, 2};
+        r["LP18Filter::new"] = {{{"input", S, 0, -1}, {"cutoff", V, 0, 0}, {"fmod", V, 0, -1}, {"resonance", V, 0, 1}},
+                                {"output"}, emit_lp18, 0, 2};
+        r["Delay::new"] = {{{"input", S, 0, -1}, {"delay_samples", V, 0, 0}, {"feedback", V, 0, 1}}, {"output"}, emit_delay, 0, 2};
         r["HardClip::new"] = {{{"input", S, 0, -1}}, {"output"}, emit_hardclip, 0, 0};
         r["AmplitudeSource::new"] = {{{"frequency", V, 440.0f, -1}, {"gate", E, 0, -1}, {"brightness", V, 30.0f, -1},
                                       {"velocity_scaling", V, 50.0f, -1}, {"decay_rate", V, 90.0f, -1},
@@ -859,6 +1002,17 @@ const std::map<std::string, NodeTypeInfo>& registry()
 }
 
 } // namespace
+
+uint32_t RingSpec::capacity(float graph_sr) const
+{
+    const float want = 2.0f * (graph_sr * rate_factor); // delay/mod.rs:62-66: (2.0 * sr) as usize, capped at 88200
+    size_t n = want > 0.0f ? (size_t)want : 0;
+    n = std::min<size_t>(n, 88200);
+    n = std::max<size_t>(n, 1);
+    uint32_t c = 1;
+    while (c < n) c <<= 1; // RingBuffer::new -> PowerOfTwo mode (ring_buffer/mod.rs:29-41)
+    return c;
+}
 
 std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
 {
@@ -936,6 +1090,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     std::map<int, std::vector<OutEdge>> out_edges; // graph output index -> sources
     std::vector<std::set<int>> deps(g.nodes.size()); // node -> nodes it reads
     std::vector<std::set<int>> out_deps(g.outputs.size());
+    std::vector<std::set<int>> fb_deps(g.nodes.size()); // feedback edges: liveness only, no ordering
+    bool any_feedback = false;
+    cg.emitted.assign(g.nodes.size(), 0);
     auto bus_node_of = [&](const std::string& endpoint) -> int {
         std::string nm = endpoint.substr(0, endpoint.find('.'));
         while (!nm.empty() && isspace((unsigned char)nm.back())) nm.pop_back();
@@ -1026,7 +1183,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         } else {
             if (src_is_event_input) fail("event source '" + e.src + "' cannot feed '" + e.dst + "'");
             dst.in_edges[dp].push_back({src, e.policy});
-            deps[nit->second].insert(src_nodes.begin(), src_nodes.end());
+            if (e.feedback) { // outgoing leg of `src -> [via] -> dst` (ir/lower.rs:553-570)
+                if (src->t != Expr::Ref || src->port.empty()) fail("a feedback edge must start at a node output ('" + e.src + "')");
+                const int via = *src_nodes.begin();
+                if (g.nodes[via].type.rfind("Delay::", 0) != 0)
+                    fail("node '" + g.nodes[via].name + "' cannot close a feedback loop: only Delay implements AllowsFeedback");
+                fb_deps[nit->second].insert(via);
+                cg.fb_sources.insert("n" + std::to_string(via) + "." + src->port);
+                any_feedback = true;
+            } else {
+                deps[nit->second].insert(src_nodes.begin(), src_nodes.end());
+            }
         }
     }
 
@@ -1042,6 +1209,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             if (live[n]) continue;
             live[n] = 1;
             for (int d : deps[n]) q.push_back(d);
+            for (int d : fb_deps[n]) q.push_back(d);
         }
         for (size_t i = 0; i < g.nodes.size(); ++i) cg.nodes[i].live = live[i];
     }
@@ -1080,8 +1248,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 if (--indeg[u] == 0) ready.push_back(u);
         }
         if (order.size() != n_live)
-            fail("graph contains a non-feedback cycle (feedback edges are not supported by this version)");
+            fail("graph contains a non-feedback cycle (use `-> [N] ->` to insert a delay buffer, or `-> [delay_node] ->` to "
+                 "route through a declared Delay node)");
     }
+
+    if (any_feedback && cg.N > 1) fail("feedback edges in graphs with oversampled (`* N`) nodes are not supported by this version");
 
     // ---- rate domains (emit_frame.rs:183-215; taint analysis emit_node.rs:516-584) ------------
     // 1 = oversampled inner loop; outer nodes downstream of an inner node run after the loop (2)
@@ -1109,7 +1280,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     cg.stage_of.assign(g.nodes.size(), 0);
     {
         const char* env_split = getenv("OGC_SPLIT");
-        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2;
+        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback;
         const char* env_cut = getenv("OGC_CUT");
         const bool depth_cut = env_cut && std::string(env_cut) == "depth";
         if (want && !depth_cut) {
@@ -1203,6 +1374,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             cg.os() << "        // " << n.decl->name << " = " << n.decl->type
                     << (dom == 1 ? " * " + std::to_string(cg.N) : std::string()) << "\n";
             n.type->emit(x);
+            cg.emitted[ni] = 1;
             out.node_order.push_back(n.decl->name);
         }
     }

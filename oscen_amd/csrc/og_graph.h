@@ -64,6 +64,9 @@ struct GEdge {
     std::string src; // endpoint or compound expression: "env.output", "a.x * b.y", "gate"
     std::string dst; // "node.port" or graph output name
     std::string policy; // "", "sinc", "sinc_iir", "linear", "latch"
+    // outgoing leg of `src -> [via] -> dst` (ir/lower.rs:342-347): imposes no ordering; a consumer
+    // scheduled before `via` reads the output `via` produced on the previous frame
+    bool feedback = false;
 };
 
 struct GraphDesc {
@@ -91,6 +94,12 @@ struct UniformProg {
     int dst;
     std::function<uint32_t(const UEnv&)> fn;
 };
+struct RingSpec { // a per-voice delay line in HBM (Delay's RingBuffer, delay/mod.rs:59-69)
+    std::string name;
+    float rate_factor = 1.0f;
+    // next_power_of_two(min((2.0 * sr) as usize, 88200))
+    uint32_t capacity(float graph_sr) const;
+};
 struct CompiledGraph {
     std::string name;
     std::string source; // complete HIP translation unit for this graph
@@ -98,6 +107,7 @@ struct CompiledGraph {
     std::vector<InputInfo> inputs;
     std::vector<StateWord> state;      // per-voice words
     std::vector<StateWord> lane_state; // per-(voice, lane) words of LPV > 1 graphs
+    std::vector<RingSpec> rings;       // delay lines (at most OG_MAX_RINGS)
     int lpv = 1;                       // lanes per voice (32 for the electric-piano voice)
     bool can_split = false;            // a two-wave pipeline variant of the kernel exists (og_k2_*)
     // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>

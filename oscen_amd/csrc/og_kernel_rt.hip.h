@@ -53,6 +53,8 @@ struct OgEvent {
     float value;     // scalar payload (gate velocity) or the new value
 };
 
+#define OG_MAX_RINGS 4
+
 struct OgBlockArgs {
     uint32_t n_voices;
     uint32_t frames;
@@ -68,6 +70,8 @@ struct OgBlockArgs {
     const float* ramp_table;   // [n_ramps][frames] per-frame values of ramped inputs
     float* taps;               // [n_taps][frames] per-voice output taps (or null)
     const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
+    float* rings[OG_MAX_RINGS];        // delay lines: [capacity][n_voices] each (slot-major, voices contiguous)
+    uint32_t ring_cap[OG_MAX_RINGS];   // capacity in samples (a power of two, ring_buffer/mod.rs:35-41)
     uint32_t slots[OG_MAX_SLOTS]; // block-uniform values (f32 or u32 bits)
 };
 

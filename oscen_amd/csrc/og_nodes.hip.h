@@ -378,6 +378,121 @@ OG_DEV float oscillator_tick(float& phase, float frequency_in, float frequency_m
 OG_DEV float hardclip(float in) { return clampf(in * 1.5f, -0.7f, 0.7f); }
 
 // ---------------------------------------------------------------------------
+// IirLowpass  oscen-lib/src/filters/iir_lowpass/mod.rs:84-164
+// ---------------------------------------------------------------------------
+constexpr float F32_PI = 3.14159274101257324f;
+
+// update_coefficients :84-101 (runs when frame_counter == 0, i.e. every 32nd tick)
+OG_DEV void iir_lowpass_coeffs(float cutoff, float q_in, float sr, float nyquist, float& b0, float& b1, float& b2,
+                               float& a1, float& a2)
+{
+    const float freq = clampf(cutoff, 20.0f, nyquist);
+    const float q = fmaxf(q_in, 0.01f);
+    const float n = 1.0f / og_tanf_q1(F32_PI * freq / sr);
+    const float n2 = n * n;
+    const float iq = 1.0f / q;
+    const float c1 = 1.0f / (1.0f + iq * n + n2);
+    b0 = c1;
+    b1 = c1 * 2.0f;
+    b2 = c1;
+    a1 = c1 * 2.0f * (1.0f - n2);
+    a2 = c1 * (1.0f - iq * n + n2);
+}
+
+// process_sample :109-134 (transposed direct form II with the 1e-15 denormal snaps)
+OG_DEV float iir_lowpass_tick(float in, float& v1, float& v2, float b0, float b1, float b2, float a1, float a2)
+{
+    constexpr float DENORMAL_THRESHOLD = 1e-15f;
+    in = (fabsf(in) < DENORMAL_THRESHOLD) ? 0.0f : in;
+    const float out = b0 * in + v1;
+    v1 = b1 * in - a1 * out + v2;
+    v2 = b2 * in - a2 * out;
+    v1 = (fabsf(v1) < DENORMAL_THRESHOLD) ? 0.0f : v1;
+    v2 = (fabsf(v2) < DENORMAL_THRESHOLD) ? 0.0f : v2;
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// LP18Filter  examples/nih-twin-peaks/src/lp18_filter.rs:63-107
+// ---------------------------------------------------------------------------
+OG_DEV void lp18_params(float cutoff, float fmod, float resonance, float sr, float& g, float& h, float& last_cutoff,
+                        float& last_fmod, float& last_resonance)
+{
+    if (cutoff != last_cutoff || fmod != last_fmod) { // :82-86, update_cutoff_coefficient :63-67
+        last_cutoff = cutoff;
+        last_fmod = fmod;
+        g = og_tanf_q1(F32_PI * clampf((cutoff + fmod) / sr, 0.001f, 0.33f));
+    }
+    if (resonance != last_resonance) { // :88-92
+        last_resonance = resonance;
+        h = 2.0f * clampf(resonance, 0.0f, 0.99f);
+    }
+}
+
+OG_DEV float lp18_tick(float in, float& z0, float& z1, float& z2, float g, float h) // :94-106
+{
+    const float hp = (in - h * z0 - z1 - z2) / (1.0f + g);
+    const float bp1 = g * hp + z0;
+    z0 = tanhf(bp1);
+    const float bp2 = g * bp1 + z1;
+    z1 = bp2;
+    const float lp = g * bp2 + z2;
+    z2 = lp;
+    return lp;
+}
+
+// ---------------------------------------------------------------------------
+// Delay  oscen-lib/src/delay/mod.rs:47-83 over RingBuffer (PowerOfTwo mode)
+// oscen-lib/src/ring_buffer/mod.rs:56-203.  The line of voice v lives in HBM at
+// ring[slot * n_voices + v]: the 64 voices of a wave read/write one 256-byte
+// row per access.  write_pos / frame_counter / the two parameter fields are
+// ordinary per-voice state words.
+// ---------------------------------------------------------------------------
+OG_DEV float ring_get(const float* ring, uint32_t nv, uint32_t v, uint32_t cap, uint32_t wp, float offset) // :167-203
+{
+    const uint32_t mask = cap - 1u;
+    const float o = fmaxf(offset, 0.0f);
+    const float fr = o - truncf(o);
+    if (fr < 1e-6f || (1.0f - fr) < 1e-6f) { // (almost) whole samples: the exact sample :178-191
+        const unsigned long long os = (unsigned long long)roundf(o);
+        const uint32_t idx = ((wp + cap) - ((uint32_t)os & mask) - 1u) & mask;
+        return ring[(size_t)idx * nv + v];
+    }
+    // get_cubic :120-164 (capacity >= 4 always holds for a prepared Delay); read_pos :80-92 in f32
+    const float n = (float)cap;
+    float rp = (float)wp - o - 1.0f;
+    rp = fmodf(fmodf(rp, n) + n, n);
+    const uint32_t i = (uint32_t)rp;
+    const float f = rp - truncf(rp);
+    const float v0 = ring[(size_t)((i - 1u) & mask) * nv + v];
+    const float v1 = ring[(size_t)(i & mask) * nv + v];
+    const float v2 = ring[(size_t)((i + 1u) & mask) * nv + v];
+    const float v3 = ring[(size_t)((i + 2u) & mask) * nv + v];
+    const float c0 = v1;
+    const float c1 = 0.5f * (v2 - v0);
+    const float c2 = v0 - 2.5f * v1 + 2.0f * v2 - 0.5f * v3;
+    const float c3 = 0.5f * (v3 - v0) + 1.5f * (v1 - v2);
+    return c0 + f * (c1 + f * (c2 + f * c3));
+}
+
+OG_DEV float delay_tick(float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float in, float& delay_samples,
+                        float& feedback, uint32_t& wp, uint32_t& fc)
+{
+    if (fc == 0u) { // apply_parameter_updates :47-56
+        delay_samples = clampf(delay_samples, 0.0f, (float)cap - 1.0f);
+        feedback = clampf(feedback, 0.0f, 0.99f);
+    }
+    fc = (fc + 1u) & 31u;
+    float delayed = 0.0f;
+    if (valid) {
+        delayed = ring_get(ring, nv, v, cap, wp, delay_samples);
+        ring[(size_t)wp * nv + v] = in + delayed * feedback; // push :57-77
+    }
+    wp = (wp + 1u) & (cap - 1u);
+    return delayed;
+}
+
+// ---------------------------------------------------------------------------
 // Cross-rate kernels  oscen-lib/src/resample/{sinc_fir,halfband_iir,linear,latch}.rs
 // Histories are kept UNROTATED in registers: index 0 is always the newest
 // sample, a push shifts the array (the reference's ring + head gives the same

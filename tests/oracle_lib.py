@@ -69,6 +69,17 @@ class IirLowpass(C.Structure):
                 ("frame_counter", C.c_uint32), ("frames_per_update", C.c_uint32)]
 
 
+class Ring(C.Structure):
+    _fields_ = [("buffer", C.POINTER(C.c_float)), ("write_pos", C.c_size_t), ("capacity", C.c_size_t),
+                ("mask", C.c_size_t), ("mode", C.c_int32)]
+
+
+class Delay(C.Structure):
+    _fields_ = [("input", C.c_float), ("delay_samples", C.c_float), ("feedback", C.c_float), ("output", C.c_float),
+                ("buffer", Ring), ("sample_rate", C.c_float), ("frames_per_update", C.c_size_t),
+                ("frame_counter", C.c_size_t)]
+
+
 class Lp18(C.Structure):
     _fields_ = [("input", C.c_float), ("cutoff", C.c_float), ("fmod", C.c_float), ("resonance", C.c_float),
                 ("output", C.c_float), ("z", C.c_float * 3), ("g", C.c_float), ("h", C.c_float),
@@ -211,6 +222,12 @@ def load():
     lib.oo_iir_lowpass_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_iir_lowpass_process_sample.argtypes = [C.c_void_p, C.c_float]
     lib.oo_iir_lowpass_process_sample.restype = C.c_float
+    lib.oo_ring_new.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lib.oo_ring_push.argtypes = [C.c_void_p, C.c_float]
+    for fn in (lib.oo_ring_get, lib.oo_ring_get_linear, lib.oo_ring_get_cubic):
+        fn.argtypes = [C.c_void_p, C.c_float]
+        fn.restype = C.c_float
+    lib.oo_delay_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_lp18_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_adsr_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.oo_ramp_new.argtypes = [C.c_void_p, C.c_float]

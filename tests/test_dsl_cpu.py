@@ -98,6 +98,46 @@ def test_dsl_diagnostics():
     assert "line 3" in str(e.value)
     with pytest.raises(oscen_amd.OscenError):
         oscen_amd.Graph(dsl="name: X; input a: value = 1.0;", per_voice=["nope"])
+    # a cycle that is not routed through a delay: the reference's "non-feedback cycle" diagnostic (ir/lower.rs:1080)
     with pytest.raises(oscen_amd.OscenError) as e:
-        oscen_amd.Graph(dsl="name: X; output o: stream; nodes { d = Gain::new(1.0); } connections { d.output -> [4] -> d.input; }")
-    assert "inline delays" in str(e.value)
+        oscen_amd.Graph(dsl="name: X; output o: stream; nodes { a = Gain::new(1.0); b = Gain::new(1.0); } "
+                            "connections { a.output -> b.input; b.output -> a.input; b.output -> o; }").kernel_source()
+    assert "non-feedback cycle" in str(e.value)
+    # only Delay implements AllowsFeedback (oscen-macros/tests/ui/feedback_marker_missing.rs)
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Graph(dsl="name: X; output o: stream; nodes { a = Gain::new(1.0); b = Gain::new(1.0); } "
+                            "connections { a.output -> [b] -> a.input; a.output -> o; }").kernel_source()
+    assert "AllowsFeedback" in str(e.value)
+
+
+def test_dsl_feedback_through_delay():
+    """`src -> [N] -> dst` and `src -> [node] -> dst` (ir/lower.rs:342-347): two edges, the second a feedback edge."""
+    text = """
+    name: Echo;
+    input frequency: value = 220.0;
+    input gate: event;
+    output out: stream;
+    nodes {
+        osc = PolyBlepOscillator::saw(220.0, 0.5);
+        env = AdsrEnvelope::new(0.01, 0.1, 0.5, 0.2);
+        mix = Mixer::new();
+        fbk = Gain::new(0.4);
+        d = Delay::new(100.0, 0.0);
+    }
+    connections {
+        frequency -> osc.frequency;
+        gate -> env.gate;
+        osc.output * env.output -> mix.input_a;
+        mix.output -> [d] -> fbk.input;
+        fbk.output -> mix.input_b;
+        mix.output -> [3] -> out;
+    }
+    """
+    g = oscen_amd.Graph(dsl=text, per_voice=["frequency"])
+    src = g.kernel_source()
+    assert src.count("og::delay_tick(") == 2 and "A.rings[1]" in src
+    assert "_output_z" in src  # fbk runs before d: it reads d's previous output
+    back = g.to_dsl()
+    assert "mix.output -> [d] -> fbk.input;" in back and "mix.output -> [3] -> out;" in back
+    g2 = oscen_amd.Graph(dsl=back, per_voice=["frequency"])
+    assert g2.kernel_source() == src

@@ -610,3 +610,81 @@ def test_iir_lowpass_dc_gain_impulse_stability_denormal(lib):
         assert abs(f.output) < 10.0
     f = _iir(lib, 100.0, q)
     assert lib.oo_iir_lowpass_process_sample(C.byref(f), 1e-20) == 0.0
+
+
+# --------------------------------------------------------------------------
+# RingBuffer / Delay  oscen-lib/src/ring_buffer/tests.rs (N3 row)
+# --------------------------------------------------------------------------
+def _ring(lib, size, mode, values=()):
+    r = ol.Ring()
+    lib.oo_ring_new(C.byref(r), size, mode)
+    for v in values:
+        lib.oo_ring_push(C.byref(r), v)
+    return r
+
+
+def test_ring_initialization_and_wrap(lib):
+    # tests.rs:7-109
+    for size, mode, cap in ((5, 0, 8), (8, 0, 8), (9, 0, 16), (17, 0, 32), (0, 0, 1), (5, 1, 5), (8, 1, 8), (0, 1, 1)):
+        r = _ring(lib, size, mode)
+        assert r.capacity == cap
+        if mode == 0:
+            assert r.mask == cap - 1
+        assert all(r.buffer[i] == 0.0 for i in range(cap))
+        lib.oo_ring_free(C.byref(r))
+    r = _ring(lib, 4, 0, [1, 2, 3, 4])
+    assert (r.write_pos, r.buffer[0], r.buffer[3]) == (0, 1.0, 4.0)
+    lib.oo_ring_push(C.byref(r), 5.0)
+    assert (r.write_pos, r.buffer[0], r.buffer[1]) == (1, 5.0, 2.0)
+    lib.oo_ring_push(C.byref(r), 6.0)
+    assert (r.write_pos, r.buffer[1]) == (2, 6.0)
+    r = _ring(lib, 3, 1, [1, 2, 3])
+    assert (r.write_pos, r.buffer[0], r.buffer[2]) == (0, 1.0, 3.0)
+    lib.oo_ring_push(C.byref(r), 4.0)
+    assert (r.write_pos, r.buffer[0], r.buffer[1]) == (1, 4.0, 2.0)
+
+
+def test_ring_get_vectors(lib):
+    # tests.rs:112-214, epsilon 1e-6
+    def near(a, b):
+        assert abs(a - b) <= 1e-6, (a, b)
+
+    r = _ring(lib, 5, 1, [1, 2, 3, 4])
+    for off, want in ((0, 4), (1, 3), (2, 2), (3, 1)):
+        near(lib.oo_ring_get(C.byref(r), off), want)
+    lib.oo_ring_push(C.byref(r), 5.0)
+    lib.oo_ring_push(C.byref(r), 6.0)
+    for off, want in ((0, 6), (1, 5), (2, 4), (3, 3), (4, 2), (5, 6), (-1, 6)):
+        near(lib.oo_ring_get(C.byref(r), off), want)
+    r = _ring(lib, 4, 0, [1, 3, 5, 7])
+    for off, want in ((0, 7), (1, 5), (2, 3), (3, 1)):
+        near(lib.oo_ring_get(C.byref(r), off), want)
+    for off, want in ((0.5, 6), (1.5, 4), (2.5, 2)):
+        near(lib.oo_ring_get_linear(C.byref(r), off), want)
+    lib.oo_ring_push(C.byref(r), 9.0)
+    near(lib.oo_ring_get_linear(C.byref(r), 0.5), 8.0)
+    r = _ring(lib, 5, 1, [1, 2, 4, 8, 16])
+    for off, want in ((0, 16), (1, 8), (4, 1)):
+        near(lib.oo_ring_get(C.byref(r), off), want)
+    near(lib.oo_ring_get_cubic(C.byref(r), 0.5), 13.1875)
+    r = _ring(lib, 3, 1, [1, 5, 9])
+    near(lib.oo_ring_get(C.byref(r), 0.5), 7.0)
+    r = _ring(lib, 0, 0, [5.0])
+    near(lib.oo_ring_get(C.byref(r), 0.0), 5.0)
+
+
+def test_delay_is_a_pure_delay_without_feedback(lib):
+    # delay/mod.rs:72-83: output[n] = input[n - 1 - delay_samples]; prepare() sizes the ring from the rate
+    d = ol.Delay()
+    lib.oo_delay_new(C.byref(d), 10.0, 0.0)
+    d.sample_rate = 48000.0
+    lib.oo_delay_prepare(C.byref(d))
+    assert d.buffer.capacity == 131072  # next_power_of_two(min(96000, 88200))
+    xs = np.arange(1, 101, dtype=f32)
+    ys = []
+    for x in xs:
+        d.input = float(x)
+        lib.oo_delay_process(C.byref(d))
+        ys.append(d.output)
+    assert ys[:11] == [0.0] * 11 and ys[11:] == list(xs[:89])
+    lib.oo_delay_free(C.byref(d))
