@@ -21,7 +21,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(voices, block):
+def pmc_traffic(voices, block, graph):
     """HBM bytes per launch of the voice kernel from the committed rocprofv3 PMC passes
     (profiles/*_summary.json, written by scripts/prof_summary.py): FETCH_SIZE and WRITE_SIZE are
     collected in separate --pmc runs of this same command, so they cannot be measured in-process."""
@@ -33,11 +33,13 @@ def pmc_traffic(voices, block):
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("voices") == voices and d.get("frames") == block and "hbm_traffic" in d:
+        if (d.get("voices") == voices and d.get("frames") == block and d.get("graph", "fm_voice") == graph
+                and "hbm_traffic" in d):
             best = (path, d)
     if not best:
-        return None, None
-    return best[1]["hbm_traffic"]["total_bytes_corrected"], os.path.relpath(best[0], ROOT)
+        return None, None, None
+    valu = best[1].get("pmc_voice_kernel", {}).get("SQ_INSTS_VALU", {}).get("avg_per_dispatch")
+    return best[1]["hbm_traffic"]["total_bytes_corrected"], os.path.relpath(best[0], ROOT), valu
 
 
 def cpu_baseline(block, seed):
@@ -173,8 +175,10 @@ def main():
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
         n_wg = (V * eng.lanes_per_voice + lanes - 1) // lanes
         bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
+        # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
+        bytes_per_launch += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        pmc_bytes, pmc_src = pmc_traffic(V, block)
+        pmc_bytes, pmc_src, pmc_valu = pmc_traffic(V, block, args.graph)
         traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
         line = {
             "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
@@ -216,7 +220,19 @@ def main():
                 "voices_per_wave": lanes,
                 "two_wave_pipeline": eng.uses_split_kernel,
                 "bytes_per_voice_sample": bytes_per_launch / float(V * block),
-                "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block",
+                "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block; "
+                        "see valu_issue for the bound that applies",
+                # The limiter (DESIGN.md "Measurement"): wave64 f32 VALU instructions retire one per
+                # 4 cycles per SIMD.  achieved = SQ_INSTS_VALU per launch (committed PMC pass) / the
+                # kernel duration measured in this run; peak = 1024 SIMDs x 2.4 GHz / 4.
+                "valu_issue": None if not (pmc_valu and kern_ms > 0) else {
+                    "achieved": pmc_valu / (kern_ms * 1e-3) / 1e9,
+                    "peak": 1024 * 2.4 / 4.0,
+                    "unit": "G wave-instructions/s",
+                    "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 4.0),
+                    "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block),
+                    "source": pmc_src,
+                },
             },
         }
         if world_size == 1 and not args.no_cpu_baseline:

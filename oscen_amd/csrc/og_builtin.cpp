@@ -141,6 +141,41 @@ GraphDesc sub_voice()
     return g;
 }
 
+// Echo voice: the sub-style voice into the feedback echo of examples/simple-echo/src/lib.rs:35-64
+// (Delay::new(11025, 0) -> TptFilter::new(4000, 0.7), filter output fed back into the delay input,
+// dry/wet mix), written as a graph with a `-> [delay] ->` feedback edge.  The delay line of every
+// voice lives in HBM: this is the configuration whose traffic is dominated by HBM rather than state.
+GraphDesc echo_voice()
+{
+    GraphDesc g;
+    g.name = "echo_voice";
+    g.inputs.push_back(voice_in("frequency", 440.0f));
+    g.inputs.push_back(event_in("gate"));
+    g.inputs.push_back(value_in("delay_samples", 11025.0f));
+    g.inputs.push_back(value_in("feedback", 0.4f));
+    g.inputs.push_back(value_in("cutoff", 4000.0f));
+    g.inputs.push_back(value_in("dry", 0.65f));
+    g.inputs.push_back(value_in("wet", 0.35f));
+    g.outputs.push_back({"audio", Kind::Stream});
+    g.nodes.push_back({"osc", "PolyBlepOscillator::saw", {440.0f, 0.6f}, 1});
+    g.nodes.push_back({"envelope", "AdsrEnvelope::new", {0.01f, 0.1f, 0.7f, 0.2f}, 1});
+    g.nodes.push_back({"sum", "Mixer::new", {}, 1});
+    g.nodes.push_back({"echo", "Delay::new", {11025.0f, 0.0f}, 1});
+    g.nodes.push_back({"filter", "TptFilter::new", {4000.0f, 0.7f}, 1});
+    g.edges.push_back({"frequency", "osc.frequency", ""});
+    g.edges.push_back({"gate", "envelope.gate", ""});
+    g.edges.push_back({"delay_samples", "echo.delay_samples", ""});
+    g.edges.push_back({"cutoff", "filter.cutoff", ""});
+    g.edges.push_back({"osc.output * envelope.output", "sum.input_a", ""});
+    g.edges.push_back({"filter.output * feedback", "sum.input_b", ""});
+    g.edges.push_back({"sum.output", "echo.input", ""});
+    GEdge fb{"echo.output", "filter.input", ""};
+    fb.feedback = true;
+    g.edges.push_back(fb);
+    g.edges.push_back({"osc.output * envelope.output * dry + filter.output * wet", "audio", ""});
+    return g;
+}
+
 // SatGraph_{1,4}x (examples/oversampled-saturator/src/main.rs:64-80): saw -> HardClip, both `* N`,
 // `[sinc] clip.output -> audio_out`.  The oscillator frequency is a per-voice input here (the
 // reference fixes 2000 Hz) so that a bank of voices is not N copies of one signal.
@@ -196,7 +231,7 @@ GraphDesc epiano_voice()
 
 } // namespace
 
-std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice", "epiano_voice"}; }
+std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice", "epiano_voice", "echo_voice"}; }
 
 GraphDesc builtin_graph(const std::string& name)
 {
@@ -205,6 +240,7 @@ GraphDesc builtin_graph(const std::string& name)
     if (name == "sat4x_voice") return sat_voice(4);
     if (name == "sat1x_voice") return sat_voice(1);
     if (name == "epiano_voice") return epiano_voice();
+    if (name == "echo_voice") return echo_voice();
     throw std::runtime_error("unknown builtin graph '" + name + "'");
 }
 

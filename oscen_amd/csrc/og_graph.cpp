@@ -277,6 +277,7 @@ struct Codegen {
     // kernel simply concatenates both sets.
     struct Sect {
         std::ostringstream decl, load, derive, pre, post, pre_store, store;
+        std::ostringstream chunk_begin; // top of every OG_BUS_CHUNK-frame chunk (delay-line staging)
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
@@ -881,8 +882,16 @@ void emit_delay(NodeCtx& x)
     // to that frame's value only (delay/mod.rs:47-56 after the generated edge copy)
     if (x.connected("delay_samples")) x.cg.os() << "        " << dsv << " = " << ds.e << ";\n";
     if (x.connected("feedback")) x.cg.os() << "        " << fbv << " = " << fb.e << ";\n";
-    x.set_out("output", "og::delay_tick(A.rings[" + std::to_string(k) + "], A.ring_cap[" + std::to_string(k) +
-                            "], A.n_voices, c.v, c.valid, " + in.e + ", " + dsv + ", " + fbv + ", " + wp + ", " + fc + ")");
+    // whole-sample reads are staged a chunk ahead (og::ring_chunk_begin); the offset the staging assumes is
+    // the connected input when that is constant over the block, else the field as the last tick left it
+    const std::string K = std::to_string(k), pre = x.p + "pre";
+    const bool hint_input = x.connected("delay_samples") && ds.rate <= Rate::VBlock && ds.rate != Rate::UFrame;
+    x.cg.S().decl << "    og::RingPre " << pre << " = {og::RING_NONE, og::RING_NONE, {}};\n";
+    x.cg.S().chunk_begin << "        og::ring_chunk_begin(A.rings[" << K << "], A.ring_cap[" << K << "], A.n_voices, c.v, c.valid, "
+                         << (hint_input ? ds.e : dsv) << ", " << wp << ", " << pre << ", ring_lds[" << K
+                         << "], c.lane, base + OG_BUS_CHUNK < A.frames);\n";
+    x.set_out("output", "og::delay_tick(A.rings[" + K + "], A.ring_cap[" + K + "], A.n_voices, c.v, c.valid, " + in.e + ", " +
+                            dsv + ", " + fbv + ", " + wp + ", " + fc + ", " + pre + ", ring_lds[" + K + "], c.lane, f - cbase)");
 }
 
 // (inputs are resolved in separate statements: operand evaluation order is unspecified in C++ and
@@ -1280,7 +1289,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     cg.stage_of.assign(g.nodes.size(), 0);
     {
         const char* env_split = getenv("OGC_SPLIT");
-        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback;
+        bool any_delay = false; // delay lines are staged per chunk by the ordinary kernel only
+        for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
+        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback &&
+                    !any_delay;
         const char* env_cut = getenv("OGC_CUT");
         const bool depth_cut = env_cut && std::string(env_cut) == "depth";
         if (want && !depth_cut) {
@@ -1480,12 +1492,18 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     body << "template <bool RAMPS, bool TAPS>\n"
          << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
          << "    __shared__ og::BusLds bus;\n"
+         << (out.rings.empty() ? std::string()
+                               : "    __shared__ float ring_lds[" + std::to_string(out.rings.size()) +
+                                     "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
          << cg.common_decl.str() << cg.sec[0].decl.str() << cg.sec[1].decl.str() << "    if (c.valid) {\n"
          << cg.common_load.str() << cg.sec[0].load.str() << cg.sec[1].load.str() << "    }\n";
     body << "    auto derive = [&]() {\n" << cg.sec[0].derive.str() << cg.sec[1].derive.str() << "    };\n";
     body << cg.sec[0].pre.str() << cg.sec[1].pre.str() << "    derive();\n";
+    if (!out.rings.empty()) // state loads complete here, so that no wait for them lands inside the chunk loop,
+                            // where it would also sit out the delay-line loads staged for the next chunk
+        body << "    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
     body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << tick_code(0);
     for (auto& xv : cg.xvals) body << "        const float " << xv.second << " = " << xv.first << ";\n";
@@ -1494,6 +1512,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     body << events_code({0, 1});
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
+         << (out.rings.empty() ? std::string() : "        cbase = base;\n" + cg.sec[0].chunk_begin.str() + cg.sec[1].chunk_begin.str())
          << "        if (n == OG_BUS_CHUNK && __all((int)(c.next_ev >= base + OG_BUS_CHUNK))) {\n"
          << "            // no lane of this wave has an event in the chunk: straight-line body\n"
          << "#pragma unroll " << unroll << "\n"

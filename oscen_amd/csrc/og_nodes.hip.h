@@ -457,7 +457,7 @@ OG_DEV float ring_get(const float* ring, uint32_t nv, uint32_t v, uint32_t cap, 
         const unsigned long long os = (unsigned long long)roundf(o);
         const uint32_t idx = ((wp + cap) - ((uint32_t)os & mask) - 1u) & mask;
         return ring[(size_t)idx * nv + v];
-    }
+    } // (delay_tick takes this path through ring_whole_offset; kept here so that ring_get is the whole of get())
     // get_cubic :120-164 (capacity >= 4 always holds for a prepared Delay); read_pos :80-92 in f32
     const float n = (float)cap;
     float rp = (float)wp - o - 1.0f;
@@ -475,17 +475,83 @@ OG_DEV float ring_get(const float* ring, uint32_t nv, uint32_t v, uint32_t cap, 
     return c0 + f * (c1 + f * (c2 + f * c3));
 }
 
-OG_DEV float delay_tick(float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float in, float& delay_samples,
-                        float& feedback, uint32_t& wp, uint32_t& fc)
+// Whole-sample reads are staged one 16-frame chunk ahead: at the top of a chunk the 16 samples the
+// NEXT chunk will read are requested from HBM into registers (one exposed latency per chunk at most,
+// none when the delay is >= 32 samples) and the ones requested a chunk ago move to an LDS column that
+// the ticks read.  The staged samples are only a prediction: every tick recomputes the reference's
+// index and falls back to a direct load when the offset it finds is not the predicted one.
+constexpr uint32_t RING_NONE = 0xffffffffu;
+struct RingPre {
+    uint32_t pred;      // (offset_samples & mask) the LDS column was loaded for, or RING_NONE
+    uint32_t pred_next; // same for next[]
+    float next[OG_BUS_CHUNK];
+};
+
+// offset_samples % capacity of the exact-sample path of RingBuffer::get (:178-191), RING_NONE on the cubic path.
+// On this path fract < 1e-6 or > 1 - 1e-6, so round() is trunc or trunc + 1; `as usize` is exact below 2^32
+// and goes through the 64-bit conversion above (floats there are whole multiples of 512).
+OG_DEV uint32_t ring_whole_offset(float offset, uint32_t cap)
 {
-    if (fc == 0u) { // apply_parameter_updates :47-56
-        delay_samples = clampf(delay_samples, 0.0f, (float)cap - 1.0f);
-        feedback = clampf(feedback, 0.0f, 0.99f);
+    const float o = fmaxf(offset, 0.0f);
+    const float t = truncf(o);
+    const float fr = o - t;
+    const bool lo = fr < 1e-6f, hi = (1.0f - fr) < 1e-6f;
+    const float r = lo ? t : t + 1.0f;
+    uint32_t om = (uint32_t)r;
+    if (r >= 4294967296.0f) om = (uint32_t)((unsigned long long)r);
+    return (lo || hi) ? (om & (cap - 1u)) : RING_NONE;
+}
+
+OG_DEV void ring_chunk_begin(const float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float offset_hint,
+                             uint32_t wp, RingPre& P, float (*lds)[OG_WAVE], uint32_t lane, bool more)
+{
+    const uint32_t mask = cap - 1u;
+    const uint32_t om = valid ? ring_whole_offset(offset_hint, cap) : RING_NONE;
+    if (P.pred_next != RING_NONE) { // requested a chunk ago for exactly this write position
+#pragma unroll
+        for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) lds[j][lane] = P.next[j];
+        P.pred = P.pred_next;
+    } else if (om != RING_NONE && om >= OG_BUS_CHUNK) { // first chunk of a launch / short delays
+#pragma unroll
+        for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) lds[j][lane] = ring[(size_t)((wp + j - om - 1u) & mask) * nv + v];
+        P.pred = om;
+    } else {
+        P.pred = RING_NONE;
     }
+    if (more && om != RING_NONE && om >= 2u * OG_BUS_CHUNK) {
+#pragma unroll
+        for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j)
+            P.next[j] = ring[(size_t)((wp + OG_BUS_CHUNK + j - om - 1u) & mask) * nv + v];
+        P.pred_next = om;
+    } else {
+        P.pred_next = RING_NONE;
+    }
+}
+
+OG_DEV float delay_tick(float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float in, float& delay_samples,
+                        float& feedback, uint32_t& wp, uint32_t& fc, const RingPre& P, const float (*lds)[OG_WAVE],
+                        uint32_t lane, uint32_t j)
+{
+    // apply_parameter_updates :47-56 (selects, not a branch: the counter is the same in every lane)
+    const bool upd = fc == 0u;
+    const float ds_c = clampf(delay_samples, 0.0f, (float)cap - 1.0f), fb_c = clampf(feedback, 0.0f, 0.99f);
+    delay_samples = upd ? ds_c : delay_samples;
+    feedback = upd ? fb_c : feedback;
     fc = (fc + 1u) & 31u;
     float delayed = 0.0f;
     if (valid) {
-        delayed = ring_get(ring, nv, v, cap, wp, delay_samples);
+        const uint32_t om = ring_whole_offset(delay_samples, cap);
+        if (om != RING_NONE && om == P.pred) {
+            delayed = lds[j][lane]; // staged a chunk ago
+        } else {
+            if (om == RING_NONE)
+                delayed = ring_get(ring, nv, v, cap, wp, delay_samples);
+            else
+                delayed = ring[(size_t)((wp + cap - om - 1u) & (cap - 1u)) * nv + v];
+            // finish the load inside this (rare) branch: otherwise the wait for it is placed after the join
+            // as vmcnt(0), where the common path would sit out every store and staging load in flight
+            asm volatile("" : "+v"(delayed));
+        }
         ring[(size_t)wp * nv + v] = in + delayed * feedback; // push :57-77
     }
     wp = (wp + 1u) & (cap - 1u);

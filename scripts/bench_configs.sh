@@ -16,3 +16,5 @@ run --graph sub_voice --voices-per-gpu 262144
 run --graph epiano_voice --voices-per-gpu 262144
 run --graph sat4x_voice --voices-per-gpu 131072
 run --graph sat1x_voice --voices-per-gpu 131072
+run --graph echo_voice --voices-per-gpu 65536
+run --graph echo_voice --voices-per-gpu 262144

@@ -1,13 +1,19 @@
 """Condense gpurun_out/prof_<tag>/ (rocprofv3 rocpd databases written by scripts/gpu_profile.sh)
-into profiles/<tag>_summary.{json,md}.  usage: python scripts/prof_summary.py <tag> [voices] [frames]"""
+into profiles/<tag>_summary.{json,md}.  usage: python scripts/prof_summary.py <tag> [voices] [frames] [graph]"""
 import glob, json, os, sqlite3, sys
 
 tag = sys.argv[1]
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 FR = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+GRAPH = sys.argv[4] if len(sys.argv) > 4 else "fm_voice"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-out = {"tag": tag, "command": "python bench.py --steps 94 --warmup 4 --no-cpu-baseline", "voices": V, "frames": FR}
+cmd = "python bench.py --steps 94 --warmup 4 --no-cpu-baseline"
+if GRAPH != "fm_voice":
+    cmd += " --graph " + GRAPH
+if V != 65536:
+    cmd += " --voices-per-gpu %d" % V
+out = {"tag": tag, "command": cmd, "graph": GRAPH, "voices": V, "frames": FR}
 con = sqlite3.connect(os.path.join(base, "stats", "stats_results.db"))
 out["kernel_stats"] = [dict(name=r[0], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])
                        for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6")]
