@@ -218,7 +218,7 @@ def main():
                 "kernel_launches": n_launch,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "voices_per_wave": lanes,
-                "two_wave_pipeline": eng.uses_split_kernel,
+                "pipeline_waves_per_64_voices": eng.pipeline_depth,
                 "bytes_per_voice_sample": bytes_per_launch / float(V * block),
                 "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block; "
                         "see valu_issue for the bound that applies",

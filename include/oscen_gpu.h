@@ -160,7 +160,8 @@ uint64_t og_frames_processed(const og_engine* e);
 /* layout facts used by the roofline accounting */
 uint32_t og_state_words_per_voice(const og_engine* e);
 uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 32 for graphs with per-harmonic arrays */
-int og_uses_split_kernel(const og_engine* e); /* 1 when the two-wave pipeline variant is launched (small banks) */
+int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched kernel: 0 = one wave per 64 voices,
+                                                 2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
 uint64_t og_events_dropped(const og_engine* e);
 /* average device time of the voice kernel over the launches since the last

@@ -193,7 +193,7 @@ struct og_engine {
 
     uint32_t n_wg = 0;
     uint32_t lanes = OG_WAVE;
-    bool split = false;
+    uint32_t split = 0; // pipeline depth of the launched kernel variant: 0 (ordinary), 2 or 4 waves per 64 voices
     uint32_t* d_state = nullptr;
     uint32_t* d_lane_state = nullptr;
     float* d_ring[OG_MAX_RINGS] = {nullptr, nullptr, nullptr, nullptr}; // delay lines [capacity][V]
@@ -356,7 +356,7 @@ struct og_engine {
         A.n_voices = V;
         A.frames = frames;
         A.lanes = lanes;
-        A.split = split ? 1u : 0u;
+        A.split = split;
         A.frame0 = frame_now;
         A.state = d_state;
         A.lane_state = d_lane_state;
@@ -711,9 +711,20 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
                 if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
             }
             e->lanes = lanes;
-            // two-wave pipeline variant: only when the bank cannot put two ordinary waves on every SIMD
-            e->split = e->cg->can_split && ((n_voices + OG_WAVE - 1) / OG_WAVE) < 2 * simds;
-            if (const char* ev = getenv("OSCEN_GPU_SPLIT")) e->split = e->cg->can_split && atoi(ev) != 0;
+            // pipelined variants for banks too small to put four ordinary waves on every SIMD.  Measured on
+            // MI355X (fm_voice, 256-frame block): 32 768 voices 0.081 ms with two waves per 64 voices, 0.063 ms
+            // with four; 65 536 voices 0.096 / 0.086 / 0.105 ms with one / two / four (the four-wave form
+            // issues ~20% more instructions and runs at the pace of its heaviest stage).
+            const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
+            uint32_t depth = 0;
+            if (e->cg->max_pipeline >= 4 && waves1 * 2 <= simds) depth = 4;
+            else if (e->cg->max_pipeline >= 2 && waves1 < 2 * simds) depth = 2;
+            if (const char* ev = getenv("OSCEN_GPU_SPLIT")) {
+                const int want = atoi(ev);
+                depth = (want >= 4 && e->cg->max_pipeline >= 4) ? 4 : ((want >= 2 && e->cg->max_pipeline >= 2) ? 2 : 0);
+                if (want == 1 && e->cg->max_pipeline >= 2) depth = 2; // (old boolean meaning)
+            }
+            e->split = depth;
         }
         e->n_wg = (uint32_t)(((size_t)n_voices * e->cg->lpv + e->lanes - 1) / e->lanes);
         HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));

@@ -235,9 +235,9 @@ struct NodeTypeInfo {
 // rough VALU cost per tick of a node type (used to balance the two-stage split)
 int node_weight(const std::string& type)
 {
-    if (type.rfind("AdsrEnvelope", 0) == 0) return 12;
-    if (type.rfind("FmOperator", 0) == 0) return 23;
-    if (type.rfind("TptFilter", 0) == 0) return 17;
+    if (type.rfind("AdsrEnvelope", 0) == 0) return 10;
+    if (type.rfind("FmOperator", 0) == 0) return 24;
+    if (type.rfind("TptFilter", 0) == 0) return 25;
     if (type.rfind("PolyBlepOscillator", 0) == 0) return 30;
     if (type.rfind("Oscillator", 0) == 0) return 22;
     if (type.rfind("IirLowpass", 0) == 0) return 14;
@@ -272,9 +272,9 @@ struct Codegen {
     std::map<std::string, std::string> fb_vars;  // ... -> state variable holding last frame's value
     std::vector<char> emitted;                   // per node
 
-    // Emitted code sections.  There are two sets: a graph may be cut into two pipeline stages
-    // (see "two-stage split" in compile()); nodes of stage 1 write into sec[1].  The ordinary
-    // kernel simply concatenates both sets.
+    // Emitted code sections.  There are up to four sets: a graph may be cut into pipeline stages
+    // (see "pipeline stages" in compile()); nodes of stage s write into sec[s].  The ordinary
+    // kernel simply concatenates the sets; the pipelined kernels give groups of them to separate waves.
     struct Sect {
         std::ostringstream decl, load, derive, pre, post, pre_store, store;
         std::ostringstream chunk_begin; // top of every OG_BUS_CHUNK-frame chunk (delay-line staging)
@@ -284,7 +284,7 @@ struct Codegen {
         std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
         std::map<int, std::ostringstream> ev_handlers; // per graph event input
     };
-    Sect sec[2];
+    Sect sec[4];
     int cs = 0;  // stage being emitted
     int dom = 0; // rate domain being emitted: 0 pre, 1 inner, 2 post
     Sect& S() { return sec[cs]; }
@@ -293,10 +293,30 @@ struct Codegen {
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
     bool any_derive = false;
-    // two-stage split bookkeeping
+    // pipeline bookkeeping
     bool split = false;
-    std::vector<int> stage_of;                   // per node
-    std::vector<std::pair<std::string, std::string>> xvals; // (stage-0 variable, stage-1 alias) crossing the cut
+    int n_stages = 1;
+    std::vector<int> stage_of; // per node
+    struct XVal {              // a node output read by a later stage
+        std::string var, alias;
+        int from;
+        std::set<int> users; // consuming stages
+    };
+    std::vector<XVal> xvals;
+    // envelopes whose stage-end fix-up has not been emitted yet: (countdown expression, fix-up code).
+    // Flushed as ONE wave-uniform check before the next node that is not an envelope (which may read
+    // their outputs), before the stage changes and before the graph output is formed.
+    std::vector<std::pair<std::string, std::string>> pending_post;
+    void flush_post()
+    {
+        if (pending_post.empty()) return;
+        std::string m = pending_post[0].first;
+        for (size_t i = 1; i < pending_post.size(); ++i) m = "min(" + m + ", " + pending_post[i].first + ")";
+        os() << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n";
+        for (auto& pp : pending_post) os() << pp.second;
+        os() << "        }\n";
+        pending_post.clear();
+    }
 
     Codegen(const GraphDesc& gd, CompiledGraph& cg) : g(gd), out(cg) {}
 
@@ -454,15 +474,16 @@ struct Codegen {
             if (vit == node_outputs.end())
                 fail("node '" + e->node + "' has no output '" + e->port + "' (or it is read before it runs)");
             Val v = vit->second;
-            if (split && cs == 1 && stage_of[nit->second] == 0) { // value crosses the pipeline cut
-                std::string alias;
+            if (split && cs > stage_of[nit->second]) { // value crosses a pipeline cut
+                XVal* x = nullptr;
                 for (auto& xv : xvals)
-                    if (xv.first == v.e) alias = xv.second;
-                if (alias.empty()) {
-                    alias = "x" + std::to_string(xvals.size()) + "_" + v.e;
-                    xvals.push_back({v.e, alias});
+                    if (xv.var == v.e) x = &xv;
+                if (!x) {
+                    xvals.push_back({v.e, "x" + std::to_string(xvals.size()) + "_" + v.e, stage_of[nit->second], {}});
+                    x = &xvals.back();
                 }
-                v.e = alias;
+                x->users.insert(cs);
+                v.e = x->alias;
             }
             return v;
         }
@@ -603,10 +624,10 @@ struct NodeCtx {
         cg.S().store << "        og::st_u(A, c, " << w << ", " << var << ");\n";
         return var;
     }
-    void set_out(const std::string& port, const std::string& expr)
+    void set_out(const std::string& port, const std::string& expr, bool patched_later = false)
     {
         std::string var = p + port;
-        cg.os() << "        const float " << var << " = " << expr << ";\n";
+        cg.os() << "        " << (patched_later ? "" : "const ") << "float " << var << " = " << expr << ";\n";
         Val v;
         v.e = var;
         v.rate = Rate::Vary;
@@ -682,15 +703,13 @@ void emit_adsr(NodeCtx& x)
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
             x.cg.S().ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
-    x.set_out("output", "og::adsr_tick(" + E + ")");
-    if (x.n.domain == 1) { // oversampled: N ticks per frame, finish a stage end right away
-        x.cg.os() << "        og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", " << x.su(s_dn)
-                   << ");\n";
-    } else { // the non-output half of a stage end is handled once per frame for all envelopes of the voice
-        x.cg.S().post_zero.push_back(E + ".cnt");
-        x.cg.S().post << "            og::adsr_complete(" << E << ", " << x.sf(s_ac) << ", " << x.sf(s_dc) << ", "
-                  << x.su(s_dn) << ");\n";
-    }
+    x.set_out("output", "og::adsr_tick(" + E + ")", true);
+    const std::string fix = "og::adsr_complete(" + E + ", " + x.sf(s_ac) + ", " + x.sf(s_dc) + ", " + x.su(s_dn) + ", " + x.p +
+                            "output);\n";
+    if (x.n.domain == 1) // oversampled: N ticks per frame, finish a stage end right away
+        x.cg.os() << "        " << fix;
+    else // one check for a whole run of envelopes, emitted before anything can read their outputs
+        x.cg.pending_post.push_back({E + ".cnt", "            " + fix});
 }
 
 void emit_fm_operator(NodeCtx& x)
@@ -1280,100 +1299,88 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
     }
 
-    // ---- two-stage split ---------------------------------------------------------------------
+    // ---- pipeline stages ------------------------------------------------------------------------
     // With one wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave retires an instruction only
-    // every ~5.5 cycles, two co-resident waves every ~3.9 (measured).  The frame's node
-    // sequence is therefore also emitted as a 2-wave pipeline: wave 0 runs the first half of the
-    // nodes one 8-frame chunk ahead and hands the values that cross the cut to wave 1 through LDS.
-    // The cut is the position in the emission order that balances the estimated VALU cost.
+    // every ~5.5 cycles; four co-resident waves reach the 4-cycle issue limit (measured).
+    // The frame's node sequence is therefore also emitted as a pipeline of waves over the same 64
+    // voices: the emission (topological) order is cut into up to four contiguous stages of balanced
+    // estimated VALU cost; stage s works one hand-off chunk behind stage s-1 and the values that cross
+    // a cut travel through LDS.  The two-wave kernel merges stages {0,1} and {2,3}; the ordinary
+    // kernel merges all of them.
     cg.stage_of.assign(g.nodes.size(), 0);
+    cg.n_stages = 1;
     {
         const char* env_split = getenv("OGC_SPLIT");
         bool any_delay = false; // delay lines are staged per chunk by the ordinary kernel only
         for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
         bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback &&
                     !any_delay;
-        const char* env_cut = getenv("OGC_CUT");
-        const bool depth_cut = env_cut && std::string(env_cut) == "depth";
-        if (want && !depth_cut) {
-            // Default: the prefix of the emission (topological) order that balances the estimated cost.
-            // Measured on MI355X for fm_voice: 0.094 ms per block against 0.105 ms for the
-            // depth-ordered partition below, although the latter balances the static estimate better
-            // and crosses fewer values.
-            int total = 0;
-            for (int ni : order) total += node_weight(cg.nodes[ni].decl->type);
-            int acc = 0, best = -1, best_diff = 1 << 30;
-            for (size_t k = 0; k + 1 < order.size(); ++k) {
-                acc += node_weight(cg.nodes[order[k]].decl->type);
-                const int diff = std::abs(2 * acc - total);
-                if (diff < best_diff) {
-                    best_diff = diff;
-                    best = (int)k;
+        int total = 0;
+        std::vector<int> w;
+        for (int ni : order) {
+            w.push_back(node_weight(cg.nodes[ni].decl->type));
+            total += w.back();
+        }
+        // contiguous partition of the emission order into `parts` stages minimising the heaviest stage
+        // (the last stage also carries the mix-bus work); ties: smallest sum of squares
+        const int BUS_W = 7;
+        // (a run of consecutive envelopes is one unit: its stage-end check is shared, see flush_post())
+        std::vector<int> unit_w, unit_end; // weight and one-past-last order index of every unit
+        for (size_t k = 0; k < order.size(); ++k) {
+            const bool env = cg.nodes[order[k]].decl->type.rfind("AdsrEnvelope::", 0) == 0;
+            const bool prev_env = k > 0 && cg.nodes[order[k - 1]].decl->type.rfind("AdsrEnvelope::", 0) == 0;
+            if (env && prev_env) {
+                unit_w.back() += w[k];
+                unit_end.back() = (int)k + 1;
+            } else {
+                unit_w.push_back(w[k]);
+                unit_end.push_back((int)k + 1);
+            }
+        }
+        auto partition = [&](int parts) {
+            const int n = (int)unit_w.size();
+            std::vector<int> pre(n + 1, 0);
+            for (int k = 0; k < n; ++k) pre[k + 1] = pre[k] + unit_w[k];
+            struct Best {
+                long mx = 1L << 40, sq = 1L << 40;
+                std::vector<int> ends; // one-past-last ORDER index of every stage
+            };
+            std::vector<std::vector<Best>> dp(parts + 1, std::vector<Best>(n + 1));
+            dp[0][0].mx = 0;
+            dp[0][0].sq = 0;
+            for (int p2 = 1; p2 <= parts; ++p2)
+                for (int e = p2; e <= n; ++e)
+                    for (int b0 = p2 - 1; b0 < e; ++b0) {
+                        const Best& prev = dp[p2 - 1][b0];
+                        if (prev.mx >= (1L << 40)) continue;
+                        const long wgt = pre[e] - pre[b0] + ((p2 == parts && e == n) ? BUS_W : 0);
+                        const long mx = std::max(prev.mx, wgt), sq = prev.sq + wgt * wgt;
+                        Best& cur = dp[p2][e];
+                        if (mx < cur.mx || (mx == cur.mx && sq < cur.sq)) {
+                            cur.mx = mx;
+                            cur.sq = sq;
+                            cur.ends = prev.ends;
+                            cur.ends.push_back(unit_end[e - 1]);
+                        }
+                    }
+            return dp[parts][n].ends;
+        };
+        if (want && total >= 40 && unit_w.size() >= 2) {
+            const int n = (int)order.size();
+            const int parts = (total >= 80 && unit_w.size() >= 4) ? 4 : 2;
+            const std::vector<int> ends = partition(parts);
+            if ((int)ends.size() == parts) {
+                cg.n_stages = parts;
+                int st = 0;
+                for (int k = 0; k < n; ++k) {
+                    while (k >= ends[st]) ++st;
+                    cg.stage_of[order[k]] = st;
                 }
-            }
-            if (best >= 0 && total >= 40) {
-                cg.split = true;
-                for (size_t k = 0; k < order.size(); ++k) cg.stage_of[order[k]] = (int)k > best ? 1 : 0;
-            }
-        } else if (want) {
-            // Stage 0 = the nodes farthest (longest path) from the graph output, up to half the
-            // estimated cost.  A node's sources are always strictly farther from the output than the
-            // node itself, so every prefix of the depth-descending order is closed under dependencies.
-            std::vector<int> depth(g.nodes.size(), 0), pos(g.nodes.size(), 0);
-            for (size_t k = 0; k < order.size(); ++k) pos[order[k]] = (int)k;
-            for (size_t k = order.size(); k-- > 0;) {
-                const int ni = order[k];
-                for (int d : deps[ni]) depth[d] = std::max(depth[d], depth[ni] + 1);
-            }
-            std::vector<int> by_depth(order);
-            std::stable_sort(by_depth.begin(), by_depth.end(), [&](int x, int y) {
-                if (depth[x] != depth[y]) return depth[x] > depth[y];
-                return pos[x] < pos[y];
-            });
-            int total = 0;
-            for (int ni : order) total += node_weight(cg.nodes[ni].decl->type);
-            // all nodes deeper than the level where the running cost crosses one half, plus the subset
-            // of that level which balances best (levels are small: brute force)
-            int acc = 0, level = -1;
-            for (int ni : by_depth) {
-                acc += node_weight(cg.nodes[ni].decl->type);
-                if (2 * acc >= total) {
-                    level = depth[ni];
-                    break;
-                }
-            }
-            std::vector<int> fixed, tie;
-            int w_fixed = 0;
-            for (int ni : by_depth) {
-                if (depth[ni] > level) {
-                    fixed.push_back(ni);
-                    w_fixed += node_weight(cg.nodes[ni].decl->type);
-                } else if (depth[ni] == level) {
-                    tie.push_back(ni);
-                }
-            }
-            if (tie.size() > 12) tie.resize(12);
-            uint32_t best_mask = 0;
-            int best_diff = 1 << 30;
-            for (uint32_t mask = 0; mask < (1u << tie.size()); ++mask) {
-                int w = w_fixed;
-                for (size_t i = 0; i < tie.size(); ++i)
-                    if (mask >> i & 1u) w += node_weight(cg.nodes[tie[i]].decl->type);
-                const int diff = std::abs(2 * w - total);
-                if (w > 0 && w < total && diff < best_diff) {
-                    best_diff = diff;
-                    best_mask = mask;
-                }
-            }
-            if (best_diff < (1 << 30) && total >= 40) {
-                cg.split = true;
-                for (int ni : order) cg.stage_of[ni] = 1;
-                for (int ni : fixed) cg.stage_of[ni] = 0;
-                for (size_t i = 0; i < tie.size(); ++i)
-                    if (best_mask >> i & 1u) cg.stage_of[tie[i]] = 0;
             }
         }
     }
+    cg.split = cg.n_stages > 1;
+
 
     // ---- emit nodes: outer (pre), inner, outer (post), each in topological order -------------
     for (int dom = 0; dom < 3; ++dom) {
@@ -1381,6 +1388,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         for (int ni : order) {
             NodeInst& n = cg.nodes[ni];
             if (n.domain != dom) continue;
+            const bool is_env = n.decl->type.rfind("AdsrEnvelope::", 0) == 0;
+            if (!is_env || cg.cs != cg.stage_of[ni]) cg.flush_post(); // (into the stream of the stage that owns them)
             cg.cs = cg.stage_of[ni];
             NodeCtx x{cg, n, "n" + std::to_string(n.id) + "_"};
             cg.os() << "        // " << n.decl->name << " = " << n.decl->type
@@ -1389,12 +1398,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             cg.emitted[ni] = 1;
             out.node_order.push_back(n.decl->name);
         }
+        cg.flush_post();
     }
 
     // ---- graph output (outer rate, last stage) -------------------------------------------------
     std::string bus_expr = "0.0f";
     cg.dom = 2;
-    cg.cs = cg.split ? 1 : 0;
+    cg.cs = cg.n_stages - 1;
     {
         int n_stream = 0;
         for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
@@ -1415,8 +1425,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             bus_expr = "g_out";
         }
     }
-    if (cg.split && cg.xvals.size() > 8) fail("internal: pipeline cut crosses more than 8 values"); // not reached by the built-ins
     out.can_split = cg.split;
+    out.max_pipeline = cg.n_stages;
 
     if (out.n_slots > 160) fail("graph needs more than 160 uniform slots");
 
@@ -1431,7 +1441,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         t << S.s_down.str() << S.s_post.str();
         return t.str();
     };
-    auto post_code = [&](std::initializer_list<int> stages) {
+    auto post_code = [&](const std::vector<int>& stages) {
         std::vector<std::string> zeros;
         std::string code;
         for (int st : stages) {
@@ -1447,7 +1457,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         return t.str();
     };
     // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
-    auto events_code = [&](std::initializer_list<int> stages) {
+    auto events_code = [&](const std::vector<int>& stages) {
         std::ostringstream t;
         t << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
           << "        if (f == c.next_ev) {\n"
@@ -1487,6 +1497,49 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     int unroll = 2; // frames per straight-line scheduling region of the quiet-chunk loop
     if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
+    // A kernel is assembled from GROUPS of consecutive stages, one wave per group: the ordinary kernel
+    // has the single group {0..n-1}, the pipelined ones two or four groups.
+    const int NS = cg.n_stages;
+    auto cat = [&](const std::vector<int>& st, std::ostringstream Codegen::Sect::*m) {
+        std::string r;
+        for (int k : st) r += (cg.sec[k].*m).str();
+        return r;
+    };
+    // group index of a stage under a grouping
+    auto group_of = [](const std::vector<std::vector<int>>& groups, int stage) {
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int k : groups[gi])
+                if (k == stage) return (int)gi;
+        return -1;
+    };
+    // per-frame code of one group: stage code in order; a value read by a later stage is aliased right
+    // after its producer (same wave) or travels through its LDS channel (other wave)
+    auto group_tick = [&](const std::vector<std::vector<int>>& groups, int gi) {
+        std::ostringstream t;
+        const std::vector<int>& st = groups[gi];
+        for (size_t k = 0; k < cg.xvals.size(); ++k) {
+            const auto& xv = cg.xvals[k];
+            bool used_here = false;
+            for (int u : xv.users) used_here = used_here || group_of(groups, u) == gi;
+            if (used_here && group_of(groups, xv.from) != gi)
+                t << "        const float " << xv.alias << " = chan" << k << "[ch % " << "XD" << k << "][j][c.lane];\n";
+        }
+        for (int fs : st) {
+            t << tick_code(fs);
+            for (size_t k = 0; k < cg.xvals.size(); ++k) {
+                const auto& xv = cg.xvals[k];
+                if (xv.from != fs) continue;
+                bool local = false, remote = false;
+                for (int u : xv.users) (group_of(groups, u) == gi ? local : remote) = true;
+                if (local) t << "        const float " << xv.alias << " = " << xv.var << ";\n";
+                if (remote) t << "        chan" << k << "[ch % XD" << k << "][j][c.lane] = " << xv.var << ";\n";
+            }
+        }
+        return t.str();
+    };
+    std::vector<int> all_stages;
+    for (int k = 0; k < NS; ++k) all_stages.push_back(k);
+
     // ---- ordinary kernel: one wave = 64 voices, the whole node sequence -------------------------
     std::ostringstream body;
     body << "template <bool RAMPS, bool TAPS>\n"
@@ -1497,22 +1550,21 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                                      "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
-         << cg.common_decl.str() << cg.sec[0].decl.str() << cg.sec[1].decl.str() << "    if (c.valid) {\n"
-         << cg.common_load.str() << cg.sec[0].load.str() << cg.sec[1].load.str() << "    }\n";
-    body << "    auto derive = [&]() {\n" << cg.sec[0].derive.str() << cg.sec[1].derive.str() << "    };\n";
-    body << cg.sec[0].pre.str() << cg.sec[1].pre.str() << "    derive();\n";
+         << cg.common_decl.str() << cat(all_stages, &Codegen::Sect::decl) << "    if (c.valid) {\n"
+         << cg.common_load.str() << cat(all_stages, &Codegen::Sect::load) << "    }\n";
+    body << "    auto derive = [&]() {\n" << cat(all_stages, &Codegen::Sect::derive) << "    };\n";
+    body << cat(all_stages, &Codegen::Sect::pre) << "    derive();\n";
     if (!out.rings.empty()) // state loads complete here, so that no wait for them lands inside the chunk loop,
                             // where it would also sit out the delay-line loads staged for the next chunk
         body << "    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
-    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n" << tick_code(0);
-    for (auto& xv : cg.xvals) body << "        const float " << xv.second << " = " << xv.first << ";\n";
-    body << tick_code(1) << post_code({0, 1});
+    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n"
+         << group_tick({all_stages}, 0) << post_code(all_stages);
     body << "        return " << bus_expr << ";\n    };\n";
-    body << events_code({0, 1});
+    body << events_code(all_stages);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
-         << (out.rings.empty() ? std::string() : "        cbase = base;\n" + cg.sec[0].chunk_begin.str() + cg.sec[1].chunk_begin.str())
+         << (out.rings.empty() ? std::string() : "        cbase = base;\n" + cat(all_stages, &Codegen::Sect::chunk_begin))
          << "        if (n == OG_BUS_CHUNK && __all((int)(c.next_ev >= base + OG_BUS_CHUNK))) {\n"
          << "            // no lane of this wave has an event in the chunk: straight-line body\n"
          << "#pragma unroll " << unroll << "\n"
@@ -1526,53 +1578,60 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"
          << "    }\n";
     body << "    og::bus_flush(A, c, bus);\n"
-         << cg.sec[0].pre_store.str() << cg.sec[1].pre_store.str() << "    if (c.valid) {\n"
-         << cg.sec[0].store.str() << cg.sec[1].store.str() << vin_store();
+         << cat(all_stages, &Codegen::Sect::pre_store) << "    if (c.valid) {\n"
+         << cat(all_stages, &Codegen::Sect::store) << vin_store();
     body << "    }\n    og::voice_end(A, c);\n}\n";
 
-    // ---- two-stage kernel: workgroup = 2 waves over the same 64 voices -----------------------------
-    if (cg.split) {
-        const size_t nx = std::max<size_t>(1, cg.xvals.size());
-        body << "\n// Two-wave pipeline over the same 64 voices (used when the bank is too small to put two waves\n"
-             << "// on every SIMD): wave 0 = nodes";
-        for (int ni : order)
-            if (cg.stage_of[ni] == 0) body << " " << g.nodes[ni].name;
-        body << ";\n// wave 1 = the rest + the mix bus.  " << cg.xvals.size() << " values cross the cut through LDS, "
-             << "OG_XCH frames per hand-off.\n"
-             << "template <bool RAMPS, bool TAPS>\n"
-             << "__device__ __forceinline__ void voice_block_split(const OgBlockArgs& A)\n{\n"
-             << "    __shared__ og::BusLds bus;\n"
-             << "    __shared__ float chan[2][OG_XCH][" << nx << "][OG_WAVE];\n"
-             << "    const uint32_t stage = threadIdx.x / OG_WAVE;\n"
+    // ---- pipelined kernels: workgroup = K waves over the same 64 voices ----------------------------
+    // All waves take the same n_chunks + K - 1 steps, one barrier per step; at step t the wave of group
+    // s works on hand-off chunk t - s.  A value produced by group a and read by group b lives in an LDS
+    // ring of b - a + 1 chunks.  Which wave of the workgroup takes which group rotates with the
+    // workgroup index, so that the SIMDs of a CU do not each collect one kind of stage.
+    auto emit_pipeline = [&](const std::vector<std::vector<int>>& groups) {
+        const int K = (int)groups.size();
+        body << "\n// " << K << "-wave pipeline over the same 64 voices (small banks: more waves per SIMD).\n";
+        for (int gi = 0; gi < K; ++gi) {
+            body << "//   wave " << gi << ":";
+            for (int ni : order)
+                if (group_of(groups, cg.stage_of[ni]) == gi) body << " " << g.nodes[ni].name;
+            body << (gi == K - 1 ? " + the mix bus\n" : "\n");
+        }
+        body << "template <bool RAMPS, bool TAPS>\n"
+             << "__device__ __forceinline__ void voice_block_p" << K << "(const OgBlockArgs& A)\n{\n"
+             << "    __shared__ og::BusLds bus;\n";
+        for (size_t k = 0; k < cg.xvals.size(); ++k) {
+            const auto& xv = cg.xvals[k];
+            int far = group_of(groups, xv.from);
+            for (int u : xv.users) far = std::max(far, group_of(groups, u));
+            const int depth = far - group_of(groups, xv.from) + 1;
+            body << "    constexpr uint32_t XD" << k << " = " << depth << ";\n";
+            if (depth > 1) body << "    __shared__ float chan" << k << "[XD" << k << "][OG_XCH][OG_WAVE];\n";
+        }
+        body << "    const uint32_t stage = (threadIdx.x / OG_WAVE + blockIdx.x) % " << K << "u;\n"
              << "    og::VoiceCtx c;\n"
              << "    og::voice_begin_split<TAPS>(A, c);\n"
              << cg.common_decl.str() << "    if (c.valid) {\n" << cg.common_load.str() << "    }\n"
              << "    const uint32_t n_chunks = (A.frames + OG_XCH - 1) / OG_XCH;\n";
-        for (int st = 0; st < 2; ++st) {
-            Codegen::Sect& S = cg.sec[st];
-            body << (st == 0 ? "    if (stage == 0) {\n" : "    } else {\n");
-            body << S.decl.str() << "    if (c.valid) {\n" << S.load.str() << "    }\n";
-            body << "    auto derive = [&]() {\n" << S.derive.str() << "    };\n";
-            body << S.pre.str() << "    derive();\n";
-            if (st == 0) {
-                body << "    auto tick = [&](const uint32_t f, const uint32_t buf, const uint32_t j) __attribute__((always_inline)) {\n"
-                     << tick_code(0);
-                for (size_t k = 0; k < cg.xvals.size(); ++k)
-                    body << "        chan[buf][j][" << k << "][c.lane] = " << cg.xvals[k].first << ";\n";
-                body << post_code({0}) << "    };\n";
-            } else {
-                body << "    auto tick = [&](const uint32_t f, const uint32_t buf, const uint32_t j) __attribute__((always_inline)) -> float {\n";
-                for (size_t k = 0; k < cg.xvals.size(); ++k)
-                    body << "        const float " << cg.xvals[k].second << " = chan[buf][j][" << k << "][c.lane];\n";
-                body << tick_code(1) << post_code({1}) << "        return " << bus_expr << ";\n    };\n";
-            }
-            body << events_code({st});
-            if (st == 1) body << "    __syncthreads(); // chunk 0 has been produced\n";
+        for (int gi = 0; gi < K; ++gi) {
+            const std::vector<int>& st = groups[gi];
+            const bool last = gi == K - 1;
+            body << (gi == 0 ? "    if (stage == 0) {\n" : "    } else if (stage == " + std::to_string(gi) + ") {\n");
+            body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
+            body << "    auto derive = [&]() {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
+            body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
+            body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j) __attribute__((always_inline))"
+                 << (last ? " -> float" : "") << " {\n"
+                 << group_tick(groups, gi) << post_code(st);
+            if (last) body << "        return " << bus_expr << ";\n";
+            body << "    };\n";
+            body << events_code(st);
             // SALU instructions cost issue slots like VALU ones: the quiet chunk is a straight-line,
             // fully unrolled body; per-frame tests only exist on the (rare) event path
-            const std::string call = st == 0 ? "tick(f, ch & 1u, j);"
-                                             : "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, tick(f, ch & 1u, j));";
-            body << "    for (uint32_t ch = 0; ch < n_chunks; ++ch) {\n"
+            const std::string call =
+                last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, tick(f, ch, j));" : "tick(f, ch, j);";
+            body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
+                 << "        const uint32_t ch = t - " << gi << "u;\n"
+                 << "        if (ch < n_chunks) {\n"
                  << "        const uint32_t base = ch * OG_XCH;\n"
                  << "        const uint32_t n = min((uint32_t)OG_XCH, A.frames - base);\n"
                  << "        if (n == OG_XCH && __all((int)(c.next_ev >= base + OG_XCH))) {\n"
@@ -1588,24 +1647,26 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                  << "                " << call << "\n"
                  << "            }\n"
                  << "        }\n";
-            if (st == 1)
+            if (last)
                 body << "        { // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / OG_XCH hand-offs\n"
-                     << "            const uint32_t last = base + n - 1;\n"
-                     << "            if ((last % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || last + 1 == A.frames)\n"
-                     << "                og::bus_chunk_reduce(A, c, bus, last - (last % OG_BUS_CHUNK), (last % OG_BUS_CHUNK) + 1);\n"
+                     << "            const uint32_t lastf = base + n - 1;\n"
+                     << "            if ((lastf % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || lastf + 1 == A.frames)\n"
+                     << "                og::bus_chunk_reduce(A, c, bus, lastf - (lastf % OG_BUS_CHUNK), (lastf % OG_BUS_CHUNK) + 1);\n"
                      << "        }\n";
-            body << "        __syncthreads(); // hand-off: wave 0 stays one chunk ahead of wave 1\n"
+            body << "        }\n"
+                 << "        __syncthreads(); // hand-off: every wave stays one chunk ahead of the next one\n"
                  << "    }\n";
-            if (st == 0) {
-                body << "    __syncthreads(); // wave 1 has consumed the last chunk\n"
-                     << S.pre_store.str() << "    if (c.valid) {\n" << S.store.str() << vin_store() << "    }\n"
-                     << "    og::voice_end(A, c);\n";
-            } else {
-                body << "    og::bus_flush(A, c, bus);\n"
-                     << S.pre_store.str() << "    if (c.valid) {\n" << S.store.str() << "    }\n";
-            }
+            if (last) body << "    og::bus_flush(A, c, bus);\n";
+            body << cat(st, &Codegen::Sect::pre_store) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::store)
+                 << (gi == 0 ? vin_store() : std::string()) << "    }\n";
+            if (gi == 0) body << "    og::voice_end(A, c);\n";
         }
         body << "    }\n}\n";
+    };
+    if (NS == 2) emit_pipeline({{0}, {1}});
+    if (NS == 4) {
+        emit_pipeline({{0, 1}, {2, 3}});
+        emit_pipeline({{0}, {1}, {2}, {3}});
     }
 
     const std::string body_s = body.str();
@@ -1632,20 +1693,23 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     for (auto& v : variants)
         src << "extern \"C\" __global__ __launch_bounds__(64) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
-    if (cg.split)
+    std::vector<int> depths;
+    if (NS >= 2) depths.push_back(2);
+    if (NS == 4) depths.push_back(4);
+    for (int K : depths)
         for (auto& v : variants)
-            src << "extern \"C\" __global__ __launch_bounds__(128) void og_k2_" << hs << "_" << v[0]
-                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_split<" << v[1] << ", " << v[2] << ">(A); }\n";
+            src << "extern \"C\" __global__ __launch_bounds__(" << 64 * K << ") void og_k" << K << "_" << hs << "_" << v[0]
+                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p" << K << "<" << v[1] << ", " << v[2] << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
         << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n";
-    if (cg.split)
-        src << "    if (A.split) { // two waves per 64 voices\n"
-            << "        const dim3 g2((A.n_voices + OG_WAVE - 1) / OG_WAVE), b2(2 * OG_WAVE);\n"
-            << "        if (!ramps && !taps) hipLaunchKernelGGL(og_k2_" << hs << "_00, g2, b2, 0, s, A);\n"
-            << "        else if (ramps && !taps) hipLaunchKernelGGL(og_k2_" << hs << "_10, g2, b2, 0, s, A);\n"
-            << "        else if (!ramps && taps) hipLaunchKernelGGL(og_k2_" << hs << "_01, g2, b2, 0, s, A);\n"
-            << "        else hipLaunchKernelGGL(og_k2_" << hs << "_11, g2, b2, 0, s, A);\n"
+    for (int K : depths)
+        src << "    if (A.split == " << K << "u) { // " << K << " waves per 64 voices\n"
+            << "        const dim3 gk((A.n_voices + OG_WAVE - 1) / OG_WAVE), bk(" << K << " * OG_WAVE);\n"
+            << "        if (!ramps && !taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_00, gk, bk, 0, s, A);\n"
+            << "        else if (ramps && !taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_10, gk, bk, 0, s, A);\n"
+            << "        else if (!ramps && taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_01, gk, bk, 0, s, A);\n"
+            << "        else hipLaunchKernelGGL(og_k" << K << "_" << hs << "_11, gk, bk, 0, s, A);\n"
             << "        return;\n    }\n";
     src << "    if (!ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_00, grid, block, 0, s, A);\n"
         << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"

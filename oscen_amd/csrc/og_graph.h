@@ -110,6 +110,7 @@ struct CompiledGraph {
     std::vector<RingSpec> rings;       // delay lines (at most OG_MAX_RINGS)
     int lpv = 1;                       // lanes per voice (32 for the electric-piano voice)
     bool can_split = false;            // a two-wave pipeline variant of the kernel exists (og_k2_*)
+    int max_pipeline = 1;              // deepest pipeline variant generated: 1, 2 (og_k2_*) or 4 (og_k4_*)
     // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>
     bool bus_tremolo = false;
     HostFn tremolo_rate, tremolo_depth;

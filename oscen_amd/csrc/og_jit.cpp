@@ -76,6 +76,7 @@ struct JitImpl : OgJitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn[4] = {};
     hipFunction_t fn2[4] = {}; // two-wave pipeline variants (when the graph has them)
+    hipFunction_t fn4[4] = {}; // four-wave pipeline variants
     unsigned lpv = 1;
     ~JitImpl() override
     {
@@ -87,10 +88,13 @@ struct JitImpl : OgJitKernel {
         size_t sz = sizeof a;
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
         const int vi = (ramps ? 1 : 0) + (taps ? 2 : 0);
-        const bool two = a.split && fn2[vi];
-        const unsigned grid = two ? (a.n_voices + OG_WAVE - 1) / OG_WAVE
-                                  : (unsigned)(((size_t)a.n_voices * lpv + a.lanes - 1) / a.lanes);
-        hipError_t e = hipModuleLaunchKernel(two ? fn2[vi] : fn[vi], grid, 1, 1, two ? 2 * OG_WAVE : OG_WAVE, 1, 1, 0,
+        unsigned K = 1;
+        if (a.split == 4 && fn4[vi]) K = 4;
+        else if (a.split >= 2 && fn2[vi]) K = 2;
+        a.split = K > 1 ? K : 0;
+        const unsigned grid = K > 1 ? (a.n_voices + OG_WAVE - 1) / OG_WAVE
+                                    : (unsigned)(((size_t)a.n_voices * lpv + a.lanes - 1) / a.lanes);
+        hipError_t e = hipModuleLaunchKernel(K == 4 ? fn4[vi] : (K == 2 ? fn2[vi] : fn[vi]), grid, 1, 1, K * OG_WAVE, 1, 1, 0,
                                              stream, nullptr, cfg);
         if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));
     }
@@ -120,10 +124,15 @@ std::unique_ptr<OgJitKernel> og_jit_compile(const ogc::CompiledGraph& cg)
         std::string name = std::string("og_k_") + hs + "_" + var[i];
         if (hipModuleGetFunction(&k->fn[i], k->mod, name.c_str()) != hipSuccess)
             throw std::runtime_error("oscen jit: kernel " + name + " not found in module");
-        if (cg.can_split) {
+        if (cg.max_pipeline >= 2) {
             const std::string name2 = std::string("og_k2_") + hs + "_" + var[i];
             if (hipModuleGetFunction(&k->fn2[i], k->mod, name2.c_str()) != hipSuccess)
                 throw std::runtime_error("oscen jit: kernel " + name2 + " not found in module");
+        }
+        if (cg.max_pipeline >= 4) {
+            const std::string name4 = std::string("og_k4_") + hs + "_" + var[i];
+            if (hipModuleGetFunction(&k->fn4[i], k->mod, name4.c_str()) != hipSuccess)
+                throw std::runtime_error("oscen jit: kernel " + name4 + " not found in module");
         }
     }
     return k;

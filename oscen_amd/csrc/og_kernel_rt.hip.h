@@ -43,7 +43,7 @@ using __hip_internal::uint64_t;
 #define OG_MAX_BLOCK 512
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16
-#define OG_XCH 8 // frames per hand-off between the two waves of the split kernel
+#define OG_XCH 8 // frames per hand-off between the waves of the pipelined kernels
 #define OG_NO_EVENT 0xFFFFFFFFu
 #define OG_EV_SETVALUE 0x80000000u
 
@@ -59,7 +59,7 @@ struct OgBlockArgs {
     uint32_t n_voices;
     uint32_t frames;
     uint32_t lanes;            // active lanes per wave (64; experiment knob)
-    uint32_t split;            // launch the two-wave pipeline variant (small banks, see og_graph.cpp)
+    uint32_t split;            // pipeline depth to launch: 0 = ordinary kernel, 2 / 4 = waves per 64 voices (og_graph.cpp)
     uint64_t frame0;
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
     uint32_t* lane_state;      // [n_lane_words][n_voices][LPV]: words of voices that span LPV lanes

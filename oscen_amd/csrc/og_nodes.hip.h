@@ -78,14 +78,18 @@ enum : int { ADSR_A_N = 0, ADSR_D_N, ADSR_R_N, ADSR_A_C, ADSR_D_C, ADSR_SUSTAIN,
 //    not re-executed;
 //  * `if current <= 0 {0} else {-current/n}` is -current/n for current >= 0
 //    (-0/n = -0, and x + -0 = x);
-//  * a stage end changes this frame's output only through `lv = tgt`; the
-//    rest of complete_stage() is deferred to one check per frame for all of a
-//    voice's envelopes (adsr_complete, called at the end of the frame).
+//  * a stage end (countdown reaching 0) is rare: the tick does not test for it.
+//    One check per run of consecutive envelopes (adsr_complete, emitted right
+//    after the run and before anything reads their outputs) puts the level and
+//    this frame's output on the stage's target and does complete_stage();
+//  * Release adds rs * (-lv / n) with rs = 1 in Release and 0 elsewhere, one
+//    fma instead of a compare and a select (1*q + lv rounds like lv + q; n >= 1
+//    while a stage is ticking, so q is finite and 0*q + lv == lv).
 constexpr uint32_t ADSR_HOLD = 0xFFFFFFFFu;
 
 struct Adsr {
     uint32_t stage, cnt;
-    float lv, tgt, cf, vel, sus;
+    float lv, tgt, cf, vel, sus, rs;
 };
 
 OG_DEV void adsr_enter(Adsr& e, uint32_t stage, uint32_t n, float a_c, float d_c)
@@ -95,6 +99,7 @@ OG_DEV void adsr_enter(Adsr& e, uint32_t stage, uint32_t n, float a_c, float d_c
     e.cnt = (stage == ST_SUSTAIN || stage == ST_IDLE) ? ADSR_HOLD : n;
     e.tgt = att ? 1.0f : (dec ? e.sus : 0.0f);
     e.cf = att ? a_c : (dec ? d_c : 0.0f);
+    e.rs = (stage == ST_RELEASE) ? 1.0f : 0.0f;
 }
 
 // Once per block: load + the part of apply_parameters()/update_sustain_level()
@@ -151,20 +156,18 @@ OG_DEV float adsr_tick(Adsr& e)
     // Release: lv += -lv / samples_remaining, increment re-derived every sample (adsr.rs:162-173)
     // (computed unconditionally: a wave-uniform "any lane releasing" test costs more issue slots
     //  than it saves -- the compiler if-converts it into the same arithmetic plus scalar selects)
-    const float lv_r = lv + div_near(-lv, (float)e.cnt);
-    lv = (e.stage == ST_RELEASE) ? lv_r : lv;
-    // samples_remaining -= 1; at 0 the stage ends on its target level
-    const uint32_t c = e.cnt - 1u;
-    lv = (c == 0u) ? e.tgt : lv;
-    e.cnt = c;
+    lv = fmaf(e.rs, div_near(-lv, (float)e.cnt), lv);
+    e.cnt -= 1u; // samples_remaining -= 1; reaching 0 is handled by adsr_complete()
     e.lv = lv;
     return lv;
 }
 
 // complete_stage  adsr.rs:175-204 for an envelope whose countdown hit 0 this frame
-OG_DEV void adsr_complete(Adsr& e, float a_c, float d_c, uint32_t d_n)
+OG_DEV void adsr_complete(Adsr& e, float a_c, float d_c, uint32_t d_n, float& out)
 {
     if (e.cnt == 0u) {
+        e.lv = e.tgt; // the stage ends on its target level, which is also this frame's output
+        out = e.lv;
         const uint32_t next = (e.stage + 1u) & 7u; // Attack -> Decay -> Sustain, Release -> Idle
         adsr_enter(e, next, d_n, a_c, d_c);
     }

@@ -125,6 +125,44 @@ def test_fm_bank_default_params_ragged_voice_count():
     assert worst <= TOL, worst
 
 
+@pytest.mark.parametrize("depth", [0, 2, 4])
+def test_fm_bank_every_pipeline_depth(depth, monkeypatch):
+    """The same bank through the ordinary kernel and the 2- and 4-wave pipelines (OSCEN_GPU_SPLIT pins the
+    variant the engine would otherwise pick from the bank size): ragged voice count, block lengths that are
+    not multiples of the 8-frame hand-off or the 16-frame bus tile, ramps, per-voice frequency events."""
+    monkeypatch.setenv("OSCEN_GPU_SPLIT", str(depth))
+    n = 150
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    assert p.eng.pipeline_depth == max(1, depth)
+    for op in ("op3", "op2", "op1", "filter"):
+        p.set_value(op + "_attack", 0.002)
+        p.set_value(op + "_decay", 0.004)
+        p.set_value(op + "_release", 0.006)
+    p.set_value("op3_level", 0.4)
+    p.set_value("op3_feedback", 0.3)
+    p.set_value("route", 0.35)
+    p.set_value("filter_env_amount", 2500.0)
+    p.set_freqs(midi_freqs(n, 11))
+    events = random_note_script(n, 2300, 12, span=(300, 900))
+    blocks = [256, 7, 249, 100, 512, 1, 15, 17, 256, 300, 333, 254]
+    f0, worst = 0, 0.0
+    for bi, frames in enumerate(blocks):
+        for fr, v, val in events:
+            if f0 <= fr < f0 + frames:
+                p.gate(v, fr - f0, val)
+        if bi == 3:
+            p.set_value_with_ramp("filter_cutoff", 5200.0, 400)
+        if bi == 5:
+            for v in range(0, n, 7):
+                p.freq(v, 0, 330.0 + v)
+        bus, taps, ref_bus, ref_taps, ref64 = p.block(frames)
+        worst = max(worst, rel_err(taps, ref_taps))
+        scale = max(1.0, float(np.max(np.sum(np.abs(ref_taps), axis=0))))
+        assert np.max(np.abs(bus[:, 0] - ref64)) <= TOL * scale
+        f0 += frames
+    assert worst <= TOL, worst
+
+
 def test_fm_bank_fast_envelopes_all_stages():
     # short A/D/R so attack, decay, sustain, release, idle and retrigger-from-release all occur
     n = 128
