@@ -278,13 +278,15 @@ struct Codegen {
     struct Sect {
         std::ostringstream decl, load, derive, pre, post, pre_store, store;
         std::ostringstream chunk_begin; // top of every OG_BUS_CHUNK-frame chunk (delay-line staging)
+        std::vector<std::string> env_cnts; // countdowns of this stage's envelopes (a chunk in which none of them
+                                           // reaches 0 runs the tick without the stage-end checks)
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
         std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
         std::map<int, std::ostringstream> ev_handlers; // per graph event input
     };
-    Sect sec[4];
+    Sect sec[16];
     int cs = 0;  // stage being emitted
     int dom = 0; // rate domain being emitted: 0 pre, 1 inner, 2 post
     Sect& S() { return sec[cs]; }
@@ -296,6 +298,7 @@ struct Codegen {
     // pipeline bookkeeping
     bool split = false;
     int n_stages = 1;
+    std::vector<std::vector<int>> groups2, groups4; // stages of every wave of the 2- / 4-wave pipelines (or empty)
     std::vector<int> stage_of; // per node
     struct XVal {              // a node output read by a later stage
         std::string var, alias;
@@ -312,9 +315,11 @@ struct Codegen {
         if (pending_post.empty()) return;
         std::string m = pending_post[0].first;
         for (size_t i = 1; i < pending_post.size(); ++i) m = "min(" + m + ", " + pending_post[i].first + ")";
-        os() << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n";
+        os() << "        if constexpr (decltype(chk)::value) { // (compiled out of chunks in which no countdown can reach 0)\n"
+             << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n";
         for (auto& pp : pending_post) os() << pp.second;
-        os() << "        }\n";
+        os() << "        }\n        }\n";
+        for (auto& pp : pending_post) S().env_cnts.push_back(pp.first);
         pending_post.clear();
     }
 
@@ -763,14 +768,28 @@ void emit_tpt(NodeCtx& x)
     std::string g = x.state_f("g", [coef](const UEnv& e) { return coef(e, 1); });
     std::string kk = x.state_f("k", [coef](const UEnv& e) { return coef(e, 2); });
     const bool nomod = (fmod.rate == Rate::Const) && !x.connected("f_mod") && x.def("f_mod") == 0.0f;
-    if (nomod)
-        x.cg.os() << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << x.sf(s_maxc) << ", "
-                  << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", " << cq
-                  << ", " << h << ", " << g << ", " << kk << ");\n";
-    else
-        x.cg.os() << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << x.sf(s_maxc)
-                  << ", " << x.sf(s_two_sr) << ", " << x.sf(s_period) << ", " << x.sf(s_nyq) << ", " << cc << ", "
-                  << cq << ", " << h << ", " << g << ", " << kk << ");\n";
+    auto block_const = [](const Val& v) { return v.rate <= Rate::VBlock && v.rate != Rate::UFrame; };
+    const std::string tail = x.sf(s_maxc) + ", " + x.sf(s_two_sr) + ", " + x.sf(s_period) + ", " + x.sf(s_nyq) + ", " + cc + ", " +
+                             cq + ", " + h + ", " + g + ", " + kk + ");\n";
+    if (nomod && block_const(cutoff) && block_const(q) && x.n.domain != 1) {
+        // cutoff and q cannot change between events: apply_parameter_updates() finds nothing to do after the
+        // first frame of the block, so it runs in derive() (block start and after per-voice value events)
+        x.cg.S().derive << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << tail;
+        x.cg.any_derive = true;
+    } else if (nomod && getenv("OGC_TPT_FLAT") && atoi(getenv("OGC_TPT_FLAT")) != 0) {
+        // experiment: branch-free update (see og::tpt_params_nomod_flat); measured slower on MI355X for
+        // fm_voice (65 536 voices 0.098 ms against 0.087 ms; 262 144 voices 0.293 against 0.234): the
+        // branch is wave-uniformly skipped whenever no lane's envelope moves
+
+        std::string iq;
+        if (block_const(q)) iq = x.hoist("inv_q", "1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f)");
+        else iq = "(1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f))";
+        x.cg.os() << "        og::tpt_params_nomod_flat(" << cutoff.e << ", " << q.e << ", " << iq << ", " << tail;
+    } else if (nomod) {
+        x.cg.os() << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << tail;
+    } else {
+        x.cg.os() << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << tail;
+    }
     x.set_out("output", "og::tpt_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + h + ", " + g + ", " + kk + ")");
 }
 
@@ -1302,11 +1321,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     // ---- pipeline stages ------------------------------------------------------------------------
     // With one wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave retires an instruction only
     // every ~5.5 cycles; four co-resident waves reach the 4-cycle issue limit (measured).
-    // The frame's node sequence is therefore also emitted as a pipeline of waves over the same 64
-    // voices: the emission (topological) order is cut into up to four contiguous stages of balanced
-    // estimated VALU cost; stage s works one hand-off chunk behind stage s-1 and the values that cross
-    // a cut travel through LDS.  The two-wave kernel merges stages {0,1} and {2,3}; the ordinary
-    // kernel merges all of them.
+    // The frame's node sequence is therefore also emitted as pipelines of two and of four waves over
+    // the same 64 voices: every node (or run of envelopes) is a stage; a wave takes a contiguous group
+    // of stages of balanced estimated VALU cost, works one hand-off chunk behind the previous wave,
+    // and the values that cross between waves travel through LDS.  The ordinary kernel is the single
+    // group of all stages.
     cg.stage_of.assign(g.nodes.size(), 0);
     cg.n_stages = 1;
     {
@@ -1315,16 +1334,30 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
         bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback &&
                     !any_delay;
+        // estimated per-tick VALU cost of every node, in emission order
         int total = 0;
         std::vector<int> w;
         for (int ni : order) {
-            w.push_back(node_weight(cg.nodes[ni].decl->type));
-            total += w.back();
+            const NodeInst& n = cg.nodes[ni];
+            int wt = node_weight(n.decl->type);
+            if (n.decl->type.rfind("TptFilter", 0) == 0) { // a cutoff fed by another node moves every sample: the
+                bool moving = false;                         // coefficient update (tan, reciprocal) runs on every tick
+                for (const char* port : {"cutoff", "q", "f_mod"}) {
+                    auto it = n.in_edges.find(port);
+                    if (it == n.in_edges.end()) continue;
+                    for (const auto& src : it->second) {
+                        std::vector<const Expr*> refs;
+                        collect_refs(src.e, refs);
+                        for (const Expr* r : refs) moving = moving || !r->port.empty();
+                    }
+                }
+                wt = moving ? 30 : 12;
+            }
+            w.push_back(wt);
+            total += wt;
         }
-        // contiguous partition of the emission order into `parts` stages minimising the heaviest stage
-        // (the last stage also carries the mix-bus work); ties: smallest sum of squares
-        const int BUS_W = 7;
-        // (a run of consecutive envelopes is one unit: its stage-end check is shared, see flush_post())
+        // Stage = unit: a node, or a run of consecutive envelopes (their stage-end check is shared, see
+        // flush_post()).  At most 16 stages: the lightest adjacent pair is merged until they fit.
         std::vector<int> unit_w, unit_end; // weight and one-past-last order index of every unit
         for (size_t k = 0; k < order.size(); ++k) {
             const bool env = cg.nodes[order[k]].decl->type.rfind("AdsrEnvelope::", 0) == 0;
@@ -1337,13 +1370,25 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 unit_end.push_back((int)k + 1);
             }
         }
-        auto partition = [&](int parts) {
+        while (unit_w.size() > 16) {
+            size_t best = 0;
+            for (size_t k = 0; k + 1 < unit_w.size(); ++k)
+                if (unit_w[k] + unit_w[k + 1] < unit_w[best] + unit_w[best + 1]) best = k;
+            unit_w[best] += unit_w[best + 1];
+            unit_end[best] = unit_end[best + 1];
+            unit_w.erase(unit_w.begin() + best + 1);
+            unit_end.erase(unit_end.begin() + best + 1);
+        }
+        // contiguous grouping of the stages into `parts` waves minimising the heaviest wave (the last wave
+        // also carries the mix-bus work); ties: smallest sum of squares
+        const int BUS_W = 7;
+        auto grouping = [&](int parts) {
             const int n = (int)unit_w.size();
             std::vector<int> pre(n + 1, 0);
             for (int k = 0; k < n; ++k) pre[k + 1] = pre[k] + unit_w[k];
             struct Best {
                 long mx = 1L << 40, sq = 1L << 40;
-                std::vector<int> ends; // one-past-last ORDER index of every stage
+                std::vector<int> ends; // one-past-last stage of every wave
             };
             std::vector<std::vector<Best>> dp(parts + 1, std::vector<Best>(n + 1));
             dp[0][0].mx = 0;
@@ -1360,23 +1405,33 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                             cur.mx = mx;
                             cur.sq = sq;
                             cur.ends = prev.ends;
-                            cur.ends.push_back(unit_end[e - 1]);
+                            cur.ends.push_back(e);
                         }
                     }
-            return dp[parts][n].ends;
+            std::vector<std::vector<int>> groups;
+            int lo = 0;
+            for (int e : dp[parts][n].ends) {
+                groups.emplace_back();
+                for (int k = lo; k < e; ++k) groups.back().push_back(k);
+                lo = e;
+            }
+            return groups;
         };
         if (want && total >= 40 && unit_w.size() >= 2) {
-            const int n = (int)order.size();
-            const int parts = (total >= 80 && unit_w.size() >= 4) ? 4 : 2;
-            const std::vector<int> ends = partition(parts);
-            if ((int)ends.size() == parts) {
-                cg.n_stages = parts;
-                int st = 0;
-                for (int k = 0; k < n; ++k) {
-                    while (k >= ends[st]) ++st;
-                    cg.stage_of[order[k]] = st;
-                }
+            cg.n_stages = (int)unit_w.size();
+            int st = 0;
+            for (int k = 0; k < (int)order.size(); ++k) {
+                while (k >= unit_end[st]) ++st;
+                cg.stage_of[order[k]] = st;
             }
+            cg.groups2 = grouping(2);
+            if (const char* ec = getenv("OGC_CUT2")) { // experiment knob: first wave = the first k stages
+                const int ku = std::max(1, std::min(cg.n_stages - 1, atoi(ec)));
+                cg.groups2 = {{}, {}};
+                for (int k = 0; k < cg.n_stages; ++k) cg.groups2[k < ku ? 0 : 1].push_back(k);
+            }
+            const char* ep = getenv("OGC_PARTS");
+            if (total >= 80 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(4);
         }
     }
     cg.split = cg.n_stages > 1;
@@ -1426,7 +1481,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
     }
     out.can_split = cg.split;
-    out.max_pipeline = cg.n_stages;
+    out.max_pipeline = !cg.groups4.empty() ? 4 : (!cg.groups2.empty() ? 2 : 1);
 
     if (out.n_slots > 160) fail("graph needs more than 160 uniform slots");
 
@@ -1558,7 +1613,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                             // where it would also sit out the delay-line loads staged for the next chunk
         body << "    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
-    body << "    auto tick = [&](const uint32_t f) __attribute__((always_inline)) -> float {\n"
+    // min over the countdowns of a group's envelopes, or "" when it has none
+    const bool chunk_chk = !(getenv("OGC_CHUNK_CHK") && atoi(getenv("OGC_CHUNK_CHK")) == 0);
+    auto min_cnt = [&](const std::vector<int>& st) {
+        std::string m;
+        if (!chunk_chk) return m;
+        for (int k : st)
+            for (const auto& cexp : cg.sec[k].env_cnts) m = m.empty() ? cexp : "min(" + m + ", " + cexp + ")";
+        return m;
+    };
+    body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> float {\n"
          << group_tick({all_stages}, 0) << post_code(all_stages);
     body << "        return " << bus_expr << ";\n    };\n";
     body << events_code(all_stages);
@@ -1566,13 +1630,28 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
          << (out.rings.empty() ? std::string() : "        cbase = base;\n" + cat(all_stages, &Codegen::Sect::chunk_begin))
          << "        if (n == OG_BUS_CHUNK && __all((int)(c.next_ev >= base + OG_BUS_CHUNK))) {\n"
-         << "            // no lane of this wave has an event in the chunk: straight-line body\n"
-         << "#pragma unroll " << unroll << "\n"
-         << "            for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j));\n"
-         << "        } else {\n"
+         << "            // no lane of this wave has an event in the chunk: straight-line body\n";
+    {
+        const std::string mc = min_cnt(all_stages);
+        auto quiet = [&](const char* flag, const char* ind) {
+            body << ind << "#pragma unroll " << unroll << "\n"
+                 << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j, og::BoolC<"
+                 << flag << ">{}));\n";
+        };
+        if (mc.empty()) {
+            quiet("true", "            ");
+        } else {
+            body << "            if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n";
+            quiet("false", "                ");
+            body << "            } else {\n";
+            quiet("true", "                ");
+            body << "            }\n";
+        }
+    }
+    body << "        } else {\n"
          << "            for (uint32_t j = 0; j < n; ++j) {\n"
          << "                events(base + j);\n"
-         << "                og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j));\n"
+         << "                og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j, og::BoolC<true>{}));\n"
          << "            }\n"
          << "        }\n"
          << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"
@@ -1607,7 +1686,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << "    constexpr uint32_t XD" << k << " = " << depth << ";\n";
             if (depth > 1) body << "    __shared__ float chan" << k << "[XD" << k << "][OG_XCH][OG_WAVE];\n";
         }
-        body << "    const uint32_t stage = (threadIdx.x / OG_WAVE + blockIdx.x) % " << K << "u;\n"
+        const char* rot_expr[5] = {"0u", "blockIdx.x", "(blockIdx.x >> 3)", "(blockIdx.x >> 5)", "(blockIdx.x >> 8)"};
+        int rot = 1;
+        if (const char* er = getenv("OGC_ROT")) rot = std::max(0, std::min(4, atoi(er)));
+        body << "    const uint32_t stage = (threadIdx.x / OG_WAVE + " << rot_expr[rot] << ") % " << K << "u;\n"
              << "    og::VoiceCtx c;\n"
              << "    og::voice_begin_split<TAPS>(A, c);\n"
              << cg.common_decl.str() << "    if (c.valid) {\n" << cg.common_load.str() << "    }\n"
@@ -1619,7 +1701,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
             body << "    auto derive = [&]() {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
             body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
-            body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j) __attribute__((always_inline))"
+            body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
                  << group_tick(groups, gi) << post_code(st);
             if (last) body << "        return " << bus_expr << ";\n";
@@ -1627,24 +1709,38 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << events_code(st);
             // SALU instructions cost issue slots like VALU ones: the quiet chunk is a straight-line,
             // fully unrolled body; per-frame tests only exist on the (rare) event path
-            const std::string call =
-                last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, tick(f, ch, j));" : "tick(f, ch, j);";
+            auto call = [&](const char* flag) {
+                const std::string t = std::string("tick(f, ch, j, og::BoolC<") + flag + ">{})";
+                return last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, " + t + ");" : t + ";";
+            };
+            auto quiet = [&](const char* flag, const char* ind) {
+                body << ind << "#pragma unroll\n"
+                     << ind << "for (uint32_t j = 0; j < OG_XCH; ++j) {\n"
+                     << ind << "    const uint32_t f = base + j;\n"
+                     << ind << "    " << call(flag) << "\n"
+                     << ind << "}\n";
+            };
+            const std::string mc = min_cnt(st);
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
                  << "        const uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"
                  << "        const uint32_t base = ch * OG_XCH;\n"
                  << "        const uint32_t n = min((uint32_t)OG_XCH, A.frames - base);\n"
-                 << "        if (n == OG_XCH && __all((int)(c.next_ev >= base + OG_XCH))) {\n"
-                 << "#pragma unroll\n"
-                 << "            for (uint32_t j = 0; j < OG_XCH; ++j) {\n"
-                 << "                const uint32_t f = base + j;\n"
-                 << "                " << call << "\n"
-                 << "            }\n"
-                 << "        } else {\n"
+                 << "        if (n == OG_XCH && __all((int)(c.next_ev >= base + OG_XCH))) {\n";
+            if (mc.empty()) {
+                quiet("true", "            ");
+            } else {
+                body << "            if (__all((int)(" << mc << " > (uint32_t)OG_XCH))) { // no envelope stage ends in this chunk\n";
+                quiet("false", "                ");
+                body << "            } else {\n";
+                quiet("true", "                ");
+                body << "            }\n";
+            }
+            body << "        } else {\n"
                  << "            for (uint32_t j = 0; j < n; ++j) {\n"
                  << "                const uint32_t f = base + j;\n"
                  << "                events(f);\n"
-                 << "                " << call << "\n"
+                 << "                " << call("true") << "\n"
                  << "            }\n"
                  << "        }\n";
             if (last)
@@ -1663,11 +1759,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         body << "    }\n}\n";
     };
-    if (NS == 2) emit_pipeline({{0}, {1}});
-    if (NS == 4) {
-        emit_pipeline({{0, 1}, {2, 3}});
-        emit_pipeline({{0}, {1}, {2}, {3}});
-    }
+    if (!cg.groups2.empty()) emit_pipeline(cg.groups2);
+    if (!cg.groups4.empty()) emit_pipeline(cg.groups4);
 
     const std::string body_s = body.str();
     out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
@@ -1691,11 +1784,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
     for (auto& v : variants)
-        src << "extern \"C\" __global__ __launch_bounds__(64) void og_k_" << hs << "_" << v[0]
+        src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
     std::vector<int> depths;
-    if (NS >= 2) depths.push_back(2);
-    if (NS == 4) depths.push_back(4);
+    if (!cg.groups2.empty()) depths.push_back(2);
+    if (!cg.groups4.empty()) depths.push_back(4);
     for (int K : depths)
         for (auto& v : variants)
             src << "extern \"C\" __global__ __launch_bounds__(" << 64 * K << ") void og_k" << K << "_" << hs << "_" << v[0]

@@ -85,6 +85,12 @@ __device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)a.slots[i]);
 }
 
+// compile-time flag passed to the generated tick lambdas (stage-end checks on / off)
+template <bool B>
+struct BoolC {
+    static constexpr bool value = B;
+};
+
 struct VoiceCtx {
     uint32_t v;     // voice index
     bool valid;     // v < n_voices

@@ -36,7 +36,7 @@ OG_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 // quotient (q' = q + (a - q*b) * rcp(b)).  Correctly rounded except for rare
 // 1-ulp misses; 5 VALU ops instead of the 12 of the IEEE expansion.  Only
 // used where the reference's quotient feeds a contracting recurrence (the
-// ADSR release slope), never for phase increments.
+// ADSR release slope, the TPT coefficient h), never for phase increments.
 OG_DEV float div_near(float a, float b)
 {
     const float rb = __builtin_amdgcn_rcpf(b);
@@ -215,7 +215,9 @@ OG_DEV void tpt_update_coefficients(float cutoff, float q, float two_sr, float p
     const float freq = clampf(cutoff, 20.0f, nyquist);
     const float f = two_sr * og_tanf_q1(F32_TAU * freq * period) * period;
     const float inv_q = 1.0f / q;
-    h = 1.0f / (1.0f + inv_q * f + f * f);
+    // (rcp + one Newton step: within an ulp of the IEEE quotient, a third of its instructions; the
+    //  coefficient already carries og_tanf_q1's few-ulp error)
+    h = div_near(1.0f, 1.0f + inv_q * f + f * f);
     g = f;
     k = f + inv_q;
     cur_c = cutoff;
@@ -241,6 +243,8 @@ OG_DEV void tpt_params_mod(float cutoff_in, float q_in, float f_mod, float max_c
 // factor = clamp(1.0, 20/cb, max/cb) == 1.0 exactly because correctly rounded
 // 20/cb <= 1 <= max/cb for cb in [20, max]; cb*1.0 == cb; the outer clamp is
 // then the identity.  Result-identical, two divides cheaper.
+// Used where cutoff and q cannot change between events (block-uniform or per-voice
+// values): the caller runs it once per block and after per-voice value events.
 OG_DEV void tpt_params_nomod(float cutoff_in, float q_in, float max_cutoff, float two_sr, float period,
                              float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
 {
@@ -248,6 +252,33 @@ OG_DEV void tpt_params_nomod(float cutoff_in, float q_in, float max_cutoff, floa
     const float q = clampf(q_in, 0.1f, 10.0f);
     if (fabsf(cutoff - cur_c) > F32_EPSILON || fabsf(q - cur_q) > F32_EPSILON)
         tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+}
+
+// The same update for a cutoff that moves every sample (an envelope on the cutoff, FMVoice): written
+// without a branch -- the new coefficients are computed on every tick and selected in.  A branch per
+// frame costs more than it saves here: it is taken on most frames anyway, and it cuts the unrolled
+// frames into separate scheduling regions, so the (serial) sine and filter chains of consecutive
+// frames cannot be overlapped.
+OG_DEV void tpt_params_nomod_flat(float cutoff_in, float q_in, float inv_q_in, float max_cutoff, float two_sr, float period,
+                                  float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
+{
+    const float cutoff = clampf(cutoff_in, 20.0f, max_cutoff);
+    const float q = clampf(q_in, 0.1f, 10.0f); // inv_q_in = 1.0f / q, formed by the caller (hoisted when q is block-constant)
+    const bool upd = fabsf(cutoff - cur_c) > F32_EPSILON || fabsf(q - cur_q) > F32_EPSILON;
+    const float freq = clampf(cutoff, 20.0f, nyquist);
+    // og_tanf_q1 flattened: x <= pi/4 -> poly(x), else 1 / poly(pi/2 - x)
+    const float x = F32_TAU * freq * period;
+    const bool big = x > 0x1.921fb6p-1f;
+    const float y = big ? ((0x1.921fb6p+0f - x) + -0x1.777a5cp-25f) : x;
+    const float t0 = og_tan_poly(y);
+    const float t = big ? div_near(1.0f, t0) : t0;
+    const float f = two_sr * t * period;
+    const float nh = div_near(1.0f, 1.0f + inv_q_in * f + f * f);
+    h = upd ? nh : h;
+    g = upd ? f : g;
+    k = upd ? f + inv_q_in : k;
+    cur_c = upd ? cutoff : cur_c;
+    cur_q = upd ? q : cur_q;
 }
 
 // state-variable core :114-122

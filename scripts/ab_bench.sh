@@ -3,7 +3,9 @@
 TAGS=${1:-"base"}; ROUNDS=${2:-3}; shift; shift
 for r in $(seq 1 $ROUNDS); do
   for t in $TAGS; do
-    unset OGC_UNROLL
+    unset OGC_UNROLL OGC_ROT OGC_PARTS OGC_CUT2
+    # a variant's build environment must also be in force at run time (the engine re-derives the kernel hash)
+    if [ -f "$PWD/oscen_amd/_build/liboscen_gpu_$t.env" ]; then set -a; . "$PWD/oscen_amd/_build/liboscen_gpu_$t.env"; set +a; fi
     if [ "$t" = "base" ]; then unset OSCEN_GPU_LIB; else export OSCEN_GPU_LIB=$PWD/oscen_amd/_build/liboscen_gpu_$t.so; fi
     case $t in u[0-9]*) export OGC_UNROLL=${t#u};; esac
     python bench.py --steps 94 --warmup 4 --no-cpu-baseline "$@" 2>/dev/null | python -c "

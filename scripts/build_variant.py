@@ -13,6 +13,9 @@ if "--" in rest:
     i = rest.index("--"); flags = rest[i + 1:]; rest = rest[:i]
 for kv in rest:
     k, v = kv.split("=", 1); env[k] = v
+with open(os.path.join(b.BUILD, "liboscen_gpu_%s.env" % tag), "w") as f:  # read back by scripts/ab_bench.sh
+    for kv in rest:
+        f.write(kv + "\n")
 vdir = os.path.join(b.BUILD, "variant_" + tag)
 os.makedirs(vdir, exist_ok=True)
 b.generate()
