@@ -26,38 +26,43 @@
 #include "og_registry.h"
 
 // Sum the per-workgroup partial rows (fixed association, no atomics).
-// One workgroup per 64 frames, 16 row-slices x 64 frames = 1024 threads: thread
-// (slice s, frame f) adds rows s, s+16, s+32, ... in order with four
-// independent accumulators (64 independent loads in flight per row-slice keep
-// the HBM/L2 latency covered; the first version walked all rows from 4 waves
-// and took 40 us for 1024 rows), then slice 0 adds the 16 slice sums in order.
-#define OG_RED_SLICES 16
+// One workgroup per 16 frames, 64 row-slices x 16 frames = 1024 threads: thread (slice s, frame f) adds
+// rows s, s+64, s+128, ... of its group of <= 1024 rows with eight independent accumulators -- its
+// <= 16 loads are all in flight together, so the pass costs about two memory latencies (the rows
+// were written by other XCDs, they come from HBM/MALL) -- then the 64 slice sums are folded 4 -> 1
+// and 16 -> 1 through LDS.  History: 4 waves walking all rows 40 us; 16 slices x 64 frames 6.5 us.
+#define OG_RED_SLICES 64
+#define OG_RED_FRAMES 16
 #define OG_RED_GROUP 1024 // rows per workgroup; larger banks take a second pass over the group sums
 __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
                                                       uint32_t frames, float* __restrict__ out)
 {
-    __shared__ float part[OG_RED_SLICES][64];
-    const uint32_t fx = threadIdx.x & 63u;
-    const uint32_t slice = threadIdx.x >> 6;
-    const uint32_t f = blockIdx.x * 64u + fx;
+    __shared__ float part[OG_RED_SLICES][OG_RED_FRAMES];
+    __shared__ float quad[OG_RED_SLICES / 4][OG_RED_FRAMES];
+    const uint32_t fx = threadIdx.x % OG_RED_FRAMES;
+    const uint32_t slice = threadIdx.x / OG_RED_FRAMES;
+    const uint32_t f = blockIdx.x * OG_RED_FRAMES + fx;
     const uint32_t row0 = blockIdx.y * OG_RED_GROUP;
     const uint32_t row1 = min(n_rows, row0 + OG_RED_GROUP);
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (f < frames) {
         uint32_t r = row0 + slice;
-        for (; r + 3 * OG_RED_SLICES < row1; r += 4 * OG_RED_SLICES) {
+        for (; r + 7 * OG_RED_SLICES < row1; r += 8 * OG_RED_SLICES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += partials[(size_t)(r + i * OG_RED_SLICES) * frames + f];
+            for (int i = 0; i < 8; ++i) acc[i] += partials[(size_t)(r + i * OG_RED_SLICES) * frames + f];
         }
         for (int i = 0; r < row1; r += OG_RED_SLICES, ++i) acc[i] += partials[(size_t)r * frames + f];
     }
-    part[slice][fx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    part[slice][fx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (slice < OG_RED_SLICES / 4)
+        quad[slice][fx] = (part[4 * slice][fx] + part[4 * slice + 1][fx]) + (part[4 * slice + 2][fx] + part[4 * slice + 3][fx]);
     __syncthreads();
     if (slice == 0 && f < frames) {
-        float s = 0.0f;
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < OG_RED_SLICES; ++i) s += part[i][fx];
-        out[(size_t)blockIdx.y * frames + f] = s;
+        for (int i = 0; i < OG_RED_SLICES / 4; ++i) s[i & 3] += quad[i][fx];
+        out[(size_t)blockIdx.y * frames + f] = (s[0] + s[1]) + (s[2] + s[3]);
     }
 }
 
@@ -427,13 +432,13 @@ struct og_engine {
             float* tmp = d_partials2;
             while (rows > OG_RED_GROUP) {
                 const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
-                hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64, groups), dim3(1024), 0, stream, src, rows,
+                hipLaunchKernelGGL(og_bus_reduce, dim3((frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0, stream, src, rows,
                                    frames, tmp);
                 src = tmp;
                 rows = groups;
                 tmp = tmp + (size_t)groups * OG_MAX_BLOCK; // next level writes behind this one
             }
-            hipLaunchKernelGGL(og_bus_reduce, dim3((frames + 63) / 64, 1), dim3(1024), 0, stream, src, rows, frames,
+            hipLaunchKernelGGL(og_bus_reduce, dim3((frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, 1), dim3(1024), 0, stream, src, rows, frames,
                                sum_dst);
         }
         HIPCK(hipGetLastError());
