@@ -1,0 +1,76 @@
+// NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE (no rustc/cargo): shipped as source for the
+// maintainer of the reference.  Kept in sync with INTEGRATION.md (tests/test_capi_cpu.py checks it).
+// oscen-gpu-sys/src/lib.rs
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_float, c_int, c_void};
+
+#[repr(C)] pub struct og_graph_desc { _p: [u8; 0] }
+#[repr(C)] pub struct og_engine { _p: [u8; 0] }
+
+pub const OG_KIND_VALUE: c_int = 0;
+pub const OG_KIND_EVENT: c_int = 1;
+pub const OG_KIND_STREAM: c_int = 2;
+pub const OG_IN_PER_VOICE: u32 = 1;
+pub const OG_E_OVERFLOW: c_int = -5;
+
+#[link(name = "oscen_gpu")]
+extern "C" {
+    pub fn og_graph_new(name: *const c_char, out: *mut *mut og_graph_desc) -> c_int;
+    pub fn og_graph_builtin(name: *const c_char, out: *mut *mut og_graph_desc) -> c_int;
+    pub fn og_graph_add_input(g: *mut og_graph_desc, name: *const c_char, kind: c_int,
+                              default_value: c_float, ramp_frames: u32, flags: u32) -> c_int;
+    pub fn og_graph_add_output(g: *mut og_graph_desc, name: *const c_char, kind: c_int) -> c_int;
+    pub fn og_graph_add_node(g: *mut og_graph_desc, name: *const c_char, type_ctor: *const c_char,
+                             args: *const c_float, n_args: u32, rate_factor: u32) -> c_int;
+    pub fn og_graph_connect(g: *mut og_graph_desc, src: *const c_char, dst: *const c_char,
+                            policy: *const c_char) -> c_int;
+    pub fn og_graph_free(g: *mut og_graph_desc);
+    pub fn og_create(g: *const og_graph_desc, n_voices: u32, device: c_int,
+                     out: *mut *mut og_engine) -> c_int;
+    pub fn og_destroy(e: *mut og_engine);
+    pub fn og_init(e: *mut og_engine, sample_rate: c_float) -> c_int;
+    pub fn og_input_index(e: *const og_engine, name: *const c_char) -> c_int;
+    pub fn og_set_value(e: *mut og_engine, input: u32, v: c_float) -> c_int;
+    pub fn og_set_value_ramp(e: *mut og_engine, input: u32, v: c_float, frames: u32) -> c_int;
+    pub fn og_set_value_immediate(e: *mut og_engine, input: u32, v: c_float) -> c_int;
+    pub fn og_set_voice_value(e: *mut og_engine, input: u32, voice: u32, v: c_float) -> c_int;
+    pub fn og_push_voice_event(e: *mut og_engine, input: u32, voice: u32, frame_offset: u32,
+                               scalar: c_float) -> c_int;
+    pub fn og_push_voice_value(e: *mut og_engine, input: u32, voice: u32, frame_offset: u32,
+                               v: c_float) -> c_int;
+    pub fn og_process_block(e: *mut og_engine, frames: u32, out_bus: *mut c_float) -> c_int;
+    pub fn og_process_block_async(e: *mut og_engine, frames: u32, d_out_bus: *mut c_void) -> c_int;
+    pub fn og_synchronize(e: *mut og_engine) -> c_int;
+    pub fn og_render(e: *mut og_engine, total_frames: u64, block: u32, out: *mut c_float) -> c_int;
+    pub fn og_latency_samples(e: *const og_engine) -> u32;
+    pub fn og_last_error() -> *const c_char;
+}
+
+// ---- the rest of include/oscen_gpu.h (DSL text front end, feedback edges, bus nodes, MIDI, WAV, state) ----
+#[repr(C)] pub struct og_midi { _p: [u8; 0] }
+extern "C" {
+    pub fn og_graph_add_bus_node(g: *mut og_graph_desc, name: *const c_char, type_ctor: *const c_char,
+                                 args: *const c_float, n_args: u32) -> c_int;
+    pub fn og_graph_connect_via(g: *mut og_graph_desc, src: *const c_char, via: *const c_char,
+                                dst: *const c_char) -> c_int;
+    pub fn og_graph_parse(dsl_text: *const c_char, per_voice_inputs: *const c_char,
+                          out: *mut *mut og_graph_desc) -> c_int;
+    pub fn og_graph_to_dsl(g: *const og_graph_desc, buf: *mut c_char, cap: usize) -> i64;
+    pub fn og_set_voice_values(e: *mut og_engine, input: u32, first: u32, count: u32, v: *const c_float) -> c_int;
+    pub fn og_schedule_voice_event(e: *mut og_engine, input: u32, voice: u32, abs_frame: u64, scalar: c_float) -> c_int;
+    pub fn og_schedule_voice_value(e: *mut og_engine, input: u32, voice: u32, abs_frame: u64, v: c_float) -> c_int;
+    pub fn og_set_stream(e: *mut og_engine, hip_stream: *mut c_void) -> c_int;
+    pub fn og_channels(e: *const og_engine) -> u32;
+    pub fn og_num_voices(e: *const og_engine) -> u32;
+    pub fn og_state_bytes(e: *const og_engine) -> usize;
+    pub fn og_save_state(e: *mut og_engine, dst: *mut c_void, cap: usize) -> c_int;
+    pub fn og_load_state(e: *mut og_engine, src: *const c_void, len: usize) -> c_int;
+    pub fn og_midi_create(e: *mut og_engine, n_voices: u32, frequency_input: *const c_char,
+                          gate_input: *const c_char, out: *mut *mut og_midi) -> c_int;
+    pub fn og_midi_destroy(m: *mut og_midi);
+    pub fn og_midi_send(m: *mut og_midi, bytes: *const u8, len: u32, frame_offset: u32) -> c_int;
+    pub fn og_midi_flush(m: *mut og_midi) -> c_int;
+    pub fn og_midi_process_block(m: *mut og_midi, frames: u32, out_bus: *mut c_float) -> c_int;
+    pub fn og_write_wav(path: *const c_char, interleaved: *const c_float, frames: u64, channels: u32,
+                        sample_rate: u32, bits: u32) -> c_int;
+}

@@ -159,3 +159,26 @@ def test_multirate_lowering(lib):
     g.connect("a.output", "c.input").connect("c.output", "out")
     with pytest.raises(oscen_amd.OscenError):
         g.kernel_source()
+
+
+def test_rust_sys_crate_declares_only_header_symbols_with_matching_arity():
+    """bindings/rust/oscen-gpu-sys (shipped as source: no rustc here) must bind what include/oscen_gpu.h
+    declares -- same names, same number of parameters."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "oscen_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decl = {}
+    for m in re.finditer(r"\b(og_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        decl[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rs = open(os.path.join(root, "bindings", "rust", "oscen-gpu-sys", "src", "lib.rs")).read()
+    bound = {}
+    for m in re.finditer(r"pub fn (og_\w+)\s*\(([^)]*)\)", rs, flags=re.S):
+        args = m.group(2).strip()
+        bound[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert len(bound) >= 40
+    for name, n in bound.items():
+        assert name in decl, name + " is not declared in include/oscen_gpu.h"
+        assert decl[name] == n, (name, decl[name], n)
