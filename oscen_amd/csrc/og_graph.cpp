@@ -306,6 +306,7 @@ struct Codegen {
         std::set<int> users; // consuming stages
     };
     std::vector<XVal> xvals;
+    bool bus_all_lanes = false; // every lane of a multi-lane voice contributes a share to the mix bus (og::ep_bank_tick)
     // envelopes whose stage-end fix-up has not been emitted yet: (countdown expression, fix-up code).
     // Flushed as ONE wave-uniform check before the next node that is not an envelope (which may read
     // their outputs), before the stage changes and before the graph output is formed.
@@ -997,7 +998,32 @@ void emit_ep_bank(NodeCtx& x)
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second) x.cg.S().ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
-    x.set_out("output", "og::ep_bank_tick(" + B + ", c.h, " + fr.e + ", " + amp.e + ", " + x.sf(s_sr) + ")");
+    // update_multipliers(): the frequency test of process() can only fire when the frequency changed
+    const std::string upd = "og::ep_bank_update(" + B + ", c.h, " + fr.e + ", " + x.sf(s_sr) + ");\n";
+    if (fr.rate <= Rate::VBlock && fr.rate != Rate::UFrame) {
+        x.cg.S().derive << "        " << upd;
+        x.cg.any_derive = true;
+    } else {
+        x.cg.os() << "        " << upd;
+    }
+    // Does the output feed nothing but the graph output?  Then every lane may hand its own share to the
+    // mix bus instead of folding the 32 harmonics first (taps still need the folded voice output).
+    int uses = 0;
+    bool only_bus = true;
+    const std::string me = x.n.decl->name + ".output";
+    for (const GEdge& e : x.cg.g.edges) {
+        if (e.src.find(x.n.decl->name + ".") == std::string::npos) continue;
+        std::string t = e.src;
+        t.erase(std::remove_if(t.begin(), t.end(), [](char ch) { return isspace((unsigned char)ch) || ch == '(' || ch == ')'; }), t.end());
+        ++uses;
+        bool bus_dst = false;
+        for (const GNode& nd : x.cg.g.nodes)
+            if (nd.bus && e.dst.rfind(nd.name + ".", 0) == 0) bus_dst = true; // (post-mix nodes read the summed bus)
+        if (t != me || (e.dst.find('.') != std::string::npos && !bus_dst) || !e.policy.empty()) only_bus = false;
+    }
+    const bool share = uses == 1 && only_bus;
+    if (share) x.cg.bus_all_lanes = true;
+    x.set_out("output", std::string("og::ep_bank_tick<") + (share ? "TAPS" : "true") + ">(" + B + ", " + amp.e + ")");
 }
 
 const std::map<std::string, NodeTypeInfo>& registry()
@@ -1635,7 +1661,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         const std::string mc = min_cnt(all_stages);
         auto quiet = [&](const char* flag, const char* ind) {
             body << ind << "#pragma unroll " << unroll << "\n"
-                 << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j, og::BoolC<"
+                 << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "") << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<"
                  << flag << ">{}));\n";
         };
         if (mc.empty()) {
@@ -1651,7 +1677,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     body << "        } else {\n"
          << "            for (uint32_t j = 0; j < n; ++j) {\n"
          << "                events(base + j);\n"
-         << "                og::bus_put<TAPS>(A, c, bus, base + j, j, tick(base + j, og::BoolC<true>{}));\n"
+         << "                og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "") << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<true>{}));\n"
          << "            }\n"
          << "        }\n"
          << "        og::bus_chunk_reduce(A, c, bus, base, n);\n"

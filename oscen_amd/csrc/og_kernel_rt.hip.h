@@ -213,11 +213,12 @@ struct BusLds {
 };
 
 // one sample of one voice into the wave's transpose tile (row j = frame within the chunk)
-template <bool TAPS>
+template <bool TAPS, bool ALL_LANES = false>
 __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, uint32_t j,
                                         float out)
 {
-    const float y = (c.valid && c.lead) ? out : 0.0f;
+    // ALL_LANES: every lane of a multi-lane voice holds a share of the voice's output (see og::ep_bank_tick)
+    const float y = (c.valid && (ALL_LANES || c.lead)) ? out : 0.0f;
     lds.tile[j][c.lane] = y;
     if (TAPS) {
         if (c.tap >= 0 && c.lead) a.taps[(size_t)c.tap * a.frames + f] = y;

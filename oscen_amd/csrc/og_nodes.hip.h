@@ -851,8 +851,10 @@ OG_DEV void ep_bank_gate(EpBank& b, float v) // on_gate :115-122
     }
 }
 
-// OscillatorBank::process :154-169 (update_multipliers :126-150); returns the voice output on every lane
-OG_DEV float ep_bank_tick(EpBank& b, uint32_t h, float frequency, float amp, float sr)
+// update_multipliers :126-150 behind the frequency-change test of process() :155-158.  The caller runs
+// it every tick, or -- when the frequency can only change through per-voice value events -- in
+// derive() (block start and after such an event), which is when the reference's test can fire.
+OG_DEV void ep_bank_update(EpBank& b, uint32_t h, float frequency, float sr)
 {
     if (frequency > 0.0f && !(fabsf(b.last_frequency - frequency) < 0.01f)) {
         b.last_frequency = frequency;
@@ -869,18 +871,27 @@ OG_DEV float ep_bank_tick(EpBank& b, uint32_t h, float frequency, float amp, flo
         b.re = 1.0f;
         b.im = 0.0f;
     }
+}
+
+// OscillatorBank::process :159-169.  VOICE_SUM: fold the 32 harmonics of the voice (reference: sequential
+// f32 fold; here a butterfly inside the 32-lane half of the wave -- re-association only) and return the
+// voice output on every lane.  Otherwise return this lane's share: used when the output feeds nothing but
+// the mix bus, whose reduction adds the lanes anyway (5 cross-lane adds per frame saved).
+template <bool VOICE_SUM>
+OG_DEV float ep_bank_tick(EpBank& b, float amp)
+{
     const float new_re = b.re * b.mre - b.im * b.mim; // Complex::mul :66-72
     const float new_im = b.re * b.mim + b.im * b.mre;
     b.re = new_re;
     b.im = new_im;
-    // sum over the 32 harmonics of the voice (reference: sequential f32 fold; here a butterfly
-    // inside the 32-lane half of the wave -- re-association only)
     float s = new_im * amp;
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 8);
-    s += __shfl_xor(s, 16);
+    if (VOICE_SUM) {
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+    }
     return s * 3.0f;
 }
 
