@@ -280,6 +280,7 @@ struct Codegen {
         std::ostringstream chunk_begin; // top of every OG_BUS_CHUNK-frame chunk (delay-line staging)
         std::vector<std::string> env_cnts; // countdowns of this stage's envelopes (a chunk in which none of them
                                            // reaches 0 runs the tick without the stage-end checks)
+        std::vector<std::string> env_rs;   // their release flags (1.0f in Release): no lane releasing -> no release arithmetic
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
@@ -320,7 +321,10 @@ struct Codegen {
              << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n";
         for (auto& pp : pending_post) os() << pp.second;
         os() << "        }\n        }\n";
-        for (auto& pp : pending_post) S().env_cnts.push_back(pp.first);
+        for (auto& pp : pending_post) {
+            S().env_cnts.push_back(pp.first);
+            S().env_rs.push_back(pp.first.substr(0, pp.first.size() - 4) + ".rs"); // "<E>.cnt" -> "<E>.rs"
+        }
         pending_post.clear();
     }
 
@@ -709,7 +713,7 @@ void emit_adsr(NodeCtx& x)
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
             x.cg.S().ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
-    x.set_out("output", "og::adsr_tick(" + E + ")", true);
+    x.set_out("output", x.n.domain == 1 ? "og::adsr_tick(" + E + ")" : "og::adsr_tick<decltype(chk)::release>(" + E + ")", true);
     const std::string fix = "og::adsr_complete(" + E + ", " + x.sf(s_ac) + ", " + x.sf(s_dc) + ", " + x.su(s_dn) + ", " + x.p +
                             "output);\n";
     if (x.n.domain == 1) // oversampled: N ticks per frame, finish a stage end right away
@@ -1648,6 +1652,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             for (const auto& cexp : cg.sec[k].env_cnts) m = m.empty() ? cexp : "min(" + m + ", " + cexp + ")";
         return m;
     };
+    auto rs_sum = [&](const std::vector<int>& st) {
+        std::string m;
+        for (int k : st)
+            for (const auto& r : cg.sec[k].env_rs) m = m.empty() ? r : "(" + m + " + " + r + ")";
+        return m;
+    };
     body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> float {\n"
          << group_tick({all_stages}, 0) << post_code(all_stages);
     body << "        return " << bus_expr << ";\n    };\n";
@@ -1667,9 +1677,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         if (mc.empty()) {
             quiet("true", "            ");
         } else {
-            body << "            if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n";
-            quiet("false", "                ");
-            body << "            } else {\n";
+            body << "            if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n"
+                 << "                if (__all((int)(" << rs_sum(all_stages) << " == 0.0f))) { // ... and no lane is in Release\n";
+            quiet("false, false", "                    ");
+            body << "                } else {\n";
+            quiet("false", "                    ");
+            body << "                }\n            } else {\n";
             quiet("true", "                ");
             body << "            }\n";
         }
@@ -1756,9 +1769,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             if (mc.empty()) {
                 quiet("true", "            ");
             } else {
-                body << "            if (__all((int)(" << mc << " > (uint32_t)OG_XCH))) { // no envelope stage ends in this chunk\n";
-                quiet("false", "                ");
-                body << "            } else {\n";
+                body << "            if (__all((int)(" << mc << " > (uint32_t)OG_XCH))) { // no envelope stage ends in this chunk\n"
+                     << "                if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
+                quiet("false, false", "                    ");
+                body << "                } else {\n";
+                quiet("false", "                    ");
+                body << "                }\n            } else {\n";
                 quiet("true", "                ");
                 body << "            }\n";
             }

@@ -85,10 +85,12 @@ __device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)a.slots[i]);
 }
 
-// compile-time flag passed to the generated tick lambdas (stage-end checks on / off)
-template <bool B>
+// compile-time flags passed to the generated tick lambdas: `value` = envelope stage-end checks on,
+// `release` = envelope release arithmetic on (off in chunks where no lane of the wave is releasing)
+template <bool B, bool R = true>
 struct BoolC {
     static constexpr bool value = B;
+    static constexpr bool release = R;
 };
 
 struct VoiceCtx {

@@ -149,6 +149,7 @@ OG_DEV void adsr_gate(Adsr& e, float v, const OgBlockArgs& A, int k)
 }
 
 // process_stage  adsr.rs:206-248, the per-sample part
+template <bool RELEASE = true>
 OG_DEV float adsr_tick(Adsr& e)
 {
     // Attack: lv += (1 - lv) * attack_coeff; Decay: lv += (sustain_level - lv) * decay_coeff; else cf == 0
@@ -156,7 +157,8 @@ OG_DEV float adsr_tick(Adsr& e)
     // Release: lv += -lv / samples_remaining, increment re-derived every sample (adsr.rs:162-173)
     // (computed unconditionally: a wave-uniform "any lane releasing" test costs more issue slots
     //  than it saves -- the compiler if-converts it into the same arithmetic plus scalar selects)
-    lv = fmaf(e.rs, div_near(-lv, (float)e.cnt), lv);
+    // (RELEASE = false: the caller has established rs == 0 in every lane for the whole chunk)
+    if (RELEASE) lv = fmaf(e.rs, div_near(-lv, (float)e.cnt), lv);
     e.cnt -= 1u; // samples_remaining -= 1; reaching 0 is handled by adsr_complete()
     e.lv = lv;
     return lv;
