@@ -804,8 +804,22 @@ void emit_polyblep(NodeCtx& x)
         pw = x.in("pulse_width");
     int s_sr = x.sr_slot();
     std::string phase = x.state_f("phase", [](const UEnv&) { return 0.0f; });
-    x.set_out("output", "og::polyblep_tick<" + std::to_string(x.n.type->variant) + "u>(" + phase + ", " + fr.e + ", " +
-                            fm.e + ", " + pm.e + ", " + amp.e + ", " + pw.e + ", " + x.sf(s_sr) + ")");
+    // frequency * (1 + frequency_mod) and its per-sample increment (an IEEE division): per block for a
+    // voice whose frequency inputs only change through events, per tick otherwise
+    const std::string f_expr = "og::polyblep_frequency(" + fr.e + ", " + fm.e + ")";
+    std::string f, inc;
+    const Rate rr = join(fr.rate, fm.rate);
+    if (rr <= Rate::VBlock && rr != Rate::UFrame) {
+        f = x.hoist("freq", f_expr);
+        inc = x.hoist("inc", "og::polyblep_increment(" + f + ", " + x.sf(s_sr) + ")");
+    } else {
+        f = x.p + "freq";
+        inc = x.p + "inc";
+        x.cg.os() << "        const float " << f << " = " << f_expr << ";\n"
+                  << "        const float " << inc << " = og::polyblep_increment(" << f << ", " << x.sf(s_sr) << ");\n";
+    }
+    x.set_out("output", "og::polyblep_tick<" + std::to_string(x.n.type->variant) + "u>(" + phase + ", " + f + ", " + inc + ", " +
+                            pm.e + ", " + amp.e + ", " + pw.e + ", " + x.sf(s_sr) + ")");
 }
 
 void emit_oscillator(NodeCtx& x)

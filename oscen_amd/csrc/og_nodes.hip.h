@@ -301,64 +301,73 @@ OG_DEV float tpt_tick(float in, float& z0, float& z1, float h, float g, float k)
 // ---------------------------------------------------------------------------
 enum : uint32_t { PB_SINE = 0, PB_SAW = 1, PB_SQUARE = 2, PB_TRIANGLE = 3 };
 
+// x % 1.0 (Rust `%` = C fmod): x - trunc(x) is that value exactly (the subtraction is exact: both
+// operands share the exponent range of x and the result has fewer significant bits).  Two VALU ops
+// instead of the general fmod loop.  (Differs from fmod only in the sign of a zero result for -0.0.)
+OG_DEV float fmod1(float x) { return x - truncf(x); }
+
 OG_DEV float wrap_phase(float p) // rem_euclid(1.0) :171-173
 {
-    float r = fmodf(p, 1.0f);
+    const float r = fmod1(p);
     return (r < 0.0f) ? r + 1.0f : r;
 }
 
-OG_DEV float poly_blep(float t, float dt) // :139-153
+// poly_blep :139-153 and poly_blamp :155-169, written without branches: in a bank some lane is next to
+// a discontinuity on almost every sample, so both sides are evaluated and selected.  rdt = rcp(dt) is
+// shared by the two quotients, each refined by one Newton step (see div_near).
+OG_DEV float div_rcp(float a, float b, float rb)
 {
-    float res = 0.0f;
-    if (dt > F32_EPSILON) {
-        if (t < dt) {
-            const float x = t / dt;
-            res = x + x - x * x - 1.0f;
-        } else if (t > 1.0f - dt) {
-            const float x = (t - 1.0f) / dt;
-            res = x * x + x + x + 1.0f;
-        }
-    }
-    return res;
+    const float q = a * rb;
+    const float r = fmaf(-q, b, a);
+    return fmaf(r, rb, q);
 }
 
-OG_DEV float poly_blamp(float t, float dt) // :155-169
+OG_DEV float poly_blep(float t, float dt, float rdt)
 {
-    float res = 0.0f;
-    if (dt > F32_EPSILON) {
-        if (t < dt) {
-            const float x = t / dt - 1.0f;
-            res = -(x * x * x) / 3.0f;
-        } else if (t > 1.0f - dt) {
-            const float x = (t - 1.0f) / dt + 1.0f;
-            res = (x * x * x) / 3.0f;
-        }
-    }
-    return res;
+    const float x1 = div_rcp(t, dt, rdt);
+    const float r1 = x1 + x1 - x1 * x1 - 1.0f;
+    const float x2 = div_rcp(t - 1.0f, dt, rdt);
+    const float r2 = x2 * x2 + x2 + x2 + 1.0f;
+    const float res = (t < dt) ? r1 : ((t > 1.0f - dt) ? r2 : 0.0f);
+    return (dt > F32_EPSILON) ? res : 0.0f;
 }
+
+OG_DEV float poly_blamp(float t, float dt, float rdt)
+{
+    const float x1 = div_rcp(t, dt, rdt) - 1.0f;
+    const float r1 = -(x1 * x1 * x1) / 3.0f;
+    const float x2 = div_rcp(t - 1.0f, dt, rdt) + 1.0f;
+    const float r2 = (x2 * x2 * x2) / 3.0f;
+    const float res = (t < dt) ? r1 : ((t > 1.0f - dt) ? r2 : 0.0f);
+    return (dt > F32_EPSILON) ? res : 0.0f;
+}
+
+// frequency after modulation and its per-sample increment (:176-180).  Constant over the block for a
+// voice whose frequency inputs are; the caller then forms them in derive().
+OG_DEV float polyblep_frequency(float frequency_in, float frequency_mod) { return fmaxf(frequency_in * (1.0f + frequency_mod), 0.0f); }
+OG_DEV float polyblep_increment(float frequency, float sr) { return frequency / fmaxf(sr, F32_EPSILON); }
 
 template <uint32_t WAVE>
-OG_DEV float polyblep_tick(float& phase_state, float frequency_in, float frequency_mod, float phase_mod,
+OG_DEV float polyblep_tick(float& phase_state, float frequency, float freq_per_sample, float phase_mod,
                            float amplitude, float pulse_width_in, float sr)
 {
-    const float frequency = fmaxf(frequency_in * (1.0f + frequency_mod), 0.0f);
     float pulse_width = clampf(pulse_width_in, 0.0001f, 0.9999f);
     float phase = wrap_phase(phase_state + phase_mod);
-    const float freq_per_sample = frequency / fmaxf(sr, F32_EPSILON);
     const float dt = fminf(freq_per_sample, 1.0f);
+    const float rdt = __builtin_amdgcn_rcpf(dt);
     if (pulse_width <= 0.0f) pulse_width = 0.0001f;
     float value;
     if (frequency >= sr * 0.25f || WAVE == PB_SINE) {
         value = og_sinf(phase * F32_TAU);
     } else if (WAVE == PB_SAW) {
         float y = 2.0f * phase - 1.0f;
-        y -= poly_blep(phase, dt);
+        y -= poly_blep(phase, dt, rdt);
         value = y;
     } else if (WAVE == PB_SQUARE) {
         float y = (phase < pulse_width) ? 1.0f : -1.0f;
-        y += poly_blep(phase, dt);
+        y += poly_blep(phase, dt, rdt);
         const float t = wrap_phase(phase + 1.0f - pulse_width);
-        y -= poly_blep(t, dt);
+        y -= poly_blep(t, dt, rdt);
         value = y;
     } else {
         float y = 4.0f * phase;
@@ -369,7 +378,7 @@ OG_DEV float polyblep_tick(float& phase_state, float frequency_in, float frequen
         }
         const float t1 = wrap_phase(phase + 0.25f);
         const float t2 = wrap_phase(phase + 0.75f);
-        value = y + 4.0f * dt * (poly_blamp(t1, dt) - poly_blamp(t2, dt));
+        value = y + 4.0f * dt * (poly_blamp(t1, dt, rdt) - poly_blamp(t2, dt, rdt));
     }
     value = value * amplitude;
     phase_state = wrap_phase(phase_state + freq_per_sample);
@@ -385,7 +394,7 @@ template <uint32_t WAVE>
 OG_DEV float oscillator_tick(float& phase, float frequency_in, float frequency_mod, float amplitude, float sr)
 {
     const float frequency = frequency_in * (1.0f + frequency_mod);
-    const float p = fmodf(phase, 1.0f);
+    const float p = fmod1(phase);
     float w;
     if (WAVE == OSC_SINE) {
         w = og_sinf(p * 2.0f * 3.14159274101257324f); // (p * 2.0 * PI).sin()
@@ -403,7 +412,7 @@ OG_DEV float oscillator_tick(float& phase, float frequency_in, float frequency_m
     }
     const float out = w * amplitude;
     phase += frequency / sr;
-    phase = fmodf(phase, 1.0f);
+    phase = fmod1(phase);
     return out;
 }
 
