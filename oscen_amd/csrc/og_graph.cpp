@@ -943,9 +943,12 @@ void emit_delay(NodeCtx& x)
     // the connected input when that is constant over the block, else the field as the last tick left it
     const std::string K = std::to_string(k), pre = x.p + "pre";
     const bool hint_input = x.connected("delay_samples") && ds.rate <= Rate::VBlock && ds.rate != Rate::UFrame;
-    x.cg.S().decl << "    og::RingPre " << pre << " = {og::RING_NONE, og::RING_NONE, {}};\n";
+    auto block_const = [](const Val& v) { return v.rate <= Rate::VBlock && v.rate != Rate::UFrame; };
+    const bool fixed = (!x.connected("delay_samples") || block_const(ds)) && (!x.connected("feedback") || block_const(fb));
+    x.cg.S().decl << "    og::RingPre " << pre << " = {og::RING_NONE, og::RING_NONE, false, {}};\n";
     x.cg.S().chunk_begin << "        og::ring_chunk_begin(A.rings[" << K << "], A.ring_cap[" << K << "], A.n_voices, c.v, c.valid, "
-                         << (hint_input ? ds.e : dsv) << ", " << wp << ", " << pre << ", ring_lds[" << K
+                         << (hint_input ? ds.e : dsv) << ", " << ((x.connected("feedback") && block_const(fb)) ? fb.e : fbv)
+                         << ", " << (fixed ? "true" : "false") << ", " << wp << ", " << pre << ", ring_lds[" << K
                          << "], c.lane, base + OG_BUS_CHUNK < A.frames);\n";
     x.set_out("output", "og::delay_tick(A.rings[" + K + "], A.ring_cap[" + K + "], A.n_voices, c.v, c.valid, " + in.e + ", " +
                             dsv + ", " + fbv + ", " + wp + ", " + fc + ", " + pre + ", ring_lds[" + K + "], c.lane, f - cbase)");

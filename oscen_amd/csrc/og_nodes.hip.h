@@ -529,6 +529,7 @@ constexpr uint32_t RING_NONE = 0xffffffffu;
 struct RingPre {
     uint32_t pred;      // (offset_samples & mask) the LDS column was loaded for, or RING_NONE
     uint32_t pred_next; // same for next[]
+    bool fast;          // wave-uniform: every tick of this chunk reads its staged sample (see ring_chunk_begin)
     float next[OG_BUS_CHUNK];
 };
 
@@ -547,8 +548,12 @@ OG_DEV uint32_t ring_whole_offset(float offset, uint32_t cap)
     return (lo || hi) ? (om & (cap - 1u)) : RING_NONE;
 }
 
+// fixed_params: delay_samples and feedback cannot change inside the chunk (block-constant inputs or
+// unconnected fields); when, in addition, every lane's offset is the staged one and the every-32nd-tick
+// clamps are no-ops, the chunk's ticks skip the index arithmetic and its branches (P.fast).
 OG_DEV void ring_chunk_begin(const float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float offset_hint,
-                             uint32_t wp, RingPre& P, float (*lds)[OG_WAVE], uint32_t lane, bool more)
+                             float feedback_hint, bool fixed_params, uint32_t wp, RingPre& P, float (*lds)[OG_WAVE],
+                             uint32_t lane, bool more)
 {
     const uint32_t mask = cap - 1u;
     const uint32_t om = valid ? ring_whole_offset(offset_hint, cap) : RING_NONE;
@@ -571,12 +576,25 @@ OG_DEV void ring_chunk_begin(const float* ring, uint32_t cap, uint32_t nv, uint3
     } else {
         P.pred_next = RING_NONE;
     }
+    const bool lane_fast = om != RING_NONE && om == P.pred && offset_hint == clampf(offset_hint, 0.0f, (float)cap - 1.0f) &&
+                           feedback_hint == clampf(feedback_hint, 0.0f, 0.99f);
+    P.fast = fixed_params && __all((int)(!valid || lane_fast));
 }
 
 OG_DEV float delay_tick(float* ring, uint32_t cap, uint32_t nv, uint32_t v, bool valid, float in, float& delay_samples,
                         float& feedback, uint32_t& wp, uint32_t& fc, const RingPre& P, const float (*lds)[OG_WAVE],
                         uint32_t lane, uint32_t j)
 {
+    if (P.fast) { // established for the whole chunk by ring_chunk_begin: clamps are no-ops, the sample is staged
+        fc = (fc + 1u) & 31u;
+        float delayed = 0.0f;
+        if (valid) {
+            delayed = lds[j][lane];
+            ring[(size_t)wp * nv + v] = in + delayed * feedback;
+        }
+        wp = (wp + 1u) & (cap - 1u);
+        return delayed;
+    }
     // apply_parameter_updates :47-56 (selects, not a branch: the counter is the same in every lane)
     const bool upd = fc == 0u;
     const float ds_c = clampf(delay_samples, 0.0f, (float)cap - 1.0f), fb_c = clampf(feedback, 0.0f, 0.99f);

@@ -182,3 +182,32 @@ def test_rust_sys_crate_declares_only_header_symbols_with_matching_arity():
     for name, n in bound.items():
         assert name in decl, name + " is not declared in include/oscen_gpu.h"
         assert decl[name] == n, (name, decl[name], n)
+
+
+def test_kernel_structure_chunk_variants_and_pipelines():
+    """What the graph compiler emits for the built-ins: pipelined 2- and 4-wave kernels with
+    per-node stages, chunk bodies without stage-end checks / release arithmetic, block-constant work hoisted
+    into derive(), delay-line staging with the wave-uniform fast path."""
+    import re
+    fm = oscen_amd.Graph(builtin="fm_voice").kernel_source()
+    assert "voice_block_p2" in fm and "voice_block_p4" in fm
+    assert re.search(r"//   wave 0: env3 env2 env1 env_filter\b", fm)  # a run of envelopes is one stage
+    for k in ("og_k_", "og_k2_", "og_k4_"):
+        assert len(re.findall(r"__global__[^\n]*\b%s[0-9a-f]{16}_(00|10|01|11)\b" % k, fm)) == 4
+    assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false>{}" in fm and "og::BoolC<true>{}" in fm
+    assert "og::adsr_tick<decltype(chk)::release>" in fm
+    assert fm.count("if constexpr (decltype(chk)::value)") >= 3
+    # the cutoff of FMVoice moves with an envelope: per-tick parameter check; sub_voice's is block-constant
+    tick = fm[fm.index("auto tick"):fm.index("auto events")]
+    assert "og::tpt_params_nomod(" in tick
+    sub = oscen_amd.Graph(builtin="sub_voice").kernel_source()
+    derive = sub[sub.index("auto derive"):sub.index("auto tick")]
+    tick = sub[sub.index("auto tick"):sub.index("auto events")]
+    assert "og::tpt_params_nomod(" in derive and "tpt_params" not in tick
+    assert "og::polyblep_increment(" in derive and "polyblep_increment" not in tick
+    echo = oscen_amd.Graph(builtin="echo_voice").kernel_source()
+    assert "og::ring_chunk_begin(A.rings[0]" in echo and "ring_lds[1]" in echo
+    assert "voice_block_p2" not in echo  # feedback edge / delay line: ordinary kernel only
+    ep = oscen_amd.Graph(builtin="epiano_voice").kernel_source()
+    assert "og::ep_bank_tick<TAPS>(" in ep and "og::bus_put<TAPS, !TAPS>" in ep
+    assert "og::ep_bank_update(" in ep[ep.index("auto derive"):ep.index("auto tick")]
