@@ -23,8 +23,12 @@ def lib():
 # --------------------------------------------------------------------------
 # 1. TptFilter  oscen-lib/src/filters/tpt/mod.rs:152-264
 # --------------------------------------------------------------------------
-IMPULSE_RESPONSE = [0.014401104, 0.052318562, 0.089890145, 0.11065749,
-                    0.11862421, 0.11729243, 0.10961619, 0.098000914]
+import json
+import os
+
+# the reference tests' own data vectors, committed as a fixture (tests/golden/reference_vectors.json)
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+IMPULSE_RESPONSE = GOLDEN["tpt_impulse_response"]["expected"]
 
 
 def _tpt(lib, channels):
@@ -463,9 +467,8 @@ def test_adsr_velocity_scales_output(lib):
 # 9. MIDI contract  oscen-lib/src/midi.rs:237-250
 # --------------------------------------------------------------------------
 def test_midi_note_to_freq(lib):
-    assert lib.oo_midi_note_to_freq(69) == 440.0
-    assert abs(lib.oo_midi_note_to_freq(60) - 261.626) < 0.01
-    assert abs(lib.oo_midi_note_to_freq(81) - 880.0) < 0.01
+    for note, hz, tol in GOLDEN["midi_note_to_freq"]["cases"]:
+        assert abs(lib.oo_midi_note_to_freq(note) - hz) <= tol
     assert abs(lib.oo_midi_velocity_to_gate(100) - 100.0 / 127.0) < 1e-7
 
 
@@ -649,26 +652,33 @@ def test_ring_get_vectors(lib):
     def near(a, b):
         assert abs(a - b) <= 1e-6, (a, b)
 
-    r = _ring(lib, 5, 1, [1, 2, 3, 4])
-    for off, want in ((0, 4), (1, 3), (2, 2), (3, 1)):
+    g = GOLDEN["ring_buffer_get_exact"]
+    r = _ring(lib, 5, 1, g["push"])
+    for off, want in g["get"]:
         near(lib.oo_ring_get(C.byref(r), off), want)
-    lib.oo_ring_push(C.byref(r), 5.0)
-    lib.oo_ring_push(C.byref(r), 6.0)
-    for off, want in ((0, 6), (1, 5), (2, 4), (3, 3), (4, 2), (5, 6), (-1, 6)):
+    for v in g["then_push"]:
+        lib.oo_ring_push(C.byref(r), v)
+    for off, want in g["then_get"]:
         near(lib.oo_ring_get(C.byref(r), off), want)
-    r = _ring(lib, 4, 0, [1, 3, 5, 7])
-    for off, want in ((0, 7), (1, 5), (2, 3), (3, 1)):
+    g = GOLDEN["ring_buffer_linear"]
+    r = _ring(lib, 4, 0, g["push"])
+    for off, want in g["get"]:
         near(lib.oo_ring_get(C.byref(r), off), want)
-    for off, want in ((0.5, 6), (1.5, 4), (2.5, 2)):
+    for off, want in g["get_linear"]:
         near(lib.oo_ring_get_linear(C.byref(r), off), want)
-    lib.oo_ring_push(C.byref(r), 9.0)
-    near(lib.oo_ring_get_linear(C.byref(r), 0.5), 8.0)
-    r = _ring(lib, 5, 1, [1, 2, 4, 8, 16])
-    for off, want in ((0, 16), (1, 8), (4, 1)):
+    for v in g["then_push"]:
+        lib.oo_ring_push(C.byref(r), v)
+    for off, want in g["then_get_linear"]:
+        near(lib.oo_ring_get_linear(C.byref(r), off), want)
+    g = GOLDEN["ring_buffer_cubic"]
+    r = _ring(lib, 5, 1, g["push"])
+    for off, want in g["get"]:
         near(lib.oo_ring_get(C.byref(r), off), want)
-    near(lib.oo_ring_get_cubic(C.byref(r), 0.5), 13.1875)
-    r = _ring(lib, 3, 1, [1, 5, 9])
-    near(lib.oo_ring_get(C.byref(r), 0.5), 7.0)
+    for off, want in g["get_cubic"]:
+        near(lib.oo_ring_get_cubic(C.byref(r), off), want)
+    r = _ring(lib, 3, 1, g["small_push"])
+    for off, want in g["small_get"]:
+        near(lib.oo_ring_get(C.byref(r), off), want)
     r = _ring(lib, 0, 0, [5.0])
     near(lib.oo_ring_get(C.byref(r), 0.0), 5.0)
 
