@@ -135,7 +135,8 @@ int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64
 
 /* process_block(frames)  codegen/mod.rs:755-873, frames <= 512, then copies
  * <out>_block[..frames] (the sum over voices, `voices.out -> out`) to host
- * memory: out_bus[frames * channels].  Blocking. */
+ * memory: out_bus[frames * channels].  Blocking.  frames == 0 runs no frame and discards the
+ * events pushed for the block (their frame_offset >= frames), like the generated loop. */
 int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
 /* Same, but the bus stays in device memory (d_out_bus[frames*channels], may be
  * NULL to keep it in the engine's own buffer) and the call only enqueues work

@@ -339,21 +339,26 @@ struct og_engine {
         ev_dirty = false;
     }
 
+    // reference: a try_push'ed event whose frame_offset >= frames is never delivered (the queues are
+    // cleared at the end of the block)
+    void drop_block_local(uint64_t lim)
+    {
+        if (n_block_local == 0) return; // (a counter: scanning a resident 200 000-event timeline per block cost 30 us)
+        size_t before = pending.size();
+        pending.erase(std::remove_if(pending.begin(), pending.end(),
+                                     [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
+                      pending.end());
+        if (pending.size() != before) ev_dirty = true;
+        dropped += before - pending.size();
+        for (auto& h : pending) h.block_local = false;
+        n_block_local = 0;
+        local_count.clear();
+    }
+
     void process_async(uint32_t frames, float* d_out)
     {
         HIPCK(hipSetDevice(device));
-        // reference: a try_push'ed event whose frame_offset >= frames is never delivered
-        if (n_block_local > 0) { // (a counter: scanning a resident 200 000-event timeline per block cost 30 us)
-            const uint64_t lim = frame_now + frames;
-            size_t before = pending.size();
-            pending.erase(std::remove_if(pending.begin(), pending.end(),
-                                         [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
-                          pending.end());
-            dropped += before - pending.size();
-            for (auto& h : pending) h.block_local = false;
-            n_block_local = 0;
-            local_count.clear();
-        }
+        drop_block_local(frame_now + frames);
         if (ev_dirty) rebuild_events();
 
         OgBlockArgs A;
@@ -898,8 +903,13 @@ int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
     if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
-    if (frames == 0 || frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 1..512");
+    if (frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 0..512");
     return guard([&] {
+        if (frames == 0) { // process_block(0): no frame runs; events queued for the block are discarded with it
+            e->drop_block_local(e->frame_now);
+            e->last_frames = 0;
+            return OG_OK;
+        }
         e->process_async(frames, d_out_bus);
         return OG_OK;
     });
@@ -920,7 +930,7 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
     int rc = og_process_block_async(e, frames, nullptr);
     if (rc) return rc;
     return guard([&] {
-        if (out_bus)
+        if (out_bus && frames)
             HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;

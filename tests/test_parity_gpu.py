@@ -339,3 +339,16 @@ def test_full_size_properties():
     first_on = int(plans["on_frame"].min())
     assert np.all(bus_a[:first_on] == 0.0)
     assert np.max(np.abs(bus_a[1024:])) > 1.0
+
+
+def test_zero_frame_block_is_a_noop_that_discards_its_events():
+    """process_block(0) (the generated loop runs no frame; the block's event queues are cleared with it):
+    nothing is rendered, a try_push'ed event is never delivered, later blocks are unaffected."""
+    eng = oscen_amd.Engine("fm_voice", 3, sample_rate=SR)
+    eng.set_voice_values("frequency", np.array([220.0, 330.0, 440.0], dtype=np.float32))
+    assert eng.push_voice_event("gate", 1, 0, 1.0) == 0
+    out = eng.process_block(0)
+    assert out.shape == (0, 1) and eng.events_dropped == 1 and eng.frames_processed == 0
+    assert np.all(eng.process_block(256) == 0.0)  # the note-on was discarded: the bank stays silent
+    assert eng.push_voice_event("gate", 1, 3, 1.0) == 0
+    assert np.abs(eng.process_block(256)).max() > 1e-3
