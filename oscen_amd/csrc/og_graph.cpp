@@ -276,7 +276,7 @@ struct Codegen {
     // (see "pipeline stages" in compile()); nodes of stage s write into sec[s].  The ordinary
     // kernel simply concatenates the sets; the pipelined kernels give groups of them to separate waves.
     struct Sect {
-        std::ostringstream decl, load, derive, pre, post, pre_store, store;
+        std::ostringstream decl, load, derive, pre, pre_store, store;
         std::ostringstream chunk_begin; // top of every OG_BUS_CHUNK-frame chunk (delay-line staging)
         std::vector<std::string> env_cnts; // countdowns of this stage's envelopes (a chunk in which none of them
                                            // reaches 0 runs the tick without the stage-end checks)
@@ -284,7 +284,6 @@ struct Codegen {
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
-        std::vector<std::string> post_zero; // u32 expressions; the end-of-frame section runs when any is 0
         std::map<int, std::ostringstream> ev_handlers; // per graph event input
     };
     Sect sec[16];
@@ -1543,21 +1542,6 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         t << S.s_down.str() << S.s_post.str();
         return t.str();
     };
-    auto post_code = [&](const std::vector<int>& stages) {
-        std::vector<std::string> zeros;
-        std::string code;
-        for (int st : stages) {
-            zeros.insert(zeros.end(), cg.sec[st].post_zero.begin(), cg.sec[st].post_zero.end());
-            code += cg.sec[st].post.str();
-        }
-        std::ostringstream t;
-        if (!zeros.empty()) {
-            std::string m = zeros[0];
-            for (size_t i = 1; i < zeros.size(); ++i) m = "min(" + m + ", " + zeros[i] + ")";
-            t << "        if (__any((int)(" << m << " == 0u))) { // rare per-voice work (stage ends)\n" << code << "        }\n";
-        }
-        return t.str();
-    };
     // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
     auto events_code = [&](const std::vector<int>& stages) {
         std::ostringstream t;
@@ -1676,7 +1660,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         return m;
     };
     body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> float {\n"
-         << group_tick({all_stages}, 0) << post_code(all_stages);
+         << group_tick({all_stages}, 0);
     body << "        return " << bus_expr << ";\n    };\n";
     body << events_code(all_stages);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
@@ -1759,7 +1743,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
-                 << group_tick(groups, gi) << post_code(st);
+                 << group_tick(groups, gi);
             if (last) body << "        return " << bus_expr << ";\n";
             body << "    };\n";
             body << events_code(st);

@@ -195,3 +195,95 @@ def test_static_complex_graph_shape():
                 ref[v, i] = c.vca.output
         worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
     assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize("depth", [0, 2, 4])
+def test_custom_graph_pipelined_variants_through_hiprtc(depth, monkeypatch):
+    """A description that is not built in, large enough for the 2- and 4-wave pipelines (two oscillators,
+    an envelope, two filters): every variant is compiled by hiprtc and must agree with the oracle nodes."""
+    import ctypes as C
+    monkeypatch.setenv("OSCEN_GPU_SPLIT", str(depth))
+    lib = ol.load()
+    sr = 48000.0
+    text = """
+    name: TwoOscVoice;
+    input frequency: value = 220.0;
+    input gate: event;
+    input cutoff: value = 1500.0;
+    output out: stream;
+    nodes {
+        a = PolyBlepOscillator::saw(220.0, 0.4);
+        b = PolyBlepOscillator::square(220.0, 0.3);
+        env = AdsrEnvelope::new(0.004, 0.03, 0.5, 0.05);
+        f1 = TptFilter::new(1500.0, 1.2);
+        f2 = IirLowpass::new(3000.0, 0.9);
+        amp = Gain::new(0.8);
+    }
+    connections {
+        frequency -> a.frequency;
+        frequency * 1.5 -> b.frequency;
+        gate -> env.gate;
+        cutoff -> f1.cutoff;
+        a.output + b.output -> f1.input;
+        f1.output * env.output -> f2.input;
+        f2.output -> amp.input;
+        amp.output -> out;
+    }
+    """
+    g = oscen_amd.Graph(dsl=text, per_voice=["frequency"])
+    src = g.kernel_source()
+    assert "voice_block_p2" in src and "voice_block_p4" in src
+    n, frames, blocks = 70, 200, 4
+    freqs = np.geomspace(55.0, 1760.0, n).astype(np.float32)
+    eng = oscen_amd.Engine(g, n, sample_rate=sr)
+    assert eng.pipeline_depth == max(1, depth)
+    eng.set_voice_values("frequency", freqs)
+    eng.set_voice_taps(list(range(n)))
+    for v in range(n):
+        eng.schedule_voice_event("gate", v, 3 + v % 50, 0.8)
+        eng.schedule_voice_event("gate", v, 400 + v, 0.0)
+    got = []
+    for _ in range(blocks):
+        eng.process_block(frames)
+        got.append(eng.read_voice_taps(frames))
+    got = np.concatenate(got, axis=1)
+
+    def ref(v):
+        a, b = ol.PolyBlep(), ol.PolyBlep()
+        lib.oo_polyblep_new(C.byref(a), 220.0, 0.4, ol.PB_SAW)
+        lib.oo_polyblep_new(C.byref(b), 220.0, 0.3, ol.PB_SQUARE)
+        e = ol.Adsr()
+        lib.oo_adsr_new(C.byref(e), 0.004, 0.03, 0.5, 0.05)
+        f1 = ol.Tpt()
+        lib.oo_tpt_new(C.byref(f1), 1500.0, 1.2, 1)
+        f2 = ol.IirLowpass()
+        lib.oo_iir_lowpass_new(C.byref(f2), 3000.0, 0.9)
+        a.sample_rate = b.sample_rate = e.sample_rate = f1.sample_rate = f2.sample_rate = sr
+        lib.oo_adsr_prepare(C.byref(e))
+        lib.oo_tpt_prepare(C.byref(f1))
+        lib.oo_iir_lowpass_prepare(C.byref(f2))
+        a.frequency = float(freqs[v])
+        b.frequency = float(np.float32(freqs[v]) * np.float32(1.5))
+        out = np.zeros(frames * blocks, dtype=np.float32)
+        for i in range(frames * blocks):
+            if i == 3 + v % 50:
+                ev = ol.Event(0, 0.8, 0)
+                lib.oo_adsr_handle_gate_event(C.byref(e), C.byref(ev))
+            if i == 400 + v:
+                ev = ol.Event(0, 0.0, 0)
+                lib.oo_adsr_handle_gate_event(C.byref(e), C.byref(ev))
+            lib.oo_polyblep_process(C.byref(a))
+            lib.oo_polyblep_process(C.byref(b))
+            lib.oo_adsr_process(C.byref(e))
+            f1.cutoff = 1500.0
+            f1.input[0] = float(np.float32(a.output) + np.float32(b.output))
+            lib.oo_tpt_process(C.byref(f1))
+            f2.input = float(np.float32(f1.output[0]) * np.float32(e.output))
+            lib.oo_iir_lowpass_process(C.byref(f2))
+            out[i] = np.float32(f2.output) * np.float32(0.8)
+        return out
+
+    r = np.stack([ref(v) for v in range(n)])
+    assert np.max(np.abs(r)) > 0.05
+    err = float(np.max(np.abs(got - r) / np.maximum(1.0, np.abs(r))))
+    assert err <= 1e-5, err
