@@ -352,3 +352,39 @@ def test_zero_frame_block_is_a_noop_that_discards_its_events():
     assert np.all(eng.process_block(256) == 0.0)  # the note-on was discarded: the bank stays silent
     assert eng.push_voice_event("gate", 1, 3, 1.0) == 0
     assert np.abs(eng.process_block(256)).max() > 1e-3
+
+
+def test_full_size_voice_shards_sum_to_the_whole_bank():
+    """Row (e): voices are independent and note streams are keyed by global voice id, so the bus of the
+    65 536-voice bank is the sum of the buses of its shards (here 4 ragged shards, as 4 ranks would hold
+    them), up to the re-association of the bus sum; and a shard's voices are bit-identical to the same
+    voices inside the whole bank."""
+    n, total, block = 65536, 1024, 256
+    cuts = [0, 16384, 32768 + 17, 49152 + 5, n]
+    probe = np.array([3, 16383, 16384, 40000, n - 1], dtype=np.uint32)
+
+    def run(lo, hi, taps):
+        eng = oscen_amd.Engine("fm_voice", hi - lo, sample_rate=SR)
+        plans = oscen_amd.note_plans(hi - lo, first_voice=lo)
+        oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+        if len(taps):
+            eng.set_voice_taps(taps)
+        bus, tp = [], []
+        for _ in range(total // block):
+            bus.append(eng.process_block(block)[:, 0].astype(np.float64))
+            if len(taps):
+                tp.append(eng.read_voice_taps(block))
+        return np.concatenate(bus), (np.concatenate(tp, axis=1) if len(taps) else None)
+
+    whole, whole_taps = run(0, n, probe)
+    parts = np.zeros_like(whole)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        local = np.array([v - lo for v in probe if lo <= v < hi], dtype=np.uint32)
+        bus, tp = run(lo, hi, local)
+        parts += bus
+        rows = [i for i, v in enumerate(probe) if lo <= v < hi]
+        if rows:
+            assert np.array_equal(tp, whole_taps[rows])
+    scale = max(1.0, float(np.max(np.abs(whole))))
+    assert np.max(np.abs(parts - whole)) <= 1e-4 * scale  # f32 partial sums of ~6e4 terms, different trees
+    assert np.max(np.abs(whole)) > 1.0
