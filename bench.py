@@ -222,14 +222,18 @@ def main():
                 "bytes_per_voice_sample": bytes_per_launch / float(V * block),
                 "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block; "
                         "see valu_issue for the bound that applies",
-                # The limiter (DESIGN.md "Measurement"): wave64 f32 VALU instructions retire one per
-                # 4 cycles per SIMD.  achieved = SQ_INSTS_VALU per launch (committed PMC pass) / the
-                # kernel duration measured in this run; peak = 1024 SIMDs x 2.4 GHz / 4.
+                # The limiter: instruction issue / dependent-instruction latency.  CDNA4 SIMDs are
+                # 32 wide: a wave64 VALU instruction issues in 2 cycles (1024 SIMDs x 2.4 GHz / 2 = the 157 TF
+                # vector peak); the measured ceiling for scalar f32 streams is ~3.05 cycles (103 TF,
+                # MI355X_MICROARCH.md; scripts/pk_probe: 3.2 with 8 waves per SIMD).  achieved = SQ_INSTS_VALU per
+                # launch (committed PMC pass) / the kernel duration measured in this run.
                 "valu_issue": None if not (pmc_valu and kern_ms > 0) else {
                     "achieved": pmc_valu / (kern_ms * 1e-3) / 1e9,
-                    "peak": 1024 * 2.4 / 4.0,
+                    "peak": 1024 * 2.4 / 2.0,
+                    "measured_ceiling": 1024 * 2.4 / 3.05,
                     "unit": "G wave-instructions/s",
-                    "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 4.0),
+                    "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 2.0),
+                    "frac_of_measured_ceiling": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 3.05),
                     "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block),
                     "source": pmc_src,
                 },

@@ -712,8 +712,8 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             HIPCK(hipGetDeviceProperties(&prop, device_id));
             const uint32_t simds = 4u * (uint32_t)prop.multiProcessorCount;
             // Measured on MI355X (65 536 fm voices): 64 lanes 0.129 ms, 32 lanes 0.185 ms, 16 lanes
-            // 0.325 ms per block -- the SIMD retires ~one wave-instruction per 4 cycles however the
-            // waves are shaped, so narrowing only multiplies instructions.  Kept as an experiment knob.
+            // 0.325 ms per block -- a wave-instruction costs the same issue time however many of its
+            // lanes are active, so narrowing only multiplies instructions.  Kept as an experiment knob.
             (void)simds;
             uint32_t lanes = OG_WAVE;
             if (const char* ev = getenv("OSCEN_GPU_LANES")) {

@@ -1366,7 +1366,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
 
     // ---- pipeline stages ------------------------------------------------------------------------
     // With one wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave retires an instruction only
-    // every ~5.5 cycles; four co-resident waves reach the 4-cycle issue limit (measured).
+    // every ~6 cycles (dependent-instruction latency); more co-resident waves approach the ~3-cycle
+    // measured issue ceiling.
     // The frame's node sequence is therefore also emitted as pipelines of two and of four waves over
     // the same 64 voices: every node (or run of envelopes) is a stage; a wave takes a contiguous group
     // of stages of balanced estimated VALU cost, works one hand-off chunk behind the previous wave,

@@ -11,8 +11,10 @@
 //
 // Voices per wave (OgBlockArgs::lanes) is 64.  Narrower waves (32/16 voices, to
 // put two waves on every SIMD at 65 536 voices) were measured and are slower:
-// the path is bound by VALU issue (~one wave-instruction per 4 cycles per SIMD
-// at any occupancy), so what counts is the number of wave-instructions.
+// the path is bound by VALU issue and dependent-instruction latency (measured
+// 3-6 cycles per wave-instruction per SIMD depending on how many waves a SIMD
+// interleaves; a half-empty wave costs the same), so what counts is the
+// number of wave-instructions.
 //
 // Mix bus (reference: `voices.audio_out -> audio_out` = sequential f32 sum in
 // voice order, oscen-graph-compiler/src/codegen/emit_node.rs:463-466): each

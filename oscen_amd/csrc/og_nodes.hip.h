@@ -70,8 +70,9 @@ enum : int { ADSR_A_N = 0, ADSR_D_N, ADSR_R_N, ADSR_A_C, ADSR_D_C, ADSR_SUSTAIN,
 // gate events.  Holding stages keep cnt at ADSR_HOLD so the per-sample
 // countdown never reaches the stage-end test for them.
 //
-// The voice kernels are VALU-issue-bound (one wave-instruction per ~4 cycles
-// per SIMD, measured), so every instruction here is paid in full:
+// The voice kernels are bound by VALU issue / dependent-instruction latency
+// (3-6 cycles per wave-instruction per SIMD, measured), so every instruction
+// here is paid in full:
 //  * the reference's per-sample clamps of `level` are provable no-ops for
 //    lv, tgt in [0,1] and cf in [0,1] (round-to-nearest cannot carry
 //    lv + (tgt-lv)*cf past tgt's side of [0,1], nor lv - lv/n below 0) and are
