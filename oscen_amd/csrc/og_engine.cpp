@@ -722,12 +722,13 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             }
             e->lanes = lanes;
             // pipelined variants for banks too small to put four ordinary waves on every SIMD.  Measured on
-            // MI355X (fm_voice, 256-frame block): 32 768 voices 0.081 ms with two waves per 64 voices, 0.063 ms
-            // with four; 65 536 voices 0.096 / 0.086 / 0.105 ms with one / two / four (the four-wave form
-            // issues ~20% more instructions and runs at the pace of its heaviest stage).
+            // MI355X (fm_voice, 256-frame block, kernel time with one / two / four waves per 64 voices):
+            // 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152: 0.077 / 0.071 /
+            // 0.063; 65 536: 0.080 / 0.075 / 0.089 (the four-wave form issues ~20% more instructions and its
+            // waves move in lockstep); 131 072 and above: the ordinary kernel.
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
             uint32_t depth = 0;
-            if (e->cg->max_pipeline >= 4 && waves1 * 2 <= simds) depth = 4;
+            if (e->cg->max_pipeline >= 4 && waves1 * 4 <= 3 * simds) depth = 4;
             else if (e->cg->max_pipeline >= 2 && waves1 < 2 * simds) depth = 2;
             if (const char* ev = getenv("OSCEN_GPU_SPLIT")) {
                 const int want = atoi(ev);
