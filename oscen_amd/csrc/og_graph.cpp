@@ -1794,7 +1794,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                      << "                og::bus_chunk_reduce(A, c, bus, lastf - (lastf % OG_BUS_CHUNK), (lastf % OG_BUS_CHUNK) + 1);\n"
                      << "        }\n";
             body << "        }\n"
-                 << "        __syncthreads(); // hand-off: every wave stays one chunk ahead of the next one\n"
+                 << (getenv("OGC_NOSYNC") ? "        // (experiment: hand-off barrier removed -- results are wrong, timing only)\n"
+                                          : "        __syncthreads(); // hand-off: every wave stays one chunk ahead of the next one\n")
                  << "    }\n";
             if (last) body << "    og::bus_flush(A, c, bus);\n";
             body << cat(st, &Codegen::Sect::pre_store) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::store)
