@@ -230,6 +230,9 @@ def load():
     lib.oo_delay_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_lp18_new.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.oo_adsr_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    lib.oo_ramped_set.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+    lib.oo_ramped_set_with_ramp.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]
+    lib.oo_ramped_set_immediate.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
     lib.oo_ramp_new.argtypes = [C.c_void_p, C.c_float]
     lib.oo_ramp_set_immediate.argtypes = [C.c_void_p, C.c_float]
     lib.oo_ramp_set_with_ramp.argtypes = [C.c_void_p, C.c_float, C.c_uint32]

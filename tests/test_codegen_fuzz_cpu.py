@@ -13,9 +13,43 @@ FILTERS = [("TptFilter::new", (1200.0, 0.8)), ("IirLowpass::new", (2000.0, 0.7))
            ("Gain::new", (0.7,)), ("HardClip::new", ()), ("AddValue::new", (0.1,))]
 
 
+class RecGraph(oscen_amd.Graph):
+    """A Graph that also keeps its description as plain data (for tests/graph_interp.py)."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.desc = {"inputs": [], "nodes": [], "edges": []}
+
+    def input_value(self, name, default=0.0, ramp=0, per_voice=False):
+        self.desc["inputs"].append((name, "value", default, ramp))
+        return super().input_value(name, default, ramp=ramp, per_voice=per_voice)
+
+    def input_event(self, name):
+        self.desc["inputs"].append((name, "event", 0.0, 0))
+        return super().input_event(name)
+
+    def node(self, name, type_ctor, *args, rate=1):
+        self.desc["nodes"].append((name, type_ctor, args))
+        return super().node(name, type_ctor, *args, rate=rate)
+
+    def connect(self, src, dst, policy=""):
+        self.desc["edges"].append((src, dst))
+        return super().connect(src, dst, policy)
+
+    def connect_via(self, src, via, dst):
+        self.desc["edges"] += [(src, "%s.input" % via), ("%s.output" % via, dst)]
+        return super().connect_via(src, via, dst)
+
+    def description(self):
+        import re
+        d = dict(self.desc)
+        d["order"] = re.search(r"// Node order: (.*)", self.kernel_source()).group(1).split()
+        return d
+
+
 def random_graph(seed):
     rng = np.random.default_rng(seed)
-    g = oscen_amd.Graph("fuzz%d" % seed)
+    g = RecGraph("fuzz%d" % seed)
     g.input_value("frequency", 220.0, per_voice=True)
     g.input_value("cutoff", 1500.0, ramp=int(rng.integers(0, 2)) * 480)
     g.input_value("amount", 0.5)
