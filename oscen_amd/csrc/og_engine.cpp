@@ -236,29 +236,29 @@ struct og_engine {
 
     ~og_engine()
     {
-        hipSetDevice(device);
-        if (stream) hipStreamSynchronize(stream);
-        hipFree(d_state);
-        hipFree(d_lane_state);
-        for (int k = 0; k < OG_MAX_RINGS; ++k) hipFree(d_ring[k]);
-        hipFree(d_mono);
-        hipFree(d_bus_phase);
-        hipFree(d_events);
-        hipFree(d_ev_end);
-        hipFree(d_ev_cursor);
-        hipFree(d_partials);
-        hipFree(d_partials2);
-        hipFree(d_bus);
-        hipFree(d_taps);
-        hipFree(d_tap_slot);
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        (void)hipFree(d_state);
+        (void)hipFree(d_lane_state);
+        for (int k = 0; k < OG_MAX_RINGS; ++k) (void)hipFree(d_ring[k]);
+        (void)hipFree(d_mono);
+        (void)hipFree(d_bus_phase);
+        (void)hipFree(d_events);
+        (void)hipFree(d_ev_end);
+        (void)hipFree(d_ev_cursor);
+        (void)hipFree(d_partials);
+        (void)hipFree(d_partials2);
+        (void)hipFree(d_bus);
+        (void)hipFree(d_taps);
+        (void)hipFree(d_tap_slot);
         for (int i = 0; i < RAMP_RING; ++i) {
-            hipFree(d_ramp[i]);
-            if (h_ramp[i]) hipHostFree(h_ramp[i]);
-            if (ramp_ev[i]) hipEventDestroy(ramp_ev[i]);
+            (void)hipFree(d_ramp[i]);
+            if (h_ramp[i]) (void)hipHostFree(h_ramp[i]);
+            if (ramp_ev[i]) (void)hipEventDestroy(ramp_ev[i]);
         }
-        for (auto ev : t_start) hipEventDestroy(ev);
-        for (auto ev : t_stop) hipEventDestroy(ev);
-        if (own_stream && stream) hipStreamDestroy(stream);
+        for (auto ev : t_start) (void)hipEventDestroy(ev);
+        for (auto ev : t_stop) (void)hipEventDestroy(ev);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
     ogc::UEnv env() const { return ogc::UEnv{sr, values.data()}; }
