@@ -1581,7 +1581,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         return t.str();
     };
-    int unroll = 2; // frames per straight-line scheduling region of the quiet-chunk loop
+    // frames per straight-line scheduling region of the ordinary kernel's quiet-chunk loop.  Since the chunk
+    // variants (no stage-end checks / no release arithmetic) the kernel sits at its 128-VGPR cap; unrolling by
+    // two spills ~20 registers and is 2-4% slower on fm_voice at >= 131 072 voices, where this kernel runs.
+    int unroll = 1;
     if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
     // A kernel is assembled from GROUPS of consecutive stages, one wave per group: the ordinary kernel
@@ -1608,8 +1611,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             const auto& xv = cg.xvals[k];
             bool used_here = false;
             for (int u : xv.users) used_here = used_here || group_of(groups, u) == gi;
-            if (used_here && group_of(groups, xv.from) != gi)
-                t << "        const float " << xv.alias << " = chan" << k << "[ch % " << "XD" << k << "][j][c.lane];\n";
+            if (used_here && group_of(groups, xv.from) != gi) // (quiet chunks: read at the top of the chunk into xp<k>[])
+                t << "        const float " << xv.alias << " = [&]() __attribute__((always_inline)) { if constexpr (decltype(chk)::pre) return xp"
+                  << k << "[j]; else return chan" << k << "[ch % XD" << k << "][j][c.lane]; }();\n";
         }
         for (int fs : st) {
             t << tick_code(fs);
@@ -1742,6 +1746,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
             body << "    auto derive = [&]() {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
             body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
+            // hand-off values this wave reads: fetched for the whole chunk before its first tick, so that the LDS
+            // latency is paid once per chunk and not in front of every frame's first dependent instruction
+            std::vector<size_t> reads;
+            for (size_t k = 0; k < cg.xvals.size(); ++k) {
+                const auto& xv = cg.xvals[k];
+                bool used_here = false;
+                for (int u : xv.users) used_here = used_here || group_of(groups, u) == gi;
+                if (used_here && group_of(groups, xv.from) != gi) reads.push_back(k);
+            }
+            for (size_t k : reads) body << "    float xp" << k << "[OG_XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
                  << group_tick(groups, gi);
@@ -1750,11 +1764,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << events_code(st);
             // SALU instructions cost issue slots like VALU ones: the quiet chunk is a straight-line,
             // fully unrolled body; per-frame tests only exist on the (rare) event path
-            auto call = [&](const char* flag) {
+            auto call = [&](const std::string& flag) {
                 const std::string t = std::string("tick(f, ch, j, og::BoolC<") + flag + ">{})";
                 return last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, " + t + ");" : t + ";";
             };
-            auto quiet = [&](const char* flag, const char* ind) {
+            auto quiet = [&](std::string flag, const char* ind) {
+                if (!reads.empty()) {
+                    if (flag == "true") flag = "true, true";
+                    if (flag == "false") flag = "false, true";
+                    flag += ", true";
+                    body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < OG_XCH; ++j) {\n";
+                    for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
+                    body << ind << "}\n";
+                }
                 body << ind << "#pragma unroll\n"
                      << ind << "for (uint32_t j = 0; j < OG_XCH; ++j) {\n"
                      << ind << "    const uint32_t f = base + j;\n"
