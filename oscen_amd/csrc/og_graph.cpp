@@ -1581,10 +1581,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         return t.str();
     };
-    // frames per straight-line scheduling region of the ordinary kernel's quiet-chunk loop.  Since the chunk
-    // variants (no stage-end checks / no release arithmetic) the kernel sits at its 128-VGPR cap; unrolling by
-    // two spills ~20 registers and is 2-4% slower on fm_voice at >= 131 072 voices, where this kernel runs.
-    int unroll = 1;
+    // frames per straight-line scheduling region of the ordinary kernel's quiet-chunk loop.  A large graph with
+    // envelopes has three copies of the chunk body (no stage-end checks / no release arithmetic) and sits at the
+    // 128-VGPR cap: unrolling by two spills ~20 registers there (fm_voice: 2-4% slower at >= 131 072 voices, where
+    // this kernel runs); small graphs gain from it (4x saturator +5%).
+    int graph_weight = 0;
+    bool has_env = false;
+    for (int ni : order) {
+        graph_weight += node_weight(cg.nodes[ni].decl->type);
+        has_env = has_env || cg.nodes[ni].decl->type.rfind("AdsrEnvelope::", 0) == 0;
+    }
+    int unroll = (has_env && graph_weight >= 100) ? 1 : 2;
     if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
     // A kernel is assembled from GROUPS of consecutive stages, one wave per group: the ordinary kernel
