@@ -388,3 +388,28 @@ def test_full_size_voice_shards_sum_to_the_whole_bank():
     scale = max(1.0, float(np.max(np.abs(whole))))
     assert np.max(np.abs(parts - whole)) <= 1e-4 * scale  # f32 partial sums of ~6e4 terms, different trees
     assert np.max(np.abs(whole)) > 1.0
+
+
+def test_render_equals_block_by_block_processing():
+    """BlockRender::render(&[], tail) (oscen-lib/src/graph/offline.rs:46-90: a driver over process_block, "output
+    is identical to realtime processing") == og_render: chunks of 512 frames with a ragged last chunk, bit for bit
+    the same bus as calling process_block, for a mono and for the stereo (post-mix Tremolo) bank."""
+    for graph, n in (("fm_voice", 96), ("epiano_voice", 12)):
+        total = 512 * 3 + 77
+        outs = []
+        for mode in ("render", "blocks"):
+            eng = oscen_amd.Engine(graph, n, sample_rate=SR)
+            plans = oscen_amd.note_plans(n)
+            oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+            if mode == "render":
+                outs.append(eng.render(total, block=512))
+            else:
+                parts, left = [], total
+                while left:
+                    k = min(512, left)
+                    parts.append(eng.process_block(k).copy())
+                    left -= k
+                outs.append(np.concatenate(parts, axis=0))
+        assert outs[0].shape == (total, 2 if graph == "epiano_voice" else 1)
+        assert np.array_equal(outs[0], outs[1])
+        assert np.abs(outs[0]).max() > 1e-3
