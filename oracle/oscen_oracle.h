@@ -24,6 +24,11 @@
  *   - process_block(N) == N x process() bit-exactness law
  *     (oscen-lib/tests/block_processing_test.rs)
  *   - multirate properties (oscen-lib/tests/multirate_graph.rs)
+ *   - IirLowpass coefficient formula / DC gain / stability / denormal snap
+ *     (oscen-lib/src/filters/iir_lowpass/mod.rs:166-330)
+ *   - RingBuffer exact / linear / Catmull-Rom reads and wrap-around vectors
+ *     (oscen-lib/src/ring_buffer/tests.rs), on which Delay rests
+ * The data vectors are committed as tests/golden/reference_vectors.json.
  * Everything else (FmOperator waveform, ADSR curve shape, OscillatorBank,
  * SincDown sample values, full-voice waveforms) is PARITY UNPINNED by any
  * reference vector: for those the oracle is a line-by-line transliteration
