@@ -281,6 +281,8 @@ struct Codegen {
         std::vector<std::string> env_cnts; // countdowns of this stage's envelopes (a chunk in which none of them
                                            // reaches 0 runs the tick without the stage-end checks)
         std::vector<std::string> env_rs;   // their release flags (1.0f in Release): no lane releasing -> no release arithmetic
+        std::vector<std::string> fast_conds; // per-lane conditions under which this stage's nodes may run their
+                                             // `steady` tick for a whole chunk of CHUNK frames (e.g. og::ep_amp_tick)
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
@@ -998,7 +1000,8 @@ void emit_ep_amp(NodeCtx& x)
         for (int ei : ev->second)
             x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h, ev.value, " << br.e << ", " << vs.e
                                  << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
-    x.set_out("amplitudes", "og::ep_amp_tick(" + A + ")");
+    x.cg.S().fast_conds.push_back("(" + A + ".step >= 1u && " + A + ".step + CHUNK <= og::EP_INTERP_STEPS)");
+    x.set_out("amplitudes", "og::ep_amp_tick<decltype(chk)::steady>(" + A + ")");
     x.cg.node_outputs["n" + std::to_string(x.n.id) + ".amplitudes"].lane = true;
 }
 
@@ -1682,21 +1685,36 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
          << "            // no lane of this wave has an event in the chunk: straight-line body\n";
     {
         const std::string mc = min_cnt(all_stages);
-        auto quiet = [&](const char* flag, const char* ind) {
-            body << ind << "#pragma unroll " << unroll << "\n"
-                 << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "") << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<"
-                 << flag << ">{}));\n";
+        std::string steady;
+        for (int k : all_stages)
+            for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
+        auto variants = [&](const std::string& tail, const std::string& ind0) {
+            auto quiet = [&](const std::string& flag, const std::string& ind) {
+                body << ind << "#pragma unroll " << unroll << "\n"
+                     << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "")
+                     << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<" << flag << tail << ">{}));\n";
+            };
+            if (mc.empty()) {
+                quiet("true, true", ind0);
+            } else {
+                body << ind0 << "if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n"
+                     << ind0 << "    if (__all((int)(" << rs_sum(all_stages) << " == 0.0f))) { // ... and no lane is in Release\n";
+                quiet("false, false", ind0 + "        ");
+                body << ind0 << "    } else {\n";
+                quiet("false, true", ind0 + "        ");
+                body << ind0 << "    }\n" << ind0 << "} else {\n";
+                quiet("true, true", ind0 + "    ");
+                body << ind0 << "}\n";
+            }
         };
-        if (mc.empty()) {
-            quiet("true", "            ");
+        if (steady.empty()) {
+            variants("", "            ");
         } else {
-            body << "            if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n"
-                 << "                if (__all((int)(" << rs_sum(all_stages) << " == 0.0f))) { // ... and no lane is in Release\n";
-            quiet("false, false", "                    ");
-            body << "                } else {\n";
-            quiet("false", "                    ");
-            body << "                }\n            } else {\n";
-            quiet("true", "                ");
+            body << "            constexpr uint32_t CHUNK = OG_BUS_CHUNK;\n"
+                 << "            if (__all((int)(!c.valid || (" << steady << ")))) { // node steady states hold for the whole chunk\n";
+            variants(", false, true", "                ");
+            body << "            } else {\n";
+            variants("", "                ");
             body << "            }\n";
         }
     }

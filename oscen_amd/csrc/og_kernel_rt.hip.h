@@ -89,12 +89,14 @@ __device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
 
 // compile-time flags passed to the generated tick lambdas: `value` = envelope stage-end checks on,
 // `release` = envelope release arithmetic on (off in chunks where no lane of the wave is releasing),
-// `pre` = the chunk's hand-off values were read from LDS into registers at the top of the chunk
-template <bool B, bool R = true, bool P = false>
+// `pre` = the chunk's hand-off values were read from LDS into registers at the top of the chunk,
+// `steady` = node-specific steady-state conditions hold for the whole chunk (Sect::fast_conds)
+template <bool B, bool R = true, bool P = false, bool S = false>
 struct BoolC {
     static constexpr bool value = B;
     static constexpr bool release = R;
     static constexpr bool pre = P;
+    static constexpr bool steady = S;
 };
 
 struct VoiceCtx {

@@ -854,8 +854,17 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h, float v, float brightness, float v
 }
 
 // AmplitudeSource::process :321-351, one harmonic
+// STEADY: the caller has established 1 <= step and step + (ticks in this chunk) <= EP_INTERP_STEPS for every
+// lane, so neither the new-target test nor the end-of-ramp branch can fire inside the chunk.
+template <bool STEADY = false>
 OG_DEV float ep_amp_tick(EpAmp& a)
 {
+    if (STEADY) {
+        const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
+        a.cur = a.cur * (1.0f - t) + a.tgt * t;
+        a.step += 1u;
+        return a.cur;
+    }
     if (a.step == 0u) a.tgt = a.cur * (a.released ? a.release : a.decay);
     if (a.step < EP_INTERP_STEPS) {
         const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
