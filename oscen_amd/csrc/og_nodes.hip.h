@@ -348,7 +348,9 @@ OG_DEV float poly_blamp(float t, float dt, float rdt)
 OG_DEV float polyblep_frequency(float frequency_in, float frequency_mod) { return fmaxf(frequency_in * (1.0f + frequency_mod), 0.0f); }
 OG_DEV float polyblep_increment(float frequency, float sr) { return frequency / fmaxf(sr, F32_EPSILON); }
 
-template <uint32_t WAVE>
+// BELOW_QUARTER: the caller has established frequency < sr / 4 for every lane (a per-voice block constant),
+// so the sine fallback of :186 and its divergent branch are compiled out.
+template <uint32_t WAVE, bool BELOW_QUARTER = false>
 OG_DEV float polyblep_tick(float& phase_state, float frequency, float freq_per_sample, float phase_mod,
                            float amplitude, float pulse_width_in, float sr)
 {
@@ -358,7 +360,7 @@ OG_DEV float polyblep_tick(float& phase_state, float frequency, float freq_per_s
     const float rdt = __builtin_amdgcn_rcpf(dt);
     if (pulse_width <= 0.0f) pulse_width = 0.0001f;
     float value;
-    if (frequency >= sr * 0.25f || WAVE == PB_SINE) {
+    if ((!BELOW_QUARTER && frequency >= sr * 0.25f) || WAVE == PB_SINE) {
         value = og_sinf(phase * F32_TAU);
     } else if (WAVE == PB_SAW) {
         float y = 2.0f * phase - 1.0f;
