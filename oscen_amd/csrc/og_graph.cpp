@@ -820,7 +820,7 @@ void emit_polyblep(NodeCtx& x)
                   << "        const float " << inc << " = og::polyblep_increment(" << f << ", " << x.sf(s_sr) << ");\n";
     }
     // the >= sr/4 sine fallback is a per-voice block constant when the frequency is: a chunk variant drops it
-    const bool steady_ok = rr <= Rate::VBlock && rr != Rate::UFrame && x.n.type->variant != 0 && x.n.domain != 1;
+    const bool steady_ok = rr <= Rate::VBlock && rr != Rate::UFrame && x.n.type->variant != 0;
     if (steady_ok) x.cg.S().fast_conds.push_back("(" + f + " < " + x.sf(s_sr) + " * 0.25f)");
     x.set_out("output", "og::polyblep_tick<" + std::to_string(x.n.type->variant) + "u" +
                             (steady_ok ? ", decltype(chk)::steady" : "") + ">(" + phase + ", " + f + ", " + inc + ", " + pm.e +

@@ -141,7 +141,7 @@ def test_unregistered_graph_compiles_with_hiprtc_for_gfx950(lib):
 def test_multirate_lowering(lib):
     src = oscen_amd.Graph(builtin="sat4x_voice").kernel_source()
     assert "for (int j = 0; j < 4; ++j)" in src and "og::sinc_down<4>" in src
-    assert "polyblep_tick<1u>" in src.split("for (int j")[1].split("sinc_down")[0]  # osc runs inside the x4 loop
+    assert "polyblep_tick<1u" in src.split("for (int j")[1].split("sinc_down")[0]  # osc runs inside the x4 loop
     # an oversampled node may not depend on an outer node that is downstream of the oversampled region
     g = oscen_amd.Graph("bad_rates")
     g.output_stream("out")
