@@ -18,7 +18,7 @@ class RecGraph(oscen_amd.Graph):
 
     def __init__(self, name):
         super().__init__(name)
-        self.desc = {"inputs": [], "nodes": [], "edges": []}
+        self.desc = {"inputs": [], "nodes": [], "edges": [], "rates": {}, "policies": {}}
 
     def input_value(self, name, default=0.0, ramp=0, per_voice=False):
         self.desc["inputs"].append((name, "value", default, ramp))
@@ -30,9 +30,13 @@ class RecGraph(oscen_amd.Graph):
 
     def node(self, name, type_ctor, *args, rate=1):
         self.desc["nodes"].append((name, type_ctor, args))
+        if rate > 1:
+            self.desc["rates"][name] = rate
         return super().node(name, type_ctor, *args, rate=rate)
 
     def connect(self, src, dst, policy=""):
+        if policy:
+            self.desc["policies"][len(self.desc["edges"])] = policy
         self.desc["edges"].append((src, dst))
         return super().connect(src, dst, policy)
 
@@ -102,3 +106,62 @@ def test_random_graphs_lower_and_compile(seed):
     g2 = oscen_amd.Graph(dsl=g.to_dsl(), per_voice=["frequency"])
     assert g2.kernel_source() == src
     assert g.jit_check() > 10000  # bytes of gfx950 code object
+
+
+POLICIES = ["", "sinc", "sinc_iir", "linear", "latch"]
+
+
+def random_multirate_graph(seed):
+    """outer source(s) -> [up policy] -> oversampled chain -> [down policy] -> (outer filter) -> out"""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([2, 4, 8]))
+    g = RecGraph("mr%d" % seed)
+    g.input_value("frequency", 220.0, per_voice=True)
+    g.input_value("cutoff", 2500.0)
+    g.input_event("gate")
+    g.output_stream("out")
+    waves = ["PolyBlepOscillator::saw", "PolyBlepOscillator::sine", "PolyBlepOscillator::square", "Oscillator::sine"]
+    g.node("o0", waves[int(rng.integers(0, 4))], 220.0, 0.6)
+    g.connect("frequency", "o0.frequency")
+    src = "o0.output"
+    if rng.random() < 0.5:
+        g.node("o1", waves[int(rng.integers(0, 4))], 220.0, 0.3)
+        g.connect("frequency * 2.0", "o1.frequency")
+        src = "o0.output + o1.output"
+    have_env = rng.random() < 0.6
+    if have_env:
+        g.node("env", "AdsrEnvelope::new", 0.003, 0.02, 0.6, 0.03)
+        g.connect("gate", "env.gate")
+    up = POLICIES[int(rng.integers(0, 5))]
+    sig, first = src, True
+    for i in range(int(rng.integers(1, 4))):
+        kind = ["HardClip::new", "Gain::new", "TptFilter::new", "Vca::new"][int(rng.integers(0, 4))]
+        if kind == "Vca::new" and not have_env:
+            kind = "HardClip::new"
+        args = {"HardClip::new": (), "Gain::new": (1.4,), "TptFilter::new": (3000.0, 0.8), "Vca::new": ()}[kind]
+        g.node("i%d" % i, kind, *args, rate=N)
+        g.connect(sig, "i%d.input" % i, up if first else "")
+        if kind == "Vca::new":
+            g.connect("env.output", "i%d.control" % i, POLICIES[int(rng.integers(0, 5))])
+        if kind == "TptFilter::new":
+            g.connect("cutoff", "i%d.cutoff" % i)
+        sig, first = "i%d.output" % i, False
+    down = POLICIES[int(rng.integers(0, 5))]
+    if rng.random() < 0.5:
+        kind = ["TptFilter::new", "IirLowpass::new", "Gain::new"][int(rng.integers(0, 3))]
+        args = {"TptFilter::new": (1800.0, 0.9), "IirLowpass::new": (2200.0, 0.7), "Gain::new": (0.9,)}[kind]
+        g.node("post", kind, *args)
+        g.connect(sig, "post.input", down)
+        g.connect("post.output" if not have_env or rng.random() < 0.5 else "post.output * env.output", "out")
+    else:
+        g.connect(sig, "out", down)
+    return g
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_multirate_graphs_lower_and_compile(seed):
+    g = random_multirate_graph(seed)
+    src = g.kernel_source()
+    assert "oversampled inner loop" in src
+    assert oscen_amd.Graph(dsl=g.to_dsl(), per_voice=["frequency"]).kernel_source() == src
+    assert g.jit_check() > 10000
