@@ -25,7 +25,10 @@ ARCH = "gfx950"
 HOST_SRCS = ["og_engine.cpp", "og_graph.cpp", "og_builtin.cpp", "og_dsl.cpp", "og_midi.cpp", "og_wav.cpp", "og_jit.cpp"]
 HEADERS = ["og_math.h", "og_nodes.hip.h", "og_kernel_rt.hip.h", "og_graph.h", "og_registry.h", "og_jit.h",
            os.path.join("..", "..", "include", "oscen_gpu.h")]
-COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + CSRC]
+# -fno-slp-vectorize: left to itself clang pairs adjacent scalar f32 ops of the tick into v_pk_*_f32; on gfx950
+# a packed f32 instruction costs more issue time than the two scalar ones it replaces (measured: fm_voice
+# 0.0741 -> 0.0708 ms at 65 536 voices, 0.194 -> 0.185 ms at 262 144; see also scripts/pk_probe)
+COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-I" + CSRC]
 
 
 def _run(cmd):

@@ -54,8 +54,8 @@ std::vector<char> compile_to_code(const ogc::CompiledGraph& cg, const char* arch
     if (hiprtcCreateProgram(&prog, cg.source.c_str(), (cg.name + ".hip").c_str(), 3, srcs, names) != HIPRTC_SUCCESS)
         throw std::runtime_error("oscen jit: hiprtcCreateProgram failed");
     std::string archopt = std::string("--offload-arch=") + arch;
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-DOG_JIT=1"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DOG_JIT=1"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
