@@ -1655,6 +1655,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                                      "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
+         << (getenv("OGC_PRIO_PARITY") ? "    if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_setprio(1); // experiment\n" : "")
          << cg.common_decl.str() << cat(all_stages, &Codegen::Sect::decl) << "    if (c.valid) {\n"
          << cg.common_load.str() << cat(all_stages, &Codegen::Sect::load) << "    }\n";
     body << "    auto derive = [&]() {\n" << cat(all_stages, &Codegen::Sect::derive) << "    };\n";
@@ -1772,6 +1773,20 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             const std::vector<int>& st = groups[gi];
             const bool last = gi == K - 1;
             body << (gi == 0 ? "    if (stage == 0) {\n" : "    } else if (stage == " + std::to_string(gi) + ") {\n");
+            {
+                // VALU issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md).  The first wave of
+                // the pipeline (the light producer: envelopes, first operator) runs at priority 1: it never becomes
+                // the straggler its consumers wait for at the hand-off barrier.  Measured, fm_voice: two waves at
+                // 65 536 voices 0.0741 -> 0.0660 ms; four waves at 32 768 voices 0.0500 -> 0.0484 ms; raising the
+                // other waves as well (2,1 / 3,2,1,0) is no better.  OGC_PRIO="p0,p1[,p2,p3]" overrides.
+                std::vector<int> pr = {1, 0, 0, 0};
+                if (const char* ep = getenv("OGC_PRIO")) {
+                    pr.clear();
+                    for (const char* q = ep; *q; ++q)
+                        if (isdigit((unsigned char)*q)) pr.push_back(*q - '0');
+                }
+                if (gi < (int)pr.size() && pr[gi] > 0) body << "    __builtin_amdgcn_s_setprio(" << pr[gi] << ");\n";
+            }
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
             body << "    auto derive = [&]() {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
             body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
