@@ -1405,7 +1405,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                         for (const Expr* r : refs) moving = moving || !r->port.empty();
                     }
                 }
-                wt = moving ? 30 : 12;
+                wt = moving ? 45 : 12; // (check 6 + tan/reciprocal update ~30 + tick 10)
             }
             w.push_back(wt);
             total += wt;
