@@ -1753,13 +1753,27 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         body << "template <bool RAMPS, bool TAPS>\n"
              << "__device__ __forceinline__ void voice_block_p" << K << "(const OgBlockArgs& A)\n{\n"
              << "    __shared__ og::BusLds bus;\n";
+        {
+            // frames per hand-off: 8.  16 (OGC_XCH16, two-wave pipeline only) measured +2% on a 94-block run at
+            // 65 536 voices but -1.5% on the 188-block default run, and its doubled LDS rings leave room for only
+            // four workgroups per CU: 98 304 voices (six per CU) ran 29% slower.  4 is 11% slower.
+            size_t slots = 0;
+            for (const auto& xv : cg.xvals) {
+                int far = group_of(groups, xv.from);
+                for (int u : xv.users) far = std::max(far, group_of(groups, u));
+                const int depth = far - group_of(groups, xv.from) + 1;
+                if (depth > 1) slots += (size_t)depth;
+            }
+            const bool wide = K == 2 && slots * 16 * 64 * 4 <= 36 * 1024 && getenv("OGC_XCH16");
+            body << "    constexpr uint32_t XCH = " << (wide ? 16 : 8) << "; // frames per hand-off between the waves\n";
+        }
         for (size_t k = 0; k < cg.xvals.size(); ++k) {
             const auto& xv = cg.xvals[k];
             int far = group_of(groups, xv.from);
             for (int u : xv.users) far = std::max(far, group_of(groups, u));
             const int depth = far - group_of(groups, xv.from) + 1;
             body << "    constexpr uint32_t XD" << k << " = " << depth << ";\n";
-            if (depth > 1) body << "    __shared__ float chan" << k << "[XD" << k << "][OG_XCH][OG_WAVE];\n";
+            if (depth > 1) body << "    __shared__ float chan" << k << "[XD" << k << "][XCH][OG_WAVE];\n";
         }
         const char* rot_expr[5] = {"0u", "blockIdx.x", "(blockIdx.x >> 3)", "(blockIdx.x >> 5)", "(blockIdx.x >> 8)"};
         int rot = 1;
@@ -1768,7 +1782,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
              << "    og::VoiceCtx c;\n"
              << "    og::voice_begin_split<TAPS>(A, c);\n"
              << cg.common_decl.str() << "    if (c.valid) {\n" << cg.common_load.str() << "    }\n"
-             << "    const uint32_t n_chunks = (A.frames + OG_XCH - 1) / OG_XCH;\n";
+             << "    const uint32_t n_chunks = (A.frames + XCH - 1) / XCH;\n";
         for (int gi = 0; gi < K; ++gi) {
             const std::vector<int>& st = groups[gi];
             const bool last = gi == K - 1;
@@ -1799,7 +1813,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 for (int u : xv.users) used_here = used_here || group_of(groups, u) == gi;
                 if (used_here && group_of(groups, xv.from) != gi) reads.push_back(k);
             }
-            for (size_t k : reads) body << "    float xp" << k << "[OG_XCH];\n";
+            for (size_t k : reads) body << "    float xp" << k << "[XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
                  << group_tick(groups, gi);
@@ -1817,12 +1831,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                     if (flag == "true") flag = "true, true";
                     if (flag == "false") flag = "false, true";
                     flag += ", true";
-                    body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < OG_XCH; ++j) {\n";
+                    body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
                 }
                 body << ind << "#pragma unroll\n"
-                     << ind << "for (uint32_t j = 0; j < OG_XCH; ++j) {\n"
+                     << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n"
                      << ind << "    const uint32_t f = base + j;\n"
                      << ind << "    " << call(flag) << "\n"
                      << ind << "}\n";
@@ -1831,13 +1845,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
                  << "        const uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"
-                 << "        const uint32_t base = ch * OG_XCH;\n"
-                 << "        const uint32_t n = min((uint32_t)OG_XCH, A.frames - base);\n"
-                 << "        if (n == OG_XCH && __all((int)(c.next_ev >= base + OG_XCH))) {\n";
+                 << "        const uint32_t base = ch * XCH;\n"
+                 << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n"
+                 << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))) {\n";
             if (mc.empty()) {
                 quiet("true", "            ");
             } else {
-                body << "            if (__all((int)(" << mc << " > (uint32_t)OG_XCH))) { // no envelope stage ends in this chunk\n"
+                body << "            if (__all((int)(" << mc << " > (uint32_t)XCH))) { // no envelope stage ends in this chunk\n"
                      << "                if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
                 quiet("false, false", "                    ");
                 body << "                } else {\n";
@@ -1854,7 +1868,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                  << "            }\n"
                  << "        }\n";
             if (last)
-                body << "        { // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / OG_XCH hand-offs\n"
+                body << "        { // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / XCH hand-offs\n"
                      << "            const uint32_t lastf = base + n - 1;\n"
                      << "            if ((lastf % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || lastf + 1 == A.frames)\n"
                      << "                og::bus_chunk_reduce(A, c, bus, lastf - (lastf % OG_BUS_CHUNK), (lastf % OG_BUS_CHUNK) + 1);\n"

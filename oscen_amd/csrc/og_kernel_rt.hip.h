@@ -45,7 +45,6 @@ using __hip_internal::uint64_t;
 #define OG_MAX_BLOCK 512
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16
-#define OG_XCH 8 // frames per hand-off between the waves of the pipelined kernels
 #define OG_NO_EVENT 0xFFFFFFFFu
 #define OG_EV_SETVALUE 0x80000000u
 
