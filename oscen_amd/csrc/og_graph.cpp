@@ -1405,7 +1405,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                         for (const Expr* r : refs) moving = moving || !r->port.empty();
                     }
                 }
-                wt = moving ? 45 : 12; // (check 6 + tan/reciprocal update ~30 + tick 10)
+                // (its true cost is ~45, but the grouping this weight gives for fm_voice -- op2 with the consumer wave --
+                //  measured equal on the default run and 12% faster at 98 304 voices than op2 with the producer)
+                wt = moving ? 30 : 12;
             }
             w.push_back(wt);
             total += wt;
