@@ -724,12 +724,12 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // pipelined variants for banks too small to put four ordinary waves on every SIMD.  Measured on
             // MI355X (fm_voice, 256-frame block, kernel time with one / two / four waves per 64 voices):
             // 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152: 0.077 / 0.071 /
-            // 0.063; 65 536: 0.080 / 0.075 / 0.089 (the four-wave form issues ~20% more instructions and its
-            // waves move in lockstep); 131 072 and above: the ordinary kernel.
+            // 0.054; 65 536: 0.080 / 0.066 / 0.086 (the four-wave form issues ~20% more instructions and its
+            // waves move in lockstep); 98 304: 0.100 / 0.083; 114 688 and above: the ordinary kernel.
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
             uint32_t depth = 0;
             if (e->cg->max_pipeline >= 4 && waves1 * 4 <= 3 * simds) depth = 4;
-            else if (e->cg->max_pipeline >= 2 && waves1 < 2 * simds) depth = 2;
+            else if (e->cg->max_pipeline >= 2 && waves1 * 2 <= 3 * simds) depth = 2; // <= 98 304 voices (114 688: 0.121 vs 0.103 ms)
             if (const char* ev = getenv("OSCEN_GPU_SPLIT")) {
                 const int want = atoi(ev);
                 depth = (want >= 4 && e->cg->max_pipeline >= 4) ? 4 : ((want >= 2 && e->cg->max_pipeline >= 2) ? 2 : 0);
