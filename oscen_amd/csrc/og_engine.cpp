@@ -725,7 +725,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // MI355X (fm_voice, 256-frame block, kernel time with one / two / four waves per 64 voices):
             // 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152: 0.077 / 0.071 /
             // 0.054; 65 536: 0.080 / 0.066 / 0.086 (the four-wave form issues ~20% more instructions and its
-            // waves move in lockstep); 98 304: 0.100 / 0.083; 114 688 and above: the ordinary kernel.
+            // waves move in lockstep); 98 304: 0.104 / 0.084; 114 688 and above: the ordinary kernel.
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
             uint32_t depth = 0;
             if (e->cg->max_pipeline >= 4 && waves1 * 4 <= 3 * simds) depth = 4;
