@@ -1487,7 +1487,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 for (int k = 0; k < cg.n_stages; ++k) cg.groups2[k < ku ? 0 : 1].push_back(k);
             }
             const char* ep = getenv("OGC_PARTS");
-            if (total >= 80 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(4);
+            if (total >= 80 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(getenv("OGC_K3") ? 3 : 4);
         }
     }
     cg.split = cg.n_stages > 1;
@@ -1743,7 +1743,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     // s works on hand-off chunk t - s.  A value produced by group a and read by group b lives in an LDS
     // ring of b - a + 1 chunks.  Which wave of the workgroup takes which group rotates with the
     // workgroup index, so that the SIMDs of a CU do not each collect one kind of stage.
-    auto emit_pipeline = [&](const std::vector<std::vector<int>>& groups) {
+    auto emit_pipeline = [&](const std::vector<std::vector<int>>& groups, int tag) {
         const int K = (int)groups.size();
         body << "\n// " << K << "-wave pipeline over the same 64 voices (small banks: more waves per SIMD).\n";
         for (int gi = 0; gi < K; ++gi) {
@@ -1753,7 +1753,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             body << (gi == K - 1 ? " + the mix bus\n" : "\n");
         }
         body << "template <bool RAMPS, bool TAPS>\n"
-             << "__device__ __forceinline__ void voice_block_p" << K << "(const OgBlockArgs& A)\n{\n"
+             << "__device__ __forceinline__ void voice_block_p" << tag << "(const OgBlockArgs& A)\n{\n"
              << "    __shared__ og::BusLds bus;\n";
         {
             // frames per hand-off: 8.  16 (OGC_XCH16, two-wave pipeline only) measured +2% on a 94-block run at
@@ -1886,8 +1886,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         body << "    }\n}\n";
     };
-    if (!cg.groups2.empty()) emit_pipeline(cg.groups2);
-    if (!cg.groups4.empty()) emit_pipeline(cg.groups4);
+    if (!cg.groups2.empty()) emit_pipeline(cg.groups2, 2);
+    if (!cg.groups4.empty()) emit_pipeline(cg.groups4, 4);
 
     const std::string body_s = body.str();
     out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
@@ -1913,19 +1913,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     for (auto& v : variants)
         src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
-    std::vector<int> depths;
-    if (!cg.groups2.empty()) depths.push_back(2);
-    if (!cg.groups4.empty()) depths.push_back(4);
-    for (int K : depths)
+    std::vector<std::pair<int, int>> depths; // (tag: what OgBlockArgs::split selects, waves per workgroup)
+    if (!cg.groups2.empty()) depths.push_back({2, (int)cg.groups2.size()});
+    if (!cg.groups4.empty()) depths.push_back({4, (int)cg.groups4.size()});
+    for (auto [K, W] : depths)
         for (auto& v : variants)
-            src << "extern \"C\" __global__ __launch_bounds__(" << 64 * K << ") void og_k" << K << "_" << hs << "_" << v[0]
+            src << "extern \"C\" __global__ __launch_bounds__(" << 64 * W << ") void og_k" << K << "_" << hs << "_" << v[0]
                 << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p" << K << "<" << v[1] << ", " << v[2] << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
         << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n";
-    for (int K : depths)
-        src << "    if (A.split == " << K << "u) { // " << K << " waves per 64 voices\n"
-            << "        const dim3 gk((A.n_voices + OG_WAVE - 1) / OG_WAVE), bk(" << K << " * OG_WAVE);\n"
+    for (auto [K, W] : depths)
+        src << "    if (A.split == " << K << "u) { // " << W << " waves per 64 voices\n"
+            << "        const dim3 gk((A.n_voices + OG_WAVE - 1) / OG_WAVE), bk(" << W << " * OG_WAVE);\n"
             << "        if (!ramps && !taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_00, gk, bk, 0, s, A);\n"
             << "        else if (ramps && !taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_10, gk, bk, 0, s, A);\n"
             << "        else if (!ramps && taps) hipLaunchKernelGGL(og_k" << K << "_" << hs << "_01, gk, bk, 0, s, A);\n"
