@@ -1828,15 +1828,20 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 const std::string t = std::string("tick(f, ch, j, og::BoolC<") + flag + ">{})";
                 return last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, " + t + ");" : t + ";";
             };
-            auto quiet = [&](std::string flag, const char* ind) {
-                if (!reads.empty()) {
-                    if (flag == "true") flag = "true, true";
-                    if (flag == "false") flag = "false, true";
-                    flag += ", true";
+            // node steady-state conditions of this wave's stages (Sect::fast_conds), as in the ordinary kernel
+            std::string steady;
+            for (int k : st)
+                for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
+            // flags: stage-end checks, release arithmetic, hand-off values prefetched, node steady states
+            auto quiet = [&](const char* chk_flag, const char* rel_flag, bool st_flag, const std::string& ind) {
+                const bool pre = !reads.empty();
+                if (pre) {
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
                 }
+                const std::string flag = std::string(chk_flag) + ", " + rel_flag + ", " + (pre ? "true" : "false") + ", " +
+                                         (st_flag ? "true" : "false");
                 body << ind << "#pragma unroll\n"
                      << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n"
                      << ind << "    const uint32_t f = base + j;\n"
@@ -1844,22 +1849,34 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                      << ind << "}\n";
             };
             const std::string mc = min_cnt(st);
+            auto variants = [&](bool st_flag, const std::string& ind0) {
+                if (mc.empty()) {
+                    quiet("true", "true", st_flag, ind0);
+                } else {
+                    body << ind0 << "if (__all((int)(" << mc << " > (uint32_t)XCH))) { // no envelope stage ends in this chunk\n"
+                         << ind0 << "    if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
+                    quiet("false", "false", st_flag, ind0 + "        ");
+                    body << ind0 << "    } else {\n";
+                    quiet("false", "true", st_flag, ind0 + "        ");
+                    body << ind0 << "    }\n" << ind0 << "} else {\n";
+                    quiet("true", "true", st_flag, ind0 + "    ");
+                    body << ind0 << "}\n";
+                }
+            };
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
                  << "        const uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"
                  << "        const uint32_t base = ch * XCH;\n"
                  << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n"
                  << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))) {\n";
-            if (mc.empty()) {
-                quiet("true", "            ");
+            if (steady.empty()) {
+                variants(false, "            ");
             } else {
-                body << "            if (__all((int)(" << mc << " > (uint32_t)XCH))) { // no envelope stage ends in this chunk\n"
-                     << "                if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
-                quiet("false, false", "                    ");
-                body << "                } else {\n";
-                quiet("false", "                    ");
-                body << "                }\n            } else {\n";
-                quiet("true", "                ");
+                body << "            constexpr uint32_t CHUNK = XCH;\n"
+                     << "            if (__all((int)(!c.valid || (" << steady << ")))) { // node steady states hold for the whole chunk\n";
+                variants(true, "                ");
+                body << "            } else {\n";
+                variants(false, "                ");
                 body << "            }\n";
             }
             body << "        } else {\n"

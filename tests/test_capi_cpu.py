@@ -194,7 +194,9 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert re.search(r"//   wave 0: env3 env2 env1 env_filter\b", fm)  # a run of envelopes is one stage
     for k in ("og_k_", "og_k2_", "og_k4_"):
         assert len(re.findall(r"__global__[^\n]*\b%s[0-9a-f]{16}_(00|10|01|11)\b" % k, fm)) == 4
-    assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false>{}" in fm and "og::BoolC<true>{}" in fm
+    # chunk variants: (stage-end checks, release arithmetic[, hand-off prefetch, node steady states])
+    assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false, true>{}" in fm and "og::BoolC<true>{}" in fm
+    assert "og::BoolC<false, false, false, false>{}" in fm and "og::BoolC<true, true, true, false>{}" in fm
     assert "og::adsr_tick<decltype(chk)::release>" in fm
     assert fm.count("if constexpr (decltype(chk)::value)") >= 3
     # the cutoff of FMVoice moves with an envelope: per-tick parameter check; sub_voice's is block-constant
