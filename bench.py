@@ -2,15 +2,24 @@
 """Benchmark of the hot path: voices*samples/sec of the fm-synth voice bank.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one 256-frame block of the fm_voice graph over this rank's voice
-shard (BASELINE.json configs[1]: 65 536 voices per GPU, 48 kHz, f32, synthetic
-note streams already resident in HBM).  Rank 0 prints ONE JSON line.
+A step = one 256-frame block of the fm_voice graph over this rank's voice shard (BASELINE.json
+configs[1]: 65 536 voices per GPU, 48 kHz, f32, synthetic note streams already resident in HBM;
+`--voices-per-gpu 262144 --gpus 8` is configs[3], the 2 097 152-voice node).  With --gpus N > 1 and
+no torch.distributed environment the script launches itself under torch.distributed.run (one rank
+per GPU, RCCL); the driver's own `python -m torch.distributed.run ... bench.py --gpus N` works too.
+Rank 0 prints ONE JSON line.
+
+Other modes (not the headline): --midi-live (events arrive through og_midi_send + the blocking
+og_process_block every block instead of a resident timeline), --graph <built-in> for the other
+BASELINE configurations.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,29 +30,37 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(voices, block, graph):
-    """HBM bytes per launch of the voice kernel from the committed rocprofv3 PMC passes
-    (profiles/*_summary.json, written by scripts/prof_summary.py): FETCH_SIZE and WRITE_SIZE are
-    collected in separate --pmc runs of this same command, so they cannot be measured in-process."""
-    import glob
-
-    best = None
+def pmc_profile(voices, block, graph, kernel_hash):
+    """The committed rocprofv3 PMC summary (profiles/*_summary.json, scripts/prof_summary.py) of THIS kernel:
+    same graph, bank size, block and kernel hash.  FETCH_SIZE / WRITE_SIZE / SQ_* come from separate --pmc
+    runs, so they cannot be measured in-process; a summary of another kernel build is never mixed in --
+    it is reported as stale instead."""
+    match, stale = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if (d.get("voices") == voices and d.get("frames") == block and d.get("graph", "fm_voice") == graph
-                and "hbm_traffic" in d):
-            best = (path, d)
-    if not best:
-        return None, None, None
-    valu = best[1].get("pmc_voice_kernel", {}).get("SQ_INSTS_VALU", {}).get("avg_per_dispatch")
-    return best[1]["hbm_traffic"]["total_bytes_corrected"], os.path.relpath(best[0], ROOT), valu
+        if d.get("voices") != voices or d.get("frames") != block or d.get("graph", "fm_voice") != graph:
+            continue
+        if d.get("kernel_hash") == kernel_hash and "hbm_traffic" in d:
+            match = (path, d)
+        else:
+            stale = path
+    if match:
+        d = match[1]
+        valu = d.get("pmc_voice_kernel", {}).get("SQ_INSTS_VALU", {}).get("avg_per_dispatch")
+        return {"bytes": d["hbm_traffic"]["total_bytes_corrected"], "valu": valu,
+                "source": os.path.relpath(match[0], ROOT), "stale": None}
+    return {"bytes": None, "valu": None, "source": None, "stale": os.path.relpath(stale, ROOT) if stale else None}
 
 
-def cpu_baseline(block, seed):
-    """Time the CPU oracle (scalar C port of the reference path) on the host cores, bounded sample."""
+def cpu_baseline(block, seed, frames, span):
+    """Time the CPU oracle (scalar C port of the reference path) on the host cores, bounded sample of the
+    same note streams.  Two shapes of the same arithmetic: banks of 8 voices per graph, each rendered block
+    by block (the reference's own `voices = [FMVoice; 8]`, examples/fm-synth/src/lib.rs:68-73, whose state
+    stays in cache) -- the headline CPU figure -- and one big bank per thread walked voice-minor every sample
+    (cache-hostile; what round 1 reported)."""
     import ctypes as C
 
     from tests import oracle_lib as ol
@@ -51,22 +68,48 @@ def cpu_baseline(block, seed):
     lib = ol.load()
     cores = os.cpu_count() or 1
     cs = C.c_double()
-    # calibrate on a tiny bank, then size the sample for ~12 s of CPU work on all cores
-    probe_v, probe_f = 64 * min(cores, 8), 2048
-    t = lib.oo_bank_bench(ol.BANK_FM, probe_v, probe_f, block, cores, seed, C.byref(cs))
-    rate = probe_v * probe_f / max(t, 1e-6)
-    frames = 12000  # first 0.25 s of the note streams (attack/decay + first note-offs)
-    voices = int(max(cores, min(65536, rate * 12.0 / frames)))
-    voices = max(cores, (voices // cores) * cores)
-    t = lib.oo_bank_bench(ol.BANK_FM, voices, frames, block, cores, seed, C.byref(cs))
+    frames = int(max(block, min(frames, 48000)))
+
+    def run(group, budget_s):
+        probe_v = 8 * cores
+        t = lib.oo_bank_bench_grouped(ol.BANK_FM, probe_v, min(frames, 2048), block, cores, group, seed, span, C.byref(cs))
+        rate = probe_v * min(frames, 2048) / max(t, 1e-6)
+        voices = int(max(8 * cores, min(1 << 20, rate * budget_s / frames)))
+        voices = (voices // (8 * cores)) * 8 * cores
+        t = lib.oo_bank_bench_grouped(ol.BANK_FM, voices, frames, block, cores, group, seed, span, C.byref(cs))
+        return voices, t
+
+    v8, t8 = run(8, 10.0)
+    vw, tw = run(0, 4.0)
     return {
-        "value": voices * frames / t,
+        "value": v8 * frames / t8,
         "unit": "voices*samples/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d voices x %d frames (block %d) of the same synthetic fm-synth note streams, "
-                  "C oracle, %d threads, %.1f s" % (voices, frames, block, cores, t),
+        "per_thread": v8 * frames / t8 / cores,
+        "sample": "%d voices x %d frames (block %d) of the same synthetic fm-synth note streams as banks of 8 voices "
+                  "(the reference's [FMVoice; 8] graph) rendered block by block, C oracle, %d threads, %.1f s"
+                  % (v8, frames, block, cores, t8),
+        "whole_bank_per_thread": {
+            "value": vw * frames / tw,
+            "per_thread": vw * frames / tw / cores,
+            "sample": "%d voices x %d frames, one bank per thread walked voice-minor per sample (cache-hostile), "
+                      "%d threads, %.1f s" % (vw, frames, cores, tw),
+        },
     }
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: one rank per GPU over RCCL."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -74,14 +117,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=188)   # 188 x 256 frames = 1 s of audio
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--voices-per-gpu", type=int, default=65536)
+    ap.add_argument("--voices-per-gpu", type=int, default=65536,
+                    help="65536 = BASELINE configs[1]; 262144 with --gpus 8 = configs[3] (2 097 152 voices)")
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sparse-events", action="store_true",
+                    help="keep the 1 s note plan as is even when the run is shorter (default: fold it into the run, "
+                         "so that note-off and retrigger fall inside the timed region)")
+    ap.add_argument("--midi-live", type=int, default=0, metavar="N",
+                    help="drop-in path: N MIDI messages per block through og_midi_send + blocking og_process_block")
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="map every rank onto GPU 0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
@@ -91,14 +143,14 @@ def main():
 
     rank, local_rank, world_size = ogd.world()
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world_size))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks = None
     if world_size > 1:
         import torch.distributed as dist
 
@@ -111,18 +163,36 @@ def main():
     lo, hi = ogd.shard_range(rank, world_size, total_voices)
     block, K, W = args.block, args.steps, args.warmup
     total_frames = (K + W) * block
+    span = 0 if args.sparse_events else min(total_frames, 48000)
 
     eng = oscen_amd.Engine(args.graph, hi - lo, device=local_rank, sample_rate=48000.0)
-    plans = oscen_amd.note_plans(hi - lo, first_voice=lo)  # global voice ids keep their note streams
-    oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span)  # global voice ids keep their note streams
+    midi = None
+    if args.midi_live:
+        eng.set_voice_values("frequency", plans["frequency"])
+        midi = oscen_amd.Midi(eng)
+        midi.set_queue_capacity(max(32, args.midi_live))
+        n_events_timed = args.midi_live * K
+    else:
+        oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+        n_events_timed = int(sum(int(np.count_nonzero((plans[k] >= W * block) & (plans[k] < total_frames)))
+                                 for k in ("on_frame", "off_frame", "retrig_frame"))) if "gate" in eng.input_names else 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     ch = eng.channels
     bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
     base = bus.data_ptr()
+    host_bus = np.zeros((K + W, block * ch), dtype=np.float32)
+    rng = np.random.default_rng(0x05CE2026 + rank)
+    live_notes = rng.integers(36, 97, size=(K + W, max(1, args.midi_live))).astype(np.uint8)
+    live_frames = np.sort(rng.integers(0, block, size=(K + W, max(1, args.midi_live))), axis=1).astype(np.uint32)
 
     def step(i):
-        eng.process_block_async(block, base + i * block * ch * 4)
+        if midi is None:
+            eng.process_block_async(block, base + i * block * ch * 4)
+        else:  # note-on / note-off pairs, alternating, through the MIDI front end and the blocking entry point
+            midi.send_many(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0))  # odd blocks release the notes of the block before
+            host_bus[i] = midi.process_block(block).reshape(-1)
 
     def reduce_bus(t):
         if args.backend == "gloo":  # CPU collective (plumbing check only)
@@ -142,6 +212,9 @@ def main():
         step(i)
     if dist is not None:  # communicator set-up (lazy in RCCL) must not land in the timed region
         reduce_bus(bus[:W] if W else torch.zeros((1, block * ch), dtype=torch.float32, device="cuda"))
+        ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
+        dist.all_reduce(ones)  # every rank of the communicator took part
+        rccl_ranks = int(round(float(ones.item())))
     torch.cuda.synchronize()
     if dist is not None:
         barrier()
@@ -166,19 +239,20 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        mix = bus[W:].float().cpu().numpy()
+        mix = host_bus[W:] if midi is not None else bus[W:].float().cpu().numpy()
         assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
         value = total_voices * K * block / elapsed
         words = eng.state_words_per_voice
         lanes = eng.voices_per_wave * eng.lanes_per_voice
         # algorithmic HBM bytes of one launch: state planes read once + written once,
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
-        n_wg = (V * eng.lanes_per_voice + lanes - 1) // lanes
+        n_wg = eng.partial_rows
         bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
         # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
         bytes_per_launch += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        pmc_bytes, pmc_src, pmc_valu = pmc_traffic(V, block, args.graph)
+        prof = pmc_profile(V, block, args.graph, eng.kernel_hash)
+        pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
         traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
         line = {
             "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
@@ -195,15 +269,23 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "fm-synth voice bank (FMVoice graph), %d voices/GPU, block=%d frames, 48 kHz, f32; "
-                            "synthetic note streams splitmix64(0x05CE2026 ^ voice) resident in HBM; "
-                            "mix bus reduced once per run over RCCL" % (V, block),
+                            "synthetic note streams splitmix64(0x05CE2026 ^ voice) resident in HBM%s; "
+                            "%d note events (on / off / retrigger) fall inside the timed region; "
+                            "mix bus reduced once per run over RCCL"
+                            % (V, block, "" if not span or span >= 48000 else
+                               ", the 1 s note plan folded into the %d-frame run" % span, n_events_timed),
                 "graph": args.graph,
                 "voices_per_gpu": V,
                 "total_voices": total_voices,
                 "block": block,
                 "sample_rate": 48000,
                 "parallelism": "voice-shard x%d" % world_size,
+                "events_in_timed_region": n_events_timed,
+                "note_plan_span_frames": span if span else 48000,
+                "event_path": "midi-live (og_midi_send + og_process_block per block)" if midi is not None
+                              else "resident timeline (og_schedule_voice_events)",
             },
+            "rccl_ranks": rccl_ranks,
             "realtime_voices_at_48k": value / 48000.0,
             "roofline": {
                 "bound": "hbm",
@@ -214,6 +296,9 @@ def main():
                 "traffic": traffic,
                 "traffic_bytes_per_launch": pmc_bytes,
                 "traffic_source": pmc_src,
+                "stale_profile": prof["stale"],  # newest summary of this configuration taken on ANOTHER kernel build
+                "kernel_hash": eng.kernel_hash,
+                "kernel_variant": eng.kernel_variant,
                 "kernel_ms_avg": kern_ms,
                 "kernel_launches": n_launch,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -226,7 +311,7 @@ def main():
                 # 32 wide: a wave64 VALU instruction issues in 2 cycles (1024 SIMDs x 2.4 GHz / 2 = the 157 TF
                 # vector peak); the measured ceiling for scalar f32 streams is ~3.05 cycles (103 TF,
                 # MI355X_MICROARCH.md; scripts/pk_probe: 3.2 with 8 waves per SIMD).  achieved = SQ_INSTS_VALU per
-                # launch (committed PMC pass) / the kernel duration measured in this run.
+                # launch (committed PMC pass of the SAME kernel hash) / the kernel duration measured in this run.
                 "valu_issue": None if not (pmc_valu and kern_ms > 0) else {
                     "achieved": pmc_valu / (kern_ms * 1e-3) / 1e9,
                     "peak": 1024 * 2.4 / 2.0,
@@ -239,8 +324,11 @@ def main():
                 },
             },
         }
+        if midi is not None:
+            line["config"]["midi_messages_per_block"] = args.midi_live
+            line["event_stats"] = eng.event_stats
         if world_size == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED)
+            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -132,6 +132,13 @@ int og_push_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint32_t f
  * og_init); consumed by whichever block contains that frame. */
 int og_schedule_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float scalar);
 int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float v);
+/* Bulk form of the two calls above (a whole score at once): `input` is an event input (values = scalar
+ * payloads) or a per-voice value input (values = new values).  Events land on the device timeline
+ * when the next block starts.  How they get there: a large batch rebuilds the timeline (O(V) upload,
+ * one stream sync); a small one (live playing: og_push_voice_event, og_midi_*) appends per-voice
+ * segments with one async copy and no synchronisation. */
+int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uint32_t* voices,
+                             const uint64_t* abs_frames, const float* values);
 
 /* process_block(frames)  codegen/mod.rs:755-873, frames <= 512, then copies
  * <out>_block[..frames] (the sum over voices, `voices.out -> out`) to host
@@ -165,6 +172,16 @@ int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched 
                                                  2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
 uint64_t og_events_dropped(const og_engine* e);
+/* which voice kernel runs: FNV-1a hash of the generated kernel body (the `<hash>` in the kernel names
+ * og_k_<hash>_*, og_k2_<hash>_*, ... that rocprofv3 reports), and whether it came from hiprtc */
+uint64_t og_kernel_hash(const og_engine* e);
+int og_kernel_is_jit(const og_engine* e);
+const char* og_kernel_name(const og_engine* e); /* "og_k_<hash>" / "og_k2_<hash>" / "og_k4_<hash>": the launched variant family */
+uint32_t og_partial_rows(const og_engine* e);   /* partial bus rows one launch writes (one per workgroup) */
+/* og_bus_reduce launches of the last block: 1, or 1 + the levels of the multi-pass tree (> 1024 partial rows) */
+uint32_t og_bus_reduce_passes(const og_engine* e);
+/* event-path counters: full timeline rebuilds, incremental (per-voice segment) updates, events resident */
+int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* incremental_updates, uint64_t* resident_events);
 /* average device time of the voice kernel over the launches since the last
  * call (HIP events on the engine's stream); returns <0 if timing is off */
 int og_enable_kernel_timing(og_engine* e, int on);
@@ -184,6 +201,12 @@ typedef struct og_midi og_midi;
 int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input, const char* gate_input, og_midi** out);
 void og_midi_destroy(og_midi* m);
 int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_offset);
+/* n three-byte messages at once: bytes3[3*n], frame_offsets[n] */
+int og_midi_send_batch(og_midi* m, const uint8_t* bytes3, const uint32_t* frame_offsets, uint32_t n);
+/* `midi_in` is an ArrayVec<EventInstance, 32> in the reference (graph/types.rs:18): the 33rd message queued for a
+ * block is dropped (OG_E_OVERFLOW).  A bank-sized instrument raises the capacity. */
+int og_midi_set_queue_capacity(og_midi* m, uint32_t capacity);
+uint64_t og_midi_dropped(const og_midi* m); /* queue overflows + messages whose frame_offset >= the block's frames */
 int og_midi_flush(og_midi* m);
 int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus);
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age);

@@ -1,15 +1,22 @@
 /*
- * oracle_bench.c -- CPU ORACLE timing leg (TEST/BENCH INFRASTRUCTURE ONLY).
+ * oracle_bench.c -- CPU ORACLE timing / full-size reference leg (TEST/BENCH INFRASTRUCTURE ONLY).
  *
- * Times the scalar restatement of the reference CPU path on the host cores:
+ * Runs the scalar restatement of the reference CPU path on the host cores:
  * same per-sample, voice-minor tick order as the reference's generated
  * process_block (oscen-graph-compiler/src/codegen/mod.rs:755-873), AoS voices.
- * Multi-threading = static partition of the voices, one private sub-bank per
- * thread (the reference itself is single-threaded per graph).
+ * Multi-threading = static partition of the voices (the reference itself is
+ * single-threaded per graph).  Inside its range a thread runs
+ * sub-banks of `group` voices: group = 8 is the reference's own shape
+ * (`voices = [FMVoice; 8]` per graph, examples/fm-synth/src/lib.rs:68-73), whose
+ * working set stays in L1/L2; group = 0 makes one sub-bank of the whole range
+ * (every voice touched once per sample: cache-hostile, kept for comparison).
+ * Results do not depend on the grouping: voices are independent and the
+ * per-frame sums are accumulated in f64.
  */
 #define _POSIX_C_SOURCE 200809L
 #include "oscen_oracle.h"
 
+#include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,9 +24,10 @@
 
 typedef struct {
     int kind;
-    uint32_t lo, hi, frames_total, block;
+    uint32_t lo, hi, frames_total, block, group, span;
     uint64_t seed;
     double checksum;
+    double *mono64, *abs64; /* [frames_total] or NULL */
 } worker_arg;
 
 static double now_s(void)
@@ -29,25 +37,23 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void *worker(void *p)
+static void render_group(worker_arg *a, uint32_t lo, uint32_t hi, oo_note_plan *plans, double *cs)
 {
-    worker_arg *a = (worker_arg *)p;
-    uint32_t n = a->hi - a->lo;
+    const uint32_t n = hi - lo;
     oo_bank *b = oo_bank_create(a->kind, n);
     oo_bank_init(b, 48000.0f);
-    oo_note_plan *plans = (oo_note_plan *)malloc(sizeof(oo_note_plan) * n);
     for (uint32_t i = 0; i < n; ++i) {
-        oo_note_plan_for_voice(a->seed, a->lo + i, &plans[i]);
+        oo_note_plan_scaled(a->seed, lo + i, a->span, &plans[i]);
         oo_bank_set_voice_frequency(b, i, plans[i].frequency);
     }
+    const int gated = a->kind != OO_BANK_SAT4X && a->kind != OO_BANK_SAT1X;
     float out[OO_MAX_BLOCK * 2];
-    double cs = 0.0;
-    uint32_t ch = oo_bank_channels(b);
+    const uint32_t ch = oo_bank_channels(b);
     for (uint32_t f0 = 0; f0 < a->frames_total; f0 += a->block) {
-        uint32_t frames = a->frames_total - f0 < a->block ? a->frames_total - f0 : a->block;
-        for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t frames = a->frames_total - f0 < a->block ? a->frames_total - f0 : a->block;
+        for (uint32_t i = 0; gated && i < n; ++i) {
             const oo_note_plan *pl = &plans[i];
-            float vel = oo_midi_velocity_to_gate(pl->velocity);
+            const float vel = oo_midi_velocity_to_gate(pl->velocity);
             if (pl->on_frame >= f0 && pl->on_frame < f0 + frames)
                 oo_bank_push_event(b, i, pl->on_frame - f0, OO_EV_GATE, vel);
             if (pl->off_frame >= f0 && pl->off_frame < f0 + frames)
@@ -56,40 +62,95 @@ static void *worker(void *p)
                 oo_bank_push_event(b, i, pl->retrig_frame - f0, OO_EV_GATE, vel);
         }
         oo_bank_process_block(b, frames, out, NULL, 0, NULL);
-        for (uint32_t k = 0; k < frames * ch; ++k) cs += (double)out[k];
+        for (uint32_t k = 0; k < frames * ch; ++k) *cs += (double)out[k];
+        if (a->mono64) {
+            const double *m = oo_bank_last_bus_f64(b), *ab = oo_bank_last_abs_f64(b);
+            for (uint32_t k = 0; k < frames; ++k) {
+                a->mono64[f0 + k] += m[k];
+                a->abs64[f0 + k] += ab[k];
+            }
+        }
     }
+    oo_bank_destroy(b);
+}
+
+static void *worker(void *p)
+{
+    worker_arg *a = (worker_arg *)p;
+    const uint32_t n = a->hi - a->lo;
+    const uint32_t g = (a->group == 0 || a->group > n) ? n : a->group;
+    oo_note_plan *plans = (oo_note_plan *)malloc(sizeof(oo_note_plan) * (g ? g : 1));
+    double cs = 0.0;
+    for (uint32_t lo = a->lo; lo < a->hi; lo += g) render_group(a, lo, lo + g < a->hi ? lo + g : a->hi, plans, &cs);
     a->checksum = cs;
     free(plans);
-    oo_bank_destroy(b);
     return NULL;
 }
 
-double oo_bank_bench(int kind, uint32_t n_voices, uint32_t frames_total, uint32_t block, uint32_t n_threads,
-                     uint64_t seed, double *checksum)
+static double run_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint32_t frames_total, uint32_t block,
+                     uint32_t n_threads, uint32_t group, uint64_t seed, uint32_t span, double *mono64, double *abs64,
+                     double *checksum)
 {
     if (n_threads == 0) n_threads = 1;
     if (n_threads > n_voices) n_threads = n_voices;
     if (block == 0 || block > OO_MAX_BLOCK) block = 256;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
     worker_arg *args = (worker_arg *)calloc(n_threads, sizeof(worker_arg));
-    double t0 = now_s();
+    const double t0 = now_s();
     for (uint32_t t = 0; t < n_threads; ++t) {
         args[t].kind = kind;
-        args[t].lo = (uint32_t)((uint64_t)n_voices * t / n_threads);
-        args[t].hi = (uint32_t)((uint64_t)n_voices * (t + 1) / n_threads);
+        args[t].lo = first_voice + (uint32_t)((uint64_t)n_voices * t / n_threads);
+        args[t].hi = first_voice + (uint32_t)((uint64_t)n_voices * (t + 1) / n_threads);
         args[t].frames_total = frames_total;
         args[t].block = block;
+        args[t].group = group;
+        args[t].span = span;
         args[t].seed = seed;
+        if (mono64) {
+            args[t].mono64 = (double *)calloc(frames_total, sizeof(double));
+            args[t].abs64 = (double *)calloc(frames_total, sizeof(double));
+        }
         pthread_create(&th[t], NULL, worker, &args[t]);
     }
     double cs = 0.0;
+    if (mono64) {
+        memset(mono64, 0, sizeof(double) * frames_total);
+        if (abs64) memset(abs64, 0, sizeof(double) * frames_total);
+    }
     for (uint32_t t = 0; t < n_threads; ++t) {
         pthread_join(th[t], NULL);
         cs += args[t].checksum;
+        if (mono64) {
+            for (uint32_t k = 0; k < frames_total; ++k) {
+                mono64[k] += args[t].mono64[k];
+                if (abs64) abs64[k] += args[t].abs64[k];
+            }
+            free(args[t].mono64);
+            free(args[t].abs64);
+        }
     }
-    double t1 = now_s();
+    const double t1 = now_s();
     if (checksum) *checksum = cs;
     free(th);
     free(args);
     return t1 - t0;
+}
+
+double oo_bank_bench(int kind, uint32_t n_voices, uint32_t frames_total, uint32_t block, uint32_t n_threads,
+                     uint64_t seed, double *checksum)
+{
+    return run_mt(kind, 0, n_voices, frames_total, block, n_threads, 0, seed, 0, NULL, NULL, checksum);
+}
+
+double oo_bank_bench_grouped(int kind, uint32_t n_voices, uint32_t frames_total, uint32_t block, uint32_t n_threads,
+                             uint32_t group, uint64_t seed, uint32_t span, double *checksum)
+{
+    return run_mt(kind, 0, n_voices, frames_total, block, n_threads, group, seed, span, NULL, NULL, checksum);
+}
+
+double oo_bank_render_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint32_t frames_total, uint32_t block,
+                         uint32_t n_threads, uint32_t group, uint64_t seed, uint32_t span, double *mono64,
+                         double *abs64)
+{
+    return run_mt(kind, first_voice, n_voices, frames_total, block, n_threads, group, seed, span, mono64, abs64, NULL);
 }

@@ -1562,6 +1562,7 @@ struct oo_bank {
     /* output */
     float out[2];
     double last_bus_f64[OO_MAX_BLOCK];
+    double last_abs_f64[OO_MAX_BLOCK]; /* sum of |voice output|: the scale of the bus-sum tolerance */
 };
 
 static const float FM_DEFAULTS[OO_FM_NUM_PARAMS] = {
@@ -1721,7 +1722,7 @@ static void bank_advance_one_frame(oo_bank *b, uint32_t frame, const uint32_t *t
 {
     bank_tick_ramps(b);
     float sum = 0.0f;
-    double sum64 = 0.0;
+    double sum64 = 0.0, abs64 = 0.0;
     for (uint32_t i = 0; i < b->n; ++i) {
         float y = 0.0f;
         switch (b->kind) {
@@ -1794,10 +1795,12 @@ static void bank_advance_one_frame(oo_bank *b, uint32_t frame, const uint32_t *t
         }
         sum += y;
         sum64 += (double)y;
+        abs64 += fabs((double)y);
         for (uint32_t t = 0; t < n_taps; ++t)
             if (tap_voices[t] == i) taps[(size_t)t * tap_stride + frame] = y;
     }
     b->last_bus_f64[frame % OO_MAX_BLOCK] = sum64;
+    b->last_abs_f64[frame % OO_MAX_BLOCK] = abs64;
     if (b->kind == OO_BANK_EPIANO) {
         b->tremolo.input = sum;
         b->tremolo.depth = bank_param(b, 6);
@@ -1899,6 +1902,7 @@ void oo_bank_process_per_sample(oo_bank *b, uint32_t frames, float *out_bus, con
 }
 
 const double *oo_bank_last_bus_f64(const oo_bank *b) { return b->last_bus_f64; }
+const double *oo_bank_last_abs_f64(const oo_bank *b) { return b->last_abs_f64; }
 
 /* ======================================================================== */
 /* bench graphs  oscen-lib/benches/static_vs_runtime.rs:5-66                 */
@@ -2017,4 +2021,16 @@ void oo_note_plan_for_voice(uint64_t seed, uint32_t voice, oo_note_plan *p)
     p->off_frame = 12000u + (uint32_t)(splitmix64(&s) % 24001);   /* U[12000,36000] */
     p->retrig_frame = 36001u + (uint32_t)(splitmix64(&s) % 8000); /* U[36001,44000] */
     p->frequency = oo_midi_note_to_freq(p->note);
+}
+
+/* The same plan folded into a shorter window: every frame scaled by span / 48000 (integer
+ * arithmetic), so that a run of `span` < 48000 frames still sees note-off and retrigger.
+ * span == 0 or >= 48000: the plan as is. */
+void oo_note_plan_scaled(uint64_t seed, uint32_t voice, uint32_t span, oo_note_plan *p)
+{
+    oo_note_plan_for_voice(seed, voice, p);
+    if (span == 0 || span >= 48000u) return;
+    p->on_frame = (uint32_t)((uint64_t)p->on_frame * span / 48000u);
+    p->off_frame = (uint32_t)((uint64_t)p->off_frame * span / 48000u);
+    p->retrig_frame = (uint32_t)((uint64_t)p->retrig_frame * span / 48000u);
 }

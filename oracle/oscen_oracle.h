@@ -341,9 +341,15 @@ void oo_bank_process_per_sample(oo_bank *b, uint32_t frames, float *out_bus,
                                 const uint32_t *tap_voices, uint32_t n_taps, float *taps);
 /* f64 sum of the per-voice outputs of the last block, [frames] (bus-parity aid) */
 const double *oo_bank_last_bus_f64(const oo_bank *b);
+/* f64 sum of |per-voice output| of the last block, [frames] (scale of the bus-sum tolerance) */
+const double *oo_bank_last_abs_f64(const oo_bank *b);
 /* multi-threaded render for the CPU baseline: voices partitioned statically */
 double oo_bank_bench(int kind, uint32_t n_voices, uint32_t frames_total, uint32_t block,
                      uint32_t n_threads, uint64_t seed, double *checksum);
+/* the same with each thread's voices run as sub-banks of `group` voices (8 = the reference's
+ * `[FMVoice; 8]` graph, cache-resident) and the note plans folded into `span` frames */
+double oo_bank_bench_grouped(int kind, uint32_t n_voices, uint32_t frames_total, uint32_t block,
+                             uint32_t n_threads, uint32_t group, uint64_t seed, uint32_t span, double *checksum);
 
 /* bench graphs  oscen-lib/benches/static_vs_runtime.rs:5-66 */
 typedef struct { oo_oscillator osc; oo_tpt filter; oo_gain gain; } oo_static_simple;
@@ -373,6 +379,17 @@ typedef struct {
     float frequency;
 } oo_note_plan;
 void oo_note_plan_for_voice(uint64_t seed, uint32_t voice, oo_note_plan *p);
+/* the same plan with every frame scaled by span / 48000 (span == 0 or >= 48000: unchanged) */
+void oo_note_plan_scaled(uint64_t seed, uint32_t voice, uint32_t span, oo_note_plan *p);
+/* Multi-threaded render of voices [first_voice, first_voice + n_voices) over their (scaled) note plans.
+ * Each thread walks its contiguous voice range in sub-banks of `group` voices (0 = one sub-bank per
+ * thread), every sub-bank rendered block by block over the whole timeline before the next one starts
+ * (group = 8 is the reference's own shape: `[FMVoice; 8]` per graph, examples/fm-synth/src/lib.rs:68-73).
+ * mono64 / abs64 (optional, [frames_total]): f64 sums over all voices of the per-voice output and of its
+ * magnitude (pre-Tremolo for the e-piano).  Returns the wall time in seconds. */
+double oo_bank_render_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint32_t frames_total, uint32_t block,
+                         uint32_t n_threads, uint32_t group, uint64_t seed, uint32_t span, double *mono64,
+                         double *abs64);
 
 #ifdef __cplusplus
 }

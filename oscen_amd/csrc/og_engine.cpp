@@ -95,6 +95,19 @@ __global__ __launch_bounds__(512) void og_bus_tremolo(const float* __restrict__ 
     }
 }
 
+// Incremental event path: point the listed voices at their freshly appended timeline segments.
+// upd = n x {voice, cursor, end}
+__global__ void og_apply_event_updates(const uint32_t* __restrict__ upd, uint32_t n, uint32_t* __restrict__ cursor,
+                                       uint32_t* __restrict__ end)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t v = upd[3 * i];
+        cursor[v] = upd[3 * i + 1];
+        end[v] = upd[3 * i + 2];
+    }
+}
+
 // ---- registry ---------------------------------------------------------------
 OgKernelEntry*& og_kernel_registry_head()
 {
@@ -163,17 +176,18 @@ struct Ramp { // ValueRampState  oscen-lib/src/graph/types.rs:300-373
     }
 };
 
-struct HostEvent {
+struct HostEvent { // a push that has not reached the device timeline yet
     uint32_t voice;
     uint64_t frame;
     uint32_t target;
     float value;
     uint64_t seq;
     bool block_local; // pushed relative to the next block (reference try_push semantics)
-    bool uploaded;
 };
 
 constexpr int RAMP_RING = 8;
+constexpr int EV_RING = 8;              // pinned staging buffers of the incremental event path
+constexpr size_t EV_STAGE_EVENTS = 32768; // events (and voice updates) one staging buffer holds
 
 } // namespace
 
@@ -222,11 +236,29 @@ struct og_engine {
     uint32_t n_taps = 0;
     uint32_t last_frames = 0;
 
-    std::vector<HostEvent> pending;
+    // ---- event timeline ---------------------------------------------------------------------------
+    // Device: d_events holds every voice's unconsumed events as one segment [cursor, end), sorted by
+    // (frame, push order).  A full rebuild lays the segments out in voice order (CSR) and uploads
+    // O(V) words; the incremental path (live pushes: og_push_voice_event / MIDI) appends a new segment
+    // for each voice that received events -- its unconsumed old events merged with the new ones -- at the
+    // tail of d_events and repoints that voice's (cursor, end) with a tiny kernel: O(#pushes) host work,
+    // one async copy from a pinned staging ring, no stream synchronisation.
+    std::vector<HostEvent> pending;      // pushes not yet on the device timeline
+    std::vector<OgEvent> h_events;       // host mirror of d_events[0, ev_tail)
+    std::vector<uint32_t> seg_begin, seg_end; // per voice: its current segment (empty vectors = all segments empty)
+    size_t ev_tail = 0;                  // bump pointer into d_events
+    bool ev_rebuild = false;             // next block must rebuild the whole timeline
+    OgEvent* h_stage_ev[EV_RING] = {};   // pinned
+    uint32_t* h_stage_upd[EV_RING] = {}; // pinned, n x {voice, cursor, end}
+    uint32_t* d_stage_upd[EV_RING] = {};
+    hipEvent_t stage_done[EV_RING] = {};
+    bool stage_used[EV_RING] = {};
+    int stage_head = 0;
+    uint64_t n_full_rebuilds = 0, n_incremental = 0;
     size_t n_block_local = 0; // events pushed with try_push semantics for the next block
     std::unordered_map<uint64_t, uint32_t> local_count; // (voice, target) -> events queued for the next block
-    bool ev_dirty = true;
     uint64_t seq = 0;
+    uint32_t bus_passes = 0; // og_bus_reduce launches of the last block (1 + levels of the multi-pass tree)
     uint64_t frame_now = 0;
     uint64_t dropped = 0;
 
@@ -255,6 +287,12 @@ struct og_engine {
             (void)hipFree(d_ramp[i]);
             if (h_ramp[i]) (void)hipHostFree(h_ramp[i]);
             if (ramp_ev[i]) (void)hipEventDestroy(ramp_ev[i]);
+        }
+        for (int i = 0; i < EV_RING; ++i) {
+            if (h_stage_ev[i]) (void)hipHostFree(h_stage_ev[i]);
+            if (h_stage_upd[i]) (void)hipHostFree(h_stage_upd[i]);
+            (void)hipFree(d_stage_upd[i]);
+            if (stage_done[i]) (void)hipEventDestroy(stage_done[i]);
         }
         for (auto ev : t_start) (void)hipEventDestroy(ev);
         for (auto ev : t_stop) (void)hipEventDestroy(ev);
@@ -303,63 +341,182 @@ struct og_engine {
         return n;
     }
 
-    void rebuild_events()
+    void reset_timeline()
     {
-        // drop what earlier blocks already consumed
-        pending.erase(std::remove_if(pending.begin(), pending.end(),
-                                     [&](const HostEvent& h) { return h.uploaded && h.frame < frame_now; }),
-                      pending.end());
-        std::stable_sort(pending.begin(), pending.end(), [](const HostEvent& a, const HostEvent& b) {
-            if (a.voice != b.voice) return a.voice < b.voice;
-            if (a.frame != b.frame) return a.frame < b.frame;
-            return a.seq < b.seq;
-        });
-        const size_t n = pending.size();
-        if (n > ev_cap) {
-            if (d_events) HIPCK(hipFree(d_events));
-            ev_cap = std::max<size_t>(n * 2, 1024);
-            HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
-        }
-        std::vector<OgEvent> evs(n);
-        std::vector<uint32_t> cursor(V), end(V);
-        size_t i = 0;
-        for (uint32_t v = 0; v < V; ++v) {
-            cursor[v] = (uint32_t)i;
-            while (i < n && pending[i].voice == v) {
-                evs[i] = OgEvent{pending[i].frame, pending[i].target, pending[i].value};
-                pending[i].uploaded = true;
-                ++i;
-            }
-            end[v] = (uint32_t)i;
-        }
-        if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
-        HIPCK(hipMemcpyAsync(d_ev_cursor, cursor.data(), V * 4, hipMemcpyHostToDevice, stream));
-        HIPCK(hipMemcpyAsync(d_ev_end, end.data(), V * 4, hipMemcpyHostToDevice, stream));
-        HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
-        ev_dirty = false;
-    }
-
-    // reference: a try_push'ed event whose frame_offset >= frames is never delivered (the queues are
-    // cleared at the end of the block)
-    void drop_block_local(uint64_t lim)
-    {
-        if (n_block_local == 0) return; // (a counter: scanning a resident 200 000-event timeline per block cost 30 us)
-        size_t before = pending.size();
-        pending.erase(std::remove_if(pending.begin(), pending.end(),
-                                     [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
-                      pending.end());
-        if (pending.size() != before) ev_dirty = true;
-        dropped += before - pending.size();
-        for (auto& h : pending) h.block_local = false;
+        pending.clear();
+        h_events.clear();
+        seg_begin.clear();
+        seg_end.clear();
+        ev_tail = 0;
+        ev_rebuild = false;
         n_block_local = 0;
         local_count.clear();
+        HIPCK(hipMemsetAsync(d_ev_cursor, 0, (size_t)V * 4, stream));
+        HIPCK(hipMemsetAsync(d_ev_end, 0, (size_t)V * 4, stream));
+    }
+
+    // unconsumed events of voice v on the device timeline (a block consumes everything before its end)
+    void old_events(uint32_t v, std::vector<OgEvent>& out) const
+    {
+        if (seg_begin.empty()) return;
+        for (uint32_t i = seg_begin[v]; i < seg_end[v]; ++i)
+            if (h_events[i].frame >= frame_now) out.push_back(h_events[i]);
+    }
+
+    static bool push_order(const HostEvent& a, const HostEvent& b)
+    {
+        if (a.voice != b.voice) return a.voice < b.voice;
+        if (a.frame != b.frame) return a.frame < b.frame;
+        return a.seq < b.seq;
+    }
+
+    // old (already on the device) before new on equal frames: the old ones were pushed earlier
+    static void merge_by_frame(const std::vector<OgEvent>& old, const HostEvent* nb, const HostEvent* ne,
+                               std::vector<OgEvent>& out)
+    {
+        size_t i = 0;
+        while (i < old.size() || nb != ne) {
+            if (nb == ne || (i < old.size() && old[i].frame <= nb->frame)) {
+                out.push_back(old[i++]);
+            } else {
+                out.push_back(OgEvent{nb->frame, nb->target, nb->value});
+                ++nb;
+            }
+        }
+    }
+
+    void full_rebuild()
+    {
+        std::stable_sort(pending.begin(), pending.end(), push_order);
+        std::vector<OgEvent> evs;
+        std::vector<uint32_t> cursor(V), end(V);
+        std::vector<OgEvent> old;
+        size_t p = 0;
+        const size_t np = pending.size();
+        const bool had = !seg_begin.empty();
+        evs.reserve(np + (had ? h_events.size() : 0));
+        for (uint32_t v = 0; v < V; ++v) {
+            cursor[v] = (uint32_t)evs.size();
+            size_t q = p;
+            while (q < np && pending[q].voice == v) ++q;
+            if (had && seg_begin[v] != seg_end[v]) {
+                old.clear();
+                old_events(v, old);
+                merge_by_frame(old, pending.data() + p, pending.data() + q, evs);
+            } else {
+                for (size_t i = p; i < q; ++i) evs.push_back(OgEvent{pending[i].frame, pending[i].target, pending[i].value});
+            }
+            p = q;
+            end[v] = (uint32_t)evs.size();
+        }
+        const size_t n = evs.size();
+        if (n > 0xFFFFFFF0ull) throw std::runtime_error("event timeline too long");
+        if (n + EV_STAGE_EVENTS > ev_cap) {
+            if (d_events) HIPCK(hipFree(d_events));
+            d_events = nullptr;
+            ev_cap = std::max<size_t>(n + n / 2, 1024) + 8 * EV_STAGE_EVENTS; // head-room for appended segments
+            HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
+        }
+        if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
+        HIPCK(hipMemcpyAsync(d_ev_cursor, cursor.data(), (size_t)V * 4, hipMemcpyHostToDevice, stream));
+        HIPCK(hipMemcpyAsync(d_ev_end, end.data(), (size_t)V * 4, hipMemcpyHostToDevice, stream));
+        HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
+        h_events.swap(evs);
+        seg_begin.swap(cursor);
+        seg_end.swap(end);
+        ev_tail = n;
+        pending.clear();
+        ev_rebuild = false;
+        n_full_rebuilds += 1;
+    }
+
+    // live pushes: O(#pushes) host work, asynchronous upload.  Returns false when the batch does not fit
+    // (staging buffer, tail of d_events): the caller falls back to full_rebuild().
+    bool incremental_update()
+    {
+        if (pending.size() > EV_STAGE_EVENTS) return false;
+        if (!h_stage_ev[0]) {
+            for (int i = 0; i < EV_RING; ++i) {
+                HIPCK(hipHostMalloc((void**)&h_stage_ev[i], EV_STAGE_EVENTS * sizeof(OgEvent), hipHostMallocDefault));
+                HIPCK(hipHostMalloc((void**)&h_stage_upd[i], EV_STAGE_EVENTS * 3 * 4, hipHostMallocDefault));
+                HIPCK(hipMalloc(&d_stage_upd[i], EV_STAGE_EVENTS * 3 * 4));
+                HIPCK(hipEventCreateWithFlags(&stage_done[i], hipEventDisableTiming));
+            }
+        }
+        if (seg_begin.empty()) {
+            seg_begin.assign(V, 0);
+            seg_end.assign(V, 0);
+        }
+        std::stable_sort(pending.begin(), pending.end(), push_order);
+        const int r = stage_head;
+        if (stage_used[r]) HIPCK(hipEventSynchronize(stage_done[r])); // (EV_RING blocks ago: long done)
+        OgEvent* sev = h_stage_ev[r];
+        uint32_t* upd = h_stage_upd[r];
+        std::vector<OgEvent> old, merged;
+        size_t n_ev = 0, n_upd = 0;
+        const size_t np = pending.size();
+        for (size_t p = 0; p < np;) {
+            const uint32_t v = pending[p].voice;
+            size_t q = p;
+            while (q < np && pending[q].voice == v) ++q;
+            old.clear();
+            merged.clear();
+            old_events(v, old);
+            merge_by_frame(old, pending.data() + p, pending.data() + q, merged);
+            if (n_ev + merged.size() > EV_STAGE_EVENTS || ev_tail + n_ev + merged.size() > ev_cap) return false;
+            memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
+            upd[3 * n_upd] = v;
+            upd[3 * n_upd + 1] = (uint32_t)(ev_tail + n_ev);
+            upd[3 * n_upd + 2] = (uint32_t)(ev_tail + n_ev + merged.size());
+            n_ev += merged.size();
+            n_upd += 1;
+            p = q;
+        }
+        // commit: host mirror, then the device
+        h_events.resize(ev_tail + n_ev);
+        memcpy(h_events.data() + ev_tail, sev, n_ev * sizeof(OgEvent));
+        for (size_t i = 0; i < n_upd; ++i) {
+            seg_begin[upd[3 * i]] = upd[3 * i + 1];
+            seg_end[upd[3 * i]] = upd[3 * i + 2];
+        }
+        if (n_ev) HIPCK(hipMemcpyAsync(d_events + ev_tail, sev, n_ev * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
+        HIPCK(hipMemcpyAsync(d_stage_upd[r], upd, n_upd * 3 * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(og_apply_event_updates, dim3((uint32_t)((n_upd + 255) / 256)), dim3(256), 0, stream, d_stage_upd[r],
+                           (uint32_t)n_upd, d_ev_cursor, d_ev_end);
+        HIPCK(hipEventRecord(stage_done[r], stream));
+        stage_used[r] = true;
+        stage_head = (stage_head + 1) % EV_RING;
+        ev_tail += n_ev;
+        pending.clear();
+        n_incremental += 1;
+        return true;
+    }
+
+    // bring the device timeline up to date before a block of `frames` frames
+    void sync_events(uint32_t frames)
+    {
+        // reference: a try_push'ed event whose frame_offset >= frames is never delivered (the queues are
+        // cleared at the end of the block)
+        if (n_block_local) {
+            const uint64_t lim = frame_now + frames;
+            const size_t before = pending.size();
+            pending.erase(std::remove_if(pending.begin(), pending.end(),
+                                         [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
+                          pending.end());
+            dropped += before - pending.size();
+            n_block_local = 0;
+            local_count.clear();
+        }
+        if (pending.empty() && !ev_rebuild) return;
+        // many voices touched at once (bulk scheduling): one compact CSR rebuild beats per-voice segments
+        const bool bulk = ev_rebuild || pending.size() > EV_STAGE_EVENTS || pending.size() > (size_t)V / 2 + 64 || !d_events;
+        if (bulk || !incremental_update()) full_rebuild();
     }
 
     void process_async(uint32_t frames, float* d_out)
     {
         HIPCK(hipSetDevice(device));
-        drop_block_local(frame_now + frames);
-        if (ev_dirty) rebuild_events();
+        sync_events(frames);
 
         OgBlockArgs A;
         memset(&A, 0, sizeof A);
@@ -435,7 +592,9 @@ struct og_engine {
             const float* src = d_partials;
             uint32_t rows = n_wg;
             float* tmp = d_partials2;
+            bus_passes = 1;
             while (rows > OG_RED_GROUP) {
+                bus_passes += 1;
                 const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
                 hipLaunchKernelGGL(og_bus_reduce, dim3((frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0, stream, src, rows,
                                    frames, tmp);
@@ -510,9 +669,9 @@ int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, flo
             return set_err(OG_E_OVERFLOW, "event queue full (32 per voice per input per block): event dropped");
         }
     }
-    e->pending.push_back(HostEvent{voice, frame, target, value, e->seq++, local, false});
+    // (an event scheduled in the past fires on the first frame of the next block, like a late event on the device)
+    e->pending.push_back(HostEvent{voice, std::max(frame, e->frame_now), target, value, e->seq++, local});
     if (local) e->n_block_local += 1;
-    e->ev_dirty = true;
     return OG_OK;
 }
 
@@ -757,6 +916,8 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         }
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
+        HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
+        HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
         HIPCK(hipMalloc(&e->d_partials2, ((size_t)e->n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK * 4));
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
@@ -785,10 +946,7 @@ int og_init(og_engine* e, float sample_rate)
         HIPCK(hipSetDevice(e->device));
         e->sr = sample_rate;
         e->upload_initial_state();
-        e->pending.clear();
-        e->n_block_local = 0;
-        e->local_count.clear();
-        e->ev_dirty = true;
+        e->reset_timeline();
         e->frame_now = 0;
         e->inited = true;
         return OG_OK;
@@ -900,6 +1058,24 @@ int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64
     return push_event(e, input, voice, abs_frame, v, false, true);
 }
 
+int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uint32_t* voices, const uint64_t* abs_frames,
+                             const float* values)
+{
+    if (!e || (n && (!voices || !abs_frames || !values))) return set_err(OG_E_INVALID, "null argument");
+    if (input >= e->cg->inputs.size()) return set_err(OG_E_INVALID, "input index out of range");
+    const auto& in = e->cg->inputs[input];
+    uint32_t target;
+    if (in.decl.kind == ogc::Kind::Event) target = (uint32_t)in.event_index;
+    else if (in.decl.kind == ogc::Kind::Value && in.decl.per_voice) target = OG_EV_SETVALUE | input;
+    else return set_err(OG_E_INVALID, "'" + in.decl.name + "' is neither an event input nor a per-voice value input");
+    for (uint32_t i = 0; i < n; ++i)
+        if (voices[i] >= e->V) return set_err(OG_E_INVALID, "voice index out of range");
+    e->pending.reserve(e->pending.size() + n);
+    for (uint32_t i = 0; i < n; ++i)
+        e->pending.push_back(HostEvent{voices[i], std::max(abs_frames[i], e->frame_now), target, values[i], e->seq++, false});
+    return OG_OK;
+}
+
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
@@ -907,7 +1083,8 @@ int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
     if (frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 0..512");
     return guard([&] {
         if (frames == 0) { // process_block(0): no frame runs; events queued for the block are discarded with it
-            e->drop_block_local(e->frame_now);
+            HIPCK(hipSetDevice(e->device));
+            e->sync_events(0);
             e->last_frames = 0;
             return OG_OK;
         }
@@ -1024,6 +1201,25 @@ uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lp
 int og_uses_split_kernel(const og_engine* e) { return e ? (int)e->split : 0; }
 uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes / (uint32_t)e->cg->lpv : 0; }
 uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
+uint64_t og_kernel_hash(const og_engine* e) { return e ? e->cg->hash : 0; }
+int og_kernel_is_jit(const og_engine* e) { return e ? (e->launch ? 0 : 1) : 0; }
+uint32_t og_bus_reduce_passes(const og_engine* e) { return e ? e->bus_passes : 0; }
+uint32_t og_partial_rows(const og_engine* e) { return e ? e->n_wg : 0; }
+const char* og_kernel_name(const og_engine* e)
+{
+    static thread_local char buf[64];
+    if (!e) return "";
+    snprintf(buf, sizeof buf, "og_k%s_%016llx", e->split == 4 ? "4" : (e->split == 2 ? "2" : ""), (unsigned long long)e->cg->hash);
+    return buf;
+}
+int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* incremental_updates, uint64_t* resident_events)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (full_rebuilds) *full_rebuilds = e->n_full_rebuilds;
+    if (incremental_updates) *incremental_updates = e->n_incremental;
+    if (resident_events) *resident_events = (uint64_t)e->ev_tail;
+    return OG_OK;
+}
 
 int og_enable_kernel_timing(og_engine* e, int on)
 {

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -28,6 +30,18 @@ struct og_midi {
     };
     std::vector<Voice> voices;
     uint32_t current_age = 0;
+    // The reference scans all voices per note (24 of them).  With N = the bank size the same decisions come from
+    // three indexes, O(log N) per note:
+    //  * voices become active in index order and never turn inactive again (release keeps `active`,
+    //    voice_allocator.rs:101-108), so "first inactive voice" is a counter;
+    //  * stealing = min over (released ? 0 : 1, age): ages are unique, so one age-ordered map per release state;
+    //  * find_voice_for_note = lowest index among the held voices playing that note: an ordered set per note.
+    uint32_t n_fresh = 0;                       // voices [0, n_fresh) are active
+    std::map<uint32_t, uint32_t> released_by_age, held_by_age; // age -> voice
+    std::set<uint32_t> held_by_note[256];
+    // `midi_in` is an ArrayVec<EventInstance, 32> (graph/types.rs:18) in front of MAX_VOICES = 24 voices; the capacity
+    // is lifted with N in the same proportion (32 per 24 voices); og_midi_set_queue_capacity overrides it
+    uint32_t queue_cap = 32;
     struct Msg {
         uint8_t bytes[3];
         uint32_t len, frame;
@@ -35,6 +49,7 @@ struct og_midi {
     };
     std::vector<Msg> queue;
     uint64_t seq = 0;
+    uint64_t dropped = 0;
     struct Out { // what reached the voices (log for detached use / tests)
         uint32_t voice, frame;
         float frequency, gate;
@@ -42,42 +57,60 @@ struct og_midi {
     };
     std::deque<Out> log;
 
+    void unindex(uint32_t i)
+    {
+        Voice& v = voices[i];
+        if (!v.active) return;
+        (v.released ? released_by_age : held_by_age).erase(v.age);
+        if (!v.released && v.note >= 0) held_by_note[v.note & 255].erase(i);
+    }
     // allocate_voice  voice_allocator.rs:57-89
     uint32_t allocate(uint8_t note)
     {
-        for (uint32_t i = 0; i < n; ++i)
-            if (!voices[i].active) return take(i, note);
-        uint32_t best = 0;
-        for (uint32_t i = 1; i < n; ++i) { // min_by_key((released ? 0 : 1, age)), first minimum wins
-            const int pa = voices[i].released ? 0 : 1, pb = voices[best].released ? 0 : 1;
-            if (pa < pb || (pa == pb && voices[i].age < voices[best].age)) best = i;
+        uint32_t i;
+        if (n_fresh < n) {
+            i = n_fresh++;
+        } else if (!released_by_age.empty()) {
+            i = released_by_age.begin()->second; // released voices first, oldest of them
+        } else {
+            i = held_by_age.begin()->second;     // all held: the oldest
         }
-        return take(best, note);
-    }
-    uint32_t take(uint32_t i, uint8_t note)
-    {
-        voices[i].active = true;
-        voices[i].released = false;
-        voices[i].note = note;
-        voices[i].age = current_age++;
+        unindex(i);
+        Voice& v = voices[i];
+        v.active = true;
+        v.released = false;
+        v.note = note;
+        v.age = current_age++;
+        held_by_age[v.age] = i;
+        held_by_note[note & 255].insert(i);
         return i;
     }
     int find(uint8_t note) const // find_voice_for_note :92-98
     {
-        for (uint32_t i = 0; i < n; ++i)
-            if (voices[i].active && !voices[i].released && voices[i].note == (int)note) return (int)i;
-        return -1;
+        const auto& s = held_by_note[note & 255];
+        return s.empty() ? -1 : (int)*s.begin();
+    }
+    void release(uint32_t i) // release_voice :101-108
+    {
+        unindex(i);
+        voices[i].released = true;
+        voices[i].note = -1;
+        released_by_age[voices[i].age] = i;
     }
     static float note_to_freq(uint8_t note) // midi.rs:69-72
     {
         const float semitone_offset = (float)note - 69.0f;
         return 440.0f * powf(2.0f, semitone_offset / 12.0f);
     }
+    int last_rc = OG_OK; // first engine error of the current flush (e.g. OG_E_OVERFLOW: 33rd gate of a voice in one block)
     void emit(uint32_t voice, uint32_t frame, bool has_f, float f, float gate)
     {
         if (engine) {
-            if (has_f) og_push_voice_value(engine, (uint32_t)freq_input, voice, frame, f);
-            og_push_voice_event(engine, (uint32_t)gate_input, voice, frame, gate);
+            int rc = OG_OK;
+            if (has_f) rc = og_push_voice_value(engine, (uint32_t)freq_input, voice, frame, f);
+            const int rc2 = og_push_voice_event(engine, (uint32_t)gate_input, voice, frame, gate);
+            if (rc == OG_OK) rc = rc2;
+            if (rc != OG_OK && last_rc == OG_OK) last_rc = rc;
         } else {
             log.push_back(Out{voice, frame, f, gate, has_f ? 1 : 0});
             if (log.size() > 65536) log.pop_front();
@@ -102,15 +135,23 @@ struct og_midi {
                     emit((uint32_t)i, m.frame, false, 0.0f, 0.0f);
                     voices[i].handler_note = -1;
                 }
-                voices[i].released = true; // release_voice :101-108
-                voices[i].note = -1;
+                release((uint32_t)i);
             }
         }
     }
-    void flush()
+    // frames: length of the block the messages are for.  A `midi_in` event whose frame_offset >= frames never
+    // reaches the parser (the generated loop only visits frames < frames and the queue is cleared with the
+    // block, codegen/mod.rs:782-871), so it must not touch the allocator either.
+    void flush(uint32_t frames = 0xFFFFFFFFu)
     {
         std::stable_sort(queue.begin(), queue.end(), [](const Msg& a, const Msg& b) { return a.frame < b.frame; });
-        for (const Msg& m : queue) apply(m);
+        for (const Msg& m : queue) {
+            if (m.frame >= frames) {
+                dropped += 1;
+                continue;
+            }
+            apply(m);
+        }
         queue.clear();
     }
 };
@@ -138,6 +179,7 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
         return OG_E_INVALID;
     }
     m->voices.resize(m->n);
+    m->queue_cap = 32u * ((m->n + 23u) / 24u);
     *out = m;
     return OG_OK;
 }
@@ -153,22 +195,49 @@ int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_
     memcpy(msg.bytes, bytes, msg.len);
     msg.frame = frame_offset;
     msg.seq = m->seq++;
+    if (m->queue.size() >= m->queue_cap) { // try_push on a full ArrayVec: Err, the event is dropped
+        m->dropped += 1;
+        return OG_E_OVERFLOW;
+    }
     m->queue.push_back(msg);
     return OG_OK;
 }
 
+int og_midi_send_batch(og_midi* m, const uint8_t* bytes3, const uint32_t* frame_offsets, uint32_t n)
+{
+    if (!m || (n && (!bytes3 || !frame_offsets))) return OG_E_INVALID;
+    int rc = OG_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int r = og_midi_send(m, bytes3 + 3 * (size_t)i, 3, frame_offsets[i]);
+        if (r != OG_OK && rc == OG_OK) rc = r;
+    }
+    return rc;
+}
+
+int og_midi_set_queue_capacity(og_midi* m, uint32_t capacity)
+{
+    if (!m || capacity == 0) return OG_E_INVALID;
+    m->queue_cap = capacity;
+    return OG_OK;
+}
+
+uint64_t og_midi_dropped(const og_midi* m) { return m ? m->dropped : 0; }
+
 int og_midi_flush(og_midi* m)
 {
     if (!m) return OG_E_INVALID;
+    m->last_rc = OG_OK;
     m->flush();
-    return OG_OK;
+    return m->last_rc;
 }
 
 int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus)
 {
     if (!m || !m->engine) return OG_E_INVALID;
-    m->flush();
-    return og_process_block(m->engine, frames, out_bus);
+    m->last_rc = OG_OK;
+    m->flush(frames);
+    const int rc = og_process_block(m->engine, frames, out_bus);
+    return rc != OG_OK ? rc : m->last_rc; // the block was rendered; a non-zero code reports a dropped event
 }
 
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age)

@@ -9,9 +9,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 94 --warmup 4 --no-cpu-baseline $EXTRA"
+CMD="python $ROOT/bench.py --no-cpu-baseline $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
-for pmc in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_TRANS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
+PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE")
+[ -n "${PROF_FULL:-}" ] && PASSES+=("SQ_INSTS_VALU_TRANS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES")
+for pmc in "${PASSES[@]}"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $pmc -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
 done

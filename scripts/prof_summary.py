@@ -8,7 +8,7 @@ FR = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 GRAPH = sys.argv[4] if len(sys.argv) > 4 else "fm_voice"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-cmd = "python bench.py --steps 94 --warmup 4 --no-cpu-baseline"
+cmd = "python bench.py --no-cpu-baseline"
 if GRAPH != "fm_voice":
     cmd += " --graph " + GRAPH
 if V != 65536:
@@ -17,6 +17,14 @@ out = {"tag": tag, "command": cmd, "graph": GRAPH, "voices": V, "frames": FR}
 con = sqlite3.connect(os.path.join(base, "stats", "stats_results.db"))
 out["kernel_stats"] = [dict(name=r[0], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])
                        for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6")]
+# the voice kernel's name carries the hash of its generated body: og_k_<hash>_<variant>, og_k2_<hash>_..., og_k4_...
+import re
+for k in out["kernel_stats"]:
+    m = re.match(r"og_k[0-9a-z]*_([0-9a-f]{16})_", k["name"])
+    if m:
+        out["kernel_hash"] = m.group(1)
+        out["kernel_name"] = k["name"]
+        break
 pmc = {}
 for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
     c = sqlite3.connect(db)
@@ -27,7 +35,8 @@ for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
                          "workgroup_size, grid_size from counters_collection where kernel_name like 'og_k_%' limit 1"):
         out["dispatch"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "workgroup", "grid"], row))
 out["pmc_voice_kernel"] = pmc
-waves = (V + 63) // 64
+LPV = {"epiano_voice": 32}.get(GRAPH, 1)
+waves = (V * LPV + 63) // 64
 d = {}
 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
     if k in pmc:

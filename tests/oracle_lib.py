@@ -130,6 +130,11 @@ class LinearUp(C.Structure):
     _fields_ = [("prev", C.c_float), ("factor", C.c_uint32)]
 
 
+class Tremolo(C.Structure):
+    _fields_ = [("input", C.c_float), ("rate", C.c_float), ("depth", C.c_float), ("output", C.c_float * 2),
+                ("phase", C.c_float), ("sample_rate", C.c_float)]
+
+
 class StaticSimple(C.Structure):
     _fields_ = [("osc", Oscillator), ("filter", Tpt), ("gain", Gain)]
 
@@ -202,6 +207,17 @@ def load():
     lib.oo_bank_bench.restype = C.c_double
     lib.oo_bank_bench.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                   C.POINTER(C.c_double)]
+    lib.oo_bank_bench_grouped.restype = C.c_double
+    lib.oo_bank_bench_grouped.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+    lib.oo_bank_render_mt.restype = C.c_double
+    lib.oo_bank_render_mt.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.oo_bank_last_abs_f64.argtypes = [C.c_void_p]
+    lib.oo_bank_last_abs_f64.restype = C.POINTER(C.c_double)
+    lib.oo_note_plan_scaled.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(NotePlan)]
+    lib.oo_tremolo_new.argtypes = [C.c_void_p]
+    lib.oo_tremolo_process.argtypes = [C.c_void_p]
     lib.oo_midi_note_to_freq.restype = C.c_float
     lib.oo_midi_note_to_freq.argtypes = [C.c_uint8]
     lib.oo_midi_velocity_to_gate.restype = C.c_float
@@ -300,6 +316,33 @@ class Bank:
     def last_bus_f64(self, frames):
         p = self.lib.oo_bank_last_bus_f64(self.h)
         return np.array([p[i] for i in range(frames)], dtype=np.float64)
+
+
+def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None, group=8, seed=0x05CE2026, span=0):
+    """Multi-threaded oracle render of a voice range over its (scaled) note plans:
+    (mono f64 sum [frames], sum of |voice output| [frames], seconds)."""
+    lib = load()
+    threads = threads or (os.cpu_count() or 1)
+    mono = np.zeros(frames_total, dtype=np.float64)
+    ab = np.zeros(frames_total, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    t = lib.oo_bank_render_mt(kind, first_voice, n_voices, frames_total, block, threads, group, seed, span,
+                              mono.ctypes.data_as(dp), ab.ctypes.data_as(dp))
+    return mono, ab, t
+
+
+def tremolo_pan(frames, rate, depth, sample_rate=48000.0):
+    """[frames, 2] = the Tremolo's (pan, 1 - pan) sequence from a fresh node (input 1.0: 1*pan is exact)."""
+    lib = load()
+    t = Tremolo()
+    lib.oo_tremolo_new(C.byref(t))
+    t.sample_rate = sample_rate
+    out = np.zeros((frames, 2), dtype=np.float32)
+    for f in range(frames):
+        t.input, t.rate, t.depth = 1.0, rate, depth
+        lib.oo_tremolo_process(C.byref(t))
+        out[f] = (t.output[0], t.output[1])
+    return out
 
 
 def note_plan(seed, voice):

@@ -213,3 +213,23 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     ep = oscen_amd.Graph(builtin="epiano_voice").kernel_source()
     assert "og::ep_bank_tick<TAPS>(" in ep and "og::bus_put<TAPS, !TAPS>" in ep
     assert "og::ep_bank_update(" in ep[ep.index("auto derive"):ep.index("auto tick")]
+
+
+def test_folded_note_plans_match_the_oracle_generator():
+    """oscen_amd.note_plans(span=...) (numpy) == oo_note_plan_scaled (C): the GPU bank and the CPU oracle
+    must see the same synthetic note streams at every window length."""
+    import ctypes as C
+
+    import oscen_amd
+    from tests import oracle_lib as ol
+
+    lib = ol.load()
+    for span in (0, 512, 1024, 6400, 47999, 48000, 50176):
+        plans = oscen_amd.note_plans(300, first_voice=65500, span=span)
+        for i in range(300):
+            p = ol.NotePlan()
+            lib.oo_note_plan_scaled(oscen_amd.SYNTH_SEED, 65500 + i, span, C.byref(p))
+            assert (p.on_frame, p.off_frame, p.retrig_frame) == (
+                int(plans["on_frame"][i]), int(plans["off_frame"][i]), int(plans["retrig_frame"][i]))
+            assert p.on_frame < p.off_frame < p.retrig_frame
+            assert abs(p.frequency - float(plans["frequency"][i])) <= 1e-4 * p.frequency

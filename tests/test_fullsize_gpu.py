@@ -1,0 +1,146 @@
+"""Full-size GPU parity at the sizes BASELINE.json names (configs 3, 4 (per-GPU shard), 5, plus 1 M voices):
+the code these banks actually run -- the ordinary kernel at >= 2 waves per SIMD and the MULTI-PASS bus
+reduction (more than 1024 partial rows) -- against the CPU oracle.
+
+Per configuration:
+  * >= 64 sampled voices vs the oracle, |a - b| <= 1e-5 * max(1, |ref|) per sample (voices are independent
+    and note streams are keyed by global voice id, so a sampled voice is compared with the same voice in a
+    small oracle bank);
+  * the WHOLE mix bus vs the oracle's f64 sum over every voice (multi-threaded oracle render), tolerance
+    scaled by sum |x_i| (the reference's sequential f32 fold, emit_node.rs:463-466, and the GPU's fixed
+    tree differ by re-association only);
+  * block 256 == block 512, bit for bit;
+  * the kernel variant the engine picks == the ordinary kernel == the two-wave pipeline, bit for bit;
+  * the multi-pass reduce really ran (og_bus_reduce_passes > 1).
+Note plans are folded into the rendered window (oscen_amd.note_plans(span=...)), so note-on, note-off in
+attack/decay and retrigger-from-release all happen inside it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+TOL = 1e-5
+
+CASES = [
+    # graph, oracle bank, voices, frames
+    ("fm_voice", ol.BANK_FM, 262144, 1024),       # config 4's per-GPU shard / config 3b size
+    ("epiano_voice", ol.BANK_EPIANO, 262144, 512),  # config 3
+    ("sat4x_voice", ol.BANK_SAT4X, 131072, 512),  # config 5
+    ("fm_voice", ol.BANK_FM, 1048576, 512),       # 10^6 voices on one GPU
+]
+
+
+def sample_voices(n, k=96):
+    rng = np.random.default_rng(n)
+    fixed = [0, 63, 64, 65535 % n, 65536 % n, n // 2, n - 65, n - 1]
+    return np.unique(np.concatenate([rng.integers(0, n, k), fixed])).astype(np.uint32)
+
+
+def run_engine(graph, n, total, block, taps, env=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        eng = oscen_amd.Engine(graph, n, sample_rate=SR)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    plans = oscen_amd.note_plans(n, span=total)
+    oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+    eng.set_voice_taps(taps)
+    bus, tp, passes = [], [], 0
+    for _ in range(total // block):
+        bus.append(eng.process_block(block).copy())
+        tp.append(eng.read_voice_taps(block))
+        passes = max(passes, eng.bus_reduce_passes)
+    info = {"depth": eng.pipeline_depth, "passes": passes, "hash": eng.kernel_hash, "stats": eng.event_stats}
+    eng.close()
+    return np.concatenate(bus, axis=0), np.concatenate(tp, axis=1), info
+
+
+def oracle_taps(kind, voices, total, block):
+    """the sampled voices in a small oracle bank fed the same (folded) note plans"""
+    bank = ol.Bank(kind, len(voices), SR)
+    plans = [ol.NotePlan() for _ in voices]
+    lib = ol.load()
+    import ctypes as C
+
+    for i, v in enumerate(voices):
+        lib.oo_note_plan_scaled(oscen_amd.SYNTH_SEED, int(v), total, C.byref(plans[i]))
+        bank.set_voice_frequency(i, plans[i].frequency)
+    out = []
+    gated = kind not in (ol.BANK_SAT4X, ol.BANK_SAT1X)
+    for f0 in range(0, total, block):
+        for i, p in enumerate(plans):
+            if not gated:
+                break
+            vel = float(np.float32(p.velocity) / np.float32(127.0))
+            for fr, val in ((p.on_frame, vel), (p.off_frame, 0.0), (p.retrig_frame, vel)):
+                if f0 <= fr < f0 + block:
+                    bank.push_event(i, fr - f0, ol.EV_GATE, val)
+        _, t = bank.process_block(block, taps=list(range(len(voices))))
+        out.append(t)
+    return np.concatenate(out, axis=1)
+
+
+@pytest.mark.parametrize("graph,kind,n,total", CASES, ids=["fm262144", "epiano262144", "sat4x131072", "fm1048576"])
+def test_full_size_bank_against_the_oracle(graph, kind, n, total):
+    taps = sample_voices(n)
+    bus, tp, info = run_engine(graph, n, total, 256, taps)
+    assert info["passes"] > 1, info  # > 1024 partial rows: the multi-pass tree of og_engine.cpp ran
+    assert info["stats"]["full_rebuilds"] == 1 and info["stats"]["incremental_updates"] == 0, info
+
+    # (1) sampled voices vs the oracle
+    ref = oracle_taps(kind, taps, total, 256)
+    err = np.abs(tp - ref) / np.maximum(1.0, np.abs(ref))
+    assert float(err.max()) <= TOL, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
+    assert np.abs(ref).max() > 1e-3  # the sampled voices do sound
+
+    # (2) the whole bus vs the oracle's f64 sum over all n voices
+    mono, abs_sum, secs = ol.render_mt(kind, 0, n, total, block=256, group=8, seed=oscen_amd.SYNTH_SEED, span=total)
+    if graph == "epiano_voice":  # voices.output -> tremolo.input -> Frame<2> (electric-piano/src/main.rs:88-96)
+        pan = ol.tremolo_pan(total, 5.0, 0.3, SR).astype(np.float64)  # rate 5, vibrato_intensity 0.3 (main.rs:45-46)
+        want = mono[:, None] * pan
+        scale = abs_sum[:, None] * np.ones((1, 2))
+    else:
+        want = mono[:, None]
+        scale = abs_sum[:, None]
+    assert bus.shape == want.shape
+    # f32 tree of n terms against the exact sum: a few ulps of sum|x_i|; plus the per-voice parity errors
+    bound = 2e-6 * scale + 1e-5
+    diff = np.abs(bus.astype(np.float64) - want)
+    assert np.all(diff <= bound), (float((diff / (scale + 1e-30)).max()), float(diff.max()))
+    assert np.abs(want).max() > 1.0
+    print("\n%s %d voices: taps max rel err %.3g, bus max |err|/sum|x| %.3g, oracle %.1f s, kernel %s depth %d, passes %d"
+          % (graph, n, float(err.max()), float((diff / (scale + 1e-30)).max()), secs, info["hash"], info["depth"],
+             info["passes"]))
+
+    # (3) block size does not change results, bit for bit
+    bus512, tp512, _ = run_engine(graph, n, total, 512, taps)
+    assert np.array_equal(tp512, tp)
+    assert np.array_equal(bus512, bus)
+
+
+@pytest.mark.parametrize("graph,n,total", [("fm_voice", 262144, 512), ("fm_voice", 65536, 512), ("sub_voice", 262144, 512)],
+                         ids=["fm262144", "fm65536", "sub262144"])
+def test_every_kernel_variant_is_bit_identical_at_full_size(graph, n, total):
+    """OSCEN_GPU_SPLIT=0 (ordinary kernel), =2 (two-wave pipeline) and the engine's own pick give the same bits."""
+    taps = sample_voices(n, 32)
+    bus_a, tp_a, ia = run_engine(graph, n, total, 256, taps)
+    bus_0, tp_0, i0 = run_engine(graph, n, total, 256, taps, env={"OSCEN_GPU_SPLIT": "0"})
+    bus_2, tp_2, i2 = run_engine(graph, n, total, 256, taps, env={"OSCEN_GPU_SPLIT": "2"})
+    assert i0["depth"] == 1 and i2["depth"] == 2
+    assert np.array_equal(tp_a, tp_0) and np.array_equal(tp_a, tp_2)
+    assert np.array_equal(bus_a, bus_0) and np.array_equal(bus_a, bus_2)
+    assert np.abs(bus_a).max() > 1.0

@@ -1,5 +1,7 @@
 """Host-side MIDI front end (MidiParser -> VoiceAllocator -> MidiVoiceHandler): the reference's own
 unit tests restated against og_midi (oscen-lib/src/voice_allocator.rs:156-258, midi.rs:237-275). CPU only."""
+import numpy as np
+
 import oscen_amd
 
 
@@ -86,3 +88,24 @@ def test_wav_writer_roundtrip(tmp_path):
     raw = open(p32, "rb").read()
     assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and raw[20:22] == b"\x03\x00"
     assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), stereo[:, 0])
+
+
+def test_midi_in_queue_capacity_and_late_messages():
+    """`midi_in` holds 32 messages per block for up to 24 voices (graph/types.rs:18): the 33rd try_push fails and the
+    message is dropped; a message whose frame_offset lies beyond the block never reaches the allocator."""
+    m = oscen_amd.Midi(n_voices=8)
+    rcs = [m.lib.og_midi_send(m.h, bytes([0x90, 40 + i, 100]), 3, i) for i in range(40)]
+    assert rcs[:32] == [0] * 32 and rcs[32:] == [oscen_amd.OG_E_OVERFLOW] * 8
+    assert m.dropped == 8
+    m.flush()
+    assert len(m.pop_outputs()) == 32
+    m.set_queue_capacity(100)
+    assert m.send_many(np.arange(50, 90, dtype=np.uint8), np.arange(40), on=True) == 0
+    # the allocator is O(log N): same decisions as the reference's scans (first free, then released-first LRU)
+    big = oscen_amd.Midi(n_voices=100000)
+    big.set_queue_capacity(1 << 20)
+    notes = (np.arange(200000) % 128).astype(np.uint8)
+    assert big.send_many(notes, np.zeros(200000, dtype=np.uint32), on=True) == 0
+    big.flush()
+    st = big.voice_state(0)
+    assert st["active"] and st["age"] == 100000  # voice 0 was the oldest held voice when the 100001st note arrived
