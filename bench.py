@@ -130,6 +130,9 @@ def main():
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="map every rank onto GPU 0")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="run the RCCL leg (process group, reduce, barrier) with a one-rank communicator: RCCL refuses two "
+                         "ranks on one GPU ('Duplicate GPU detected'), so this is how a one-GPU box exercises it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -151,9 +154,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     rccl_ranks = None
-    if world_size > 1:
+    if world_size > 1 or args.dist_single:
         import torch.distributed as dist
 
+        if world_size == 1:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            s.close()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, rank=rank, world_size=world_size)
@@ -331,10 +339,17 @@ def main():
             line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist is not None:
         barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes a version banner through C stdio: push it out first, so that the JSON is the LAST line of stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -192,6 +192,43 @@ size_t og_state_bytes(const og_engine* e);
 int og_save_state(og_engine* e, void* dst, size_t cap);
 int og_load_state(og_engine* e, const void* src, size_t len);
 
+/* ---- multi-GPU: voice banks sharded over the GPUs of one node ----------------------------
+ * The poly wrapper's `voices.out -> out` is a plain sum (codegen/emit_node.rs:463-466), so a bank shards
+ * by contiguous GLOBAL voice ranges: shard s = voices [s*V/n, (s+1)*V/n) on device_ids[s] (a device may be
+ * listed more than once).  Broadcast setters go to every shard, per-voice calls are routed by global voice
+ * id.  The only exchange on the data path is the mix bus: the mono buses of a batch of blocks are summed
+ * with ONE ncclReduce (RCCL over xGMI, root = device_ids[0]) per batch -- og_cluster_render renders up to
+ * 256 blocks per reduce and overlaps the reduce of a batch with the kernels of the next.  A post-mix node
+ * (Tremolo -> Frame<2>) runs once, on the root, after the reduce, as in the reference
+ * (examples/electric-piano/src/main.rs:88-96); fm-synth's mono bus is duplicated to L/R by the caller after
+ * the sum (examples/fm-synth/src/lib.rs:269-274).  Same conventions as og_engine: not thread-safe per
+ * cluster, no CPU fallback. */
+typedef struct og_cluster og_cluster;
+int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int* device_ids, uint32_t n_shards,
+                      og_cluster** out);
+void og_cluster_destroy(og_cluster* c);
+int og_cluster_init(og_cluster* c, float sample_rate);
+int og_cluster_input_index(const og_cluster* c, const char* name);
+int og_cluster_set_value(og_cluster* c, uint32_t input, float v);
+int og_cluster_set_value_ramp(og_cluster* c, uint32_t input, float v, uint32_t frames);
+int og_cluster_set_value_immediate(og_cluster* c, uint32_t input, float v);
+int og_cluster_set_voice_values(og_cluster* c, uint32_t input, uint64_t first_voice, uint64_t count, const float* v);
+int og_cluster_push_voice_event(og_cluster* c, uint32_t input, uint64_t voice, uint32_t frame_offset, float scalar);
+int og_cluster_push_voice_value(og_cluster* c, uint32_t input, uint64_t voice, uint32_t frame_offset, float v);
+int og_cluster_schedule_voice_events(og_cluster* c, uint32_t input, uint64_t n, const uint64_t* voices,
+                                     const uint64_t* abs_frames, const float* values);
+/* process_block(frames) on every shard + the bus reduce; out_bus[frames * channels] (host).  Blocking. */
+int og_cluster_process_block(og_cluster* c, uint32_t frames, float* out_bus);
+/* BlockRender::render over the whole cluster: total_frames in blocks of `block`, one reduce per 256 blocks. */
+int og_cluster_render(og_cluster* c, uint64_t total_frames, uint32_t block, float* out_bus);
+uint32_t og_cluster_num_shards(const og_cluster* c);
+uint32_t og_cluster_num_devices(const og_cluster* c); /* distinct GPUs = ranks of the RCCL communicator */
+uint64_t og_cluster_num_voices(const og_cluster* c);
+uint32_t og_cluster_channels(const og_cluster* c);
+uint64_t og_cluster_rccl_reduces(const og_cluster* c); /* ncclReduce batches issued so far (0 on a one-device cluster) */
+/* the engine of shard s (owned by the cluster) and its first global voice: taps, state snapshots, statistics */
+og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice);
+
 /* ---- MIDI front end (host, control rate): MidiParser -> VoiceAllocator<N> -> MidiVoiceHandler
  * (oscen-lib/src/midi.rs:40-225, voice_allocator.rs:46-136) with N = the engine's voice count.
  * og_midi_send = `midi_in.try_push(raw_midi_event(bytes))` with frame_offset; messages are applied
@@ -200,6 +237,8 @@ int og_load_state(og_engine* e, const void* src, size_t len);
 typedef struct og_midi og_midi;
 int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input, const char* gate_input, og_midi** out);
 void og_midi_destroy(og_midi* m);
+/* MidiVoiceHandler::midi_note_to_freq (midi.rs:69-72): 440 * 2^((note - 69) / 12) in f32 through the platform powf */
+float og_midi_note_to_freq(uint8_t note);
 int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_offset);
 /* n three-byte messages at once: bytes3[3*n], frame_offsets[n] */
 int og_midi_send_batch(og_midi* m, const uint8_t* bytes3, const uint32_t* frame_offsets, uint32_t n);

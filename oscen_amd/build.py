@@ -23,7 +23,7 @@ BUILD = os.path.join(PKG, "_build")
 ARCH = "gfx950"
 
 HOST_SRCS = ["og_engine.cpp", "og_graph.cpp", "og_builtin.cpp", "og_dsl.cpp", "og_midi.cpp", "og_wav.cpp", "og_jit.cpp"]
-HEADERS = ["og_math.h", "og_nodes.hip.h", "og_kernel_rt.hip.h", "og_graph.h", "og_registry.h", "og_jit.h",
+HEADERS = ["og_math.h", "og_nodes.hip.h", "og_kernel_rt.hip.h", "og_graph.h", "og_registry.h", "og_jit.h", "og_cluster.inl",
            os.path.join("..", "..", "include", "oscen_gpu.h")]
 # -fno-slp-vectorize: left to itself clang pairs adjacent scalar f32 ops of the tick into v_pk_*_f32; on gfx950
 # a packed f32 instruction costs more issue time than the two scalar ones it replaces (measured: fm_voice

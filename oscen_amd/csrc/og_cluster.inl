@@ -1,0 +1,538 @@
+// og_cluster.inl -- multi-GPU voice banks behind the C ABI (textually included at the end of og_engine.cpp:
+// it works on og_engine's internals).
+//
+// SURVEY 8(e) / examples/fm-synth/src/lib.rs:269-274: voices are independent, the only cross-voice operation is
+// the sum onto the mix bus.  A cluster owns one engine ("shard") per entry of device_ids; shard s holds the
+// contiguous global voices [s*V/n, (s+1)*V/n) (note streams and every per-voice call are keyed by GLOBAL voice
+// id), broadcast values are replicated, and the data path has exactly one exchange step: the per-device mono
+// buses of a whole BATCH of blocks are summed with one ncclReduce(sum, f32, root = first device) over xGMI (a
+// per-block 1 KB reduce would be latency-bound).  Shards that share a device are added on that device first,
+// so the communicator has one rank per distinct GPU.  A post-mix node (the e-piano Tremolo, a17) runs once, on
+// the root, after the reduce -- like the reference runs it after the voice sum.  One host thread per shard
+// issues that shard's launches (a single thread issuing 8 x 2 launches per block would be the bottleneck: a block
+// is ~66 us of device time); the reduce of batch k runs on a side stream while batch k+1's kernels are issued.
+//
+// RCCL is bound at run time (dlopen) the first time a cluster spans more than one device: a single-GPU user of
+// liboscen_gpu.so does not need it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+__global__ void og_bus_accumulate(float* __restrict__ dst, const float* __restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    void load()
+    {
+        if (lib) return;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) throw HipError(std::string("cannot load RCCL (librccl.so.1): ") + dlerror());
+        auto sym = [&](const char* s) {
+            void* p = dlsym(lib, s);
+            if (!p) throw HipError(std::string("RCCL symbol missing: ") + s);
+            return p;
+        };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        Reduce = (decltype(Reduce))sym("ncclReduce");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    }
+    void ck(ncclResult_t r, const char* what)
+    {
+        if (r != ncclSuccess) throw HipError(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
+    }
+};
+Rccl& rccl()
+{
+    static Rccl r;
+    return r;
+}
+
+// one persistent host thread per shard
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+    std::string err;
+    bool device_err = false;
+    Worker()
+    {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return quit || busy; });
+                if (quit) return;
+                std::function<void()> j = std::move(job);
+                lk.unlock();
+                std::string e;
+                bool dev = false;
+                try {
+                    j();
+                } catch (const HipError& ex) {
+                    e = ex.what();
+                    dev = true;
+                } catch (const std::exception& ex) {
+                    e = ex.what();
+                }
+                lk.lock();
+                err = e;
+                device_err = dev;
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    ~Worker()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+    void run(std::function<void()> j)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(j);
+        busy = true;
+        err.clear();
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; });
+        if (!err.empty()) {
+            if (device_err) throw HipError(err);
+            throw std::runtime_error(err);
+        }
+    }
+};
+
+constexpr uint32_t CL_BATCH_BLOCKS = 256; // blocks per reduce
+
+} // namespace
+
+struct og_cluster {
+    std::vector<og_engine*> shard;
+    std::vector<uint64_t> lo; // first global voice of every shard; lo[n] = total
+    std::vector<int> devs;    // distinct devices, devs[0] = root
+    std::vector<int> dev_of_shard;
+    std::vector<std::unique_ptr<Worker>> workers;
+    uint64_t total = 0;
+    uint32_t channels = 1;
+    bool tremolo = false;
+    bool inited = false;
+    // per shard: two batch buffers of mono partial buses + "buffer filled" events
+    size_t cap_frames = 0;
+    std::vector<float*> sh_buf[2];
+    std::vector<hipEvent_t> sh_done[2];
+    // per device: side stream + "reduce finished with buffer b" events
+    std::vector<hipStream_t> dev_stream;
+    std::vector<hipEvent_t> dev_free[2];
+    std::vector<float*> dev_acc[2]; // the buffer of the device's first shard (accumulated in place)
+    std::vector<ncclComm_t> comms;
+    bool use_rccl = false;
+    uint64_t n_reduces = 0;
+    // root: post-mix stage and host hand-over
+    float* d_out = nullptr; // [cap_frames * channels]
+    float* d_phase = nullptr;
+    float* h_pin[2] = {nullptr, nullptr}; // pinned staging of a batch
+    hipEvent_t host_ready[2] = {nullptr, nullptr};
+
+    ~og_cluster()
+    {
+        workers.clear();
+        for (og_engine* e : shard)
+            if (e) {
+                (void)hipSetDevice(e->device);
+                (void)hipStreamSynchronize(e->stream);
+            }
+        for (size_t d = 0; d < devs.size(); ++d) {
+            (void)hipSetDevice(devs[d]);
+            if (d < dev_stream.size() && dev_stream[d]) {
+                (void)hipStreamSynchronize(dev_stream[d]);
+                (void)hipStreamDestroy(dev_stream[d]);
+            }
+            for (int b = 0; b < 2; ++b)
+                if (d < dev_free[b].size() && dev_free[b][d]) (void)hipEventDestroy(dev_free[b][d]);
+        }
+        for (ncclComm_t c : comms)
+            if (c) (void)rccl().CommDestroy(c);
+        for (size_t s = 0; s < shard.size(); ++s) {
+            if (shard[s]) (void)hipSetDevice(shard[s]->device);
+            for (int b = 0; b < 2; ++b) {
+                if (s < sh_buf[b].size()) (void)hipFree(sh_buf[b][s]);
+                if (s < sh_done[b].size() && sh_done[b][s]) (void)hipEventDestroy(sh_done[b][s]);
+            }
+        }
+        if (!devs.empty()) (void)hipSetDevice(devs[0]);
+        (void)hipFree(d_out);
+        (void)hipFree(d_phase);
+        for (int b = 0; b < 2; ++b) {
+            if (h_pin[b]) (void)hipHostFree(h_pin[b]);
+            if (host_ready[b]) (void)hipEventDestroy(host_ready[b]);
+        }
+        for (og_engine* e : shard) delete e;
+    }
+
+    uint32_t shard_of(uint64_t voice) const
+    {
+        uint32_t s = (uint32_t)(std::upper_bound(lo.begin(), lo.end(), voice) - lo.begin()) - 1u;
+        return s;
+    }
+
+    void ensure_buffers(size_t frames)
+    {
+        if (frames <= cap_frames) return;
+        sync_all();
+        for (size_t s = 0; s < shard.size(); ++s) {
+            HIPCK(hipSetDevice(shard[s]->device));
+            for (int b = 0; b < 2; ++b) {
+                if (sh_buf[b][s]) HIPCK(hipFree(sh_buf[b][s]));
+                sh_buf[b][s] = nullptr;
+                HIPCK(hipMalloc(&sh_buf[b][s], frames * sizeof(float)));
+            }
+        }
+        HIPCK(hipSetDevice(devs[0]));
+        if (d_out) HIPCK(hipFree(d_out));
+        d_out = nullptr;
+        HIPCK(hipMalloc(&d_out, frames * channels * sizeof(float)));
+        for (int b = 0; b < 2; ++b) {
+            if (h_pin[b]) HIPCK(hipHostFree(h_pin[b]));
+            h_pin[b] = nullptr;
+            HIPCK(hipHostMalloc((void**)&h_pin[b], frames * channels * sizeof(float), hipHostMallocDefault));
+            if (!host_ready[b]) HIPCK(hipEventCreateWithFlags(&host_ready[b], hipEventDisableTiming));
+        }
+        cap_frames = frames;
+    }
+
+    void sync_all()
+    {
+        for (og_engine* e : shard) {
+            HIPCK(hipSetDevice(e->device));
+            HIPCK(hipStreamSynchronize(e->stream));
+        }
+        for (size_t d = 0; d < devs.size(); ++d) {
+            HIPCK(hipSetDevice(devs[d]));
+            HIPCK(hipStreamSynchronize(dev_stream[d]));
+        }
+    }
+
+    // Render `total_frames` in blocks of `block`; the summed (and post-mixed) bus ends up in out (host).
+    void render(uint64_t total_frames, uint32_t block, float* out)
+    {
+        const size_t batch_frames = (size_t)std::min<uint64_t>(total_frames, (uint64_t)CL_BATCH_BLOCKS * block);
+        ensure_buffers(batch_frames);
+        const size_t n_sh = shard.size();
+        int b = 0;
+        bool have_prev = false;
+        uint64_t prev_f0 = 0;
+        size_t prev_nf = 0;
+        for (uint64_t f0 = 0; f0 < total_frames; f0 += batch_frames, b ^= 1) {
+            const size_t nf = (size_t)std::min<uint64_t>(batch_frames, total_frames - f0);
+            // (1) every shard renders the batch into its buffer b, on its own stream, issued by its own thread
+            for (size_t s = 0; s < n_sh; ++s) {
+                og_engine* e = shard[s];
+                float* buf = sh_buf[b][s];
+                hipEvent_t done = sh_done[b][s];
+                hipEvent_t free_ev = dev_free[b][dev_of_shard[s]];
+                workers[s]->run([=] {
+                    HIPCK(hipSetDevice(e->device));
+                    HIPCK(hipStreamWaitEvent(e->stream, free_ev, 0)); // the reduce that last read this buffer is over
+                    for (size_t g = 0; g < nf; g += block) {
+                        const uint32_t frames = (uint32_t)std::min<size_t>(block, nf - g);
+                        e->process_async(frames, buf + g);
+                    }
+                    HIPCK(hipEventRecord(done, e->stream));
+                });
+            }
+            for (size_t s = 0; s < n_sh; ++s) workers[s]->wait();
+            // (2) per device: add the buffers of the other shards on that device into the first one's
+            for (size_t d = 0; d < devs.size(); ++d) {
+                HIPCK(hipSetDevice(devs[d]));
+                float* acc = nullptr;
+                for (size_t s = 0; s < n_sh; ++s) {
+                    if (dev_of_shard[s] != (int)d) continue;
+                    HIPCK(hipStreamWaitEvent(dev_stream[d], sh_done[b][s], 0));
+                    if (!acc) {
+                        acc = sh_buf[b][s];
+                    } else {
+                        hipLaunchKernelGGL(og_bus_accumulate, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, dev_stream[d], acc,
+                                           sh_buf[b][s], nf);
+                    }
+                }
+                dev_acc[b][d] = acc;
+            }
+            // (3) ONE reduce of the whole batch over xGMI (root = devs[0])
+            if (use_rccl) {
+                Rccl& R = rccl();
+                R.ck(R.GroupStart(), "ncclGroupStart");
+                for (size_t d = 0; d < devs.size(); ++d)
+                    R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
+                R.ck(R.GroupEnd(), "ncclGroupEnd");
+                n_reduces += 1;
+            }
+            // (4) root: post-mix stage, then hand the batch to the host through a pinned staging buffer
+            HIPCK(hipSetDevice(devs[0]));
+            const float* mono = dev_acc[b][0];
+            if (tremolo) {
+                og_engine* e0 = shard[0];
+                ogc::UEnv env = e0->env();
+                const float rate = e0->cg->tremolo_rate(env), depth = e0->cg->tremolo_depth(env);
+                for (size_t g = 0; g < nf; g += OG_MAX_BLOCK) {
+                    const uint32_t frames = (uint32_t)std::min<size_t>(OG_MAX_BLOCK, nf - g);
+                    hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, dev_stream[0], mono + g, frames, rate, depth, e0->sr,
+                                       d_phase, d_out + 2 * g);
+                }
+                HIPCK(hipMemcpyAsync(h_pin[b], d_out, nf * 2 * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
+            } else {
+                HIPCK(hipMemcpyAsync(h_pin[b], mono, nf * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
+            }
+            HIPCK(hipEventRecord(host_ready[b], dev_stream[0]));
+            // buffer b may be rewritten once every reader on its device is done
+            for (size_t d = 0; d < devs.size(); ++d) {
+                HIPCK(hipSetDevice(devs[d]));
+                HIPCK(hipEventRecord(dev_free[b][d], dev_stream[d]));
+            }
+            // drain the PREVIOUS batch while this one runs
+            if (have_prev) {
+                HIPCK(hipEventSynchronize(host_ready[b ^ 1]));
+                memcpy(out + prev_f0 * channels, h_pin[b ^ 1], prev_nf * channels * sizeof(float));
+            }
+            have_prev = true;
+            prev_f0 = f0;
+            prev_nf = nf;
+        }
+        if (have_prev) {
+            HIPCK(hipSetDevice(devs[0]));
+            HIPCK(hipEventSynchronize(host_ready[b ^ 1]));
+            memcpy(out + prev_f0 * channels, h_pin[b ^ 1], prev_nf * channels * sizeof(float));
+        }
+        sync_all();
+    }
+};
+
+extern "C" {
+
+int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int* device_ids, uint32_t n_shards, og_cluster** out)
+{
+    if (!g || !device_ids || !out) return set_err(OG_E_INVALID, "null argument");
+    if (n_shards == 0 || n_voices_total < n_shards) return set_err(OG_E_INVALID, "need at least one voice per shard");
+    return guard([&] {
+        std::unique_ptr<og_cluster> c(new og_cluster);
+        c->total = n_voices_total;
+        for (uint32_t s = 0; s <= n_shards; ++s) c->lo.push_back(n_voices_total * s / n_shards);
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            const uint64_t nv = c->lo[s + 1] - c->lo[s];
+            if (nv > 0xFFFFFFFFull) throw std::runtime_error("more than 2^32 voices in one shard");
+            og_engine* e = nullptr;
+            const int rc = og_create(g, (uint32_t)nv, device_ids[s], &e);
+            if (rc != OG_OK) {
+                if (rc == OG_E_DEVICE) throw HipError(g_err);
+                throw std::runtime_error(g_err);
+            }
+            e->bus_stage = false; // shards hand over the mono voice sum; the post-mix node runs once, on the root
+            c->shard.push_back(e);
+            int di = -1;
+            for (size_t d = 0; d < c->devs.size(); ++d)
+                if (c->devs[d] == device_ids[s]) di = (int)d;
+            if (di < 0) {
+                c->devs.push_back(device_ids[s]);
+                di = (int)c->devs.size() - 1;
+            }
+            c->dev_of_shard.push_back(di);
+            c->workers.emplace_back(new Worker);
+        }
+        c->channels = c->shard[0]->cg->channels;
+        c->tremolo = c->shard[0]->cg->bus_tremolo;
+        const size_t nd = c->devs.size();
+        c->dev_stream.assign(nd, nullptr);
+        for (int b = 0; b < 2; ++b) {
+            c->sh_buf[b].assign(n_shards, nullptr);
+            c->sh_done[b].assign(n_shards, nullptr);
+            c->dev_free[b].assign(nd, nullptr);
+            c->dev_acc[b].assign(nd, nullptr);
+        }
+        for (size_t d = 0; d < nd; ++d) {
+            HIPCK(hipSetDevice(c->devs[d]));
+            HIPCK(hipStreamCreateWithFlags(&c->dev_stream[d], hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b) {
+                HIPCK(hipEventCreateWithFlags(&c->dev_free[b][d], hipEventDisableTiming));
+                HIPCK(hipEventRecord(c->dev_free[b][d], c->dev_stream[d]));
+            }
+        }
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            HIPCK(hipSetDevice(c->shard[s]->device));
+            for (int b = 0; b < 2; ++b) HIPCK(hipEventCreateWithFlags(&c->sh_done[b][s], hipEventDisableTiming));
+        }
+        HIPCK(hipSetDevice(c->devs[0]));
+        if (c->tremolo) {
+            HIPCK(hipMalloc(&c->d_phase, 4));
+            HIPCK(hipMemset(c->d_phase, 0, 4));
+        }
+        const char* force = getenv("OSCEN_GPU_FORCE_RCCL"); // exercise the RCCL leg on a one-device cluster (tests)
+        if (nd > 1 || (force && atoi(force) != 0)) {
+            Rccl& R = rccl();
+            R.load();
+            c->comms.assign(nd, nullptr);
+            R.ck(R.CommInitAll(c->comms.data(), (int)nd, c->devs.data()), "ncclCommInitAll");
+            c->use_rccl = true;
+        }
+        *out = c.release();
+        return OG_OK;
+    });
+}
+
+void og_cluster_destroy(og_cluster* c) { delete c; }
+
+int og_cluster_init(og_cluster* c, float sample_rate)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    for (og_engine* e : c->shard) {
+        const int rc = og_init(e, sample_rate);
+        if (rc != OG_OK) return rc;
+    }
+    return guard([&] {
+        if (c->d_phase) {
+            HIPCK(hipSetDevice(c->devs[0]));
+            HIPCK(hipMemset(c->d_phase, 0, 4));
+        }
+        c->inited = true;
+        return OG_OK;
+    });
+}
+
+uint32_t og_cluster_num_shards(const og_cluster* c) { return c ? (uint32_t)c->shard.size() : 0; }
+uint32_t og_cluster_num_devices(const og_cluster* c) { return c ? (uint32_t)c->devs.size() : 0; }
+uint64_t og_cluster_num_voices(const og_cluster* c) { return c ? c->total : 0; }
+uint32_t og_cluster_channels(const og_cluster* c) { return c ? c->channels : 0; }
+uint64_t og_cluster_rccl_reduces(const og_cluster* c) { return c ? c->n_reduces : 0; }
+og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice)
+{
+    if (!c || s >= c->shard.size()) return nullptr;
+    if (first_voice) *first_voice = c->lo[s];
+    return c->shard[s];
+}
+
+int og_cluster_input_index(const og_cluster* c, const char* name) { return c ? og_input_index(c->shard[0], name) : set_err(OG_E_INVALID, "null cluster"); }
+
+#define OG_CLUSTER_BROADCAST(call)                   \
+    if (!c) return set_err(OG_E_INVALID, "null cluster"); \
+    for (og_engine* e : c->shard) {                  \
+        const int rc = call;                         \
+        if (rc != OG_OK) return rc;                  \
+    }                                                \
+    return OG_OK;
+
+int og_cluster_set_value(og_cluster* c, uint32_t input, float v) { OG_CLUSTER_BROADCAST(og_set_value(e, input, v)) }
+int og_cluster_set_value_ramp(og_cluster* c, uint32_t input, float v, uint32_t frames) { OG_CLUSTER_BROADCAST(og_set_value_ramp(e, input, v, frames)) }
+int og_cluster_set_value_immediate(og_cluster* c, uint32_t input, float v) { OG_CLUSTER_BROADCAST(og_set_value_immediate(e, input, v)) }
+
+int og_cluster_set_voice_values(og_cluster* c, uint32_t input, uint64_t first_voice, uint64_t count, const float* v)
+{
+    if (!c || !v) return set_err(OG_E_INVALID, "null argument");
+    if (first_voice + count > c->total) return set_err(OG_E_INVALID, "voice range out of bounds");
+    for (size_t s = 0; s < c->shard.size(); ++s) {
+        const uint64_t a = std::max(first_voice, c->lo[s]), b = std::min(first_voice + count, c->lo[s + 1]);
+        if (a >= b) continue;
+        const int rc = og_set_voice_values(c->shard[s], input, (uint32_t)(a - c->lo[s]), (uint32_t)(b - a), v + (a - first_voice));
+        if (rc != OG_OK) return rc;
+    }
+    return OG_OK;
+}
+
+int og_cluster_push_voice_event(og_cluster* c, uint32_t input, uint64_t voice, uint32_t frame_offset, float scalar)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    if (voice >= c->total) return set_err(OG_E_INVALID, "voice index out of range");
+    const uint32_t s = c->shard_of(voice);
+    return og_push_voice_event(c->shard[s], input, (uint32_t)(voice - c->lo[s]), frame_offset, scalar);
+}
+
+int og_cluster_push_voice_value(og_cluster* c, uint32_t input, uint64_t voice, uint32_t frame_offset, float v)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    if (voice >= c->total) return set_err(OG_E_INVALID, "voice index out of range");
+    const uint32_t s = c->shard_of(voice);
+    return og_push_voice_value(c->shard[s], input, (uint32_t)(voice - c->lo[s]), frame_offset, v);
+}
+
+int og_cluster_schedule_voice_events(og_cluster* c, uint32_t input, uint64_t n, const uint64_t* voices, const uint64_t* abs_frames,
+                                     const float* values)
+{
+    if (!c || (n && (!voices || !abs_frames || !values))) return set_err(OG_E_INVALID, "null argument");
+    std::vector<std::vector<uint32_t>> lv(c->shard.size());
+    std::vector<std::vector<uint64_t>> lf(c->shard.size());
+    std::vector<std::vector<float>> lx(c->shard.size());
+    for (uint64_t i = 0; i < n; ++i) {
+        if (voices[i] >= c->total) return set_err(OG_E_INVALID, "voice index out of range");
+        const uint32_t s = c->shard_of(voices[i]);
+        lv[s].push_back((uint32_t)(voices[i] - c->lo[s]));
+        lf[s].push_back(abs_frames[i]);
+        lx[s].push_back(values[i]);
+    }
+    for (size_t s = 0; s < c->shard.size(); ++s) {
+        if (lv[s].empty()) continue;
+        const int rc = og_schedule_voice_events(c->shard[s], input, (uint32_t)lv[s].size(), lv[s].data(), lf[s].data(), lx[s].data());
+        if (rc != OG_OK) return rc;
+    }
+    return OG_OK;
+}
+
+int og_cluster_render(og_cluster* c, uint64_t total_frames, uint32_t block, float* out_bus)
+{
+    if (!c || !out_bus) return set_err(OG_E_INVALID, "null argument");
+    if (block == 0 || block > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "block must be in 1..512");
+    if (!c->inited) return set_err(OG_E_STATE, "og_cluster_init must be called before processing");
+    if (total_frames == 0) return OG_OK;
+    return guard([&] {
+        c->render(total_frames, block, out_bus);
+        return OG_OK;
+    });
+}
+
+int og_cluster_process_block(og_cluster* c, uint32_t frames, float* out_bus)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    if (frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 0..512");
+    if (!c->inited) return set_err(OG_E_STATE, "og_cluster_init must be called before processing");
+    if (frames == 0) {
+        for (og_engine* e : c->shard) {
+            const int rc = og_process_block_async(e, 0, nullptr);
+            if (rc != OG_OK) return rc;
+        }
+        return OG_OK;
+    }
+    if (!out_bus) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        c->render(frames, frames, out_bus);
+        return OG_OK;
+    });
+}
+
+} // extern "C"

@@ -262,6 +262,8 @@ struct og_engine {
     uint64_t frame_now = 0;
     uint64_t dropped = 0;
 
+    bool bus_stage = true; // run the post-mix node (Tremolo) here; a cluster shard hands over the mono sum instead
+
     bool timing = false;
     std::vector<hipEvent_t> t_start, t_stop;
     size_t t_used = 0;
@@ -586,7 +588,8 @@ struct og_engine {
         }
         HIPCK(hipGetLastError());
         float* bus = d_out ? d_out : d_bus;
-        float* sum_dst = cg->bus_tremolo ? d_mono : bus;
+        const bool post_mix = cg->bus_tremolo && bus_stage;
+        float* sum_dst = post_mix ? d_mono : bus;
         {
             // fixed-association tree: groups of 1024 rows, then (for > 1024 waves) the group sums
             const float* src = d_partials;
@@ -606,7 +609,7 @@ struct og_engine {
                                sum_dst);
         }
         HIPCK(hipGetLastError());
-        if (cg->bus_tremolo) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
+        if (post_mix) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
             ogc::UEnv e = env();
             hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, d_mono, frames, cg->tremolo_rate(e),
                                cg->tremolo_depth(e), sr, d_bus_phase, bus);
@@ -1296,3 +1299,5 @@ int og_load_state(og_engine* e, const void* src, size_t len)
 }
 
 } // extern "C"
+
+#include "og_cluster.inl"

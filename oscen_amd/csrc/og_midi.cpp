@@ -186,6 +186,8 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
 
 void og_midi_destroy(og_midi* m) { delete m; }
 
+float og_midi_note_to_freq(uint8_t note) { return og_midi::note_to_freq(note); }
+
 int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_offset)
 {
     if (!m || !bytes) return OG_E_INVALID;

@@ -27,7 +27,16 @@ for p in $PARTS; do
       timeout 300 python bench.py --midi-live 1000 --no-cpu-baseline > $OUT/bench_midi_live.json 2> $OUT/bench_midi_live.err
       ;;
     nccl)
-      timeout 300 python bench.py --gpus 2 --single-device --steps 20 --warmup 4 --voices-per-gpu 32768 --no-cpu-baseline > $OUT/nccl2.json 2> $OUT/nccl2.err; echo "rc=$?" >> $OUT/nccl2.err ;;
+      # RCCL refuses two ranks on one GPU: (a) the RCCL leg with a one-rank communicator, (b) the self-launching
+      # two-rank path on one device with the reduce over gloo
+      timeout 300 python bench.py --dist-single --steps 20 --warmup 4 --no-cpu-baseline > $OUT/rccl1.json 2> $OUT/rccl1.err; echo "rc=$?" >> $OUT/rccl1.err
+      timeout 300 python bench.py --gpus 2 --single-device --backend gloo --steps 20 --warmup 4 --voices-per-gpu 32768 --no-cpu-baseline > $OUT/gloo2.json 2> $OUT/gloo2.err; echo "rc=$?" >> $OUT/gloo2.err ;;
+    dbg)
+      timeout 600 python scripts/dbg_fullsize.py > $OUT/dbg.log 2>&1 ;;
+    cluster)
+      timeout 600 python -m pytest tests/test_cluster_gpu.py -m gpu -q > $OUT/cluster.log 2>&1 ;;
+    tests_all)
+      timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log ;;
     prof)
       bash scripts/gpu_profile.sh ${TAG}_fm65536
       bash scripts/gpu_profile.sh ${TAG}_fm262144 --voices-per-gpu 262144

