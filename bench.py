@@ -66,6 +66,7 @@ def cpu_baseline(block, seed, frames, span):
     from tests import oracle_lib as ol
 
     lib = ol.load()
+    lib.oo_bench_set_fold(ol.FOLD["slice"])
     cores = os.cpu_count() or 1
     cs = C.c_double()
     frames = int(max(block, min(frames, 48000)))
@@ -123,8 +124,9 @@ def main():
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sparse-events", action="store_true",
-                    help="keep the 1 s note plan as is even when the run is shorter (default: fold it into the run, "
-                         "so that note-off and retrigger fall inside the timed region)")
+                    help="keep the 1 s note plan as is even when the run is shorter (default: every voice plays a slice "
+                         "of its cyclic plan, so that note-on, note-off and retrigger all fall inside the timed region at "
+                         "the plan's real density)")
     ap.add_argument("--midi-live", type=int, default=0, metavar="N",
                     help="drop-in path: N MIDI messages per block through og_midi_send + blocking og_process_block")
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
@@ -174,7 +176,8 @@ def main():
     span = 0 if args.sparse_events else min(total_frames, 48000)
 
     eng = oscen_amd.Engine(args.graph, hi - lo, device=local_rank, sample_rate=48000.0)
-    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span)  # global voice ids keep their note streams
+    # global voice ids keep their note streams; a run shorter than the 1 s score sees a slice of it at its real density
+    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="slice")
     midi = None
     if args.midi_live:
         eng.set_voice_values("frequency", plans["frequency"])
@@ -183,8 +186,8 @@ def main():
         n_events_timed = args.midi_live * K
     else:
         oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
-        n_events_timed = int(sum(int(np.count_nonzero((plans[k] >= W * block) & (plans[k] < total_frames)))
-                                 for k in ("on_frame", "off_frame", "retrig_frame"))) if "gate" in eng.input_names else 0
+        ev_f = plans["events"][1]
+        n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if "gate" in eng.input_names else 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     ch = eng.channels
@@ -281,7 +284,8 @@ def main():
                             "%d note events (on / off / retrigger) fall inside the timed region; "
                             "mix bus reduced once per run over RCCL"
                             % (V, block, "" if not span or span >= 48000 else
-                               ", the 1 s note plan folded into the %d-frame run" % span, n_events_timed),
+                               ", the %d-frame run shows a per-voice slice of the cyclic 1 s note plan at its real event density" % span,
+                               n_events_timed),
                 "graph": args.graph,
                 "voices_per_gpu": V,
                 "total_voices": total_voices,

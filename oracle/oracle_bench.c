@@ -30,6 +30,9 @@ typedef struct {
     double *mono64, *abs64; /* [frames_total] or NULL */
 } worker_arg;
 
+static int g_fold = 0;
+void oo_bench_set_fold(int fold) { g_fold = fold; }
+
 static double now_s(void)
 {
     struct timespec ts;
@@ -37,13 +40,13 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void render_group(worker_arg *a, uint32_t lo, uint32_t hi, oo_note_plan *plans, double *cs)
+static void render_group(worker_arg *a, uint32_t lo, uint32_t hi, oo_note_events *plans, double *cs)
 {
     const uint32_t n = hi - lo;
     oo_bank *b = oo_bank_create(a->kind, n);
     oo_bank_init(b, 48000.0f);
     for (uint32_t i = 0; i < n; ++i) {
-        oo_note_plan_scaled(a->seed, lo + i, a->span, &plans[i]);
+        oo_note_events_for_voice(a->seed, lo + i, a->span, g_fold, &plans[i]);
         oo_bank_set_voice_frequency(b, i, plans[i].frequency);
     }
     const int gated = a->kind != OO_BANK_SAT4X && a->kind != OO_BANK_SAT1X;
@@ -52,14 +55,10 @@ static void render_group(worker_arg *a, uint32_t lo, uint32_t hi, oo_note_plan *
     for (uint32_t f0 = 0; f0 < a->frames_total; f0 += a->block) {
         const uint32_t frames = a->frames_total - f0 < a->block ? a->frames_total - f0 : a->block;
         for (uint32_t i = 0; gated && i < n; ++i) {
-            const oo_note_plan *pl = &plans[i];
-            const float vel = oo_midi_velocity_to_gate(pl->velocity);
-            if (pl->on_frame >= f0 && pl->on_frame < f0 + frames)
-                oo_bank_push_event(b, i, pl->on_frame - f0, OO_EV_GATE, vel);
-            if (pl->off_frame >= f0 && pl->off_frame < f0 + frames)
-                oo_bank_push_event(b, i, pl->off_frame - f0, OO_EV_GATE, 0.0f);
-            if (pl->retrig_frame >= f0 && pl->retrig_frame < f0 + frames)
-                oo_bank_push_event(b, i, pl->retrig_frame - f0, OO_EV_GATE, vel);
+            const oo_note_events *pl = &plans[i];
+            for (uint32_t k = 0; k < pl->n; ++k)
+                if (pl->frame[k] >= f0 && pl->frame[k] < f0 + frames)
+                    oo_bank_push_event(b, i, pl->frame[k] - f0, OO_EV_GATE, pl->value[k]);
         }
         oo_bank_process_block(b, frames, out, NULL, 0, NULL);
         for (uint32_t k = 0; k < frames * ch; ++k) *cs += (double)out[k];
@@ -79,7 +78,7 @@ static void *worker(void *p)
     worker_arg *a = (worker_arg *)p;
     const uint32_t n = a->hi - a->lo;
     const uint32_t g = (a->group == 0 || a->group > n) ? n : a->group;
-    oo_note_plan *plans = (oo_note_plan *)malloc(sizeof(oo_note_plan) * (g ? g : 1));
+    oo_note_events *plans = (oo_note_events *)malloc(sizeof(oo_note_events) * (g ? g : 1));
     double cs = 0.0;
     for (uint32_t lo = a->lo; lo < a->hi; lo += g) render_group(a, lo, lo + g < a->hi ? lo + g : a->hi, plans, &cs);
     a->checksum = cs;

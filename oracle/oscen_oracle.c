@@ -2023,6 +2023,51 @@ void oo_note_plan_for_voice(uint64_t seed, uint32_t voice, oo_note_plan *p)
     p->frequency = oo_midi_note_to_freq(p->note);
 }
 
+/* The note stream of one voice as a frame-sorted event list (at most 4 gate events).
+ * fold 0 ("scale"): the plan of oo_note_plan_scaled -- on / off / retrigger compressed into `span` frames.
+ * fold 1 ("slice"): the window [0, span) shows the slice [rot, rot + span) of the voice's cyclic 1 s plan, rot = a
+ *   sixth splitmix64 draw % 48000: every event keeps the plan's REAL density (3 events per voice per 48000 frames)
+ *   and all three kinds fall inside a short run, spread over different voices.  A voice whose note is sounding at the
+ *   cut (on < rot <= off, or rot > retrig) also gets its note-on at the plan's own on-frame (0..255). */
+void oo_note_events_for_voice(uint64_t seed, uint32_t voice, uint32_t span, int fold, oo_note_events *out)
+{
+    oo_note_plan p;
+    out->n = 0;
+    if (fold == 0 || span == 0 || span >= 48000u) {
+        oo_note_plan_scaled(seed, voice, span, &p);
+        const float vel = oo_midi_velocity_to_gate(p.velocity);
+        out->frequency = p.frequency;
+        out->frame[0] = p.on_frame, out->value[0] = vel;
+        out->frame[1] = p.off_frame, out->value[1] = 0.0f;
+        out->frame[2] = p.retrig_frame, out->value[2] = vel;
+        out->n = 3;
+        return;
+    }
+    oo_note_plan_for_voice(seed, voice, &p);
+    uint64_t s = seed ^ (uint64_t)voice;
+    for (int i = 0; i < 5; ++i) (void)splitmix64(&s);
+    const uint32_t rot = (uint32_t)(splitmix64(&s) % 48000u);
+    const float vel = oo_midi_velocity_to_gate(p.velocity);
+    out->frequency = p.frequency;
+    uint32_t fr[4];
+    float va[4];
+    uint32_t n = 0;
+    const int held = (p.on_frame < rot && rot <= p.off_frame) || rot > p.retrig_frame;
+    if (held) fr[n] = p.on_frame, va[n] = vel, ++n;
+    const uint32_t t[3] = {p.on_frame, p.off_frame, p.retrig_frame};
+    const float v[3] = {vel, 0.0f, vel};
+    for (int i = 0; i < 3; ++i) fr[n] = (t[i] + 48000u - rot) % 48000u, va[n] = v[i], ++n;
+    for (uint32_t i = 1; i < n; ++i) { /* stable insertion sort by frame */
+        const uint32_t kf = fr[i];
+        const float kv = va[i];
+        uint32_t j = i;
+        while (j > 0 && fr[j - 1] > kf) fr[j] = fr[j - 1], va[j] = va[j - 1], --j;
+        fr[j] = kf, va[j] = kv;
+    }
+    for (uint32_t i = 0; i < n; ++i) out->frame[i] = fr[i], out->value[i] = va[i];
+    out->n = n;
+}
+
 /* The same plan folded into a shorter window: every frame scaled by span / 48000 (integer
  * arithmetic), so that a run of `span` < 48000 frames still sees note-off and retrigger.
  * span == 0 or >= 48000: the plan as is. */

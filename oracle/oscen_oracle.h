@@ -381,6 +381,15 @@ typedef struct {
 void oo_note_plan_for_voice(uint64_t seed, uint32_t voice, oo_note_plan *p);
 /* the same plan with every frame scaled by span / 48000 (span == 0 or >= 48000: unchanged) */
 void oo_note_plan_scaled(uint64_t seed, uint32_t voice, uint32_t span, oo_note_plan *p);
+/* the note stream of one voice as a frame-sorted list of gate events; fold 0 = scaled plan, 1 = a slice of the
+ * cyclic 1 s plan at its real event density (see oscen_oracle.c) */
+typedef struct {
+    uint32_t n;
+    uint32_t frame[4];
+    float value[4];
+    float frequency;
+} oo_note_events;
+void oo_note_events_for_voice(uint64_t seed, uint32_t voice, uint32_t span, int fold, oo_note_events *out);
 /* Multi-threaded render of voices [first_voice, first_voice + n_voices) over their (scaled) note plans.
  * Each thread walks its contiguous voice range in sub-banks of `group` voices (0 = one sub-bank per
  * thread), every sub-bank rendered block by block over the whole timeline before the next one starts
@@ -390,6 +399,8 @@ void oo_note_plan_scaled(uint64_t seed, uint32_t voice, uint32_t span, oo_note_p
 double oo_bank_render_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint32_t frames_total, uint32_t block,
                          uint32_t n_threads, uint32_t group, uint64_t seed, uint32_t span, double *mono64,
                          double *abs64);
+/* note-plan fold mode of the three multi-threaded entry points (process-wide; 0 = scale, 1 = slice) */
+void oo_bench_set_fold(int fold);
 
 #ifdef __cplusplus
 }

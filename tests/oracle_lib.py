@@ -150,6 +150,10 @@ class NotePlan(C.Structure):
                 ("off_frame", C.c_uint32), ("retrig_frame", C.c_uint32), ("frequency", C.c_float)]
 
 
+class NoteEvents(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("frame", C.c_uint32 * 4), ("value", C.c_float * 4), ("frequency", C.c_float)]
+
+
 BANK_FM, BANK_SUB, BANK_EPIANO, BANK_SAT4X, BANK_SAT1X = range(5)
 EV_GATE, EV_FREQ = 0, 1
 PB_SINE, PB_SAW, PB_SQUARE, PB_TRIANGLE = range(4)
@@ -216,6 +220,8 @@ def load():
     lib.oo_bank_last_abs_f64.argtypes = [C.c_void_p]
     lib.oo_bank_last_abs_f64.restype = C.POINTER(C.c_double)
     lib.oo_note_plan_scaled.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(NotePlan)]
+    lib.oo_note_events_for_voice.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(NoteEvents)]
+    lib.oo_bench_set_fold.argtypes = [C.c_int]
     lib.oo_tremolo_new.argtypes = [C.c_void_p]
     lib.oo_tremolo_process.argtypes = [C.c_void_p]
     lib.oo_midi_note_to_freq.restype = C.c_float
@@ -318,7 +324,11 @@ class Bank:
         return np.array([p[i] for i in range(frames)], dtype=np.float64)
 
 
-def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None, group=8, seed=0x05CE2026, span=0):
+FOLD = {"scale": 0, "slice": 1}
+
+
+def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None, group=8, seed=0x05CE2026, span=0,
+              fold="scale"):
     """Multi-threaded oracle render of a voice range over its (scaled) note plans:
     (mono f64 sum [frames], sum of |voice output| [frames], seconds)."""
     lib = load()
@@ -326,6 +336,7 @@ def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None
     mono = np.zeros(frames_total, dtype=np.float64)
     ab = np.zeros(frames_total, dtype=np.float64)
     dp = C.POINTER(C.c_double)
+    lib.oo_bench_set_fold(FOLD[fold])
     t = lib.oo_bank_render_mt(kind, first_voice, n_voices, frames_total, block, threads, group, seed, span,
                               mono.ctypes.data_as(dp), ab.ctypes.data_as(dp))
     return mono, ab, t

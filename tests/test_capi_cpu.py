@@ -233,3 +233,28 @@ def test_folded_note_plans_match_the_oracle_generator():
                 int(plans["on_frame"][i]), int(plans["off_frame"][i]), int(plans["retrig_frame"][i]))
             assert p.on_frame < p.off_frame < p.retrig_frame
             assert p.frequency == float(plans["frequency"][i])  # bit for bit: both sides go through libm powf
+
+
+def test_note_event_streams_match_the_oracle_generator_in_both_fold_modes():
+    """the frame-sorted event stream per voice ("events" of note_plans) == oo_note_events_for_voice, scale and slice"""
+    import ctypes as C
+
+    import oscen_amd
+    from tests import oracle_lib as ol
+
+    lib = ol.load()
+    for span, fold in ((6400, "slice"), (512, "slice"), (1024, "scale"), (0, "scale"), (50176, "slice")):
+        p = oscen_amd.note_plans(500, first_voice=70000, span=span, fold=fold)
+        ev_v, ev_f, ev_x = p["events"]
+        k = 0
+        for i in range(500):
+            e = ol.NoteEvents()
+            lib.oo_note_events_for_voice(oscen_amd.SYNTH_SEED, 70000 + i, span, ol.FOLD[fold], C.byref(e))
+            for j in range(e.n):
+                assert (ev_v[k], ev_f[k], ev_x[k]) == (i, e.frame[j], np.float32(e.value[j]))
+                k += 1
+            assert e.frequency == p["frequency"][i]
+        assert k == len(ev_v)
+        if fold == "slice" and 0 < span < 48000:  # all three kinds of event inside a short window
+            win = ev_f < span
+            assert (ev_x[win] > 0).sum() > 0 and (ev_x[win] == 0).sum() > 0
