@@ -71,31 +71,58 @@ def cpu_baseline(block, seed, frames, span):
     cs = C.c_double()
     frames = int(max(block, min(frames, 48000)))
 
-    def run(group, budget_s):
-        probe_v = 8 * cores
-        t = lib.oo_bank_bench_grouped(ol.BANK_FM, probe_v, min(frames, 2048), block, cores, group, seed, span, C.byref(cs))
-        rate = probe_v * min(frames, 2048) / max(t, 1e-6)
-        voices = int(max(8 * cores, min(1 << 20, rate * budget_s / frames)))
-        voices = (voices // (8 * cores)) * 8 * cores
-        t = lib.oo_bank_bench_grouped(ol.BANK_FM, voices, frames, block, cores, group, seed, span, C.byref(cs))
-        return voices, t
+    def timed(voices, nframes, threads, group):
+        t = lib.oo_bank_bench_grouped(ol.BANK_FM, voices, nframes, block, threads, group, seed, span, C.byref(cs))
+        return voices * nframes / max(t, 1e-9)
 
-    v8, t8 = run(8, 10.0)
-    vw, tw = run(0, 4.0)
+    # How many threads does this box really run?  os.cpu_count() reports the host's CPUs, a container may be
+    # throttled far below that (the round-1 figure of 1.6e5 voices*samples/s per thread against 2.6e6 on one
+    # unconstrained core was this, not cache misses).  A short scaling probe picks the thread count with the best
+    # aggregate rate; the single-thread rate is reported next to it.
+    pf = min(frames, 1024)
+    single = max(timed(64, pf, 1, 8), timed(64, pf, 1, 8))
+    best_t, best_rate = 1, single
+    t = 2
+    cand = []
+    while t < cores:
+        cand.append(t)
+        t *= 2
+    cand.append(cores)
+    for t in cand:
+        r = max(timed(64 * t, pf, t, 8), timed(64 * t, pf, t, 8))
+        if r > best_rate:
+            best_t, best_rate = t, r
+    threads = best_t
+
+    def run(group, budget_s, rate_guess):
+        for _ in range(3):  # size the sample for ~budget_s seconds of wall time, re-sizing once or twice if the guess was off
+            voices = int(max(8 * threads, min(1 << 21, rate_guess * budget_s / frames)))
+            voices = max(8 * threads, (voices // (8 * threads)) * 8 * threads)
+            rate = timed(voices, frames, threads, group)
+            secs = voices * frames / rate
+            if secs >= 0.4 * budget_s or voices >= (1 << 21):
+                break
+            rate_guess = rate
+        return voices, secs, 0.0
+
+    v8, t8, _ = run(8, 8.0, best_rate)
+    vw, tw, _ = run(0, 3.0, best_rate * 0.5)
     return {
         "value": v8 * frames / t8,
         "unit": "voices*samples/s",
-        "cores": cores,
+        "cores": threads,
+        "cpu_count": cores,
         "kind": "port",
-        "per_thread": v8 * frames / t8 / cores,
+        "per_thread": v8 * frames / t8 / threads,
+        "single_thread": single,
         "sample": "%d voices x %d frames (block %d) of the same synthetic fm-synth note streams as banks of 8 voices "
-                  "(the reference's [FMVoice; 8] graph) rendered block by block, C oracle, %d threads, %.1f s"
-                  % (v8, frames, block, cores, t8),
+                  "(the reference's [FMVoice; 8] graph) rendered block by block, C oracle, %d threads (best of a scaling "
+                  "probe over 1..%d; one thread alone: %.3g), %.1f s" % (v8, frames, block, threads, cores, single, t8),
         "whole_bank_per_thread": {
             "value": vw * frames / tw,
-            "per_thread": vw * frames / tw / cores,
+            "per_thread": vw * frames / tw / threads,
             "sample": "%d voices x %d frames, one bank per thread walked voice-minor per sample (cache-hostile), "
-                      "%d threads, %.1f s" % (vw, frames, cores, tw),
+                      "%d threads, %.1f s" % (vw, frames, threads, tw),
         },
     }
 

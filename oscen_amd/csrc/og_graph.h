@@ -59,6 +59,7 @@ struct GNode {
     std::vector<float> args;
     uint32_t rate_factor = 1; // `* N`
     bool bus = false;         // post-mix node of the wrapper graph (runs once on the summed bus, e.g. Tremolo)
+    uint32_t array_len = 0;   // `name = [Type::ctor(..); N]` (parse.rs:447-520): a node array of N elements; 0 = a single node
 };
 struct GEdge {
     std::string src; // endpoint or compound expression: "env.output", "a.x * b.y", "gate"
@@ -84,6 +85,7 @@ struct InputInfo {
     int ramp_row = -1;   // ramped inputs: row in the per-frame ramp table
     int state_word = -1; // per-voice value inputs: state plane
     int event_index = -1;
+    int stream_row = -1; // stream inputs: row of the per-frame table (after the ramp rows)
 };
 struct StateWord {
     std::string name;
@@ -117,6 +119,7 @@ struct CompiledGraph {
     std::vector<UniformProg> uprogs;
     int n_slots = 0;
     int n_ramps = 0;
+    int n_streams = 0; // graph-level stream inputs (`<stream_in>_block`): rows n_ramps.. of the per-frame table
     int n_event_inputs = 0;
     uint32_t channels = 1;
     uint32_t latency_samples = 0;
@@ -126,6 +129,44 @@ struct CompiledGraph {
 
 // Throws std::runtime_error with a diagnostic on malformed/unsupported graphs.
 std::unique_ptr<CompiledGraph> compile(const GraphDesc& g);
+
+// ---- user node types: the `#[derive(Node)]` plug-in surface (oscen-macros/src/lib.rs:7-327) -----------------
+// A node type = its endpoints (`#[input(stream|value|event)]`, `#[output(stream)]` fields), its private fields
+// (per-voice state words), the body of `SignalProcessor::process()` and of the `on_<event>()` handlers, given as
+// device source.  Inside the bodies every input is a `const float <name>`, every state field a `float& <name>` /
+// `uint32_t& <name>`, every output a `float& <name>`, plus `const float sample_rate`; an event handler also sees
+// `const float value` (the scalar payload).  The bodies are compiled into the fused voice kernel (hiprtc).
+struct UserPort {
+    std::string name;
+    Kind kind = Kind::Stream;
+    float def = 0.0f;
+    int arg = -1; // constructor argument that initialises the field, or -1
+};
+struct UserState {
+    std::string name;
+    bool is_uint = false;
+    float init_f = 0.0f;
+    uint32_t init_u = 0;
+    int arg = -1; // constructor argument that initialises it (f32 fields), or -1
+};
+struct UserNodeType {
+    std::string type; // "FmOperator::new"
+    size_t nargs = 0;
+    std::vector<UserPort> inputs;
+    std::vector<std::string> outputs;
+    std::vector<UserState> state;
+    std::string process_src;
+    std::map<std::string, std::string> handlers; // event input -> body of on_<input>()
+    int weight = 0; // estimated VALU cost per tick (0 = estimate from the source)
+};
+void register_user_node(const UserNodeType& t); // throws on malformed descriptions or a clash with a built-in type
+bool unregister_user_node(const std::string& type);
+
+// graph types usable as nodes of other graphs (nested graphs: `sub = SubGraph::new()`), expanded inline
+void register_graph_type(const std::string& name, const GraphDesc& g);
+bool unregister_graph_type(const std::string& name);
+// node arrays and nested graphs are desugared before lowering; exposed for tests / to_dsl of the expansion
+GraphDesc expand(const GraphDesc& g);
 
 uint64_t fnv1a(const std::string& s);
 
