@@ -63,6 +63,55 @@ int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float defau
 int og_graph_add_output(og_graph_desc* g, const char* name, int kind);
 int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
                       uint32_t n_args, uint32_t rate_factor);
+/* `name = [Type::ctor(..); length] [* N]` (parse.rs:447-520): an array of nodes inside the voice graph.  Edges follow
+ * the reference's fan-out rules (ir/lower.rs:784-786, codegen/emit_edge.rs:30-84): array -> array of the same length
+ * pairs the elements, scalar -> array broadcasts, `array.port -> scalar` is the sum in index order; `name[i].port`
+ * addresses one element. */
+int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type_ctor, const float* args,
+                            uint32_t n_args, uint32_t rate_factor, uint32_t length);
+
+/* ---- custom node types: the `#[derive(Node)]` plug-in surface (oscen-macros/src/lib.rs:7-327) ------------------
+ * What the reference's FmOperator / Crossfade / Vca are to oscen-lib: a struct with `#[input(stream|value|event)]`
+ * and `#[output(stream)]` fields, private fields, `impl SignalProcessor { fn process(&mut self) }` and
+ * `fn on_<event_input>(&mut self, &EventInstance)` handlers.  Here the two bodies are DEVICE SOURCE (C++): inside
+ * them every stream/value input is a `const float <name>`, every private field a `float& <name>` (or `uint32_t&`),
+ * every output a `float& <name>` to assign, plus `const float sample_rate`; an event handler also sees
+ * `const float value` (the scalar payload) but only the VALUE inputs (streams do not exist yet when an event
+ * fires).  og_math.h / og_nodes.hip.h helpers (og_sinf, og::clampf, ...) are in scope.  The bodies are compiled into
+ * the fused voice kernel by hiprtc when an engine is created for a graph that uses the type.  Process-wide registry. */
+typedef struct {
+    const char* name;
+    int kind;            /* OG_KIND_STREAM / OG_KIND_VALUE / OG_KIND_EVENT */
+    float default_value; /* field value while the input is unconnected */
+    int ctor_arg;        /* index of the constructor argument that sets that value, or -1 */
+} og_node_port;
+typedef struct {
+    const char* name;
+    int is_uint;        /* 0: f32 field, 1: u32 field */
+    float init;         /* initial value of an f32 field ... */
+    uint32_t init_uint; /* ... of a u32 field */
+    int ctor_arg;       /* f32 fields: constructor argument that initialises it, or -1 */
+} og_node_field;
+typedef struct {
+    const char* type_ctor; /* "FmOperator::new" */
+    uint32_t n_ctor_args;
+    const og_node_port* inputs;
+    uint32_t n_inputs;
+    const char* const* outputs;
+    uint32_t n_outputs;
+    const og_node_field* state;
+    uint32_t n_state;
+    const char* process_src;               /* body of process() */
+    const char* const* event_handler_src;  /* n_inputs entries (or NULL): body of on_<input>() for event inputs */
+    uint32_t cost_hint;                    /* estimated VALU instructions per tick; 0 = estimate from the source */
+} og_node_type;
+int og_register_node(const og_node_type* t);
+int og_unregister_node(const char* type_ctor);
+/* A graph description usable as a node of other graphs (`inner = InnerGraph;`, nested graphs:
+ * examples/src/bin/nested_static_graph_test.rs): expanded inline, its inputs/outputs become the node's ports. */
+int og_register_graph_type(const char* type_name, const og_graph_desc* g);
+int og_unregister_graph_type(const char* type_name);
+
 /* A node of the poly WRAPPER graph that runs once on the summed voices (e.g.
  * `tremolo = Tremolo::new()` with `voices.output -> tremolo.input; tremolo.output -> out`,
  * examples/electric-piano/src/main.rs:56,88-96).  Wire it with og_graph_connect:
@@ -154,6 +203,17 @@ int og_set_stream(og_engine* e, void* hip_stream);
 /* BlockRender::render  oscen-lib/src/graph/offline.rs:46-90: total_frames in
  * chunks of `block` (<= 512); out_bus[total_frames*channels] (host). */
 int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bus);
+
+/* Stream inputs of the graph (`pub <stream_in>_block: [f32; 512]`, codegen/mod.rs:1196): the caller fills the block
+ * before process_block; every voice of the bank reads the same samples.  The buffer keeps its contents between blocks,
+ * like the generated field. */
+int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint32_t n);
+uint32_t og_num_stream_inputs(const og_engine* e); /* BlockRender::NUM_STREAM_INPUTS */
+/* BlockRender::render(inputs, tail)  oscen-lib/src/graph/offline.rs:46-90: one buffer per stream input (declaration
+ * order), total = max input length + tail frames, shorter inputs padded with silence, chunks of 512 frames.
+ * out_bus[total * channels] (host); *frames_rendered = total (call with out_bus == NULL and total known = 0 is a no-op). */
+int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs,
+                     uint64_t tail, float* out_bus, uint64_t* frames_rendered);
 
 /* Introspection of `graph.voices[i].<out>` (tests poke node fields in the
  * reference): record the per-voice output of the listed voices during the

@@ -8,8 +8,9 @@
 //   connections { [policy] SRC_EXPR -> DST; ... }        also `connection { }` / `connection ...;`
 // KIND = value | event | stream; the only part of a [spec] the engine needs is `ramp: N`;
 // policy = latch | linear | sinc | sinc_iir; DST = node.port | node.port() | output name.
-// Not handled (diagnosed): node arrays `[V::new(); N]` (the poly wrapper is the engine itself),
-// `external`.  `src -> [N] -> dst` and `src -> [delay_node] -> dst` expand into the two edges of
+//   nodes { NAME = [path::Type::ctor(args); N] [* M]; }  node arrays inside the voice graph (parse.rs:447-520)
+//   nodes { NAME = GraphType; }  /  GraphType::new()      a registered graph type used as a node (nested graph)
+// Not handled (diagnosed): `external`.  `src -> [N] -> dst` and `src -> [delay_node] -> dst` expand into the two edges of
 // ir/lower.rs:342-347 (the second one a feedback edge).
 #include <cctype>
 #include <cstdio>
@@ -232,7 +233,7 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
     GNode n;
     n.name = lx.ident();
     lx.expect('=');
-    if (lx.peek() == '[') dfail("node arrays (`[Voice::new(); N]`) describe the poly wrapper; give the voice graph to the engine instead", lx.line);
+    const bool is_array = lx.eat('[');
     // path::to::Type::ctor  -> keep the last two segments
     std::vector<std::string> segs;
     for (;;) {
@@ -250,16 +251,27 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
         }
         break;
     }
-    if (segs.size() < 2) dfail("expected `Type::ctor(...)` for node '" + n.name + "'", lx.line);
-    n.type = segs[segs.size() - 2] + "::" + segs.back();
-    lx.expect('(');
-    if (lx.peek() != ')') {
-        for (;;) {
-            n.args.push_back(lx.number());
-            if (!lx.eat(',')) break;
+    if (lx.peek() == '(') {
+        if (segs.size() < 2) dfail("expected `Type::ctor(...)` for node '" + n.name + "'", lx.line);
+        n.type = segs[segs.size() - 2] + "::" + segs.back();
+        lx.expect('(');
+        if (lx.peek() != ')') {
+            for (;;) {
+                n.args.push_back(lx.number());
+                if (!lx.eat(',')) break;
+            }
         }
+        lx.expect(')');
+    } else { // bare `Type` (a unit struct or a nested graph type: `inner = InnerGraph;`) = Type::new()
+        n.type = segs.back() + "::new";
     }
-    lx.expect(')');
+    if (is_array) {
+        lx.expect(';');
+        const float len = lx.number();
+        if (!(len >= 1.0f) || len != (float)(uint32_t)len) dfail("node array length must be a positive integer", lx.line);
+        n.array_len = (uint32_t)len;
+        lx.expect(']');
+    }
     if (lx.eat('*')) {
         n.rate_factor = (uint32_t)lx.number();
     } else if (lx.peek() == '/') {
@@ -418,9 +430,10 @@ std::string to_dsl(const GraphDesc& g)
             continue;
         }
         if (n.name.rfind("__inline_delay_", 0) == 0) continue; // printed as `-> [N] ->`
-        o << "    " << n.name << " = " << n.type << "(";
+        o << "    " << n.name << " = " << (n.array_len ? "[" : "") << n.type << "(";
         for (size_t i = 0; i < n.args.size(); ++i) o << (i ? ", " : "") << num(n.args[i]);
         o << ")";
+        if (n.array_len) o << "; " << n.array_len << "]";
         if (n.rate_factor > 1) o << " * " << n.rate_factor;
         o << ";\n";
     }

@@ -207,6 +207,7 @@ struct og_engine {
     bool own_stream = false;
 
     std::vector<float> values; // per input: plain value, or mirror of ramp.current
+    std::vector<std::vector<float>> stream_blocks; // per input: `<stream_in>_block` (stream inputs only), OG_MAX_BLOCK samples
     std::vector<Ramp> ramps;   // per input (only meaningful when ramp_row >= 0)
     uint32_t active_ramps = 0;
 
@@ -545,8 +546,11 @@ struct og_engine {
             ogc::UEnv e = env();
             for (const auto& up : cg->uprogs) A.slots[up.dst] = up.fn(e);
         }
-        // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks
-        const bool ramps_on = active_ramps > 0 && cg->n_ramps > 0;
+        // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks.  The same
+        // per-frame table carries the graph's stream inputs (`<stream_in>_block`, one row each, broadcast to every
+        // voice); a graph with stream inputs always runs the table-reading kernel variant.
+        const bool ramping = active_ramps > 0 && cg->n_ramps > 0;
+        const bool ramps_on = ramping || cg->n_streams > 0;
         if (ramps_on) {
             const int r = ramp_head;
             ramp_head = (ramp_head + 1) % RAMP_RING;
@@ -560,9 +564,12 @@ struct og_engine {
                     tab[(size_t)row * frames + f] = ramps[i].current;
                 }
             }
-            for (size_t i = 0; i < cg->inputs.size(); ++i)
+            for (size_t i = 0; i < cg->inputs.size(); ++i) {
                 if (cg->inputs[i].ramp_row >= 0) values[i] = ramps[i].current;
-            HIPCK(hipMemcpyAsync(d_ramp[r], tab, (size_t)cg->n_ramps * frames * 4, hipMemcpyHostToDevice, stream));
+                const int srow = cg->inputs[i].stream_row;
+                if (srow >= 0) memcpy(tab + (size_t)srow * frames, stream_blocks[i].data(), (size_t)frames * 4);
+            }
+            HIPCK(hipMemcpyAsync(d_ramp[r], tab, (size_t)(cg->n_ramps + cg->n_streams) * frames * 4, hipMemcpyHostToDevice, stream));
             HIPCK(hipEventRecord(ramp_ev[r], stream));
             ramp_ev_used[r] = true;
             A.ramp_table = d_ramp[r];
@@ -743,6 +750,73 @@ int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor,
     n.rate_factor = rate_factor ? rate_factor : 1;
     g->g.nodes.push_back(n);
     return (int)g->g.nodes.size() - 1;
+}
+
+int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args,
+                            uint32_t rate_factor, uint32_t length)
+{
+    if (length == 0) return set_err(OG_E_INVALID, "node array length must be > 0");
+    int rc = og_graph_add_node(g, name, type_ctor, args, n_args, rate_factor);
+    if (rc >= 0) g->g.nodes.back().array_len = length;
+    return rc;
+}
+
+int og_register_node(const og_node_type* t)
+{
+    if (!t || !t->type_ctor || !t->process_src || (t->n_inputs && !t->inputs) || (t->n_outputs && !t->outputs) ||
+        (t->n_state && !t->state))
+        return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        ogc::UserNodeType u;
+        u.type = t->type_ctor;
+        u.nargs = t->n_ctor_args;
+        for (uint32_t i = 0; i < t->n_inputs; ++i) {
+            const og_node_port& p = t->inputs[i];
+            if (!p.name || p.kind < 0 || p.kind > 2) throw std::runtime_error("bad input port description");
+            u.inputs.push_back({p.name, (ogc::Kind)p.kind, p.default_value, p.ctor_arg});
+            if (p.kind == OG_KIND_EVENT && t->event_handler_src && t->event_handler_src[i]) u.handlers[p.name] = t->event_handler_src[i];
+        }
+        for (uint32_t i = 0; i < t->n_outputs; ++i) {
+            if (!t->outputs[i]) throw std::runtime_error("bad output name");
+            u.outputs.push_back(t->outputs[i]);
+        }
+        for (uint32_t i = 0; i < t->n_state; ++i) {
+            const og_node_field& f = t->state[i];
+            if (!f.name) throw std::runtime_error("bad state field description");
+            ogc::UserState st;
+            st.name = f.name;
+            st.is_uint = f.is_uint != 0;
+            st.init_f = f.init;
+            st.init_u = f.init_uint;
+            st.arg = f.ctor_arg;
+            u.state.push_back(st);
+        }
+        u.process_src = t->process_src;
+        u.weight = (int)t->cost_hint;
+        ogc::register_user_node(u);
+        return OG_OK;
+    });
+}
+
+int og_unregister_node(const char* type_ctor)
+{
+    if (!type_ctor) return set_err(OG_E_INVALID, "null argument");
+    return ogc::unregister_user_node(type_ctor) ? OG_OK : set_err(OG_E_INVALID, std::string("no user node type '") + type_ctor + "'");
+}
+
+int og_register_graph_type(const char* type_name, const og_graph_desc* g)
+{
+    if (!type_name || !g) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        ogc::register_graph_type(type_name, g->g);
+        return OG_OK;
+    });
+}
+
+int og_unregister_graph_type(const char* type_name)
+{
+    if (!type_name) return set_err(OG_E_INVALID, "null argument");
+    return ogc::unregister_graph_type(type_name) ? OG_OK : set_err(OG_E_INVALID, std::string("no graph type '") + type_name + "'");
 }
 
 int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args)
@@ -926,10 +1000,14 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
-        if (cg.n_ramps) {
+        e->stream_blocks.resize(cg.inputs.size());
+        for (size_t i = 0; i < cg.inputs.size(); ++i)
+            if (cg.inputs[i].stream_row >= 0) e->stream_blocks[i].assign(OG_MAX_BLOCK, 0.0f);
+        if (cg.n_ramps + cg.n_streams) {
+            const size_t rows = (size_t)(cg.n_ramps + cg.n_streams);
             for (int i = 0; i < RAMP_RING; ++i) {
-                HIPCK(hipMalloc(&e->d_ramp[i], (size_t)cg.n_ramps * OG_MAX_BLOCK * 4));
-                HIPCK(hipHostMalloc((void**)&e->h_ramp[i], (size_t)cg.n_ramps * OG_MAX_BLOCK * 4, hipHostMallocDefault));
+                HIPCK(hipMalloc(&e->d_ramp[i], rows * OG_MAX_BLOCK * 4));
+                HIPCK(hipHostMalloc((void**)&e->h_ramp[i], rows * OG_MAX_BLOCK * 4, hipHostMallocDefault));
                 HIPCK(hipEventCreateWithFlags(&e->ramp_ev[i], hipEventDisableTiming));
             }
         }
@@ -1150,6 +1228,58 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {
             hipFree(d_all);
+            throw;
+        }
+        HIPCK(hipFree(d_all));
+        return OG_OK;
+    });
+}
+
+int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint32_t n)
+{
+    if (!e || (n && !samples)) return set_err(OG_E_INVALID, "null argument");
+    if (input >= e->cg->inputs.size() || e->cg->inputs[input].stream_row < 0) return set_err(OG_E_INVALID, "not a stream input");
+    if (n > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "a stream block holds at most 512 samples");
+    memcpy(e->stream_blocks[input].data(), samples, (size_t)n * 4);
+    return OG_OK;
+}
+
+uint32_t og_num_stream_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->n_streams : 0; }
+
+int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs, uint64_t tail,
+                     float* out_bus, uint64_t* frames_rendered)
+{
+    if (!e || (n_inputs && (!inputs || !input_lens))) return set_err(OG_E_INVALID, "null argument");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
+    if (n_inputs != (uint32_t)e->cg->n_streams) // render(): assert_eq!(inputs.len(), NUM_STREAM_INPUTS)
+        return set_err(OG_E_INVALID, "render: expected " + std::to_string(e->cg->n_streams) + " input streams, got " + std::to_string(n_inputs));
+    uint64_t in_len = 0;
+    for (uint32_t i = 0; i < n_inputs; ++i) in_len = std::max(in_len, input_lens[i]);
+    const uint64_t total = in_len + tail;
+    if (frames_rendered) *frames_rendered = total;
+    if (total == 0) return OG_OK;
+    if (!out_bus) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        std::vector<int> sidx; // stream inputs in declaration order
+        for (size_t i = 0; i < e->cg->inputs.size(); ++i)
+            if (e->cg->inputs[i].stream_row >= 0) sidx.push_back((int)i);
+        const uint32_t ch = e->cg->channels;
+        float* d_all = nullptr;
+        HIPCK(hipMalloc(&d_all, (size_t)total * ch * 4));
+        try {
+            for (uint64_t pos = 0; pos < total; pos += OG_MAX_BLOCK) { // chunks of DEFAULT_MAX_BLOCK_SIZE, offline.rs:71-90
+                const uint32_t n = (uint32_t)std::min<uint64_t>(OG_MAX_BLOCK, total - pos);
+                for (uint32_t k = 0; k < n_inputs; ++k) {
+                    float* blk = e->stream_blocks[sidx[k]].data();
+                    for (uint32_t j = 0; j < n; ++j) blk[j] = (pos + j < input_lens[k]) ? inputs[k][pos + j] : 0.0f; // silence past the end
+                }
+                e->process_async(n, d_all + pos * ch);
+            }
+            HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total * ch * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(hipStreamSynchronize(e->stream));
+        } catch (...) {
+            (void)hipFree(d_all);
             throw;
         }
         HIPCK(hipFree(d_all));

@@ -68,6 +68,7 @@ struct Val {
     std::set<int> voice_inputs;   // per-voice value inputs this depends on (rate VBlock)
     bool inner = false;           // defined inside the oversampled (x N) inner loop
     bool lane = false;            // one value per lane of an LPV > 1 voice (an `[f32; 32]` endpoint)
+    bool stream = false;          // a graph-level stream input: voice-uniform, but a signal (resampled across rate domains)
 };
 
 Val vconst(float c)
@@ -230,7 +231,11 @@ struct NodeTypeInfo {
     int variant;
     size_t nargs;
     int lpv = 1; // lanes per voice this node type needs (32: per-harmonic arrays)
+    const UserNodeType* user = nullptr; // registered through og_register_node (emit_user)
 };
+
+const NodeTypeInfo* lookup_type(const std::string& type);
+int user_weight(const std::string& type);
 
 // rough VALU cost per tick of a node type (used to balance the two-stage split)
 int node_weight(const std::string& type)
@@ -245,7 +250,8 @@ int node_weight(const std::string& type)
     if (type.rfind("Delay", 0) == 0) return 30;
     if (type.rfind("Crossfade", 0) == 0) return 3;
     if (type.rfind("HardClip", 0) == 0) return 2;
-    return 1;
+    const int uw = user_weight(type);
+    return uw > 0 ? uw : 1;
 }
 
 struct NodeInst {
@@ -294,6 +300,7 @@ struct Codegen {
     Sect& S() { return sec[cs]; }
     std::ostringstream& os() { return dom == 0 ? S().s_pre : (dom == 1 ? S().s_inner : S().s_post); }
     std::ostringstream common_decl, common_load; // per-voice value inputs: visible to both stages
+    std::map<std::string, std::string> user_fns; // device functions of the user node types this graph uses
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
     bool any_derive = false;
@@ -347,6 +354,12 @@ struct Codegen {
     {
         const InputInfo& in = out.inputs[idx];
         Val v;
+        if (in.decl.kind == Kind::Stream) { // `<stream_in>_block[f]`: the same sample for every voice of the bank
+            v.e = "ST(" + std::to_string(in.stream_row) + ")";
+            v.rate = Rate::UFrame;
+            v.stream = true;
+            return v;
+        }
         if (in.decl.kind != Kind::Value) fail("input '" + in.decl.name + "' is not a value input");
         if (in.decl.per_voice) {
             v.e = "vin_" + std::to_string(idx);
@@ -393,7 +406,7 @@ struct Codegen {
         Val r;
         r.rate = Rate::Vary;
         if (dst_inner) { // Up edge (emit_frame.rs:254-307): upsample once per outer frame into a [N] buffer
-            if (v.rate != Rate::Vary || value_port || pol == "latch") { // Latch: every inner tick sees the outer value
+            if ((v.rate != Rate::Vary && !v.stream) || value_port || pol == "latch") { // Latch: every inner tick sees the outer value
                 v.inner = true;
                 return v;
             }
@@ -448,6 +461,7 @@ struct Codegen {
             r.e = "(-" + a.e + ")";
             r.rate = a.rate;
             r.inner = a.inner;
+            r.stream = a.stream;
             r.voice_inputs = a.voice_inputs;
             if (a.host) {
                 HostFn h = a.host;
@@ -503,6 +517,7 @@ struct Codegen {
             Val r;
             r.e = "(" + a.e + " " + e->op + " " + b.e + ")";
             r.rate = join(a.rate, b.rate);
+            r.stream = a.stream || b.stream;
             if (a.inner != b.inner && a.rate == Rate::Vary && b.rate == Rate::Vary)
                 fail("expression mixes outer-rate and oversampled node outputs; connect them through a cross-rate edge");
             r.inner = a.inner || b.inner;
@@ -1101,6 +1116,496 @@ const std::map<std::string, NodeTypeInfo>& registry()
     return R;
 }
 
+
+// ---- user node types (og_register_node): the #[derive(Node)] plug-in surface ---------------------------
+struct UserEntry {
+    UserNodeType t;
+    NodeTypeInfo info;
+};
+std::map<std::string, std::unique_ptr<UserEntry>>& user_registry()
+{
+    static std::map<std::string, std::unique_ptr<UserEntry>> R;
+    return R;
+}
+
+std::string sanitize(const std::string& s)
+{
+    std::string r;
+    for (char c : s) r.push_back(isalnum((unsigned char)c) ? c : '_');
+    return r;
+}
+
+bool is_ident(const std::string& s)
+{
+    if (s.empty() || !(isalpha((unsigned char)s[0]) || s[0] == '_')) return false;
+    for (char c : s)
+        if (!(isalnum((unsigned char)c) || c == '_')) return false;
+    return true;
+}
+
+// one tick of a user node: `og_user_<Type>_process(inputs..., state&..., outputs&..., sample_rate)`
+void emit_user(NodeCtx& x)
+{
+    const UserNodeType& u = *x.n.type->user;
+    const std::string fn = "og_user_" + sanitize(u.type);
+    std::vector<Val> ins;
+    std::vector<const UserPort*> in_ports;
+    for (const UserPort& p : u.inputs) {
+        if (p.kind == Kind::Event) continue;
+        // (one statement per input: resolving an input can allocate cut-crossing channels, whose numbering must be deterministic)
+        const Val v = x.in(p.name);
+        ins.push_back(v);
+        in_ports.push_back(&p);
+    }
+    const int s_sr = x.sr_slot();
+    std::vector<std::string> st;
+    for (const UserState& f : u.state) {
+        if (f.is_uint) {
+            st.push_back(x.state_u(f.name, f.init_u));
+        } else {
+            float init = f.init_f;
+            if (f.arg >= 0 && (size_t)f.arg < x.n.decl->args.size()) init = x.n.decl->args[f.arg];
+            st.push_back(x.state_f(f.name, [init](const UEnv&) { return init; }));
+        }
+    }
+    // the device functions of this type, once per graph
+    if (!x.cg.user_fns.count(u.type)) {
+        std::ostringstream d;
+        auto params = [&](bool handler) {
+            std::ostringstream q;
+            bool first = true;
+            auto sep = [&]() {
+                if (!first) q << ", ";
+                first = false;
+            };
+            if (handler) {
+                sep();
+                q << "const float value";
+            }
+            for (const UserPort& p : u.inputs) {
+                if (p.kind == Kind::Event) continue;
+                if (handler && p.kind != Kind::Value) continue; // a handler runs before the frame's streams exist
+                sep();
+                q << "const float " << p.name;
+            }
+            for (const UserState& f : u.state) {
+                sep();
+                q << (f.is_uint ? "uint32_t& " : "float& ") << f.name;
+            }
+            if (!handler)
+                for (const std::string& o : u.outputs) {
+                    sep();
+                    q << "float& " << o;
+                }
+            sep();
+            q << "const float sample_rate";
+            return q.str();
+        };
+        d << "// user node type " << u.type << " (og_register_node)\n"
+          << "__device__ __forceinline__ void " << fn << "_process(" << params(false) << ")\n{\n"
+          << u.process_src << "\n}\n";
+        for (const auto& h : u.handlers)
+            d << "__device__ __forceinline__ void " << fn << "_on_" << h.first << "(" << params(true) << ")\n{\n" << h.second
+              << "\n}\n";
+        x.cg.user_fns[u.type] = d.str();
+    }
+    // event handlers: value inputs must be known when the event fires (before the frame's nodes run)
+    for (const auto& h : u.handlers) {
+        auto ev = x.n.ev_edges.find(h.first);
+        if (ev == x.n.ev_edges.end()) continue;
+        std::ostringstream call;
+        call << "                " << fn << "_on_" << h.first << "(ev.value";
+        for (size_t i = 0; i < ins.size(); ++i) {
+            if (in_ports[i]->kind != Kind::Value) continue;
+            if (ins[i].rate == Rate::Vary || ins[i].rate == Rate::UFrame)
+                fail("node '" + x.n.decl->name + "' (" + u.type + "): value input '" + in_ports[i]->name +
+                     "' must be constant over the block because the node has an event handler");
+            call << ", " << ins[i].e;
+        }
+        for (const std::string& v : st) call << ", " << v;
+        call << ", " << x.sf(s_sr) << ");\n";
+        for (int ei : ev->second) x.cg.S().ev_handlers[ei] << call.str();
+    }
+    for (const auto& kv : x.n.ev_edges)
+        if (!u.handlers.count(kv.first))
+            fail("node '" + x.n.decl->name + "' (" + u.type + "): event input '" + kv.first + "' has no on_" + kv.first + " handler");
+    // the tick
+    std::ostringstream call;
+    for (const std::string& o : u.outputs) x.cg.os() << "        float " << x.p << o << " = 0.0f;\n";
+    call << "        " << fn << "_process(";
+    bool first = true;
+    auto sep = [&]() {
+        if (!first) call << ", ";
+        first = false;
+    };
+    for (const Val& v : ins) {
+        sep();
+        call << v.e;
+    }
+    for (const std::string& v : st) {
+        sep();
+        call << v;
+    }
+    for (const std::string& o : u.outputs) {
+        sep();
+        call << x.p << o;
+    }
+    sep();
+    call << x.sf(s_sr) << ");\n";
+    x.cg.os() << call.str();
+    for (const std::string& o : u.outputs) {
+        Val v;
+        v.e = x.p + o;
+        v.rate = Rate::Vary;
+        v.inner = x.n.domain == 1;
+        const std::string key = "n" + std::to_string(x.n.id) + "." + o;
+        x.cg.node_outputs[key] = v;
+        auto fit = x.cg.fb_vars.find(key);
+        if (fit != x.cg.fb_vars.end()) x.cg.os() << "        " << fit->second << " = " << v.e << ";\n";
+    }
+}
+
+const NodeTypeInfo* lookup_type(const std::string& type)
+{
+    auto it = registry().find(type);
+    if (it != registry().end()) return &it->second;
+    auto ut = user_registry().find(type);
+    return ut == user_registry().end() ? nullptr : &ut->second->info;
+}
+
+int user_weight(const std::string& type)
+{
+    auto ut = user_registry().find(type);
+    return ut == user_registry().end() ? 0 : ut->second->t.weight;
+}
+
+// ---- node arrays and nested graphs: desugared before lowering ------------------------------------------
+std::map<std::string, GraphDesc>& graph_types()
+{
+    static std::map<std::string, GraphDesc> R;
+    return R;
+}
+
+struct Tok {
+    enum K { Ident, Other } k;
+    std::string text;  // identifier, or the raw text of everything else
+    long index = -1;   // `ident[index]`
+    std::string port;  // `.port` following the identifier (and its index)
+    bool call = false; // legacy `.port()` accessor
+};
+
+// split an endpoint expression into identifier references (with optional [i] and .port) and the text between them
+std::vector<Tok> scan(const std::string& s)
+{
+    std::vector<Tok> out;
+    size_t i = 0;
+    auto other = [&](char c) {
+        if (out.empty() || out.back().k != Tok::Other) out.push_back({Tok::Other, ""});
+        out.back().text.push_back(c);
+    };
+    while (i < s.size()) {
+        const char c = s[i];
+        if (isalpha((unsigned char)c) || c == '_') {
+            Tok t{Tok::Ident, ""};
+            while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_')) t.text.push_back(s[i++]);
+            size_t j = i;
+            while (j < s.size() && isspace((unsigned char)s[j])) ++j;
+            if (j < s.size() && s[j] == '[') {
+                size_t k = j + 1;
+                std::string num;
+                while (k < s.size() && s[k] != ']') num.push_back(s[k++]);
+                if (k >= s.size()) fail("missing ']' in '" + s + "'");
+                t.index = strtol(num.c_str(), nullptr, 10);
+                i = k + 1;
+                j = i;
+                while (j < s.size() && isspace((unsigned char)s[j])) ++j;
+            }
+            if (j < s.size() && s[j] == '.' && j + 1 < s.size() && (isalpha((unsigned char)s[j + 1]) || s[j + 1] == '_')) {
+                size_t k = j + 1;
+                while (k < s.size() && (isalnum((unsigned char)s[k]) || s[k] == '_')) t.port.push_back(s[k++]);
+                i = k;
+                if (i + 1 < s.size() && s[i] == '(' && s[i + 1] == ')') {
+                    t.call = true;
+                    i += 2;
+                }
+            }
+            out.push_back(t);
+        } else if (isdigit((unsigned char)c) || (c == '.' && i + 1 < s.size() && isdigit((unsigned char)s[i + 1]))) {
+            // a numeric literal (may carry a rust suffix such as f32): not an identifier
+            while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '.' || s[i] == '_' ||
+                                    ((s[i] == '+' || s[i] == '-') && (s[i - 1] == 'e' || s[i - 1] == 'E'))))
+                other(s[i++]);
+        } else {
+            other(c);
+            ++i;
+        }
+    }
+    return out;
+}
+
+std::string unscan(const std::vector<Tok>& t)
+{
+    std::string r;
+    for (const Tok& k : t) {
+        r += k.text;
+        if (k.k == Tok::Ident) {
+            if (k.index >= 0) r += "[" + std::to_string(k.index) + "]";
+            if (!k.port.empty()) r += "." + k.port;
+        }
+    }
+    return r;
+}
+
+std::string elem_name(const std::string& arr, long i) { return arr + "__" + std::to_string(i); }
+
+// `name = [Type::ctor(..); N]` -> N nodes; edges by classify_fanout (ir/lower.rs:784-786, codegen/emit_edge.rs:30-84):
+// array -> array of the same length = parallel, scalar -> array = broadcast, array -> scalar = sum in index order
+GraphDesc expand_arrays(const GraphDesc& g)
+{
+    std::map<std::string, uint32_t> arr;
+    for (const GNode& n : g.nodes)
+        if (n.array_len) arr[n.name] = n.array_len;
+    if (arr.empty()) return g;
+    GraphDesc o;
+    o.name = g.name;
+    o.inputs = g.inputs;
+    o.outputs = g.outputs;
+    for (const GNode& n : g.nodes) {
+        if (!n.array_len) {
+            o.nodes.push_back(n);
+            continue;
+        }
+        for (uint32_t i = 0; i < n.array_len; ++i) {
+            GNode e = n;
+            e.name = elem_name(n.name, i);
+            e.array_len = 0;
+            o.nodes.push_back(e);
+        }
+    }
+    for (const GEdge& e : g.edges) {
+        std::vector<Tok> src = scan(e.src), dst = scan(e.dst);
+        // destination: `node.port`, `node[i].port` or a graph output
+        Tok* d = nullptr;
+        for (Tok& t : dst)
+            if (t.k == Tok::Ident) d = d ? d : &t;
+        if (!d) fail("bad destination '" + e.dst + "'");
+        uint32_t dst_n = 0;
+        if (arr.count(d->text)) {
+            if (d->index >= 0) {
+                if ((uint32_t)d->index >= arr[d->text]) fail("index out of range in '" + e.dst + "'");
+                d->text = elem_name(d->text, d->index);
+                d->index = -1;
+            } else {
+                dst_n = arr[d->text];
+            }
+        }
+        // sources: indexed array elements are plain nodes; un-indexed array references make the edge an array edge
+        uint32_t src_n = 0;
+        size_t n_refs = 0;
+        for (Tok& t : src) {
+            if (t.k != Tok::Ident) continue;
+            ++n_refs;
+            auto it = arr.find(t.text);
+            if (it == arr.end()) continue;
+            if (t.index >= 0) {
+                if ((uint32_t)t.index >= it->second) fail("index out of range in '" + e.src + "'");
+                t.text = elem_name(t.text, t.index);
+                t.index = -1;
+            } else {
+                if (src_n && src_n != it->second) fail("array sources of different lengths in '" + e.src + "'");
+                src_n = it->second;
+            }
+        }
+        auto with_index = [&](const std::vector<Tok>& toks, long i, bool is_dst) {
+            std::vector<Tok> r = toks;
+            for (Tok& t : r)
+                if (t.k == Tok::Ident && t.index < 0 && arr.count(t.text) && (is_dst ? &t - &r[0] == d - &dst[0] : true))
+                    t.text = elem_name(t.text, i);
+            return unscan(r);
+        };
+        if (dst_n) {
+            if (src_n && src_n != dst_n)
+                fail("array connection '" + e.src + " -> " + e.dst + "': lengths differ (" + std::to_string(src_n) + " vs " +
+                     std::to_string(dst_n) + ")");
+            for (uint32_t i = 0; i < dst_n; ++i) { // parallel (src_n == dst_n) or broadcast (src_n == 0)
+                GEdge x = e;
+                x.src = with_index(src, i, false);
+                x.dst = with_index(dst, i, true);
+                o.edges.push_back(x);
+            }
+        } else if (src_n) {
+            // array -> scalar: `dest = src.iter().map(|n| n.field).sum()` -- only a plain `array.field` source
+            size_t n_idents = 0;
+            bool plain = true;
+            for (const Tok& t : src) {
+                if (t.k == Tok::Ident) ++n_idents;
+                else
+                    for (char c : t.text)
+                        if (!isspace((unsigned char)c)) plain = false;
+            }
+            if (n_idents != 1 || !plain)
+                fail("array source inside a compound expression needs an array destination ('" + e.src + " -> " + e.dst + "')");
+            for (uint32_t i = 0; i < src_n; ++i) { // several sources into one input = their sum in edge (= index) order
+                GEdge x = e;
+                x.src = with_index(src, i, false);
+                x.dst = unscan(dst);
+                o.edges.push_back(x);
+            }
+        } else {
+            GEdge x = e;
+            x.src = unscan(src);
+            x.dst = unscan(dst);
+            o.edges.push_back(x);
+        }
+        (void)n_refs;
+    }
+    return o;
+}
+
+// `sub = SubGraph::new()` (or bare `SubGraph`) with SubGraph a registered graph type: its nodes and connections are
+// inlined under the prefix `sub_`; its inputs take what the outer graph connects to `sub.<input>` (or their defaults),
+// its outputs stand for the inner expressions that feed them.
+GraphDesc expand_nested(const GraphDesc& g, int depth)
+{
+    if (depth > 8) fail("nested graphs deeper than 8 levels (recursive graph type?)");
+    auto type_of = [&](const GNode& n) -> const GraphDesc* {
+        std::string t = n.type;
+        const size_t c = t.find("::");
+        if (c != std::string::npos && t.substr(c) == "::new") t = t.substr(0, c);
+        auto it = graph_types().find(t);
+        return (it == graph_types().end() || lookup_type(n.type)) ? nullptr : &it->second;
+    };
+    bool any = false;
+    for (const GNode& n : g.nodes) any = any || type_of(n);
+    if (!any) return g;
+    GraphDesc o;
+    o.name = g.name;
+    o.inputs = g.inputs;
+    o.outputs = g.outputs;
+    struct Sub {
+        GraphDesc g;                                      // expanded inner graph
+        std::map<std::string, std::vector<std::string>> in_src; // inner input -> outer source expressions (edge order)
+        std::map<std::string, std::string> out_expr;      // inner output -> expression over (prefixed) inner nodes
+    };
+    std::map<std::string, Sub> subs;
+    for (const GNode& n : g.nodes) {
+        const GraphDesc* t = type_of(n);
+        if (!t) continue;
+        if (n.rate_factor != 1) fail("nested graph '" + n.name + "' cannot be oversampled as a whole; mark its nodes instead");
+        subs[n.name].g = expand_nested(expand_arrays(*t), depth + 1);
+    }
+    // outer edges into sub-graph inputs
+    std::vector<GEdge> outer;
+    for (const GEdge& e : g.edges) {
+        std::vector<Tok> dst = scan(e.dst);
+        const Tok* d = nullptr;
+        for (const Tok& t : dst)
+            if (t.k == Tok::Ident) d = d ? d : &t;
+        if (d && subs.count(d->text) && !d->port.empty()) {
+            if (!e.policy.empty() || e.feedback) fail("connection policies / feedback edges cannot target a nested graph input ('" + e.dst + "')");
+            subs[d->text].in_src[d->port].push_back(e.src);
+            continue;
+        }
+        outer.push_back(e);
+    }
+    // inline every sub-graph
+    for (const GNode& n : g.nodes) {
+        auto sit = subs.find(n.name);
+        if (sit == subs.end()) {
+            o.nodes.push_back(n);
+            continue;
+        }
+        Sub& sb = sit->second;
+        const std::string pre = n.name + "_";
+        std::map<std::string, const GInput*> inner_in;
+        for (const GInput& in : sb.g.inputs) inner_in[in.name] = &in;
+        std::map<std::string, bool> inner_node;
+        for (const GNode& in : sb.g.nodes) inner_node[in.name] = true;
+        for (const auto& kv : sb.in_src)
+            if (!inner_in.count(kv.first)) fail("nested graph '" + n.name + "' has no input '" + kv.first + "'");
+        for (GNode in : sb.g.nodes) {
+            if (in.bus) fail("a nested graph cannot contain post-mix (bus) nodes");
+            in.name = pre + in.name;
+            o.nodes.push_back(in);
+        }
+        // rewrite an inner expression: nodes get the prefix, inputs become the outer sources (or the default)
+        auto rewrite = [&](const std::string& expr, bool& is_event, std::string& event_src) {
+            std::vector<Tok> t = scan(expr);
+            for (Tok& k : t) {
+                if (k.k != Tok::Ident) continue;
+                if (inner_node.count(k.text)) {
+                    k.text = pre + k.text;
+                    continue;
+                }
+                auto iit = inner_in.find(k.text);
+                if (iit == inner_in.end()) continue;
+                const GInput& gi = *iit->second;
+                auto src = sb.in_src.find(gi.name);
+                if (gi.kind == Kind::Event) {
+                    is_event = true;
+                    if (src == sb.in_src.end()) {
+                        event_src.clear();
+                    } else {
+                        if (src->second.size() != 1) fail("event input '" + n.name + "." + gi.name + "' needs exactly one source");
+                        event_src = src->second[0];
+                    }
+                    continue;
+                }
+                if (gi.ramp_frames) fail("ramped inputs are not supported inside nested graphs ('" + gi.name + "')");
+                std::string rep;
+                if (src == sb.in_src.end()) {
+                    rep = flit(gi.def);
+                    rep = std::to_string(0) == "0" ? rep : rep;
+                    char buf[64];
+                    snprintf(buf, sizeof buf, "%.9g", (double)gi.def);
+                    rep = buf;
+                } else {
+                    for (size_t i = 0; i < src->second.size(); ++i) rep += (i ? " + (" : "(") + src->second[i] + ")";
+                }
+                k = Tok{Tok::Other, "(" + rep + ")"};
+            }
+            return unscan(t);
+        };
+        for (const GEdge& ie : sb.g.edges) {
+            bool is_event = false;
+            std::string event_src;
+            GEdge x = ie;
+            x.src = rewrite(ie.src, is_event, event_src);
+            if (is_event) {
+                if (event_src.empty()) continue; // unconnected event input: the inner handlers never fire
+                x.src = event_src;
+            }
+            std::vector<Tok> dst = scan(ie.dst);
+            bool to_output = true;
+            for (Tok& k : dst)
+                if (k.k == Tok::Ident && inner_node.count(k.text)) {
+                    k.text = pre + k.text;
+                    to_output = false;
+                }
+            if (to_output) { // feeds an inner output: remember the expression, no edge
+                std::string& oe = sb.out_expr[ie.dst];
+                oe = oe.empty() ? "(" + x.src + ")" : oe + " + (" + x.src + ")";
+                continue;
+            }
+            x.dst = unscan(dst);
+            o.edges.push_back(x);
+        }
+    }
+    // outer edges: `sub.out` stands for the inner expression
+    for (GEdge e : outer) {
+        std::vector<Tok> t = scan(e.src);
+        for (Tok& k : t) {
+            if (k.k != Tok::Ident || !subs.count(k.text) || k.port.empty()) continue;
+            auto oe = subs[k.text].out_expr.find(k.port);
+            if (oe == subs[k.text].out_expr.end()) fail("nested graph '" + k.text + "' has no (connected) output '" + k.port + "'");
+            k = Tok{Tok::Other, "(" + oe->second + ")"};
+        }
+        e.src = unscan(t);
+        o.edges.push_back(e);
+    }
+    return o;
+}
+
 } // namespace
 
 uint32_t RingSpec::capacity(float graph_sr) const
@@ -1114,8 +1619,67 @@ uint32_t RingSpec::capacity(float graph_sr) const
     return c;
 }
 
-std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
+
+GraphDesc expand(const GraphDesc& g) { return expand_nested(expand_arrays(g), 0); }
+
+void register_user_node(const UserNodeType& t)
 {
+    if (t.type.empty()) fail("node type needs a name");
+    if (registry().count(t.type)) fail("'" + t.type + "' is a built-in node type");
+    if (t.outputs.empty()) fail("node type '" + t.type + "' needs at least one output");
+    std::set<std::string> names;
+    auto uniq = [&](const std::string& n) {
+        if (!is_ident(n)) fail("node type '" + t.type + "': '" + n + "' is not an identifier");
+        if (n == "value" || n == "sample_rate") fail("node type '" + t.type + "': '" + n + "' is reserved");
+        if (!names.insert(n).second) fail("node type '" + t.type + "': duplicate field '" + n + "'");
+    };
+    for (const auto& p : t.inputs) {
+        uniq(p.name);
+        if (p.arg >= (int)t.nargs) fail("node type '" + t.type + "': input '" + p.name + "' refers to a missing constructor argument");
+    }
+    for (const auto& o : t.outputs) uniq(o);
+    for (const auto& f : t.state) {
+        uniq(f.name);
+        if (f.arg >= (int)t.nargs) fail("node type '" + t.type + "': field '" + f.name + "' refers to a missing constructor argument");
+    }
+    for (const auto& h : t.handlers) {
+        bool ok = false;
+        for (const auto& p : t.inputs) ok = ok || (p.kind == Kind::Event && p.name == h.first);
+        if (!ok) fail("node type '" + t.type + "': handler for '" + h.first + "', which is not an event input");
+    }
+    std::unique_ptr<UserEntry> e(new UserEntry);
+    e->t = t;
+    if (e->t.weight <= 0) { // rough VALU estimate from the source: arithmetic operators, calls weigh more
+        int w = 0;
+        const std::string& src = e->t.process_src;
+        for (size_t i = 0; i < src.size(); ++i) {
+            const char c = src[i];
+            if (c == '*' || c == '+' || c == '-' || c == '/' || c == '?' || c == '<' || c == '>') ++w;
+            if (c == '(' && i > 0 && (isalnum((unsigned char)src[i - 1]) || src[i - 1] == '_')) w += 4;
+        }
+        e->t.weight = std::max(1, w);
+    }
+    for (const auto& p : e->t.inputs) e->info.inputs.push_back({p.name.c_str(), p.kind, p.def, p.arg});
+    for (const auto& o : e->t.outputs) e->info.outputs.push_back(o.c_str());
+    e->info.emit = emit_user;
+    e->info.variant = 0;
+    e->info.nargs = t.nargs;
+    e->info.user = &e->t;
+    user_registry()[t.type] = std::move(e);
+}
+
+bool unregister_user_node(const std::string& type) { return user_registry().erase(type) > 0; }
+
+void register_graph_type(const std::string& name, const GraphDesc& g)
+{
+    if (!is_ident(name)) fail("graph type name '" + name + "' is not an identifier");
+    graph_types()[name] = g;
+}
+bool unregister_graph_type(const std::string& name) { return graph_types().erase(name) > 0; }
+
+std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
+{
+    const GraphDesc g = expand(g_in);
     auto cgp = std::make_unique<CompiledGraph>();
     CompiledGraph& out = *cgp;
     out.name = g.name;
@@ -1142,11 +1706,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
                 info.slot = cg.new_slot([idx](const UEnv& e) { return fbits(e.input_values[idx]); });
                 if (in.ramp_frames) info.ramp_row = out.n_ramps++;
             }
-        } else {
-            fail("stream graph inputs are not supported by the voice-bank engine (input '" + in.name + "')");
+        } else { // stream input: one per-frame row of the block table, broadcast to every voice
+            info.stream_row = -2 - out.n_streams++; // final row = n_ramps + k, fixed below once n_ramps is known
         }
         out.inputs.push_back(info);
     }
+    for (auto& info : out.inputs)
+        if (info.stream_row <= -2) info.stream_row = out.n_ramps + (-2 - info.stream_row);
     for (size_t i = 0; i < g.outputs.size(); ++i) cg.output_by_name[g.outputs[i].name] = (int)i;
 
     // ---- nodes ------------------------------------------------------------------
@@ -1155,10 +1721,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         const GNode& nd = g.nodes[i];
         if (cg.node_by_name.count(nd.name) || cg.input_by_name.count(nd.name))
             fail("duplicate name '" + nd.name + "'");
-        auto it = registry().find(nd.type);
-        if (it == registry().end()) fail("unknown node type '" + nd.type + "' (node '" + nd.name + "')");
-        if (nd.args.size() != it->second.nargs)
-            fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(it->second.nargs) + " arguments");
+        const NodeTypeInfo* nti = lookup_type(nd.type);
+        if (!nti) fail("unknown node type '" + nd.type + "' (node '" + nd.name + "'); custom nodes are added with og_register_node");
+        if (nd.args.size() != nti->nargs)
+            fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(nti->nargs) + " arguments");
         if (nd.rate_factor != 1) { // `* N`, N in {2,4,8} (parse.rs:460-488)
             if (nd.rate_factor != 2 && nd.rate_factor != 4 && nd.rate_factor != 8)
                 fail("node '" + nd.name + "': oversampling factor must be 1, 2, 4 or 8");
@@ -1168,7 +1734,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
         }
         cg.node_by_name[nd.name] = (int)i;
         cg.nodes[i].decl = &nd;
-        cg.nodes[i].type = &it->second;
+        cg.nodes[i].type = nti;
         cg.nodes[i].id = (int)i;
         if (nd.bus) {
             if (nd.type != "Tremolo::new") fail("only Tremolo::new is available as a post-mix (bus) node in this version");
@@ -1177,7 +1743,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
             out.channels = 2; // Frame<2>
             out.tremolo_rate = [](const UEnv&) { return 5.0f; };  // Tremolo::new() defaults, tremolo.rs:27-37
             out.tremolo_depth = [](const UEnv&) { return 0.5f; };
-        } else if (!it->second.emit) {
+        } else if (!nti->emit) {
             fail("node type '" + nd.type + "' can only be used as a post-mix (bus) node");
         }
     }
@@ -1906,7 +2472,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     if (!cg.groups2.empty()) emit_pipeline(cg.groups2, 2);
     if (!cg.groups4.empty()) emit_pipeline(cg.groups4, 4);
 
-    const std::string body_s = body.str();
+    std::string user_src;
+    for (const auto& kv : cg.user_fns) user_src += kv.second;
+    const std::string body_s = user_src + body.str();
     out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
@@ -1921,10 +2489,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g)
     for (auto& nn : out.node_order) src << nn << " ";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
-        << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.frames + f] : og::slot_f(A, (slot)))\n\n"
+        << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.frames + f] : og::slot_f(A, (slot)))\n"
+        << "#define ST(row) A.ramp_table[(size_t)(row) * A.frames + f]\n\n"
         << "namespace og_gen_" << hs << " {\n"
         << "constexpr int LPV = " << out.lpv << "; // lanes per voice\n"
-        << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n\n";
+        << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n#undef ST\n\n";
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
     for (auto& v : variants)

@@ -1,0 +1,170 @@
+"""CPU checks of the graph front end's round-2 surface: custom node types (og_register_node = #[derive(Node)]),
+node arrays, nested graphs and stream inputs lower to a kernel that compiles for gfx950 (hiprtc, no device)."""
+import pytest
+
+import oscen_amd
+from tests import plugin_nodes
+
+
+def test_example_crate_nodes_as_plugins_compile_into_the_voice_kernel():
+    g = plugin_nodes.user_fm_voice()
+    src = g.kernel_source()
+    for fn in ("og_user_UFmOperator__new_process", "og_user_UCrossfade__new_process", "og_user_UMixer__new_process",
+               "og_user_UAddValue__new_process"):
+        assert src.count(fn + "(") >= 2  # definition + at least one call
+    # one definition + three operators in each of the three kernel bodies (ordinary, two-wave and four-wave pipelines)
+    assert src.count("og_user_UFmOperator__new_process(") == 1 + 3 * 3
+    assert g.jit_check("gfx950") > 10000
+    # a built-in name cannot be shadowed, malformed descriptions are rejected
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.register_node("Gain::new", [("input", "stream", 0.0, -1)], ["output"], "output = input;")
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.register_node("Bad::new", [("in put", "stream", 0.0, -1)], ["output"], "output = 0.0f;")
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.register_node("Bad::new", [("x", "stream", 0.0, 3)], ["output"], "output = x;")
+    # unknown types point at the plug-in API
+    u = oscen_amd.Graph("u")
+    u.output_stream("out")
+    u.node("n", "Nope::new")
+    u.connect("n.output", "out")
+    with pytest.raises(oscen_amd.OscenError, match="og_register_node"):
+        u.kernel_source()
+
+
+ARRAY_DSL = """
+name: Unison;
+input frequency: value = 220.0;
+input detune: value = 0.01;
+input gate: event;
+output out: stream;
+nodes {
+    env = AdsrEnvelope::new(0.01, 0.1, 0.7, 0.2);
+    oscs = [PolyBlepOscillator::saw(220.0, 0.3); 3];
+    amps = [Gain::new(1.0); 3];
+    filter = TptFilter::new(2400.0, 0.8);
+}
+connections {
+    gate -> env.gate;
+    frequency -> oscs.frequency;            // broadcast: scalar -> array
+    detune * 2.0 -> oscs[2].frequency_mod;  // one element
+    detune -> oscs[1].frequency_mod;
+    oscs.output -> amps.input;              // parallel: array -> array
+    env.output -> amps.gain;                // broadcast
+    amps.output -> filter.input;            // fan-in: sum in index order
+    filter.output -> out;
+}
+"""
+
+
+def test_node_arrays_expand_with_the_reference_fanout_rules():
+    g = oscen_amd.Graph(dsl=ARRAY_DSL, per_voice=("frequency",))
+    assert "oscs = [PolyBlepOscillator::saw(220.0, 0.300000012); 3];" in g.to_dsl()
+    src = g.kernel_source()
+    order = [ln for ln in src.splitlines() if ln.startswith("// Node order:")][0]
+    assert order.split()[3:] == ["env", "oscs__0", "oscs__1", "oscs__2", "amps__0", "amps__1", "amps__2", "filter"]
+    # the fan-in is ((amps0 + amps1) + amps2), in index order
+    assert "((x4_n4_output + x5_n5_output) + x6_n6_output)" in src
+    assert g.jit_check("gfx950") > 10000
+    # round trip through the DSL printer
+    g2 = oscen_amd.Graph(dsl=g.to_dsl(), per_voice=("frequency",))
+    assert g2.kernel_source() == src
+    # errors the reference also diagnoses
+    bad = oscen_amd.Graph(dsl=ARRAY_DSL.replace("amps = [Gain::new(1.0); 3];", "amps = [Gain::new(1.0); 2];"),
+                          per_voice=("frequency",))
+    with pytest.raises(oscen_amd.OscenError, match="lengths differ"):
+        bad.kernel_source()
+    bad = oscen_amd.Graph(dsl=ARRAY_DSL.replace("amps.output -> filter.input;", "amps.output * 0.5 -> filter.input;"),
+                          per_voice=("frequency",))
+    with pytest.raises(oscen_amd.OscenError, match="compound expression"):
+        bad.kernel_source()
+    bad = oscen_amd.Graph(dsl=ARRAY_DSL.replace("oscs[2]", "oscs[3]"), per_voice=("frequency",))
+    with pytest.raises(oscen_amd.OscenError, match="out of range"):
+        bad.kernel_source()
+
+
+INNER_DSL = """
+name: OscEnv;
+input frequency: value = 110.0;
+input level: value = 0.5;
+input gate: event;
+output out: stream;
+nodes {
+    env = AdsrEnvelope::new(0.005, 0.05, 0.6, 0.1);
+    osc = PolyBlepOscillator::square(110.0, 0.4);
+}
+connections {
+    gate -> env.gate;
+    frequency -> osc.frequency;
+    osc.output * env.output * level -> out;
+}
+"""
+OUTER_DSL = """
+name: TwoLayers;
+input frequency: value = 110.0;
+input gate: event;
+output out: stream;
+nodes {
+    low = OscEnv;
+    high = OscEnv::new();
+    filter = TptFilter::new(1800.0, 0.7);
+}
+connections {
+    gate -> low.gate;
+    gate -> high.gate;
+    frequency -> low.frequency;
+    frequency * 2.0 -> high.frequency;
+    low.out + high.out * 0.5 -> filter.input;
+    filter.output -> out;
+}
+"""
+FLAT_DSL = """
+name: TwoLayers;
+input frequency: value = 110.0;
+input gate: event;
+output out: stream;
+nodes {
+    low_env = AdsrEnvelope::new(0.005, 0.05, 0.6, 0.1);
+    low_osc = PolyBlepOscillator::square(110.0, 0.4);
+    high_env = AdsrEnvelope::new(0.005, 0.05, 0.6, 0.1);
+    high_osc = PolyBlepOscillator::square(110.0, 0.4);
+    filter = TptFilter::new(1800.0, 0.7);
+}
+connections {
+    gate -> low_env.gate;
+    (frequency) -> low_osc.frequency;
+    gate -> high_env.gate;
+    (frequency * 2.0) -> high_osc.frequency;
+    ((low_osc.output * low_env.output * (0.5))) + ((high_osc.output * high_env.output * (0.5))) * 0.5 -> filter.input;
+    filter.output -> out;
+}
+"""
+
+
+def test_nested_graphs_are_inlined():
+    inner = oscen_amd.Graph(dsl=INNER_DSL)
+    oscen_amd.register_graph_type("OscEnv", inner)
+    try:
+        nested = oscen_amd.Graph(dsl=OUTER_DSL, per_voice=("frequency",))
+        flat = oscen_amd.Graph(dsl=FLAT_DSL, per_voice=("frequency",))
+        assert nested.kernel_source() == flat.kernel_source()  # same nodes, same order, same expressions
+        assert nested.jit_check("gfx950") > 10000
+    finally:
+        oscen_amd.unregister_graph_type("OscEnv")
+    with pytest.raises(oscen_amd.OscenError, match="unknown node type"):
+        oscen_amd.Graph(dsl=OUTER_DSL, per_voice=("frequency",)).kernel_source()
+
+
+def test_stream_inputs_lower_to_the_per_frame_table():
+    g = oscen_amd.Graph("fx")
+    g.input_stream("audio_in")
+    g.input_value("cutoff", 1200.0, per_voice=True)
+    g.output_stream("out")
+    g.node("f", "TptFilter::new", 1200.0, 0.9)
+    g.node("clip", "HardClip::new", rate=4)
+    g.connect("audio_in * 0.8", "f.input")
+    g.connect("cutoff", "f.cutoff")
+    g.connect("f.output + audio_in", "clip.input")  # outer -> oversampled: the stream is upsampled (sinc) like a node output
+    g.connect("clip.output", "out")
+    src = g.kernel_source()
+    assert "ST(0)" in src and "og::sinc_up<4>" in src and "og::sinc_down<4>" in src
+    assert g.jit_check("gfx950") > 10000
