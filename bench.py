@@ -285,7 +285,7 @@ def main():
         # algorithmic HBM bytes of one launch: state planes read once + written once,
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
         n_wg = eng.partial_rows
-        bytes_per_launch = V * (2 * 4 * words + 8) + n_wg * block * 4
+        bytes_per_launch = V * (4 * (words + eng.state_words_written_per_voice) + 8) + n_wg * block * 4
         # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
         bytes_per_launch += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0

@@ -227,7 +227,10 @@ uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
 uint64_t og_frames_processed(const og_engine* e);
 /* layout facts used by the roofline accounting */
 uint32_t og_state_words_per_voice(const og_engine* e);
-uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 32 for graphs with per-harmonic arrays */
+/* words a steady-state block writes back (read-mostly tables -- e-piano decay/release/rotation multipliers -- are
+ * only stored in blocks whose events rewrote them) */
+uint32_t og_state_words_written_per_voice(const og_engine* e);
+uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 8 for graphs with per-harmonic arrays (4 harmonics per lane) */
 int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched kernel: 0 = one wave per 64 voices,
                                                  2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */

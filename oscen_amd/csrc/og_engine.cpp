@@ -316,7 +316,7 @@ struct og_engine {
         HIPCK(hipMemcpyAsync(d_state, img.data(), img.size() * 4, hipMemcpyHostToDevice, stream));
         std::vector<uint32_t> limg;
         if (!cg->lane_state.empty()) {
-            const size_t per = (size_t)V * cg->lpv;
+            const size_t per = (size_t)V * cg->lpv * cg->lane_width;
             limg.resize(cg->lane_state.size() * per);
             for (size_t k = 0; k < cg->lane_state.size(); ++k)
                 std::fill(limg.begin() + k * per, limg.begin() + (k + 1) * per, cg->lane_state[k].init(e));
@@ -986,7 +986,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         }
         HIPCK(hipMalloc(&e->d_state, std::max<size_t>(1, cg.state.size()) * (size_t)n_voices * 4));
         if (!cg.lane_state.empty())
-            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * 4));
+            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4));
         if (cg.bus_tremolo) {
             HIPCK(hipMalloc(&e->d_mono, (size_t)OG_MAX_BLOCK * 4));
             HIPCK(hipMalloc(&e->d_bus_phase, 4));
@@ -1328,7 +1328,15 @@ uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samp
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }
 uint32_t og_state_words_per_voice(const og_engine* e)
 {
-    return e ? (uint32_t)(e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) : 0;
+    return e ? (uint32_t)(e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv * e->cg->lane_width) : 0;
+}
+uint32_t og_state_words_written_per_voice(const og_engine* e)
+{
+    if (!e) return 0;
+    uint32_t n = 0;
+    for (const auto& w : e->cg->state) n += w.read_mostly ? 0u : 1u;
+    for (const auto& w : e->cg->lane_state) n += w.read_mostly ? 0u : (uint32_t)(e->cg->lpv * e->cg->lane_width);
+    return n;
 }
 uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lpv : 0; }
 int og_uses_split_kernel(const og_engine* e) { return e ? (int)e->split : 0; }
@@ -1381,7 +1389,7 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
 size_t og_state_bytes(const og_engine* e)
 {
     // (delay lines are part of the state: their size is known once og_init has sized them)
-    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) +
+    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv * e->cg->lane_width) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) +
                    e->ring_bytes()
              : 0;
 }
@@ -1392,7 +1400,7 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
     if (cap < og_state_bytes(e)) return set_err(OG_E_INVALID, "buffer too small");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
-        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * 4;
+        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
         HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
         if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync((char*)dst + a + b, e->d_bus_phase, 4, hipMemcpyDeviceToHost, e->stream));
@@ -1413,7 +1421,7 @@ int og_load_state(og_engine* e, const void* src, size_t len)
     if (len != og_state_bytes(e)) return set_err(OG_E_INVALID, "state blob size mismatch");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
-        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * 4;
+        const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
         HIPCK(hipMemcpyAsync(e->d_state, src, a, hipMemcpyHostToDevice, e->stream));
         if (b) HIPCK(hipMemcpyAsync(e->d_lane_state, (const char*)src + a, b, hipMemcpyHostToDevice, e->stream));
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync(e->d_bus_phase, (const char*)src + a + b, 4, hipMemcpyHostToDevice, e->stream));

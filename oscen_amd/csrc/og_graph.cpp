@@ -630,15 +630,18 @@ struct NodeCtx {
         cg.S().store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
         return var;
     }
-    // a word per (voice, lane) of an LPV > 1 graph
-    std::string state_lane_f(const std::string& name, float init)
+    // an array field (`[f32; 32]`) of an LPV > 1 graph: every lane keeps OG_HPL of its elements in one og::HarmV.
+    // store_if: the array is read-mostly -- written back only when that (per-lane) flag is set
+    std::string state_lane_h(const std::string& name, float init, const std::string& store_if = std::string())
     {
         std::string var = p + name;
-        cg.out.lane_state.push_back({n.decl->name + "." + name + "[h]", true, [init](const UEnv&) { return fbits(init); }});
+        cg.out.lane_state.push_back({n.decl->name + "." + name + "[h]", true, [init](const UEnv&) { return fbits(init); },
+                                     !store_if.empty()});
         int k = (int)cg.out.lane_state.size() - 1;
-        cg.S().decl << "    float " << var << " = " << flit(init) << ";\n";
-        cg.S().load << "        " << var << " = og::ldl_f<LPV>(A, c, " << k << ");\n";
-        cg.S().store << "        og::stl_f<LPV>(A, c, " << k << ", " << var << ");\n";
+        cg.S().decl << "    og::HarmV " << var << " = og::harm_splat(" << flit(init) << ");\n";
+        cg.S().load << "        " << var << " = og::ldl_h<LPV>(A, c, " << k << ");\n";
+        cg.S().store << "        " << (store_if.empty() ? std::string() : "if (" + store_if + ") ") << "og::stl_h<LPV>(A, c, " << k
+                     << ", " << var << ");\n";
         return var;
     }
     std::string state_u(const std::string& name, uint32_t init)
@@ -943,7 +946,7 @@ void emit_lp18(NodeCtx& x)
 // Delay (oscen-lib/src/delay/mod.rs): the line itself is an HBM ring per voice (CompiledGraph::rings)
 void emit_delay(NodeCtx& x)
 {
-    if (x.cg.out.lpv != 1) fail("Delay is not supported in array-valued (32 lanes per voice) graphs");
+    if (x.cg.out.lpv != 1) fail("Delay is not supported in array-valued (several lanes per voice) graphs");
     if (x.n.domain == 1) fail("Delay inside an oversampled (`* N`) region is not supported by this version");
     if (x.cg.out.rings.size() >= 4) fail("at most 4 Delay nodes per graph");
     const Val in = x.in("input");
@@ -996,20 +999,21 @@ void emit_crossfade(NodeCtx& x)
     x.set_out("output_b", in.e + " * " + m);
 }
 
-// electric piano (examples/electric-piano/src/electric_piano_voice.rs), one voice = 32 lanes
+// electric piano (examples/electric-piano/src/electric_piano_voice.rs), one voice = 8 lanes x 4 harmonics
 void emit_ep_amp(NodeCtx& x)
 {
     Val br = x.in("brightness"), vs = x.in("velocity_scaling"), dr = x.in("decay_rate"), hd = x.in("harmonic_decay"),
         ks = x.in("key_scaling"), rr = x.in("release_rate");
     (void)x.in("frequency"); // routed to the node but never read by its process()
     const std::string A = x.p + "a";
-    std::string cur = x.state_lane_f("current_value", 0.0f), tgt = x.state_lane_f("target_value", 0.0f),
-                dec = x.state_lane_f("decay", 0.0f), rel = x.state_lane_f("release", 0.0f);
+    // decay / release only change when a note starts: read-mostly planes, written back in blocks that rewrote them
+    std::string cur = x.state_lane_h("current_value", 0.0f), tgt = x.state_lane_h("target_value", 0.0f),
+                dec = x.state_lane_h("decay", 0.0f, A + ".tables_dirty"), rel = x.state_lane_h("release", 0.0f, A + ".tables_dirty");
     std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
     std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
-    x.cg.S().decl << "    og::EpAmp " << A << " = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 64u, 0.0f};\n";
+    x.cg.S().decl << "    og::EpAmp " << A << " = {};\n";
     x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", " << released
-              << ", " << step << ", " << vel << "};\n";
+              << ", " << step << ", " << vel << ", false};\n";
     // stores run before the generic store section reads the mirrors back
     x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
                    << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
@@ -1017,11 +1021,16 @@ void emit_ep_amp(NodeCtx& x)
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second)
-            x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h, ev.value, " << br.e << ", " << vs.e
+            x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h * OG_HPL, ev.value, " << br.e << ", " << vs.e
                                  << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
     x.cg.S().fast_conds.push_back("(" + A + ".step >= 1u && " + A + ".step + CHUNK <= og::EP_INTERP_STEPS)");
-    x.set_out("amplitudes", "og::ep_amp_tick<decltype(chk)::steady>(" + A + ")");
-    x.cg.node_outputs["n" + std::to_string(x.n.id) + ".amplitudes"].lane = true;
+    const std::string var = x.p + "amplitudes";
+    x.cg.os() << "        const og::HarmV " << var << " = og::ep_amp_tick<decltype(chk)::steady>(" << A << ");\n";
+    Val v;
+    v.e = var;
+    v.rate = Rate::Vary;
+    v.lane = true;
+    x.cg.node_outputs["n" + std::to_string(x.n.id) + ".amplitudes"] = v;
 }
 
 void emit_ep_bank(NodeCtx& x)
@@ -1030,18 +1039,19 @@ void emit_ep_bank(NodeCtx& x)
     if (!amp.lane) fail("node '" + x.n.decl->name + "': 'amplitudes' needs an array-valued source (AmplitudeSource.amplitudes)");
     int s_sr = x.sr_slot();
     const std::string B = x.p + "b";
-    std::string re = x.state_lane_f("osc_re", 1.0f), im = x.state_lane_f("osc_im", 0.0f),
-                mre = x.state_lane_f("mul_re", 1.0f), mim = x.state_lane_f("mul_im", 0.0f);
+    // the rotation multipliers only change with the frequency: read-mostly planes
+    std::string re = x.state_lane_h("osc_re", 1.0f), im = x.state_lane_h("osc_im", 0.0f),
+                mre = x.state_lane_h("mul_re", 1.0f, B + ".mul_dirty"), mim = x.state_lane_h("mul_im", 0.0f, B + ".mul_dirty");
     std::string lf = x.state_f("last_frequency", [](const UEnv&) { return 0.0f; });
-    x.cg.S().decl << "    og::EpBank " << B << " = {1.0f, 0.0f, 1.0f, 0.0f, 0.0f};\n";
-    x.cg.S().load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << "};\n";
+    x.cg.S().decl << "    og::EpBank " << B << " = {};\n";
+    x.cg.S().load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << ", false};\n";
     x.cg.S().pre_store << "        " << re << " = " << B << ".re; " << im << " = " << B << ".im; " << mre << " = " << B << ".mre; "
                    << mim << " = " << B << ".mim; " << lf << " = " << B << ".last_frequency;\n";
     auto ev = x.n.ev_edges.find("gate");
     if (ev != x.n.ev_edges.end())
         for (int ei : ev->second) x.cg.S().ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
     // update_multipliers(): the frequency test of process() can only fire when the frequency changed
-    const std::string upd = "og::ep_bank_update(" + B + ", c.h, " + fr.e + ", " + x.sf(s_sr) + ");\n";
+    const std::string upd = "og::ep_bank_update(" + B + ", c.h * OG_HPL, " + fr.e + ", " + x.sf(s_sr) + ");\n";
     if (fr.rate <= Rate::VBlock && fr.rate != Rate::UFrame) {
         x.cg.S().derive << "        " << upd;
         x.cg.any_derive = true;
@@ -1049,7 +1059,7 @@ void emit_ep_bank(NodeCtx& x)
         x.cg.os() << "        " << upd;
     }
     // Does the output feed nothing but the graph output?  Then every lane may hand its own share to the
-    // mix bus instead of folding the 32 harmonics first (taps still need the folded voice output).
+    // mix bus instead of folding the voice's lanes first (taps still need the folded voice output).
     int uses = 0;
     bool only_bus = true;
     const std::string me = x.n.decl->name + ".output";
@@ -1106,9 +1116,9 @@ const std::map<std::string, NodeTypeInfo>& registry()
                                       {"velocity_scaling", V, 50.0f, -1}, {"decay_rate", V, 90.0f, -1},
                                       {"harmonic_decay", V, 70.0f, -1}, {"key_scaling", V, 50.0f, -1},
                                       {"release_rate", V, 40.0f, -1}},
-                                     {"amplitudes"}, emit_ep_amp, 0, 0, 32};
+                                     {"amplitudes"}, emit_ep_amp, 0, 0, 8};
         r["OscillatorBank::new"] = {{{"frequency", V, 440.0f, -1}, {"gate", E, 0, -1}, {"amplitudes", S, 0, -1}},
-                                    {"output"}, emit_ep_bank, 0, 0, 32};
+                                    {"output"}, emit_ep_bank, 0, 0, 8};
         // post-mix only (og_graph_add_bus_node): examples/electric-piano/src/tremolo.rs
         r["Tremolo::new"] = {{{"input", S, 0, -1}, {"rate", V, 5.0f, -1}, {"depth", V, 0.5f, -1}}, {"output"}, nullptr, 0, 0};
         return r;
@@ -1885,6 +1895,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         fail("the post-mix node must be wired `<voice output> -> node.input` and `node.output -> <graph output>`");
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live) out.lpv = std::max(out.lpv, cg.nodes[i].type->lpv);
+    out.lane_width = out.lpv > 1 ? 4 : 1; // OG_HPL
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
     std::vector<int> order;
@@ -2483,7 +2494,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     src << "// GENERATED by oscen_amd/csrc/og_graph.cpp from graph '" << g.name << "' -- do not edit.\n"
         << "// One fused voice kernel: " << out.state.size() << " state words/voice, " << out.n_slots
         << " uniform slots, " << out.n_ramps << " ramped inputs, " << out.n_event_inputs << " event inputs"
-        << (out.lpv > 1 ? ", " + std::to_string(out.lane_state.size()) + " x " + std::to_string(out.lpv) + " lane words/voice" : std::string())
+        << (out.lpv > 1 ? ", " + std::to_string(out.lane_state.size()) + " arrays x " + std::to_string(out.lpv) + " lanes x " +
+                              std::to_string(out.lane_width) + " words/voice"
+                        : std::string())
         << ".\n"
         << "// Node order: ";
     for (auto& nn : out.node_order) src << nn << " ";

@@ -91,6 +91,7 @@ struct StateWord {
     std::string name;
     bool is_float = true;
     std::function<uint32_t(const UEnv&)> init; // initial bits
+    bool read_mostly = false; // written back only in blocks that changed it (tables derived from events)
 };
 struct UniformProg {
     int dst;
@@ -110,7 +111,8 @@ struct CompiledGraph {
     std::vector<StateWord> state;      // per-voice words
     std::vector<StateWord> lane_state; // per-(voice, lane) words of LPV > 1 graphs
     std::vector<RingSpec> rings;       // delay lines (at most OG_MAX_RINGS)
-    int lpv = 1;                       // lanes per voice (32 for the electric-piano voice)
+    int lpv = 1;                       // lanes per voice (8 for the electric-piano voice)
+    int lane_width = 1;                // words a lane owns of every lane_state array (OG_HPL = 4 when lpv > 1)
     bool can_split = false;            // a two-wave pipeline variant of the kernel exists (og_k2_*)
     int max_pipeline = 1;              // deepest pipeline variant generated: 1, 2 (og_k2_*) or 4 (og_k4_*)
     // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>

@@ -102,7 +102,7 @@ struct VoiceCtx {
     uint32_t v;     // voice index
     bool valid;     // v < n_voices
     bool lead;      // first lane of the voice (the only one that reports / stores per-voice things)
-    uint32_t h;     // lane within the voice: 0 for ordinary graphs, the harmonic for LPV = 32 graphs
+    uint32_t h;     // lane within the voice: 0 for ordinary graphs; LPV > 1: owns array elements h * OG_HPL .. + OG_HPL - 1
     uint32_t lane;
     // events
     uint32_t ev_cur, ev_cur0, ev_end;
@@ -120,7 +120,8 @@ __device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t 
 
 // LPV = lanes per voice: 1 for ordinary graphs (64 voices per wave).  Graphs whose nodes carry
 // per-harmonic arrays (the electric-piano voice: 32 partials, ~260 state words) spread one voice
-// over 32 lanes instead of 260 VGPRs: lane h owns harmonic h, per-voice scalars are replicated.
+// over LPV = 8 lanes instead of 260 VGPRs: lane h owns OG_HPL = 4 harmonics, per-voice scalars are
+// replicated on the voice's lanes (so the per-voice bookkeeping is paid once per four harmonics).
 template <bool TAPS, int LPV = 1>
 __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
 {
@@ -192,15 +193,30 @@ __device__ __forceinline__ void st_u(const OgBlockArgs& a, const VoiceCtx& c, in
     a.state[(size_t)w * a.n_voices + c.v] = x;
 }
 
+// Array-valued state of an LPV > 1 voice (`[f32; 32]` fields: the electric piano's per-harmonic arrays): a lane
+// owns OG_HPL consecutive elements, h = c.h * OG_HPL + j, kept in registers as one HarmV and moved as one 16-byte
+// access -- the 64 lanes of a wave read 1 KB of consecutive bytes per array.
+// The four elements sit in two 2-vectors so that the per-element arithmetic (identical and independent across
+// elements) runs on packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations per issue, each
+// rounded exactly like its scalar form).
+#define OG_HPL 4
+typedef float og_f2 __attribute__((ext_vector_type(2)));
+struct HarmV {
+    og_f2 a, b; // elements 0,1 and 2,3
+};
+__device__ __forceinline__ HarmV harm_splat(float x) { return HarmV{og_f2{x, x}, og_f2{x, x}}; }
+__device__ __forceinline__ HarmV harm_make(const float (&t)[OG_HPL]) { return HarmV{og_f2{t[0], t[1]}, og_f2{t[2], t[3]}}; }
 template <int LPV>
-__device__ __forceinline__ float ldl_f(const OgBlockArgs& a, const VoiceCtx& c, int k)
+__device__ __forceinline__ HarmV ldl_h(const OgBlockArgs& a, const VoiceCtx& c, int k)
 {
-    return __uint_as_float(a.lane_state[((size_t)k * a.n_voices + c.v) * LPV + c.h]);
+    const float4 q = *reinterpret_cast<const float4*>(a.lane_state + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL);
+    return HarmV{og_f2{q.x, q.y}, og_f2{q.z, q.w}};
 }
 template <int LPV>
-__device__ __forceinline__ void stl_f(const OgBlockArgs& a, const VoiceCtx& c, int k, float x)
+__device__ __forceinline__ void stl_h(const OgBlockArgs& a, const VoiceCtx& c, int k, const HarmV& x)
 {
-    a.lane_state[((size_t)k * a.n_voices + c.v) * LPV + c.h] = __float_as_uint(x);
+    *reinterpret_cast<float4*>(a.lane_state + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL) =
+        make_float4(x.a.x, x.a.y, x.b.x, x.b.y);
 }
 
 // All LDS traffic of the mix bus stays inside one wave (DS operations of a wave execute in order),

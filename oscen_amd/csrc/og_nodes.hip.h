@@ -803,11 +803,13 @@ OG_DEV void latch_up(float x, float (&out)[N])
 
 // ---------------------------------------------------------------------------
 // Electric piano voice  examples/electric-piano/src/electric_piano_voice.rs
-// One voice spans 32 lanes (LPV = 32): lane h owns harmonic h of AmplitudeSource
-// (current/target/decay/release) and of OscillatorBank (complex phasor +
-// rotation multiplier); per-voice scalars are replicated on the 32 lanes.
+// One voice spans LPV = 8 lanes: lane l owns harmonics 4l .. 4l+3 (OG_HPL per lane) of AmplitudeSource
+// (current/target/decay/release) and of OscillatorBank (complex phasor + rotation multiplier); per-voice
+// scalars are replicated on the voice's lanes.  (Round 1 used one harmonic per lane: every lane then
+// repeated the per-voice step/interpolation bookkeeping, and a wave carried only two voices.)
 // ---------------------------------------------------------------------------
 constexpr int EP_HARMONICS = 32;
+constexpr int EP_LPV = EP_HARMONICS / OG_HPL;
 constexpr uint32_t EP_INTERP_STEPS = 64;
 
 // reference spectra :10-48
@@ -819,14 +821,15 @@ __device__ const float EP_VEL127[EP_HARMONICS] = {
     0.000248027f, 0.00018236f, 3.27292e-05f, 6.64988e-05f, 0.0f, 0.0f, 0.0f, 0.0f};
 
 struct EpAmp {
-    float cur, tgt, decay, release; // this lane's harmonic
+    HarmV cur, tgt, decay, release; // this lane's harmonics
     uint32_t released, step;        // per voice
     float velocity;
+    bool tables_dirty;              // decay / release were rewritten in this block (they are read-mostly state)
 };
 
 // on_gate :308-318 -> trigger_note :292-299 (get_decay :244-268, get_release :270-274,
-// get_initial_amplitudes :276-290; note_pitch stays 60.0) or release_note :301-304
-OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h, float v, float brightness, float velocity_scaling, float decay_rate,
+// get_initial_amplitudes :276-290; note_pitch stays 60.0) or release_note :301-304.   h0 = first harmonic of the lane
+OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float velocity_scaling, float decay_rate,
                         float harmonic_decay, float key_scaling, float release_rate)
 {
     if (v > 0.0f) {
@@ -839,38 +842,56 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h, float v, float brightness, float v
         const float adjusted_decay = (key_scaling_factor > 0.0f) ? 1.0f - (base_decay_rate / (1.0f + key_scaling_factor))
                                                                   : 1.0f - (base_decay_rate * (1.0f - key_scaling_factor));
         float scaling = 1.0f; // scaling_h = ((1 * hs) * hs) ... h sequentially rounded products
-        for (uint32_t i = 0; i < h; ++i) scaling *= harmonic_scaling;
-        a.decay = adjusted_decay * scaling;
-        a.release = 0.999f - ((100.0f - release_rate) / 1000.0f);
-        float amp = (EP_VEL127[h] * v) + (EP_VEL0[h] * (1.0f - v));
+        for (uint32_t i = 0; i < h0; ++i) scaling *= harmonic_scaling;
+        const float rel = 0.999f - ((100.0f - release_rate) / 1000.0f);
         float brightness_scaling = -0.2f + (0.8f * (brightness * 0.01f));
         brightness_scaling += v * velocity_scaling * 0.01f * 0.5f;
-        amp *= 1.0f + brightness_scaling * (float)h;
-        a.cur = amp;
+        float dec[OG_HPL], cur[OG_HPL];
+#pragma unroll
+        for (int j = 0; j < OG_HPL; ++j) {
+            const uint32_t h = h0 + (uint32_t)j;
+            dec[j] = adjusted_decay * scaling;
+            scaling *= harmonic_scaling;
+            float amp = (EP_VEL127[h] * v) + (EP_VEL0[h] * (1.0f - v));
+            amp *= 1.0f + brightness_scaling * (float)h;
+            cur[j] = amp;
+        }
+        a.decay = harm_make(dec);
+        a.release = harm_splat(rel);
+        a.cur = harm_make(cur);
         a.released = 0u;
         a.step = 0u;
+        a.tables_dirty = true;
     } else {
         a.released = 1u;
         a.step = 0u;
     }
 }
 
-// AmplitudeSource::process :321-351, one harmonic
+// AmplitudeSource::process :321-351 for the lane's harmonics
 // STEADY: the caller has established 1 <= step and step + (ticks in this chunk) <= EP_INTERP_STEPS for every
 // lane, so neither the new-target test nor the end-of-ramp branch can fire inside the chunk.
 template <bool STEADY = false>
-OG_DEV float ep_amp_tick(EpAmp& a)
+OG_DEV HarmV ep_amp_tick(EpAmp& a)
 {
     if (STEADY) {
         const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
-        a.cur = a.cur * (1.0f - t) + a.tgt * t;
+        const float u = 1.0f - t;
+        a.cur.a = a.cur.a * u + a.tgt.a * t;
+        a.cur.b = a.cur.b * u + a.tgt.b * t;
         a.step += 1u;
         return a.cur;
     }
-    if (a.step == 0u) a.tgt = a.cur * (a.released ? a.release : a.decay);
+    if (a.step == 0u) {
+        const HarmV& m = a.released ? a.release : a.decay;
+        a.tgt.a = a.cur.a * m.a;
+        a.tgt.b = a.cur.b * m.b;
+    }
     if (a.step < EP_INTERP_STEPS) {
         const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
-        a.cur = a.cur * (1.0f - t) + a.tgt * t;
+        const float u = 1.0f - t;
+        a.cur.a = a.cur.a * u + a.tgt.a * t;
+        a.cur.b = a.cur.b * u + a.tgt.b * t;
         a.step += 1u;
     } else {
         a.cur = a.tgt;
@@ -880,58 +901,67 @@ OG_DEV float ep_amp_tick(EpAmp& a)
 }
 
 struct EpBank {
-    float re, im, mre, mim; // this lane's harmonic
+    HarmV re, im, mre, mim; // this lane's harmonics
     float last_frequency;   // per voice
+    bool mul_dirty;         // the rotation multipliers were rewritten in this block (read-mostly state)
 };
 
 OG_DEV void ep_bank_gate(EpBank& b, float v) // on_gate :115-122
 {
     if (v > 0.0f) {
-        b.re = 1.0f;
-        b.im = 0.0f;
+        b.re = harm_splat(1.0f);
+        b.im = harm_splat(0.0f);
     }
 }
 
 // update_multipliers :126-150 behind the frequency-change test of process() :155-158.  The caller runs
 // it every tick, or -- when the frequency can only change through per-voice value events -- in
 // derive() (block start and after such an event), which is when the reference's test can fire.
-OG_DEV void ep_bank_update(EpBank& b, uint32_t h, float frequency, float sr)
+OG_DEV void ep_bank_update(EpBank& b, uint32_t h0, float frequency, float sr)
 {
     if (frequency > 0.0f && !(fabsf(b.last_frequency - frequency) < 0.01f)) {
         b.last_frequency = frequency;
         const float nyquist = sr * 0.5f;
-        const float harmonic_freq = frequency * (float)(h + 1u);
-        if (harmonic_freq < nyquist) {
-            const float angle = 2.0f * 3.14159274101257324f * harmonic_freq / sr;
-            b.mre = og_cosf_exact(angle); // bit-exact libm: the rotation is applied every sample
-            b.mim = og_sinf_exact(angle);
-        } else {
-            b.mre = 1.0f;
-            b.mim = 0.0f;
+        float mre[OG_HPL], mim[OG_HPL];
+        for (int j = 0; j < OG_HPL; ++j) { // (rolled: one copy of the exact sincos code)
+            const float harmonic_freq = frequency * (float)(h0 + (uint32_t)j + 1u);
+            if (harmonic_freq < nyquist) {
+                const float angle = 2.0f * 3.14159274101257324f * harmonic_freq / sr;
+                mre[j] = og_cosf_exact(angle); // bit-exact libm: the rotation is applied every sample
+                mim[j] = og_sinf_exact(angle);
+            } else {
+                mre[j] = 1.0f;
+                mim[j] = 0.0f;
+            }
         }
-        b.re = 1.0f;
-        b.im = 0.0f;
+        b.mre = harm_make(mre);
+        b.mim = harm_make(mim);
+        b.re = harm_splat(1.0f);
+        b.im = harm_splat(0.0f);
+        b.mul_dirty = true;
     }
 }
 
-// OscillatorBank::process :159-169.  VOICE_SUM: fold the 32 harmonics of the voice (reference: sequential
-// f32 fold; here a butterfly inside the 32-lane half of the wave -- re-association only) and return the
-// voice output on every lane.  Otherwise return this lane's share: used when the output feeds nothing but
-// the mix bus, whose reduction adds the lanes anyway (5 cross-lane adds per frame saved).
+// OscillatorBank::process :159-169.  The lane folds its own harmonics in index order.  VOICE_SUM: also fold the
+// voice's lanes (reference: one sequential f32 fold over the 32 harmonics; here a butterfly inside the 8-lane
+// group -- re-association only) and return the voice output on every lane.  Otherwise return this lane's share:
+// used when the output feeds nothing but the mix bus, whose reduction adds the lanes anyway.
 template <bool VOICE_SUM>
-OG_DEV float ep_bank_tick(EpBank& b, float amp)
+OG_DEV float ep_bank_tick(EpBank& b, const HarmV& amp)
 {
-    const float new_re = b.re * b.mre - b.im * b.mim; // Complex::mul :66-72
-    const float new_im = b.re * b.mim + b.im * b.mre;
-    b.re = new_re;
-    b.im = new_im;
-    float s = new_im * amp;
+    // Complex::mul :66-72 on two harmonics per instruction
+    const og_f2 re_a = b.re.a * b.mre.a - b.im.a * b.mim.a, im_a = b.re.a * b.mim.a + b.im.a * b.mre.a;
+    const og_f2 re_b = b.re.b * b.mre.b - b.im.b * b.mim.b, im_b = b.re.b * b.mim.b + b.im.b * b.mre.b;
+    b.re.a = re_a;
+    b.im.a = im_a;
+    b.re.b = re_b;
+    b.im.b = im_b;
+    const og_f2 p = im_a * amp.a + im_b * amp.b; // (h0 + h2, h1 + h3)
+    float s = p.x + p.y;
     if (VOICE_SUM) {
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 16);
     }
     return s * 3.0f;
 }

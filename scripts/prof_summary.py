@@ -41,7 +41,7 @@ for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
                          "workgroup_size, grid_size from counters_collection where kernel_name like 'og_k_%' limit 1"):
         out["dispatch"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "workgroup", "grid"], row))
 out["pmc_voice_kernel"] = pmc
-LPV = {"epiano_voice": 32}.get(GRAPH, 1)
+LPV = {"epiano_voice": 8}.get(GRAPH, 1)
 waves = (V * LPV + 63) // 64
 d = {}
 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
