@@ -1012,8 +1012,8 @@ void emit_ep_amp(NodeCtx& x)
     std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
     std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
     x.cg.S().decl << "    og::EpAmp " << A << " = {};\n";
-    x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", " << released
-              << ", " << step << ", " << vel << ", false};\n";
+    x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", og::harm_select(" << released
+              << " != 0u, " << rel << ", " << dec << "), " << released << ", " << step << ", " << vel << ", false};\n";
     // stores run before the generic store section reads the mirrors back
     x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
                    << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
@@ -1023,9 +1023,8 @@ void emit_ep_amp(NodeCtx& x)
         for (int ei : ev->second)
             x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h * OG_HPL, ev.value, " << br.e << ", " << vs.e
                                  << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
-    x.cg.S().fast_conds.push_back("(" + A + ".step >= 1u && " + A + ".step + CHUNK <= og::EP_INTERP_STEPS)");
     const std::string var = x.p + "amplitudes";
-    x.cg.os() << "        const og::HarmV " << var << " = og::ep_amp_tick<decltype(chk)::steady>(" << A << ");\n";
+    x.cg.os() << "        const og::HarmV " << var << " = og::ep_amp_tick(" << A << ");\n";
     Val v;
     v.e = var;
     v.rate = Rate::Vary;
@@ -2237,7 +2236,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
          << (getenv("OGC_PRIO_PARITY") ? "    if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_setprio(1); // experiment\n" : "")
          << cg.common_decl.str() << cat(all_stages, &Codegen::Sect::decl) << "    if (c.valid) {\n"
          << cg.common_load.str() << cat(all_stages, &Codegen::Sect::load) << "    }\n";
-    body << "    auto derive = [&]() {\n" << cat(all_stages, &Codegen::Sect::derive) << "    };\n";
+    body << "    auto derive = [&]() __attribute__((always_inline)) {\n" << cat(all_stages, &Codegen::Sect::derive) << "    };\n";
     body << cat(all_stages, &Codegen::Sect::pre) << "    derive();\n";
     if (!out.rings.empty()) // state loads complete here, so that no wait for them lands inside the chunk loop,
                             // where it would also sit out the delay-line loads staged for the next chunk
@@ -2381,7 +2380,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (gi < (int)pr.size() && pr[gi] > 0) body << "    __builtin_amdgcn_s_setprio(" << pr[gi] << ");\n";
             }
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
-            body << "    auto derive = [&]() {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
+            body << "    auto derive = [&]() __attribute__((always_inline)) {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
             body << cat(st, &Codegen::Sect::pre) << "    derive();\n";
             // hand-off values this wave reads: fetched for the whole chunk before its first tick, so that the LDS
             // latency is paid once per chunk and not in front of every frame's first dependent instruction

@@ -204,6 +204,27 @@ typedef float og_f2 __attribute__((ext_vector_type(2)));
 struct HarmV {
     og_f2 a, b; // elements 0,1 and 2,3
 };
+// (a value select: `c ? x : y` on two HarmV lvalues would select ADDRESSES and pin both to scratch memory)
+__device__ __forceinline__ HarmV harm_select(bool c, const HarmV& x, const HarmV& y)
+{
+    return HarmV{og_f2{c ? x.a.x : y.a.x, c ? x.a.y : y.a.y}, og_f2{c ? x.b.x : y.b.x, c ? x.b.y : y.b.y}};
+}
+// element-wise helpers; OG_EP_SCALAR (experiment switch) forces one scalar instruction per element
+#ifdef OG_EP_SCALAR
+__device__ __forceinline__ float og_opaque(float x)
+{
+    asm volatile("" : "+v"(x)); // keeps the two halves of a pair apart so that the back end cannot re-pack them
+    return x;
+}
+__device__ __forceinline__ og_f2 f2_mul(og_f2 x, og_f2 y) { return og_f2{og_opaque(x.x * y.x), og_opaque(x.y * y.y)}; }
+__device__ __forceinline__ og_f2 f2_add(og_f2 x, og_f2 y) { return og_f2{og_opaque(x.x + y.x), og_opaque(x.y + y.y)}; }
+__device__ __forceinline__ og_f2 f2_sub(og_f2 x, og_f2 y) { return og_f2{og_opaque(x.x - y.x), og_opaque(x.y - y.y)}; }
+#else
+__device__ __forceinline__ og_f2 f2_mul(og_f2 x, og_f2 y) { return x * y; }
+__device__ __forceinline__ og_f2 f2_add(og_f2 x, og_f2 y) { return x + y; }
+__device__ __forceinline__ og_f2 f2_sub(og_f2 x, og_f2 y) { return x - y; }
+#endif
+__device__ __forceinline__ og_f2 f2_mul(og_f2 x, float y) { return f2_mul(x, og_f2{y, y}); }
 __device__ __forceinline__ HarmV harm_splat(float x) { return HarmV{og_f2{x, x}, og_f2{x, x}}; }
 __device__ __forceinline__ HarmV harm_make(const float (&t)[OG_HPL]) { return HarmV{og_f2{t[0], t[1]}, og_f2{t[2], t[3]}}; }
 template <int LPV>

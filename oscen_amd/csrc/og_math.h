@@ -173,7 +173,11 @@ OG_HD float og_sincosf_exact(float y, int which)
         const double s = sign[q & 3];
         return og_sincos_poly(x * s, x * x, (q & 2) != 0, which ? (n ^ 1) : n);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nanf(""); // (device code never gets here: every caller's angle is below pi; keeps libm's Payne-Hanek out of the kernels)
+#else
     return which ? cosf(y) : sinf(y);
+#endif
 }
 OG_HD float og_sinf_exact(float y) { return og_sincosf_exact(y, 0); }
 OG_HD float og_cosf_exact(float y) { return og_sincosf_exact(y, 1); }

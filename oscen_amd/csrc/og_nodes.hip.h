@@ -822,6 +822,7 @@ __device__ const float EP_VEL127[EP_HARMONICS] = {
 
 struct EpAmp {
     HarmV cur, tgt, decay, release; // this lane's harmonics
+    HarmV mult;                     // released ? release : decay (what the next target is formed with)
     uint32_t released, step;        // per voice
     float velocity;
     bool tables_dirty;              // decay / release were rewritten in this block (they are read-mostly state)
@@ -866,37 +867,30 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
         a.released = 1u;
         a.step = 0u;
     }
+    a.mult = harm_select(a.released != 0u, a.release, a.decay); // (by value: see harm_select)
 }
 
-// AmplitudeSource::process :321-351 for the lane's harmonics
-// STEADY: the caller has established 1 <= step and step + (ticks in this chunk) <= EP_INTERP_STEPS for every
-// lane, so neither the new-target test nor the end-of-ramp branch can fire inside the chunk.
-template <bool STEADY = false>
+// AmplitudeSource::process :321-351 for the lane's harmonics, written without branches: with eight voices per wave
+// some voice is next to a ramp boundary on most frames, so a divergent `if` costs both of its sides.
+//   step == 0            -> new target = current * (released ? release : decay)       (select)
+//   step < 64            -> current = current * (1 - t) + target * t, t = (step + 1) / 64; step += 1
+//   step == 64           -> current = target; step = 0: the same lerp with t = 1 (x * 0 + y * 1 == y for the finite,
+//                           non-negative amplitudes here)
+// `mult` is the table the next target uses (release or decay): it only changes in the gate handler.
 OG_DEV HarmV ep_amp_tick(EpAmp& a)
 {
-    if (STEADY) {
-        const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
-        const float u = 1.0f - t;
-        a.cur.a = a.cur.a * u + a.tgt.a * t;
-        a.cur.b = a.cur.b * u + a.tgt.b * t;
-        a.step += 1u;
-        return a.cur;
-    }
-    if (a.step == 0u) {
-        const HarmV& m = a.released ? a.release : a.decay;
-        a.tgt.a = a.cur.a * m.a;
-        a.tgt.b = a.cur.b * m.b;
-    }
-    if (a.step < EP_INTERP_STEPS) {
-        const float t = (float)(a.step + 1u) / (float)EP_INTERP_STEPS;
-        const float u = 1.0f - t;
-        a.cur.a = a.cur.a * u + a.tgt.a * t;
-        a.cur.b = a.cur.b * u + a.tgt.b * t;
-        a.step += 1u;
-    } else {
-        a.cur = a.tgt;
-        a.step = 0u;
-    }
+    const bool fresh = a.step == 0u;
+    const og_f2 ta = f2_mul(a.cur.a, a.mult.a), tb = f2_mul(a.cur.b, a.mult.b);
+    a.tgt.a.x = fresh ? ta.x : a.tgt.a.x;
+    a.tgt.a.y = fresh ? ta.y : a.tgt.a.y;
+    a.tgt.b.x = fresh ? tb.x : a.tgt.b.x;
+    a.tgt.b.y = fresh ? tb.y : a.tgt.b.y;
+    const bool ramping = a.step < EP_INTERP_STEPS;
+    const float t = ramping ? (float)(a.step + 1u) / (float)EP_INTERP_STEPS : 1.0f;
+    const float u = 1.0f - t;
+    a.cur.a = f2_add(f2_mul(a.cur.a, u), f2_mul(a.tgt.a, t));
+    a.cur.b = f2_add(f2_mul(a.cur.b, u), f2_mul(a.tgt.b, t));
+    a.step = ramping ? a.step + 1u : 0u;
     return a.cur;
 }
 
@@ -914,6 +908,27 @@ OG_DEV void ep_bank_gate(EpBank& b, float v) // on_gate :115-122
     }
 }
 
+// The rotation multipliers of the lane's harmonics (update_multipliers :130-146): cos/sin of 2*pi*f_h/sr through the
+// bit-exact libm restatement (the rotation is applied every sample, an ulp here is a drift there).  Out of line on
+// purpose: this is a few hundred instructions that run only when a note changes the frequency; inlined into the voice
+// kernel they cost the hot loop its registers (the kernel spilled).  out = mre[OG_HPL] then mim[OG_HPL].
+__device__ __attribute__((noinline)) void ep_bank_tables(float frequency, float sr, uint32_t h0, float* __restrict__ out)
+{
+    const float nyquist = sr * 0.5f;
+#pragma unroll 1
+    for (int j = 0; j < OG_HPL; ++j) {
+        const float harmonic_freq = frequency * (float)(h0 + (uint32_t)j + 1u);
+        float c = 1.0f, s = 0.0f;
+        if (harmonic_freq < nyquist) {
+            const float angle = 2.0f * 3.14159274101257324f * harmonic_freq / sr;
+            c = og_cosf_exact(angle);
+            s = og_sinf_exact(angle);
+        }
+        out[j] = c;
+        out[OG_HPL + j] = s;
+    }
+}
+
 // update_multipliers :126-150 behind the frequency-change test of process() :155-158.  The caller runs
 // it every tick, or -- when the frequency can only change through per-voice value events -- in
 // derive() (block start and after such an event), which is when the reference's test can fire.
@@ -921,21 +936,10 @@ OG_DEV void ep_bank_update(EpBank& b, uint32_t h0, float frequency, float sr)
 {
     if (frequency > 0.0f && !(fabsf(b.last_frequency - frequency) < 0.01f)) {
         b.last_frequency = frequency;
-        const float nyquist = sr * 0.5f;
-        float mre[OG_HPL], mim[OG_HPL];
-        for (int j = 0; j < OG_HPL; ++j) { // (rolled: one copy of the exact sincos code)
-            const float harmonic_freq = frequency * (float)(h0 + (uint32_t)j + 1u);
-            if (harmonic_freq < nyquist) {
-                const float angle = 2.0f * 3.14159274101257324f * harmonic_freq / sr;
-                mre[j] = og_cosf_exact(angle); // bit-exact libm: the rotation is applied every sample
-                mim[j] = og_sinf_exact(angle);
-            } else {
-                mre[j] = 1.0f;
-                mim[j] = 0.0f;
-            }
-        }
-        b.mre = harm_make(mre);
-        b.mim = harm_make(mim);
+        float tab[2 * OG_HPL];
+        ep_bank_tables(frequency, sr, h0, tab);
+        b.mre = HarmV{og_f2{tab[0], tab[1]}, og_f2{tab[2], tab[3]}};
+        b.mim = HarmV{og_f2{tab[4], tab[5]}, og_f2{tab[6], tab[7]}};
         b.re = harm_splat(1.0f);
         b.im = harm_splat(0.0f);
         b.mul_dirty = true;
@@ -950,13 +954,13 @@ template <bool VOICE_SUM>
 OG_DEV float ep_bank_tick(EpBank& b, const HarmV& amp)
 {
     // Complex::mul :66-72 on two harmonics per instruction
-    const og_f2 re_a = b.re.a * b.mre.a - b.im.a * b.mim.a, im_a = b.re.a * b.mim.a + b.im.a * b.mre.a;
-    const og_f2 re_b = b.re.b * b.mre.b - b.im.b * b.mim.b, im_b = b.re.b * b.mim.b + b.im.b * b.mre.b;
+    const og_f2 re_a = f2_sub(f2_mul(b.re.a, b.mre.a), f2_mul(b.im.a, b.mim.a)), im_a = f2_add(f2_mul(b.re.a, b.mim.a), f2_mul(b.im.a, b.mre.a));
+    const og_f2 re_b = f2_sub(f2_mul(b.re.b, b.mre.b), f2_mul(b.im.b, b.mim.b)), im_b = f2_add(f2_mul(b.re.b, b.mim.b), f2_mul(b.im.b, b.mre.b));
     b.re.a = re_a;
     b.im.a = im_a;
     b.re.b = re_b;
     b.im.b = im_b;
-    const og_f2 p = im_a * amp.a + im_b * amp.b; // (h0 + h2, h1 + h3)
+    const og_f2 p = f2_add(f2_mul(im_a, amp.a), f2_mul(im_b, amp.b)); // (h0 + h2, h1 + h3)
     float s = p.x + p.y;
     if (VOICE_SUM) {
         s += __shfl_xor(s, 1);
