@@ -155,7 +155,10 @@ def main():
                          "of its cyclic plan, so that note-on, note-off and retrigger all fall inside the timed region at "
                          "the plan's real density)")
     ap.add_argument("--midi-live", type=int, default=0, metavar="N",
-                    help="drop-in path: N MIDI messages per block through og_midi_send + blocking og_process_block")
+                    help="live path: N MIDI messages per block through og_midi_send_batch; the block is enqueued with "
+                         "og_midi_process_block_async (the host parses block k+1 while block k renders)")
+    ap.add_argument("--midi-blocking", action="store_true",
+                    help="with --midi-live: the blocking drop-in entry og_midi_process_block (= process_block + bus to host)")
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="map every rank onto GPU 0")
@@ -222,15 +225,22 @@ def main():
     base = bus.data_ptr()
     host_bus = np.zeros((K + W, block * ch), dtype=np.float32)
     rng = np.random.default_rng(0x05CE2026 + rank)
-    live_notes = rng.integers(36, 97, size=(K + W, max(1, args.midi_live))).astype(np.uint8)
-    live_frames = np.sort(rng.integers(0, block, size=(K + W, max(1, args.midi_live))), axis=1).astype(np.uint32)
+    live = []
+    if midi is not None:  # messages built once: the timed loop pays for the engine's live path, not for numpy
+        live_notes = rng.integers(36, 97, size=(K + W, args.midi_live)).astype(np.uint8)
+        live_frames = np.sort(rng.integers(0, block, size=(K + W, args.midi_live)), axis=1).astype(np.uint32)
+        for i in range(K + W):  # even blocks play notes, odd blocks release the notes of the block before
+            live.append(midi.pack_messages(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0)))
 
     def step(i):
         if midi is None:
             eng.process_block_async(block, base + i * block * ch * 4)
-        else:  # note-on / note-off pairs, alternating, through the MIDI front end and the blocking entry point
-            midi.send_many(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0))  # odd blocks release the notes of the block before
-            host_bus[i] = midi.process_block(block).reshape(-1)
+        else:
+            midi.send_packed(live[i])
+            if args.midi_blocking:
+                host_bus[i] = midi.process_block(block).reshape(-1)
+            else:
+                midi.process_block_async(block, base + i * block * ch * 4)
 
     def reduce_bus(t):
         if args.backend == "gloo":  # CPU collective (plumbing check only)
@@ -277,7 +287,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        mix = host_bus[W:] if midi is not None else bus[W:].float().cpu().numpy()
+        mix = host_bus[W:] if (midi is not None and args.midi_blocking) else bus[W:].float().cpu().numpy()
         assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
         value = total_voices * K * block / elapsed
         words = eng.state_words_per_voice
@@ -321,7 +331,9 @@ def main():
                 "parallelism": "voice-shard x%d" % world_size,
                 "events_in_timed_region": n_events_timed,
                 "note_plan_span_frames": span if span else 48000,
-                "event_path": "midi-live (og_midi_send + og_process_block per block)" if midi is not None
+                "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
+                               ("og_midi_process_block, blocking" if args.midi_blocking else "og_midi_process_block_async"))
+                              if midi is not None
                               else "resident timeline (og_schedule_voice_events)",
             },
             "rccl_ranks": rccl_ranks,

@@ -311,6 +311,9 @@ int og_midi_set_queue_capacity(og_midi* m, uint32_t capacity);
 uint64_t og_midi_dropped(const og_midi* m); /* queue overflows + messages whose frame_offset >= the block's frames */
 int og_midi_flush(og_midi* m);
 int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus);
+/* the same over og_process_block_async: the bus stays on the device (d_out_bus or the engine's own buffer), so the
+ * host can parse the next block's messages while this block renders */
+int og_midi_process_block_async(og_midi* m, uint32_t frames, float* d_out_bus);
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age);
 int og_midi_pop_output(og_midi* m, uint32_t* voice, uint32_t* frame, float* frequency, int* has_frequency, float* gate);
 

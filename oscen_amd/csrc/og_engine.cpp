@@ -247,6 +247,10 @@ struct og_engine {
     std::vector<HostEvent> pending;      // pushes not yet on the device timeline
     std::vector<OgEvent> h_events;       // host mirror of d_events[0, ev_tail)
     std::vector<uint32_t> seg_begin, seg_end; // per voice: its current segment (empty vectors = all segments empty)
+    std::vector<uint64_t> seg_last;           // per voice: frame of the segment's last event (< frame_now: all consumed)
+    std::vector<uint32_t> grp_head, grp_tail, grp_next, grp_voices; // incremental path: pending events chained per voice
+    std::vector<uint8_t> local_cnt;      // [voice * n_event_inputs + event input]: try_push'ed events queued for the next block
+    std::vector<uint32_t> local_touched; // entries of local_cnt to clear when the block starts
     size_t ev_tail = 0;                  // bump pointer into d_events
     bool ev_rebuild = false;             // next block must rebuild the whole timeline
     OgEvent* h_stage_ev[EV_RING] = {};   // pinned
@@ -257,7 +261,6 @@ struct og_engine {
     int stage_head = 0;
     uint64_t n_full_rebuilds = 0, n_incremental = 0;
     size_t n_block_local = 0; // events pushed with try_push semantics for the next block
-    std::unordered_map<uint64_t, uint32_t> local_count; // (voice, target) -> events queued for the next block
     uint64_t seq = 0;
     uint32_t bus_passes = 0; // og_bus_reduce launches of the last block (1 + levels of the multi-pass tree)
     uint64_t frame_now = 0;
@@ -350,18 +353,25 @@ struct og_engine {
         h_events.clear();
         seg_begin.clear();
         seg_end.clear();
+        seg_last.clear();
         ev_tail = 0;
         ev_rebuild = false;
         n_block_local = 0;
-        local_count.clear();
+        clear_local_counts();
         HIPCK(hipMemsetAsync(d_ev_cursor, 0, (size_t)V * 4, stream));
         HIPCK(hipMemsetAsync(d_ev_end, 0, (size_t)V * 4, stream));
+    }
+
+    void clear_local_counts()
+    {
+        for (uint32_t k : local_touched) local_cnt[k] = 0;
+        local_touched.clear();
     }
 
     // unconsumed events of voice v on the device timeline (a block consumes everything before its end)
     void old_events(uint32_t v, std::vector<OgEvent>& out) const
     {
-        if (seg_begin.empty()) return;
+        if (seg_begin.empty() || seg_begin[v] == seg_end[v] || seg_last[v] < frame_now) return; // (no look at h_events: cold memory)
         for (uint32_t i = seg_begin[v]; i < seg_end[v]; ++i)
             if (h_events[i].frame >= frame_now) out.push_back(h_events[i]);
     }
@@ -393,6 +403,7 @@ struct og_engine {
         std::stable_sort(pending.begin(), pending.end(), push_order);
         std::vector<OgEvent> evs;
         std::vector<uint32_t> cursor(V), end(V);
+        std::vector<uint64_t> last(V, 0);
         std::vector<OgEvent> old;
         size_t p = 0;
         const size_t np = pending.size();
@@ -411,13 +422,14 @@ struct og_engine {
             }
             p = q;
             end[v] = (uint32_t)evs.size();
+            if (end[v] != cursor[v]) last[v] = evs.back().frame;
         }
         const size_t n = evs.size();
         if (n > 0xFFFFFFF0ull) throw std::runtime_error("event timeline too long");
         if (n + EV_STAGE_EVENTS > ev_cap) {
             if (d_events) HIPCK(hipFree(d_events));
             d_events = nullptr;
-            ev_cap = std::max<size_t>(n + n / 2, 1024) + 8 * EV_STAGE_EVENTS; // head-room for appended segments
+            ev_cap = std::max<size_t>(n + n / 2, 1024) + 64 * EV_STAGE_EVENTS; // head-room for appended segments (32 MB)
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
         }
         if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
@@ -427,6 +439,7 @@ struct og_engine {
         h_events.swap(evs);
         seg_begin.swap(cursor);
         seg_end.swap(end);
+        seg_last.swap(last);
         ev_tail = n;
         pending.clear();
         ev_rebuild = false;
@@ -449,38 +462,73 @@ struct og_engine {
         if (seg_begin.empty()) {
             seg_begin.assign(V, 0);
             seg_end.assign(V, 0);
+            seg_last.assign(V, 0);
         }
-        std::stable_sort(pending.begin(), pending.end(), push_order);
+        // group the pending pushes per voice without sorting the batch: chain them in arrival order (O(n)), then put
+        // every (short) chain into (frame, push order)
+        const size_t np = pending.size();
+        constexpr uint32_t NONE = 0xFFFFFFFFu;
+        if (grp_head.empty()) {
+            grp_head.assign(V, NONE);
+            grp_tail.assign(V, NONE);
+        }
+        grp_next.assign(np, NONE);
+        grp_voices.clear();
+        for (size_t i = 0; i < np; ++i) {
+            const uint32_t v = pending[i].voice;
+            if (grp_head[v] == NONE) {
+                grp_head[v] = (uint32_t)i;
+                grp_voices.push_back(v);
+            } else {
+                grp_next[grp_tail[v]] = (uint32_t)i;
+            }
+            grp_tail[v] = (uint32_t)i;
+        }
         const int r = stage_head;
         if (stage_used[r]) HIPCK(hipEventSynchronize(stage_done[r])); // (EV_RING blocks ago: long done)
         OgEvent* sev = h_stage_ev[r];
         uint32_t* upd = h_stage_upd[r];
         std::vector<OgEvent> old, merged;
+        std::vector<HostEvent> mine;
         size_t n_ev = 0, n_upd = 0;
-        const size_t np = pending.size();
-        for (size_t p = 0; p < np;) {
-            const uint32_t v = pending[p].voice;
-            size_t q = p;
-            while (q < np && pending[q].voice == v) ++q;
+        bool fits = true;
+        for (const uint32_t v : grp_voices) {
+            mine.clear();
+            for (uint32_t i = grp_head[v]; i != NONE; i = grp_next[i]) mine.push_back(pending[i]);
+            grp_head[v] = NONE; // (left clean for the next batch, also on the early exit below)
+            if (!fits) continue;
+            for (size_t i = 1; i < mine.size(); ++i) { // insertion sort by frame; arrival order breaks ties
+                const HostEvent k = mine[i];
+                size_t j = i;
+                while (j > 0 && mine[j - 1].frame > k.frame) {
+                    mine[j] = mine[j - 1];
+                    --j;
+                }
+                mine[j] = k;
+            }
             old.clear();
             merged.clear();
             old_events(v, old);
-            merge_by_frame(old, pending.data() + p, pending.data() + q, merged);
-            if (n_ev + merged.size() > EV_STAGE_EVENTS || ev_tail + n_ev + merged.size() > ev_cap) return false;
+            merge_by_frame(old, mine.data(), mine.data() + mine.size(), merged);
+            if (n_ev + merged.size() > EV_STAGE_EVENTS || ev_tail + n_ev + merged.size() > ev_cap) {
+                fits = false;
+                continue;
+            }
             memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
             upd[3 * n_upd] = v;
             upd[3 * n_upd + 1] = (uint32_t)(ev_tail + n_ev);
             upd[3 * n_upd + 2] = (uint32_t)(ev_tail + n_ev + merged.size());
             n_ev += merged.size();
             n_upd += 1;
-            p = q;
         }
+        if (!fits) return false;
         // commit: host mirror, then the device
         h_events.resize(ev_tail + n_ev);
         memcpy(h_events.data() + ev_tail, sev, n_ev * sizeof(OgEvent));
         for (size_t i = 0; i < n_upd; ++i) {
             seg_begin[upd[3 * i]] = upd[3 * i + 1];
             seg_end[upd[3 * i]] = upd[3 * i + 2];
+            seg_last[upd[3 * i]] = sev[upd[3 * i + 2] - 1 - ev_tail].frame;
         }
         if (n_ev) HIPCK(hipMemcpyAsync(d_events + ev_tail, sev, n_ev * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
         HIPCK(hipMemcpyAsync(d_stage_upd[r], upd, n_upd * 3 * 4, hipMemcpyHostToDevice, stream));
@@ -508,7 +556,7 @@ struct og_engine {
                           pending.end());
             dropped += before - pending.size();
             n_block_local = 0;
-            local_count.clear();
+            clear_local_counts();
         }
         if (pending.empty() && !ev_rebuild) return;
         // many voices touched at once (bulk scheduling): one compact CSR rebuild beats per-voice segments
@@ -671,8 +719,12 @@ int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, flo
         target = (uint32_t)in.event_index;
     }
     if (local && !setvalue) { // ArrayVec<EventInstance, 32> capacity per endpoint per block
-        uint32_t& cnt = e->local_count[((uint64_t)voice << 32) | target];
+        const size_t ne = (size_t)std::max(1, e->cg->n_event_inputs);
+        if (e->local_cnt.empty()) e->local_cnt.assign((size_t)e->V * ne, 0);
+        const size_t k = (size_t)voice * ne + target;
+        uint8_t& cnt = e->local_cnt[k];
         if (cnt < OG_MAX_EVENTS_PER_BLOCK) {
+            if (cnt == 0) e->local_touched.push_back((uint32_t)k);
             cnt += 1;
         } else {
             e->dropped += 1;

@@ -11,8 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
-#include <map>
-#include <set>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -31,14 +30,35 @@ struct og_midi {
     std::vector<Voice> voices;
     uint32_t current_age = 0;
     // The reference scans all voices per note (24 of them).  With N = the bank size the same decisions come from
-    // three indexes, O(log N) per note:
+    // three indexes (binary heaps with lazy deletion: ~tens of ns per note, no allocation in steady state):
     //  * voices become active in index order and never turn inactive again (release keeps `active`,
     //    voice_allocator.rs:101-108), so "first inactive voice" is a counter;
-    //  * stealing = min over (released ? 0 : 1, age): ages are unique, so one age-ordered map per release state;
-    //  * find_voice_for_note = lowest index among the held voices playing that note: an ordered set per note.
-    uint32_t n_fresh = 0;                       // voices [0, n_fresh) are active
-    std::map<uint32_t, uint32_t> released_by_age, held_by_age; // age -> voice
-    std::set<uint32_t> held_by_note[256];
+    //  * stealing = min over (released ? 0 : 1, age): ages are unique, so one age-ordered heap per release state;
+    //  * find_voice_for_note = lowest index among the held voices playing that note: a min-heap of indices per note.
+    // An entry is stale when the voice has since changed state (its age / note / release flag no longer match).
+    uint32_t n_fresh = 0; // voices [0, n_fresh) are active
+    struct AgeEntry {
+        uint32_t age, voice;
+        bool operator>(const AgeEntry& o) const { return age > o.age; }
+    };
+    template <class T>
+    struct MinHeap {
+        std::vector<T> v;
+        void push(const T& x)
+        {
+            v.push_back(x);
+            std::push_heap(v.begin(), v.end(), std::greater<T>());
+        }
+        void pop()
+        {
+            std::pop_heap(v.begin(), v.end(), std::greater<T>());
+            v.pop_back();
+        }
+        const T& top() const { return v.front(); }
+        bool empty() const { return v.empty(); }
+    };
+    MinHeap<AgeEntry> released_by_age, held_by_age;
+    MinHeap<uint32_t> held_by_note[256];
     // `midi_in` is an ArrayVec<EventInstance, 32> (graph/types.rs:18) in front of MAX_VOICES = 24 voices; the capacity
     // is lifted with N in the same proportion (32 per 24 voices); og_midi_set_queue_capacity overrides it
     uint32_t queue_cap = 32;
@@ -48,6 +68,7 @@ struct og_midi {
         uint64_t seq;
     };
     std::vector<Msg> queue;
+    bool queue_sorted = true; // messages arrived in frame order so far (the usual case): flush() skips the sort
     uint64_t seq = 0;
     uint64_t dropped = 0;
     struct Out { // what reached the voices (log for detached use / tests)
@@ -57,45 +78,69 @@ struct og_midi {
     };
     std::deque<Out> log;
 
-    void unindex(uint32_t i)
-    {
-        Voice& v = voices[i];
-        if (!v.active) return;
-        (v.released ? released_by_age : held_by_age).erase(v.age);
-        if (!v.released && v.note >= 0) held_by_note[v.note & 255].erase(i);
-    }
+    bool held_ok(const AgeEntry& e) const { return voices[e.voice].active && !voices[e.voice].released && voices[e.voice].age == e.age; }
+    bool released_ok(const AgeEntry& e) const { return voices[e.voice].active && voices[e.voice].released && voices[e.voice].age == e.age; }
     // allocate_voice  voice_allocator.rs:57-89
     uint32_t allocate(uint8_t note)
     {
         uint32_t i;
         if (n_fresh < n) {
             i = n_fresh++;
-        } else if (!released_by_age.empty()) {
-            i = released_by_age.begin()->second; // released voices first, oldest of them
         } else {
-            i = held_by_age.begin()->second;     // all held: the oldest
+            while (!released_by_age.empty() && !released_ok(released_by_age.top())) released_by_age.pop();
+            if (!released_by_age.empty()) {
+                i = released_by_age.top().voice; // released voices first, the oldest of them
+                released_by_age.pop();
+            } else {
+                while (!held_ok(held_by_age.top())) held_by_age.pop(); // all held: the oldest (never empty here)
+                i = held_by_age.top().voice;
+                held_by_age.pop();
+            }
         }
-        unindex(i);
         Voice& v = voices[i];
         v.active = true;
         v.released = false;
         v.note = note;
         v.age = current_age++;
-        held_by_age[v.age] = i;
-        held_by_note[note & 255].insert(i);
+        held_by_age.push(AgeEntry{v.age, i});
+        held_by_note[note].push(i);
+        // stale entries never outnumber the live ones by much: rebuild a heap that has grown past 4 N
+        if (held_by_age.v.size() > 4u * (size_t)n + 64u) rebuild();
         return i;
     }
-    int find(uint8_t note) const // find_voice_for_note :92-98
+    void rebuild()
     {
-        const auto& s = held_by_note[note & 255];
-        return s.empty() ? -1 : (int)*s.begin();
+        held_by_age.v.clear();
+        released_by_age.v.clear();
+        for (auto& h : held_by_note) h.v.clear();
+        for (uint32_t i = 0; i < n_fresh; ++i) {
+            const Voice& v = voices[i];
+            if (v.released) {
+                released_by_age.v.push_back(AgeEntry{v.age, i});
+            } else {
+                held_by_age.v.push_back(AgeEntry{v.age, i});
+                if (v.note >= 0) held_by_note[v.note & 255].v.push_back(i);
+            }
+        }
+        std::make_heap(held_by_age.v.begin(), held_by_age.v.end(), std::greater<AgeEntry>());
+        std::make_heap(released_by_age.v.begin(), released_by_age.v.end(), std::greater<AgeEntry>());
+        for (auto& h : held_by_note) std::make_heap(h.v.begin(), h.v.end(), std::greater<uint32_t>());
+    }
+    int find(uint8_t note) // find_voice_for_note :92-98
+    {
+        auto& h = held_by_note[note];
+        while (!h.empty()) {
+            const Voice& v = voices[h.top()];
+            if (v.active && !v.released && v.note == (int)note) return (int)h.top();
+            h.pop();
+        }
+        return -1;
     }
     void release(uint32_t i) // release_voice :101-108
     {
-        unindex(i);
         voices[i].released = true;
         voices[i].note = -1;
-        released_by_age[voices[i].age] = i;
+        released_by_age.push(AgeEntry{voices[i].age, i});
     }
     static float note_to_freq(uint8_t note) // midi.rs:69-72
     {
@@ -144,7 +189,8 @@ struct og_midi {
     // block, codegen/mod.rs:782-871), so it must not touch the allocator either.
     void flush(uint32_t frames = 0xFFFFFFFFu)
     {
-        std::stable_sort(queue.begin(), queue.end(), [](const Msg& a, const Msg& b) { return a.frame < b.frame; });
+        if (!queue_sorted) std::stable_sort(queue.begin(), queue.end(), [](const Msg& a, const Msg& b) { return a.frame < b.frame; });
+        queue_sorted = true;
         for (const Msg& m : queue) {
             if (m.frame >= frames) {
                 dropped += 1;
@@ -201,6 +247,7 @@ int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_
         m->dropped += 1;
         return OG_E_OVERFLOW;
     }
+    if (!m->queue.empty() && m->queue.back().frame > msg.frame) m->queue_sorted = false;
     m->queue.push_back(msg);
     return OG_OK;
 }
@@ -240,6 +287,15 @@ int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus)
     m->flush(frames);
     const int rc = og_process_block(m->engine, frames, out_bus);
     return rc != OG_OK ? rc : m->last_rc; // the block was rendered; a non-zero code reports a dropped event
+}
+
+int og_midi_process_block_async(og_midi* m, uint32_t frames, float* d_out_bus)
+{
+    if (!m || !m->engine) return OG_E_INVALID;
+    m->last_rc = OG_OK;
+    m->flush(frames);
+    const int rc = og_process_block_async(m->engine, frames, d_out_bus);
+    return rc != OG_OK ? rc : m->last_rc;
 }
 
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age)
