@@ -250,7 +250,11 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 int og_enable_kernel_timing(og_engine* e, int on);
 double og_kernel_time_ms(og_engine* e, uint32_t* n_launches);
 
-/* state snapshot (flat SoA blob) */
+/* State snapshot: the DSP state (SoA planes, per-harmonic arrays, post-mix phase, delay lines) followed by a control
+ * block -- frame counter, value / ValueRampState of every input, every event that has not fired yet -- so that loading
+ * it into an engine of the same graph, voice count and sample rate continues the render sample for sample, also from
+ * the middle of a ramp or with notes still scheduled.  og_state_bytes() is the size needed NOW (it grows with the
+ * number of pending events). */
 size_t og_state_bytes(const og_engine* e);
 int og_save_state(og_engine* e, void* dst, size_t cap);
 int og_load_state(og_engine* e, const void* src, size_t len);

@@ -275,7 +275,9 @@ struct og_engine {
     ~og_engine()
     {
         (void)hipSetDevice(device);
-        if (stream) (void)hipStreamSynchronize(stream);
+        // a borrowed stream (og_set_stream) may already be gone: wait for the device instead of touching it
+        if (own_stream && stream) (void)hipStreamSynchronize(stream);
+        else (void)hipDeviceSynchronize();
         (void)hipFree(d_state);
         (void)hipFree(d_lane_state);
         for (int k = 0; k < OG_MAX_RINGS; ++k) (void)hipFree(d_ring[k]);
@@ -623,7 +625,8 @@ struct og_engine {
             A.ramp_table = d_ramp[r];
         }
         const bool taps_on = n_taps > 0;
-        if (timing) {
+        const bool timed = timing && t_used < 8192; // (a host that never collects the timings stops adding events)
+        if (timed) {
             if (t_used == t_start.size()) {
                 hipEvent_t a, b;
                 HIPCK(hipEventCreate(&a));
@@ -637,7 +640,7 @@ struct og_engine {
             launch(A, ramps_on, taps_on, stream);
         else
             jit->launch(A, ramps_on, taps_on, stream);
-        if (timing) {
+        if (timed) {
             HIPCK(hipEventRecord(t_stop[t_used], stream));
             ++t_used;
         }
@@ -1023,6 +1026,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
                 depth = (want >= 4 && e->cg->max_pipeline >= 4) ? 4 : ((want >= 2 && e->cg->max_pipeline >= 2) ? 2 : 0);
                 if (want == 1 && e->cg->max_pipeline >= 2) depth = 2; // (old boolean meaning)
             }
+            if (e->lanes != OG_WAVE) depth = 0; // the pipelined variants always run 64 voices per workgroup
             e->split = depth;
         }
         e->n_wg = (uint32_t)(((size_t)n_voices * e->cg->lpv + e->lanes - 1) / e->lanes);
@@ -1048,6 +1052,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
+        HIPCK(hipMemset(e->d_partials, 0, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
         HIPCK(hipMalloc(&e->d_partials2, ((size_t)e->n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK * 4));
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
@@ -1438,18 +1443,71 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
     return avg;
 }
 
+} // extern "C"
+
+// ---- state snapshot ---------------------------------------------------------------------------------------------
+// blob = DSP state (state planes, lane arrays, post-mix phase, delay lines) + control block: frame counter, the value
+// and ValueRampState of every input, the ramp counter and every event that has not fired yet (resident timeline and
+// queued pushes).  Loading it into an engine of the same graph / voice count / sample rate continues the render
+// sample for sample.
+namespace {
+struct SnapHeader {
+    uint32_t magic, version;
+    uint64_t frame_now;
+    uint32_t n_inputs, active_ramps;
+    uint64_t n_events;
+};
+struct SnapRamp {
+    float current, target, increment;
+    uint32_t frames_remaining;
+};
+struct SnapEvent {
+    uint32_t voice, target;
+    uint64_t frame;
+    float value;
+    uint32_t block_local;
+};
+constexpr uint32_t SNAP_MAGIC = 0x3253474Fu; // "OGS2"
+
+size_t dsp_bytes(const og_engine* e)
+{
+    return (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv * e->cg->lane_width) * (size_t)e->V * 4 +
+           (e->cg->bus_tremolo ? 4 : 0) + e->ring_bytes();
+}
+void collect_unconsumed(const og_engine* e, std::vector<SnapEvent>& out)
+{
+    std::vector<OgEvent> old;
+    if (!e->seg_begin.empty())
+        for (uint32_t v = 0; v < e->V; ++v) {
+            old.clear();
+            e->old_events(v, old);
+            for (const OgEvent& ev : old) out.push_back(SnapEvent{v, ev.target, ev.frame, ev.value, 0u});
+        }
+    for (const HostEvent& h : e->pending) out.push_back(SnapEvent{h.voice, h.target, h.frame, h.value, h.block_local ? 1u : 0u});
+}
+size_t control_bytes(const og_engine* e, size_t n_events)
+{
+    return sizeof(SnapHeader) + e->cg->inputs.size() * (sizeof(float) + sizeof(SnapRamp)) + n_events * sizeof(SnapEvent);
+}
+} // namespace
+
+extern "C" {
+
 size_t og_state_bytes(const og_engine* e)
 {
     // (delay lines are part of the state: their size is known once og_init has sized them)
-    return e ? (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv * e->cg->lane_width) * (size_t)e->V * 4 + (e->cg->bus_tremolo ? 4 : 0) +
-                   e->ring_bytes()
-             : 0;
+    if (!e) return 0;
+    std::vector<SnapEvent> evs;
+    collect_unconsumed(e, evs);
+    return dsp_bytes(e) + control_bytes(e, evs.size());
 }
 
 int og_save_state(og_engine* e, void* dst, size_t cap)
 {
     if (!e || !dst) return set_err(OG_E_INVALID, "null argument");
-    if (cap < og_state_bytes(e)) return set_err(OG_E_INVALID, "buffer too small");
+    std::vector<SnapEvent> evs;
+    collect_unconsumed(e, evs);
+    if (cap < dsp_bytes(e) + control_bytes(e, evs.size())) return set_err(OG_E_INVALID, "buffer too small");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
@@ -1463,6 +1521,18 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
             off += n;
         }
         HIPCK(hipStreamSynchronize(e->stream));
+        char* p = (char*)dst + off;
+        const SnapHeader h{SNAP_MAGIC, 2u, e->frame_now, (uint32_t)e->cg->inputs.size(), e->active_ramps, (uint64_t)evs.size()};
+        memcpy(p, &h, sizeof h);
+        p += sizeof h;
+        memcpy(p, e->values.data(), e->values.size() * sizeof(float));
+        p += e->values.size() * sizeof(float);
+        for (const Ramp& r : e->ramps) {
+            const SnapRamp sr{r.current, r.target, r.increment, r.frames_remaining};
+            memcpy(p, &sr, sizeof sr);
+            p += sizeof sr;
+        }
+        if (!evs.empty()) memcpy(p, evs.data(), evs.size() * sizeof(SnapEvent));
         return OG_OK;
     });
 }
@@ -1470,7 +1540,12 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
 int og_load_state(og_engine* e, const void* src, size_t len)
 {
     if (!e || !src) return set_err(OG_E_INVALID, "null argument");
-    if (len != og_state_bytes(e)) return set_err(OG_E_INVALID, "state blob size mismatch");
+    const size_t dsp = dsp_bytes(e);
+    if (len < dsp + sizeof(SnapHeader)) return set_err(OG_E_INVALID, "state blob size mismatch");
+    SnapHeader h;
+    memcpy(&h, (const char*)src + dsp, sizeof h);
+    if (h.magic != SNAP_MAGIC || h.version != 2u || h.n_inputs != e->cg->inputs.size() || len != dsp + control_bytes(e, (size_t)h.n_events))
+        return set_err(OG_E_INVALID, "state blob does not belong to this graph / voice count (or is from another version)");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
@@ -1483,7 +1558,30 @@ int og_load_state(og_engine* e, const void* src, size_t len)
             if (n) HIPCK(hipMemcpyAsync(e->d_ring[k], (const char*)src + off, n, hipMemcpyHostToDevice, e->stream));
             off += n;
         }
+        e->reset_timeline();
         HIPCK(hipStreamSynchronize(e->stream));
+        const char* p = (const char*)src + off + sizeof h;
+        memcpy(e->values.data(), p, e->values.size() * sizeof(float));
+        p += e->values.size() * sizeof(float);
+        for (Ramp& r : e->ramps) {
+            SnapRamp sr;
+            memcpy(&sr, p, sizeof sr);
+            p += sizeof sr;
+            r.current = sr.current;
+            r.target = sr.target;
+            r.increment = sr.increment;
+            r.frames_remaining = sr.frames_remaining;
+        }
+        e->active_ramps = h.active_ramps;
+        e->frame_now = h.frame_now;
+        for (uint64_t i = 0; i < h.n_events; ++i) {
+            SnapEvent ev;
+            memcpy(&ev, p, sizeof ev);
+            p += sizeof ev;
+            if (ev.voice >= e->V) throw std::runtime_error("state blob: event voice out of range");
+            e->pending.push_back(HostEvent{ev.voice, ev.frame, ev.target, ev.value, e->seq++, ev.block_local != 0u});
+            if (ev.block_local) e->n_block_local += 1;
+        }
         return OG_OK;
     });
 }

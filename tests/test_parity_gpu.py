@@ -295,6 +295,48 @@ def test_state_snapshot_roundtrip():
     assert np.array_equal(a, b)
 
 
+def test_state_snapshot_carries_ramps_frame_counter_and_pending_events():
+    """a snapshot taken in the middle of a parameter ramp, with note-offs still scheduled and a try_push'ed event queued
+    for the next block, loaded into a FRESH engine: the continuation is the original render, bit for bit"""
+    n, block = 96, 128
+    freqs = midi_freqs(n, 5)
+
+    def fresh():
+        e = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+        e.set_voice_values("frequency", freqs)
+        e.set_voice_taps(np.arange(n, dtype=np.uint32))
+        return e
+
+    eng = fresh()
+    for v in range(n):
+        eng.schedule_voice_event("gate", v, 3 + v, 0.8)
+        eng.schedule_voice_event("gate", v, 700 + 5 * v, 0.0)     # still pending at the snapshot
+        eng.schedule_voice_event("gate", v, 1500 + 3 * v, 0.6)
+    eng.process_block(block)
+    eng.set_value_with_ramp("filter_cutoff", 6000.0, 900)          # ramp spans the snapshot point
+    eng.set_value("op3_feedback", 0.1)
+    eng.set_value("route", 0.3)
+    for _ in range(3):
+        eng.process_block(block)
+    assert eng.push_voice_event("gate", 7, 11, 0.0) == 0            # queued for the next block
+    blob = eng.save_state()
+    want = []
+    for _ in range(12):
+        eng.process_block(block)
+        want.append(eng.read_voice_taps(block))
+    other = fresh()
+    other.load_state(blob)
+    assert other.frames_processed == 4 * block
+    got = []
+    for _ in range(12):
+        other.process_block(block)
+        got.append(other.read_voice_taps(block))
+    assert np.array_equal(np.concatenate(got, axis=1), np.concatenate(want, axis=1))
+    assert abs(other.get_value("filter_cutoff") - eng.get_value("filter_cutoff")) == 0.0
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.Engine("fm_voice", n + 1, sample_rate=SR).load_state(blob)
+
+
 # --------------------------------------------------------------------------
 # full-size properties (BASELINE.json configs[1]: 65 536 voices, block 256)
 # --------------------------------------------------------------------------
