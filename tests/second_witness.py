@@ -1,0 +1,468 @@
+"""A SECOND, independent restatement of the unpinned numerics (TEST INFRASTRUCTURE).
+
+The reference cannot be built here (nightly Rust), so FmOperator waveforms, the ADSR curve and the electric-piano voice
+have no reference-held vectors: the C oracle (oracle/oscen_oracle.c) is a transliteration.  This module is a second
+transliteration, written from the RUST sources (not from the C), in numpy float32 scalar arithmetic -- every `+ - * /` on
+np.float32 rounds to f32 exactly like Rust's f32 ops -- with the transcendental functions taken from the platform libm
+through ctypes (sinf / cosf / tanf / expf: what Rust's f32::sin etc. bind to on Linux).  tests/test_second_witness.py
+demands BIT equality with the C oracle: two hand translations agreeing to the last bit on tens of thousands of samples is
+the substitute for an oracle/_ref build.
+
+Sources followed:
+  AdsrEnvelope     oscen-lib/src/envelope/adsr.rs:57-306
+  FmOperator       examples/fm-synth/src/nodes/fm_operator.rs:34-76
+  Crossfade/Mixer/AddValue  examples/fm-synth/src/nodes/{crossfade.rs:37-44,mixer.rs:30-34,add_value.rs:31-35}
+  Gain             oscen-lib/src/gain/mod.rs:30-34
+  TptFilter<f32>   oscen-lib/src/filters/tpt/mod.rs:47-123
+  FMVoice          examples/fm-synth/src/fm_voice.rs:6-156 (schedule: any topological order, the graph is feed-forward)
+  AmplitudeSource / OscillatorBank / ElectricPianoVoiceNode  examples/electric-piano/src/electric_piano_voice.rs:50-402
+"""
+import ctypes
+import ctypes.util
+
+import numpy as np
+
+f32 = np.float32
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+for _n in ("sinf", "cosf", "tanf", "expf"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float]
+
+
+def sinf(x):
+    return f32(_libm.sinf(float(x)))
+
+
+def cosf(x):
+    return f32(_libm.cosf(float(x)))
+
+
+def tanf(x):
+    return f32(_libm.tanf(float(x)))
+
+
+def expf(x):
+    return f32(_libm.expf(float(x)))
+
+
+def clamp(x, lo, hi):  # f32::clamp
+    x, lo, hi = f32(x), f32(lo), f32(hi)
+    if x < lo:
+        return lo
+    if x > hi:
+        return hi
+    return x
+
+
+def as_u32(x):  # Rust `f32 as u32`: saturating, NaN -> 0
+    x = float(x)
+    if not x > 0.0:
+        return 0
+    if x >= 4294967296.0:
+        return 4294967295
+    return int(x)
+
+
+EPS = f32(1.1920929e-07)
+PI = f32(3.14159274101257324)
+TAU = f32(6.28318548202514648)
+
+IDLE, ATTACK, DECAY, SUSTAIN, RELEASE = range(5)
+MIN_TIME_SECONDS = f32(1.0e-5)
+CURVE_TIME_CONSTANT = f32(4.605_170_2)
+
+
+class Adsr:
+    """envelope/adsr.rs"""
+
+    def __init__(self, attack, decay, sustain, release):  # new() :57-82
+        self.attack, self.decay, self.sustain, self.release = f32(attack), f32(decay), f32(sustain), f32(release)
+        self.output = f32(0)
+        self.stage = IDLE
+        self.attack_samples = self.decay_samples = self.release_samples = 0
+        self.samples_remaining = 0
+        self.attack_coeff = self.decay_coeff = self.release_increment = f32(0)
+        self.level = self.target_level = f32(0)
+        self.sustain_level = clamp(self.sustain, 0.0, 1.0)
+        self.velocity = f32(1)
+        self.sample_rate = f32(44100.0)
+        self.update_sustain_level()
+
+    def apply_parameters(self):  # :84-90
+        self.attack = max(self.attack, f32(0))
+        self.decay = max(self.decay, f32(0))
+        self.sustain = clamp(self.sustain, 0.0, 1.0)
+        self.release = max(self.release, f32(0))
+        self.update_sustain_level()
+
+    def update_sustain_level(self):  # :92-115
+        self.sustain_level = clamp(f32(self.sustain * self.velocity), 0.0, 1.0)
+        self.recalculate_cached_steps()
+        if self.samples_remaining > 0:
+            if self.stage == ATTACK:
+                self.samples_remaining = max(min(self.samples_remaining, self.attack_samples), 1)
+            elif self.stage == DECAY:
+                self.samples_remaining = max(min(self.samples_remaining, self.decay_samples), 1)
+            elif self.stage == RELEASE:
+                self.samples_remaining = max(min(self.samples_remaining, self.release_samples), 1)
+        if self.stage in (DECAY, SUSTAIN):
+            self.target_level = self.sustain_level
+        elif self.stage == RELEASE:
+            self.target_level = f32(0)
+        if self.stage == RELEASE:
+            self.update_release_increment()
+
+    def recalculate_cached_steps(self):  # :117-134
+        sr = max(self.sample_rate, f32(1))
+        self.attack_samples = max(as_u32(f32(max(self.attack, MIN_TIME_SECONDS) * sr)), 1)
+        self.decay_samples = max(as_u32(f32(max(self.decay, MIN_TIME_SECONDS) * sr)), 1)
+        self.release_samples = max(as_u32(f32(max(self.release, MIN_TIME_SECONDS) * sr)), 1)
+        self.attack_coeff = f32(f32(1) - expf(f32(-CURVE_TIME_CONSTANT / f32(self.attack_samples))))
+        self.decay_coeff = f32(f32(1) - expf(f32(-CURVE_TIME_CONSTANT / f32(self.decay_samples))))
+
+    def set_stage(self, stage, target_level):  # :136-159
+        self.stage = stage
+        self.target_level = clamp(target_level, 0.0, 1.0)
+        samples = {ATTACK: self.attack_samples, DECAY: self.decay_samples, RELEASE: self.release_samples}.get(stage, 0)
+        if samples == 0:
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+            self.level = self.target_level
+            if stage not in (SUSTAIN, IDLE):
+                self.complete_stage()
+        else:
+            self.samples_remaining = samples
+            self.update_release_increment()
+
+    def update_release_increment(self):  # :161-173
+        if self.samples_remaining == 0 or self.stage != RELEASE:
+            self.release_increment = f32(0)
+            return
+        current = clamp(self.level, 0.0, 1.0)
+        self.release_increment = f32(0) if current <= 0 else f32(-current / f32(self.samples_remaining))
+
+    def complete_stage(self):  # :175-204
+        if self.stage == ATTACK:
+            self.level = f32(1)
+            self.set_stage(DECAY, self.sustain_level)
+        elif self.stage == DECAY:
+            self.level = self.sustain_level
+            self.stage = SUSTAIN
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+        elif self.stage == RELEASE:
+            self.level = f32(0)
+            self.stage = IDLE
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+        elif self.stage == SUSTAIN:
+            self.level = self.sustain_level
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+        else:
+            self.level = f32(0)
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+
+    def process_stage(self):  # :206-248
+        if self.stage == ATTACK:
+            if self.samples_remaining > 0:
+                self.level = f32(self.level + f32(f32(f32(1) - self.level) * self.attack_coeff))
+                self.samples_remaining -= 1
+                self.level = clamp(self.level, 0.0, 1.0)
+            if self.samples_remaining == 0:
+                self.level = f32(1)
+                self.complete_stage()
+        elif self.stage == DECAY:
+            if self.samples_remaining > 0:
+                self.level = f32(self.level + f32(f32(self.sustain_level - self.level) * self.decay_coeff))
+                self.samples_remaining -= 1
+                self.level = clamp(self.level, 0.0, 1.0)
+            if self.samples_remaining == 0:
+                self.level = self.sustain_level
+                self.complete_stage()
+        elif self.stage == RELEASE:
+            if self.samples_remaining > 0:
+                self.level = f32(self.level + self.release_increment)
+                self.samples_remaining -= 1
+                self.level = clamp(self.level, 0.0, 1.0)
+            if self.samples_remaining == 0:
+                self.level = f32(0)
+                self.complete_stage()
+        elif self.stage == SUSTAIN:
+            self.level = self.sustain_level
+        else:
+            self.level = f32(0)
+
+    def on_gate(self, velocity):  # handle_gate_event :250-273 (scalar payload)
+        velocity = f32(velocity)
+        if velocity > 0:
+            self.velocity = clamp(velocity, 0.0, 1.0)
+            self.update_sustain_level()
+            if self.attack <= MIN_TIME_SECONDS:
+                self.level = f32(1)
+                self.set_stage(DECAY, self.sustain_level)
+            else:
+                self.set_stage(ATTACK, f32(1))
+        elif self.release <= MIN_TIME_SECONDS:
+            self.stage = IDLE
+            self.level = f32(0)
+            self.samples_remaining = 0
+            self.release_increment = f32(0)
+        else:
+            self.set_stage(RELEASE, f32(0))
+
+    def prepare(self, sr):
+        self.sample_rate = f32(sr)
+        self.update_sustain_level()
+
+    def process(self):  # :282-292
+        self.apply_parameters()
+        self.process_stage()
+        self.output = self.level
+
+
+class FmOperator:
+    """nodes/fm_operator.rs"""
+
+    def __init__(self):
+        self.phase = self.prev_output = f32(0)
+        self.sample_rate = f32(44100.0)
+        self.base_freq, self.ratio = f32(440), f32(1)
+        self.phase_mod = self.feedback = f32(0)
+        self.envelope = self.level = f32(1)
+        self.output = f32(0)
+
+    def process(self):  # :58-76
+        frequency = f32(self.base_freq * self.ratio)
+        feedback_mod = f32(self.prev_output * self.feedback)
+        total_phase_mod = f32(self.phase_mod + feedback_mod)
+        phase_rad = f32(f32(self.phase + total_phase_mod) * TAU)
+        output = f32(f32(sinf(phase_rad) * self.envelope) * self.level)
+        self.output = output
+        self.prev_output = output
+        phase_inc = f32(frequency / self.sample_rate)
+        self.phase = f32(self.phase + phase_inc)
+        self.phase = f32(self.phase - np.trunc(self.phase))  # fract()
+
+
+class Tpt:
+    """filters/tpt/mod.rs, F = f32"""
+
+    def __init__(self, cutoff, q):  # new() :47-66
+        self.input = f32(0)
+        self.cutoff, self.q, self.f_mod = f32(cutoff), f32(q), f32(0)
+        self.output = f32(0)
+        self.current_cutoff, self.current_q = f32(cutoff), f32(q)
+        self.z = [f32(0), f32(0)]
+        self.h = self.g = self.r = self.k = f32(0)
+        self.sample_rate = f32(44100.0)
+        self.update_coefficients(f32(44100.0), self.cutoff, self.q)
+
+    def update_coefficients(self, sample_rate, cutoff, q):  # :69-82
+        nyquist = f32(f32(sample_rate * f32(0.5)) - EPS)
+        freq = clamp(cutoff, 20.0, nyquist)
+        period = f32(f32(0.5) / sample_rate)
+        f = f32(f32(f32(f32(2) * sample_rate) * tanf(f32(f32(f32(f32(2) * PI) * freq) * period))) * period)
+        inv_q = f32(f32(1) / q)
+        self.h = f32(f32(1) / f32(f32(f32(1) + f32(inv_q * f)) + f32(f * f)))
+        self.g = f
+        self.r = inv_q
+        self.k = f32(self.g + self.r)
+        self.current_cutoff = f32(cutoff)
+        self.current_q = f32(q)
+
+    def prepare(self, sr):  # :129-131
+        self.sample_rate = f32(sr)
+        self.update_coefficients(self.sample_rate, self.cutoff, self.q)
+
+    def process(self):  # :85-122
+        sr = self.sample_rate
+        nyquist = f32(f32(sr * f32(0.5)) - EPS)
+        max_cutoff = min(nyquist, f32(20000))
+        cutoff_base = clamp(self.cutoff, 20.0, max_cutoff)
+        q = clamp(self.q, 0.1, 10.0)
+        modulation = clamp(self.f_mod, -1.0, 1.0)
+        min_factor = f32(f32(20) / cutoff_base)
+        max_factor = f32(max_cutoff / cutoff_base)
+        factor = clamp(f32(f32(1) + modulation), min_factor, max_factor)
+        cutoff = clamp(f32(cutoff_base * factor), 20.0, max_cutoff)
+        if abs(f32(cutoff - self.current_cutoff)) > EPS or abs(f32(q - self.current_q)) > EPS:
+            self.update_coefficients(sr, cutoff, q)
+        high = f32(f32(f32(self.input - f32(self.z[0] * self.k)) - self.z[1]) * self.h)
+        band = f32(f32(high * self.g) + self.z[0])
+        low = f32(f32(band * self.g) + self.z[1])
+        self.z[0] = f32(f32(high * self.g) + band)
+        self.z[1] = f32(f32(band * self.g) + low)
+        self.output = low
+
+
+FM_DEFAULTS = dict(  # fm_voice.rs:10-48
+    op3_ratio=3.0, op3_level=0.5, op3_feedback=0.0, op3_attack=0.01, op3_decay=0.1, op3_sustain=0.7, op3_release=0.3,
+    op2_ratio=2.0, op2_level=0.5, op2_feedback=0.0, op2_attack=0.01, op2_decay=0.1, op2_sustain=0.7, op2_release=0.3,
+    op1_ratio=1.0, op1_attack=0.01, op1_decay=0.2, op1_sustain=0.8, op1_release=0.5, route=0.0, filter_cutoff=2000.0,
+    filter_resonance=0.707, filter_attack=0.01, filter_decay=0.2, filter_sustain=0.5, filter_release=0.3,
+    filter_env_amount=0.0)
+
+
+class FMVoice:
+    """fm_voice.rs: nodes :51-80, connections :82-155"""
+
+    def __init__(self, sr):
+        self.p = {k: f32(v) for k, v in FM_DEFAULTS.items()}
+        self.frequency = f32(440)
+        self.env3, self.env2 = Adsr(0.01, 0.1, 0.7, 0.3), Adsr(0.01, 0.1, 0.7, 0.3)
+        self.env1, self.env_filter = Adsr(0.01, 0.2, 0.8, 0.5), Adsr(0.01, 0.2, 0.5, 0.3)
+        self.op3, self.op2, self.op1 = FmOperator(), FmOperator(), FmOperator()
+        self.filter = Tpt(2000.0, 0.707)
+        for e in (self.env3, self.env2, self.env1, self.env_filter):
+            e.prepare(sr)
+        for o in (self.op3, self.op2, self.op1):
+            o.sample_rate = f32(sr)
+        self.filter.prepare(sr)
+        self.audio_out = f32(0)
+
+    def frame(self, gate=None):
+        p = self.p
+        # envelopes: value edges, then the gate event, then process() (emit_node.rs order)
+        for env, pre in ((self.env3, "op3"), (self.env2, "op2"), (self.env1, "op1"), (self.env_filter, "filter")):
+            env.attack, env.decay = p[pre + "_attack"], p[pre + "_decay"]
+            env.sustain, env.release = p[pre + "_sustain"], p[pre + "_release"]
+            if gate is not None:
+                env.on_gate(gate)
+            env.process()
+        # filter envelope -> Gain(amount) -> AddValue(cutoff)      (gain/mod.rs:30-34, add_value.rs:31-35)
+        filter_env_gain = f32(self.env_filter.output * p["filter_env_amount"])
+        cutoff_mod = f32(filter_env_gain + p["filter_cutoff"])
+        o3 = self.op3
+        o3.base_freq, o3.ratio, o3.feedback = self.frequency, p["op3_ratio"], p["op3_feedback"]
+        o3.envelope, o3.level = self.env3.output, p["op3_level"]
+        o3.process()
+        mix = clamp(p["route"], 0.0, 1.0)  # crossfade.rs:37-44
+        route_a = f32(o3.output * f32(f32(1) - mix))
+        route_b = f32(o3.output * mix)
+        o2 = self.op2
+        o2.phase_mod = route_a
+        o2.base_freq, o2.ratio, o2.feedback = self.frequency, p["op2_ratio"], p["op2_feedback"]
+        o2.envelope, o2.level = self.env2.output, p["op2_level"]
+        o2.process()
+        o1 = self.op1
+        o1.phase_mod = f32(o2.output + route_b)  # mixer.rs:30-34
+        o1.base_freq, o1.ratio, o1.envelope = self.frequency, p["op1_ratio"], self.env1.output
+        o1.process()
+        fl = self.filter
+        fl.input, fl.cutoff, fl.q = o1.output, cutoff_mod, p["filter_resonance"]
+        fl.process()
+        self.audio_out = f32(fl.output * f32(0.3))  # output_gain = Gain::new(0.3)
+        return self.audio_out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+NUM_HARMONICS = 32
+INTERPOLATION_STEPS = 64
+VELOCITY_0_SPECTRUM = np.zeros(32, dtype=f32)
+VELOCITY_0_SPECTRUM[:2] = [0.02, 0.05]
+VELOCITY_127_SPECTRUM = np.array(
+    [0.150869, 0.385766, 0.215543, 0.117811, 0.100411, 0.0128637, 0.0288844, 0.00243388, 0.00963092, 0.0035634, 0.00256945,
+     0.00184799, 0.000399878, 0.000660576, 3.00995e-05, 0.00021866, 9.33705e-05, 0.000177973, 0.0002545, 0.000323602,
+     0.000779045, 0.000116569, 0.000772873, 0.000364486, 0.000248027, 0.00018236, 3.27292e-05, 6.64988e-05, 0.0, 0.0, 0.0,
+     0.0], dtype=f32)
+
+
+class EPianoVoice:
+    """electric_piano_voice.rs: AmplitudeSource :174-356 -> OscillatorBank :79-170 (numpy float32 arrays: element-wise
+    ops round per element like the Rust loops)"""
+
+    def __init__(self, sr):
+        self.sr = f32(sr)
+        self.frequency = f32(440)
+        self.brightness, self.velocity_scaling, self.decay_rate = f32(30), f32(50), f32(90)
+        self.harmonic_decay, self.key_scaling, self.release_rate = f32(70), f32(50), f32(40)
+        self.current_value = np.zeros(32, dtype=f32)
+        self.target_value = np.zeros(32, dtype=f32)
+        self.decay = np.zeros(32, dtype=f32)
+        self.release = np.zeros(32, dtype=f32)
+        self.released = False
+        self.note_pitch = f32(60)
+        self.step = INTERPOLATION_STEPS
+        self.osc_re = np.ones(32, dtype=f32)
+        self.osc_im = np.zeros(32, dtype=f32)
+        self.mul_re = np.ones(32, dtype=f32)
+        self.mul_im = np.zeros(32, dtype=f32)
+        self.last_frequency = f32(0)
+        self.output = f32(0)
+
+    def get_decay(self, note):  # :244-268
+        base_decay_rate = f32(f32(f32(100) - self.decay_rate) / f32(40000))
+        harmonic_scaling = f32(f32(1) - f32(f32(f32(100) - self.harmonic_decay) / f32(200000)))
+        scaling_multiplier = f32(f32(f32(48) - note) / f32(12))
+        key_scaling_factor = f32(scaling_multiplier * f32(self.key_scaling * f32(0.02)))
+        if key_scaling_factor > 0:
+            adjusted = f32(f32(1) - f32(base_decay_rate / f32(f32(1) + key_scaling_factor)))
+        else:
+            adjusted = f32(f32(1) - f32(base_decay_rate * f32(f32(1) - key_scaling_factor)))
+        decay = np.zeros(32, dtype=f32)
+        scaling = f32(1)
+        for i in range(32):
+            decay[i] = f32(adjusted * scaling)
+            scaling = f32(scaling * harmonic_scaling)
+        return decay
+
+    def on_gate(self, velocity):  # AmplitudeSource::on_gate :308-318, OscillatorBank::on_gate :115-122
+        velocity = f32(velocity)
+        if velocity > 0:
+            self.velocity = velocity  # trigger_note :292-299
+            self.decay = self.get_decay(self.note_pitch)
+            rel = f32(f32(0.999) - f32(f32(f32(100) - self.release_rate) / f32(1000)))
+            self.release = np.full(32, rel, dtype=f32)
+            amps = (VELOCITY_127_SPECTRUM * velocity + VELOCITY_0_SPECTRUM * f32(f32(1) - velocity)).astype(f32)
+            bs = f32(f32(-0.2) + f32(f32(0.8) * f32(self.brightness * f32(0.01))))
+            bs = f32(bs + f32(f32(f32(velocity * self.velocity_scaling) * f32(0.01)) * f32(0.5)))
+            idx = np.arange(32, dtype=f32)
+            amps = (amps * (f32(1) + bs * idx).astype(f32)).astype(f32)
+            self.current_value = amps
+            self.released = False
+            self.step = 0
+            self.osc_re = np.ones(32, dtype=f32)
+            self.osc_im = np.zeros(32, dtype=f32)
+        else:
+            self.released = True  # release_note :301-304
+            self.step = 0
+
+    def frame(self, gate=None):
+        if gate is not None:
+            self.on_gate(gate)
+        # AmplitudeSource::process :321-351
+        if self.step == 0:
+            mult = self.release if self.released else self.decay
+            self.target_value = (self.current_value * mult).astype(f32)
+        if self.step < INTERPOLATION_STEPS:
+            t = f32(f32(self.step + 1) / f32(INTERPOLATION_STEPS))
+            self.current_value = ((self.current_value * f32(f32(1) - t)).astype(f32) + (self.target_value * t).astype(f32)).astype(f32)
+            self.step += 1
+        else:
+            self.current_value = self.target_value.copy()
+            self.step = 0
+        amplitudes = self.current_value
+        # OscillatorBank::process :154-169
+        if self.frequency > 0 and not (abs(f32(self.last_frequency - self.frequency)) < f32(0.01)):  # update_multipliers :126-150
+            self.last_frequency = self.frequency
+            nyquist = f32(self.sr * f32(0.5))
+            for i in range(32):
+                hf = f32(self.frequency * f32(i + 1))
+                if hf < nyquist:
+                    angle = f32(f32(f32(f32(2) * PI) * hf) / self.sr)
+                    self.mul_re[i], self.mul_im[i] = cosf(angle), sinf(angle)
+                else:
+                    self.mul_re[i], self.mul_im[i] = f32(1), f32(0)
+            self.osc_re = np.ones(32, dtype=f32)
+            self.osc_im = np.zeros(32, dtype=f32)
+        new_re = ((self.osc_re * self.mul_re).astype(f32) - (self.osc_im * self.mul_im).astype(f32)).astype(f32)  # Complex::mul :66-72
+        new_im = ((self.osc_re * self.mul_im).astype(f32) + (self.osc_im * self.mul_re).astype(f32)).astype(f32)
+        self.osc_re, self.osc_im = new_re, new_im
+        prod = (self.osc_im * amplitudes).astype(f32)
+        s = f32(0)
+        for i in range(32):  # sequential f32 fold
+            s = f32(s + prod[i])
+        self.output = f32(s * f32(3))
+        return self.output

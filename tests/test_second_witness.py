@@ -1,0 +1,71 @@
+"""The C oracle against a second, independent transliteration of the Rust sources (tests/second_witness.py, numpy
+float32 + the platform libm).  BIT equality: for the numerics no reference-held vector pins (ADSR curve, FmOperator,
+FMVoice wiring, AmplitudeSource / OscillatorBank) two hand translations that agree to the last bit are the available
+substitute for an oracle/_ref build of the reference.  CPU only."""
+import numpy as np
+
+from tests import oracle_lib as ol
+from tests import second_witness as sw
+
+SR = 48000.0
+
+
+def oracle_voice(kind, params, freq, gates, frames):
+    bank = ol.Bank(kind, 1, SR)
+    names = ol.FM_PARAMS if kind == ol.BANK_FM else ol.EPIANO_PARAMS
+    for k, v in params.items():
+        bank.set_value_immediate(names.index(k), v) if kind == ol.BANK_FM else bank.set_value(names.index(k), v)
+    bank.set_voice_frequency(0, freq)
+    out = []
+    for f0 in range(0, frames, 256):
+        n = min(256, frames - f0)
+        for fr, v in gates:
+            if f0 <= fr < f0 + n:
+                bank.push_event(0, fr - f0, ol.EV_GATE, v)
+        _, taps = bank.process_block(n, taps=[0])
+        out.append(taps[0])
+    return np.concatenate(out)
+
+
+def witness_fm(params, freq, gates, frames):
+    v = sw.FMVoice(SR)
+    for k, x in params.items():
+        v.p[k] = np.float32(x)
+    v.frequency = np.float32(freq)
+    g = dict(gates)
+    return np.array([v.frame(g.get(f)) for f in range(frames)], dtype=np.float32)
+
+
+def test_fm_voice_config1_bit_identical_between_the_two_restatements():
+    """BASELINE config 1: note 69 (440 Hz), gate on frame 0 velocity 100/127, gate off frame 24 000; every stage of the
+    four envelopes (attack, decay, sustain, release, idle) is crossed inside 48 000 frames"""
+    vel = float(np.float32(100.0) / np.float32(127.0))
+    gates = [(0, vel), (24000, 0.0)]
+    a = oracle_voice(ol.BANK_FM, {}, 440.0, gates, 48000)
+    b = witness_fm({}, 440.0, gates, 48000)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 0.05 and np.abs(a[-200:]).max() < 0.01 * np.abs(a).max()  # sounded, and the linear release has all but run out
+
+
+def test_fm_voice_variant_with_feedback_route_filter_envelope_and_retrigger():
+    params = {"op3_feedback": 0.11, "op2_feedback": 0.07, "route": 0.35, "filter_env_amount": 2500.0, "op3_level": 0.8,
+              "filter_resonance": 2.5, "op1_release": 0.05, "op2_attack": 0.0, "filter_cutoff": 900.0}
+    gates = [(3, 0.9), (2000, 0.0), (2600, 0.4), (7000, 0.0), (7001, 1.0)]  # retrigger from release, off + on back to back
+    a = oracle_voice(ol.BANK_FM, params, 196.0, gates, 12000)
+    b = witness_fm(params, 196.0, gates, 12000)
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() > 0.05
+
+
+def test_electric_piano_voice_bit_identical_between_the_two_restatements():
+    """AmplitudeSource -> OscillatorBank: 64-sample interpolation cycles, decay and release tables, phasor rotation with
+    libm cos/sin multipliers, harmonics above Nyquist frozen, a retrigger"""
+    for freq, gates in ((261.6256, [(5, 0.8), (3000, 0.0)]), (1975.533, [(0, 0.3), (700, 1.0), (2500, 0.0)])):
+        frames = 5000
+        a = oracle_voice(ol.BANK_EPIANO, {}, freq, gates, frames)
+        v = sw.EPianoVoice(SR)
+        v.frequency = np.float32(freq)
+        g = dict(gates)
+        b = np.array([v.frame(g.get(f)) for f in range(frames)], dtype=np.float32)
+        assert np.array_equal(a, b)
+        assert np.abs(a).max() > 1e-3
