@@ -482,6 +482,9 @@ struct Codegen {
             if (vit == node_outputs.end() && fb_sources.count(key) && !emitted[nit->second] && nodes[nit->second].live) {
                 // feedback edge whose producer runs later in the frame: the consumer sees the field the
                 // producer wrote on the previous frame (the struct field persists, codegen/emit_node.rs)
+                if ((nodes[nit->second].domain == 1) != (dom == 1))
+                    fail("feedback edge from '" + e->node + "' crosses the oversampled region: both ends of a feedback edge must "
+                         "run at the same rate in this version");
                 auto fit = fb_vars.find(key);
                 if (fit == fb_vars.end()) {
                     const std::string var = "n" + std::to_string(nit->second) + "_" + e->port + "_z";
@@ -947,7 +950,6 @@ void emit_lp18(NodeCtx& x)
 void emit_delay(NodeCtx& x)
 {
     if (x.cg.out.lpv != 1) fail("Delay is not supported in array-valued (several lanes per voice) graphs");
-    if (x.n.domain == 1) fail("Delay inside an oversampled (`* N`) region is not supported by this version");
     if (x.cg.out.rings.size() >= 4) fail("at most 4 Delay nodes per graph");
     const Val in = x.in("input");
     const Val ds = x.in("delay_samples");
@@ -969,6 +971,14 @@ void emit_delay(NodeCtx& x)
     auto block_const = [](const Val& v) { return v.rate <= Rate::VBlock && v.rate != Rate::UFrame; };
     const bool fixed = (!x.connected("delay_samples") || block_const(ds)) && (!x.connected("feedback") || block_const(fb));
     x.cg.S().decl << "    og::RingPre " << pre << " = {og::RING_NONE, og::RING_NONE, false, {}};\n";
+    if (x.n.domain == 1) {
+        // `Delay::new(..) * N`: the line runs at the oversampled rate (its ring is sized from sr * N, RingSpec::capacity), N
+        // ticks per outer frame.  The chunk-ahead staging assumes one tick per frame; here every tick reads its sample
+        // directly (the RingPre above stays empty, so og::delay_tick takes its un-staged path).
+        x.set_out("output", "og::delay_tick(A.rings[" + K + "], A.ring_cap[" + K + "], A.n_voices, c.v, c.valid, " + in.e + ", " +
+                                dsv + ", " + fbv + ", " + wp + ", " + fc + ", " + pre + ", ring_lds[" + K + "], c.lane, 0u)");
+        return;
+    }
     x.cg.S().chunk_begin << "        og::ring_chunk_begin(A.rings[" << K << "], A.ring_cap[" << K << "], A.n_voices, c.v, c.valid, "
                          << (hint_input ? ds.e : dsv) << ", " << ((x.connected("feedback") && block_const(fb)) ? fb.e : fbv)
                          << ", " << (fixed ? "true" : "false") << ", " << wp << ", " << pre << ", ring_lds[" << K
@@ -1928,7 +1938,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                  "route through a declared Delay node)");
     }
 
-    if (any_feedback && cg.N > 1) fail("feedback edges in graphs with oversampled (`* N`) nodes are not supported by this version");
+    // (feedback edges in graphs with oversampled nodes: allowed when both ends tick at the same rate -- checked where
+    //  the consumer reads the previous tick's value, Codegen::eval)
 
     // ---- rate domains (emit_frame.rs:183-215; taint analysis emit_node.rs:516-584) ------------
     // 1 = oversampled inner loop; outer nodes downstream of an inner node run after the loop (2)

@@ -102,3 +102,58 @@ def test_cross_rate_edge_kernels_via_jit(up_kind, down_kind, N):
         ref = _oracle_chain(lib, 3 * frames, float(freqs[v]), up_kind, down_kind, N)
         worst = max(worst, rel_err(got[v], ref))
     assert worst <= 1e-5, worst
+
+
+def test_delay_and_feedback_edge_inside_an_oversampled_region():
+    """`Delay::new(..) * 2` ticks at the oversampled rate (ring sized from sr * 2, delay/mod.rs:59-69) and closes a
+    feedback loop whose both ends are inner-rate nodes (ir/lower.rs:580-652 allows it): the consumer scheduled before
+    the delay reads what the delay produced on the previous INNER tick."""
+    from tests.graph_interp import VoiceInterp
+
+    g = oscen_amd.Graph("os_echo")
+    g.input_value("frequency", 220.0, per_voice=True)
+    g.input_value("fb", 0.45)
+    g.output_stream("out")
+    g.node("osc", "PolyBlepOscillator::saw", 220.0, 0.3)
+    g.node("mix", "Mixer::new", rate=2)
+    g.node("clip", "HardClip::new", rate=2)
+    g.node("fbk", "Gain::new", 0.4, rate=2)
+    g.node("d", "Delay::new", 37.0, 0.2, rate=2)
+    g.connect("frequency", "osc.frequency")
+    g.connect("osc.output", "mix.input_a", "linear")
+    g.connect("fb", "fbk.gain")
+    g.connect("mix.output", "clip.input")
+    g.connect_via("clip.output", "d", "fbk.input")
+    g.connect("fbk.output", "mix.input_b")
+    g.connect("clip.output", "out", "sinc")
+    src = g.kernel_source()
+    order = [ln for ln in src.splitlines() if ln.startswith("// Node order:")][0].split()[3:]
+    assert order.index("fbk") < order.index("d")  # the consumer of the feedback edge runs first
+    n, frames, blocks = 5, 160, 4
+    freqs = np.array([98.0, 220.0, 587.33, 1318.5, 2093.0], dtype=np.float32)
+    eng = oscen_amd.Engine(g, n, sample_rate=SR)
+    eng.set_voice_values("frequency", freqs)
+    eng.set_voice_taps(list(range(n)))
+    desc = {"inputs": [("frequency", "value", 220.0, 0), ("fb", "value", 0.45, 0)],
+            "nodes": [("osc", "PolyBlepOscillator::saw", [220.0, 0.3]), ("mix", "Mixer::new", []), ("clip", "HardClip::new", []),
+                      ("fbk", "Gain::new", [0.4]), ("d", "Delay::new", [37.0, 0.2])],
+            "edges": [("frequency", "osc.frequency"), ("osc.output", "mix.input_a"), ("fb", "fbk.gain"),
+                      ("mix.output", "clip.input"), ("clip.output", "d.input"), ("d.output", "fbk.input"),
+                      ("fbk.output", "mix.input_b"), ("clip.output", "out")],
+            "order": order, "rates": {"mix": 2, "clip": 2, "fbk": 2, "d": 2}, "policies": {1: "linear", 7: "sinc"}}
+    voices = [VoiceInterp(desc, SR, {"frequency": float(freqs[v])}) for v in range(n)]
+    got, ref = [], np.zeros((n, frames * blocks), dtype=np.float32)
+    for b in range(blocks):
+        if b == 2:
+            eng.set_value("fb", 0.6)
+            for vi in voices:
+                vi.set_value("fb", 0.6)
+        eng.process_block(frames)
+        got.append(eng.read_voice_taps(frames))
+        for v, vi in enumerate(voices):
+            for i in range(frames):
+                ref[v, b * frames + i] = vi.frame([])
+    got = np.concatenate(got, axis=1)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 1e-2
+    err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    assert err <= 1e-5, err
