@@ -74,3 +74,48 @@ extern "C" {
     pub fn og_write_wav(path: *const c_char, interleaved: *const c_float, frames: u64, channels: u32,
                         sample_rate: u32, bits: u32) -> c_int;
 }
+
+// ---- round 2: bulk scheduling, stream inputs / render(inputs, tail), node arrays, custom nodes, nested graphs,
+// ---- multi-GPU clusters, async MIDI ----
+#[repr(C)] pub struct og_cluster { _p: [u8; 0] }
+#[repr(C)] pub struct og_node_port { pub name: *const c_char, pub kind: c_int, pub default_value: c_float, pub ctor_arg: c_int }
+#[repr(C)] pub struct og_node_field { pub name: *const c_char, pub is_uint: c_int, pub init: c_float, pub init_uint: u32, pub ctor_arg: c_int }
+#[repr(C)] pub struct og_node_type {
+    pub type_ctor: *const c_char, pub n_ctor_args: u32,
+    pub inputs: *const og_node_port, pub n_inputs: u32,
+    pub outputs: *const *const c_char, pub n_outputs: u32,
+    pub state: *const og_node_field, pub n_state: u32,
+    pub process_src: *const c_char, pub event_handler_src: *const *const c_char, pub cost_hint: u32,
+}
+extern "C" {
+    pub fn og_graph_add_node_array(g: *mut og_graph_desc, name: *const c_char, type_ctor: *const c_char,
+                                   args: *const c_float, n_args: u32, rate_factor: u32, length: u32) -> c_int;
+    pub fn og_register_node(t: *const og_node_type) -> c_int;
+    pub fn og_unregister_node(type_ctor: *const c_char) -> c_int;
+    pub fn og_register_graph_type(type_name: *const c_char, g: *const og_graph_desc) -> c_int;
+    pub fn og_unregister_graph_type(type_name: *const c_char) -> c_int;
+    pub fn og_schedule_voice_events(e: *mut og_engine, input: u32, n: u32, voices: *const u32,
+                                    abs_frames: *const u64, values: *const c_float) -> c_int;
+    pub fn og_set_stream_block(e: *mut og_engine, input: u32, samples: *const c_float, n: u32) -> c_int;
+    pub fn og_num_stream_inputs(e: *const og_engine) -> u32;
+    pub fn og_render_inputs(e: *mut og_engine, inputs: *const *const c_float, input_lens: *const u64, n_inputs: u32,
+                            tail: u64, out_bus: *mut c_float, frames_rendered: *mut u64) -> c_int;
+    pub fn og_kernel_hash(e: *const og_engine) -> u64;
+    pub fn og_midi_send_batch(m: *mut og_midi, bytes3: *const u8, frame_offsets: *const u32, n: u32) -> c_int;
+    pub fn og_midi_set_queue_capacity(m: *mut og_midi, capacity: u32) -> c_int;
+    pub fn og_midi_process_block_async(m: *mut og_midi, frames: u32, d_out_bus: *mut c_float) -> c_int;
+    pub fn og_midi_note_to_freq(note: u8) -> c_float;
+    pub fn og_cluster_create(g: *const og_graph_desc, n_voices_total: u64, device_ids: *const c_int, n_shards: u32,
+                             out: *mut *mut og_cluster) -> c_int;
+    pub fn og_cluster_destroy(c: *mut og_cluster);
+    pub fn og_cluster_init(c: *mut og_cluster, sample_rate: c_float) -> c_int;
+    pub fn og_cluster_input_index(c: *const og_cluster, name: *const c_char) -> c_int;
+    pub fn og_cluster_set_value(c: *mut og_cluster, input: u32, v: c_float) -> c_int;
+    pub fn og_cluster_set_value_ramp(c: *mut og_cluster, input: u32, v: c_float, frames: u32) -> c_int;
+    pub fn og_cluster_set_voice_values(c: *mut og_cluster, input: u32, first_voice: u64, count: u64, v: *const c_float) -> c_int;
+    pub fn og_cluster_push_voice_event(c: *mut og_cluster, input: u32, voice: u64, frame_offset: u32, scalar: c_float) -> c_int;
+    pub fn og_cluster_push_voice_value(c: *mut og_cluster, input: u32, voice: u64, frame_offset: u32, v: c_float) -> c_int;
+    pub fn og_cluster_process_block(c: *mut og_cluster, frames: u32, out_bus: *mut c_float) -> c_int;
+    pub fn og_cluster_render(c: *mut og_cluster, total_frames: u64, block: u32, out_bus: *mut c_float) -> c_int;
+    pub fn og_cluster_channels(c: *const og_cluster) -> u32;
+}
