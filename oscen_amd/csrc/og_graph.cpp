@@ -497,6 +497,7 @@ struct Codegen {
                 Val v;
                 v.e = fit->second;
                 v.rate = Rate::Vary;
+                v.inner = nodes[nit->second].domain == 1; // last tick's value, at the producer's rate
                 return v;
             }
             if (vit == node_outputs.end())
