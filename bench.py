@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bus-batch", type=int, default=8,
+                    help="blocks per bus-reduce launch (og_set_bus_batching; 1 = a reduce after every block)")
     ap.add_argument("--sparse-events", action="store_true",
                     help="keep the 1 s note plan as is even when the run is shorter (default: every voice plays a slice "
                          "of its cyclic plan, so that note-on, note-off and retrigger all fall inside the timed region at "
@@ -220,6 +222,8 @@ def main():
         n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if "gate" in eng.input_names else 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
+    if args.bus_batch > 1:  # one bus-reduce launch per 8 blocks; every bus is complete before the timed region closes (flush below)
+        eng.set_bus_batching(args.bus_batch)
     ch = eng.channels
     bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
     base = bus.data_ptr()
@@ -258,6 +262,7 @@ def main():
 
     for i in range(W):
         step(i)
+    eng.flush()
     if dist is not None:  # communicator set-up (lazy in RCCL) must not land in the timed region
         reduce_bus(bus[:W] if W else torch.zeros((1, block * ch), dtype=torch.float32, device="cuda"))
         ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
@@ -271,6 +276,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
+    eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
     if dist is not None:
         reduce_bus(bus[W:])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
     torch.cuda.synchronize()
@@ -331,6 +337,7 @@ def main():
                 "parallelism": "voice-shard x%d" % world_size,
                 "events_in_timed_region": n_events_timed,
                 "note_plan_span_frames": span if span else 48000,
+                "bus_reduce_batch_blocks": args.bus_batch,
                 "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
                                ("og_midi_process_block, blocking" if args.midi_blocking else "og_midi_process_block_async"))
                               if midi is not None

@@ -199,6 +199,12 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
  * on the engine's stream. */
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus);
 int og_synchronize(og_engine* e);
+/* Throughput option for streaming callers of og_process_block_async: sum the partial buses of up to `blocks`
+ * (1..8) consecutive blocks with ONE reduce launch per tree level instead of one per block.  The bus of an async block
+ * is then complete after the last block of its batch, after og_flush() (enqueues the pending reduces, does not wait)
+ * or after og_synchronize(); og_process_block / og_render* always deliver complete buses.  Same tree, same bits. */
+int og_set_bus_batching(og_engine* e, uint32_t blocks);
+int og_flush(og_engine* e);
 int og_set_stream(og_engine* e, void* hip_stream);
 /* BlockRender::render  oscen-lib/src/graph/offline.rs:46-90: total_frames in
  * chunks of `block` (<= 512); out_bus[total_frames*channels] (host). */

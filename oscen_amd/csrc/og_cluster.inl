@@ -268,6 +268,7 @@ struct og_cluster {
                         const uint32_t frames = (uint32_t)std::min<size_t>(block, nf - g);
                         e->process_async(frames, buf + g);
                     }
+                    e->flush_bus(); // (shards batch their bus reduces: og_cluster_create)
                     HIPCK(hipEventRecord(done, e->stream));
                 });
             }
@@ -357,6 +358,10 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
                 throw std::runtime_error(g_err);
             }
             e->bus_stage = false; // shards hand over the mono voice sum; the post-mix node runs once, on the root
+            {
+                HIPCK(hipSetDevice(e->device));
+                e->alloc_bus_buffers(OG_RED_BATCH); // one reduce launch per 8 blocks of a batch
+            }
             c->shard.push_back(e);
             int di = -1;
             for (size_t d = 0; d < c->devs.size(); ++d)

@@ -34,8 +34,8 @@
 #define OG_RED_SLICES 64
 #define OG_RED_FRAMES 16
 #define OG_RED_GROUP 1024 // rows per workgroup; larger banks take a second pass over the group sums
-__global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
-                                                      uint32_t frames, float* __restrict__ out)
+__device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ partials, uint32_t n_rows, uint32_t frames,
+                                                   float* __restrict__ out)
 {
     __shared__ float part[OG_RED_SLICES][OG_RED_FRAMES];
     __shared__ float quad[OG_RED_SLICES / 4][OG_RED_FRAMES];
@@ -64,6 +64,28 @@ __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ 
         for (int i = 0; i < OG_RED_SLICES / 4; ++i) s[i & 3] += quad[i][fx];
         out[(size_t)blockIdx.y * frames + f] = (s[0] + s[1]) + (s[2] + s[3]);
     }
+}
+
+__global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
+                                                      uint32_t frames, float* __restrict__ out)
+{
+    og_bus_reduce_body(partials, n_rows, frames, out);
+}
+
+// The same for up to OG_RED_BATCH consecutive blocks in one launch (og_set_bus_batching): blockIdx.z = the block.
+// Same tree, same association, same results -- one launch (and one inter-kernel gap) per batch instead of per block.
+#define OG_RED_BATCH 8
+struct OgRedBatch {
+    const float* src[OG_RED_BATCH];
+    float* dst[OG_RED_BATCH];
+    uint32_t frames[OG_RED_BATCH];
+    uint32_t rows;
+};
+__global__ __launch_bounds__(1024) void og_bus_reduce_batch(OgRedBatch B)
+{
+    const uint32_t k = blockIdx.z;
+    if (blockIdx.x * OG_RED_FRAMES >= B.frames[k]) return; // (workgroup-uniform: ragged last block of a batch)
+    og_bus_reduce_body(B.src[k], B.rows, B.frames[k], B.dst[k]);
 }
 
 // Post-mix Tremolo (examples/electric-piano/src/tremolo.rs:40-62) on the summed bus -> Frame<2>.
@@ -226,6 +248,19 @@ struct og_engine {
     uint32_t* d_ev_cursor = nullptr;
     float* d_partials = nullptr;
     float* d_partials2 = nullptr; // group sums of the multi-pass bus reduce
+    // bus batching (og_set_bus_batching): the voice kernels of up to `bus_batch` consecutive async blocks write their
+    // partial rows into a ring; ONE reduce launch per tree level (plus the post-mix kernels) serves the whole batch
+    uint32_t bus_batch = 1;
+    size_t partials_stride = 0, partials2_stride = 0; // floats per ring entry
+    struct PendingBus {
+        const float* partials;
+        float* tmp;      // this entry's scratch for the upper tree levels
+        float* mono;     // this entry's pre-post-mix sum (post-mix graphs)
+        float* dst;      // where the block's bus goes
+        uint32_t frames;
+        float trem_rate, trem_depth;
+    };
+    std::vector<PendingBus> bus_pending;
     float* d_bus = nullptr;
     float* d_ramp[RAMP_RING] = {};
     float* h_ramp[RAMP_RING] = {};
@@ -566,6 +601,76 @@ struct og_engine {
         if (bulk || !incremental_update()) full_rebuild();
     }
 
+    // sum the partial rows of every pending block (fixed-association tree: groups of 1024 rows, then, for > 1024
+    // waves, the group sums), then the post-mix stage in block order
+    void flush_bus()
+    {
+        if (bus_pending.empty()) return;
+        const bool post_mix = cg->bus_tremolo && bus_stage;
+        const size_t n = bus_pending.size();
+        uint32_t max_frames = 0;
+        for (const auto& pb : bus_pending) max_frames = std::max(max_frames, pb.frames);
+        std::vector<const float*> src(n);
+        std::vector<float*> tmp(n);
+        for (size_t k = 0; k < n; ++k) {
+            src[k] = bus_pending[k].partials;
+            tmp[k] = bus_pending[k].tmp;
+        }
+        uint32_t rows = n_wg;
+        bus_passes = 0;
+        for (;;) {
+            const bool last = rows <= OG_RED_GROUP;
+            const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
+            bus_passes += 1;
+            if (n == 1) {
+                float* dst = last ? (post_mix ? bus_pending[0].mono : bus_pending[0].dst) : tmp[0];
+                hipLaunchKernelGGL(og_bus_reduce, dim3((bus_pending[0].frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0,
+                                   stream, src[0], rows, bus_pending[0].frames, dst);
+            } else {
+                OgRedBatch B;
+                memset(&B, 0, sizeof B);
+                for (size_t k = 0; k < n; ++k) {
+                    B.src[k] = src[k];
+                    B.dst[k] = last ? (post_mix ? bus_pending[k].mono : bus_pending[k].dst) : tmp[k];
+                    B.frames[k] = bus_pending[k].frames;
+                }
+                B.rows = rows;
+                hipLaunchKernelGGL(og_bus_reduce_batch, dim3((max_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups, (uint32_t)n), dim3(1024),
+                                   0, stream, B);
+            }
+            if (last) break;
+            for (size_t k = 0; k < n; ++k) {
+                src[k] = tmp[k];
+                tmp[k] = tmp[k] + (size_t)groups * OG_MAX_BLOCK; // next level writes behind this one
+            }
+            rows = groups;
+        }
+        HIPCK(hipGetLastError());
+        if (post_mix) {
+            for (const auto& pb : bus_pending)
+                hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, pb.mono, pb.frames, pb.trem_rate, pb.trem_depth, sr,
+                                   d_bus_phase, pb.dst);
+            HIPCK(hipGetLastError());
+        }
+        bus_pending.clear();
+    }
+
+    void alloc_bus_buffers(uint32_t batch)
+    {
+        HIPCK(hipStreamSynchronize(stream));
+        if (d_partials) HIPCK(hipFree(d_partials));
+        if (d_partials2) HIPCK(hipFree(d_partials2));
+        if (d_mono) HIPCK(hipFree(d_mono));
+        d_partials = d_partials2 = d_mono = nullptr;
+        partials_stride = (size_t)n_wg * OG_MAX_BLOCK;
+        partials2_stride = ((size_t)n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK;
+        HIPCK(hipMalloc(&d_partials, partials_stride * batch * 4));
+        HIPCK(hipMemset(d_partials, 0, partials_stride * batch * 4));
+        HIPCK(hipMalloc(&d_partials2, partials2_stride * batch * 4));
+        if (cg->bus_tremolo) HIPCK(hipMalloc(&d_mono, (size_t)OG_MAX_BLOCK * batch * 4));
+        bus_batch = batch;
+    }
+
     void process_async(uint32_t frames, float* d_out)
     {
         HIPCK(hipSetDevice(device));
@@ -583,7 +688,8 @@ struct og_engine {
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
-        A.partials = d_partials;
+        const size_t slot = bus_pending.size(); // ring entry of this block (0 when batching is off)
+        A.partials = d_partials + slot * partials_stride;
         A.taps = d_taps;
         A.tap_slot = d_tap_slot;
         for (size_t k = 0; k < cg->rings.size(); ++k) {
@@ -646,33 +752,22 @@ struct og_engine {
         }
         HIPCK(hipGetLastError());
         float* bus = d_out ? d_out : d_bus;
-        const bool post_mix = cg->bus_tremolo && bus_stage;
-        float* sum_dst = post_mix ? d_mono : bus;
         {
-            // fixed-association tree: groups of 1024 rows, then (for > 1024 waves) the group sums
-            const float* src = d_partials;
-            uint32_t rows = n_wg;
-            float* tmp = d_partials2;
-            bus_passes = 1;
-            while (rows > OG_RED_GROUP) {
-                bus_passes += 1;
-                const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
-                hipLaunchKernelGGL(og_bus_reduce, dim3((frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0, stream, src, rows,
-                                   frames, tmp);
-                src = tmp;
-                rows = groups;
-                tmp = tmp + (size_t)groups * OG_MAX_BLOCK; // next level writes behind this one
+            PendingBus pb;
+            pb.partials = A.partials;
+            pb.tmp = d_partials2 + slot * partials2_stride;
+            pb.mono = d_mono ? d_mono + slot * OG_MAX_BLOCK : nullptr;
+            pb.dst = bus;
+            pb.frames = frames;
+            pb.trem_rate = pb.trem_depth = 0.0f;
+            if (cg->bus_tremolo && bus_stage) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
+                ogc::UEnv ev = env();
+                pb.trem_rate = cg->tremolo_rate(ev);
+                pb.trem_depth = cg->tremolo_depth(ev);
             }
-            hipLaunchKernelGGL(og_bus_reduce, dim3((frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, 1), dim3(1024), 0, stream, src, rows, frames,
-                               sum_dst);
+            bus_pending.push_back(pb);
         }
-        HIPCK(hipGetLastError());
-        if (post_mix) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
-            ogc::UEnv e = env();
-            hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, d_mono, frames, cg->tremolo_rate(e),
-                               cg->tremolo_depth(e), sr, d_bus_phase, bus);
-            HIPCK(hipGetLastError());
-        }
+        if (bus_pending.size() >= bus_batch) flush_bus();
         frame_now += frames;
         last_frames = frames;
     }
@@ -1043,17 +1138,12 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMalloc(&e->d_state, std::max<size_t>(1, cg.state.size()) * (size_t)n_voices * 4));
         if (!cg.lane_state.empty())
             HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4));
-        if (cg.bus_tremolo) {
-            HIPCK(hipMalloc(&e->d_mono, (size_t)OG_MAX_BLOCK * 4));
-            HIPCK(hipMalloc(&e->d_bus_phase, 4));
-        }
+        if (cg.bus_tremolo) HIPCK(hipMalloc(&e->d_bus_phase, 4));
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
-        HIPCK(hipMalloc(&e->d_partials, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
-        HIPCK(hipMemset(e->d_partials, 0, (size_t)e->n_wg * OG_MAX_BLOCK * 4));
-        HIPCK(hipMalloc(&e->d_partials2, ((size_t)e->n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK * 4));
+        e->alloc_bus_buffers(1);
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
@@ -1083,6 +1173,7 @@ int og_init(og_engine* e, float sample_rate)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->sr = sample_rate;
+        e->bus_pending.clear();
         e->upload_initial_state();
         e->reset_timeline();
         e->frame_now = 0;
@@ -1236,7 +1327,30 @@ int og_synchronize(og_engine* e)
     if (!e) return set_err(OG_E_INVALID, "null engine");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
+int og_set_bus_batching(og_engine* e, uint32_t blocks)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (blocks == 0 || blocks > OG_RED_BATCH) return set_err(OG_E_INVALID, "bus batching: 1..8 blocks");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
+        if (blocks != e->bus_batch) e->alloc_bus_buffers(blocks);
+        return OG_OK;
+    });
+}
+
+int og_flush(og_engine* e)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         return OG_OK;
     });
 }
@@ -1246,6 +1360,7 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
     int rc = og_process_block_async(e, frames, nullptr);
     if (rc) return rc;
     return guard([&] {
+        e->flush_bus();
         if (out_bus && frames)
             HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
@@ -1258,6 +1373,7 @@ int og_set_stream(og_engine* e, void* s)
     if (!e) return set_err(OG_E_INVALID, "null engine");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         HIPCK(hipStreamSynchronize(e->stream));
         if (e->own_stream) HIPCK(hipStreamDestroy(e->stream));
         e->own_stream = false;
@@ -1281,6 +1397,7 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
                 const uint32_t frames = (uint32_t)std::min<uint64_t>(block, total_frames - f0);
                 e->process_async(frames, d_all + f0 * ch);
             }
+            e->flush_bus();
             HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total_frames * ch * 4, hipMemcpyDeviceToHost, e->stream));
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {
@@ -1333,6 +1450,7 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
                 }
                 e->process_async(n, d_all + pos * ch);
             }
+            e->flush_bus();
             HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total * ch * 4, hipMemcpyDeviceToHost, e->stream));
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {

@@ -295,6 +295,25 @@ def test_state_snapshot_roundtrip():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("graph,n", [("fm_voice", 300), ("fm_voice", 70000), ("epiano_voice", 9000), ("sat4x_voice", 66000)])
+def test_batched_bus_reduce_gives_the_same_bits(graph, n):
+    """og_set_bus_batching: one reduce launch per 8 blocks (per tree level; 70 000 fm voices = 1 094 partial rows and
+    9 000 e-piano voices = 1 125 rows take two levels; the e-piano adds the post-mix Tremolo in block order) -- same
+    tree, same association: the bus must not change by a bit, including a ragged last block and a partial last batch"""
+    total, block = 256 * 10 + 100, 256
+    outs = []
+    for batch in (1, 8, 3):
+        eng = oscen_amd.Engine(graph, n, sample_rate=SR)
+        eng.set_bus_batching(batch)
+        plans = oscen_amd.note_plans(n, span=total)
+        oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+        outs.append(eng.render(total, block=block))
+        # blocking blocks after a batched render still deliver their own bus
+        assert eng.process_block(64).shape[0] == 64
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.abs(outs[0]).max() > 1e-2
+
+
 def test_state_snapshot_carries_ramps_frame_counter_and_pending_events():
     """a snapshot taken in the middle of a parameter ramp, with note-offs still scheduled and a try_push'ed event queued
     for the next block, loaded into a FRESH engine: the continuation is the original render, bit for bit"""
