@@ -285,7 +285,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kern_ms, n_launch = eng.kernel_time_ms()
+    kern_ms, n_launch = eng.kernel_time_ms()       # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
+    n_blocks_timed = eng.kernel_blocks_timed         # blocks those launches rendered (8 per launch with --bus-batch 8)
     eng.enable_kernel_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
@@ -301,9 +302,14 @@ def main():
         # algorithmic HBM bytes of one launch: state planes read once + written once,
         # the two event-cursor words read per voice, one partial-bus row written per workgroup
         n_wg = eng.partial_rows
-        bytes_per_launch = V * (4 * (words + eng.state_words_written_per_voice) + 8) + n_wg * block * 4
+        # SURVEY 8(d)'s per-unit figure (state read + written once per 256-frame block, event cursors, one partial row per
+        # workgroup) x the units one launch processes: a launch that renders several queued blocks is charged that many
+        # blocks' worth, although it touches the state planes only once
+        bytes_per_block = V * (4 * (words + eng.state_words_written_per_voice) + 8) + n_wg * block * 4
         # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
-        bytes_per_launch += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
+        bytes_per_block += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
+        blocks_per_launch = n_blocks_timed / float(max(1, n_launch))
+        bytes_per_launch = bytes_per_block * blocks_per_launch
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         prof = pmc_profile(V, block, args.graph, eng.kernel_hash)
         pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
@@ -359,10 +365,12 @@ def main():
                 "kernel_variant": eng.kernel_variant,
                 "kernel_ms_avg": kern_ms,
                 "kernel_launches": n_launch,
+                "blocks_per_launch": blocks_per_launch,
+                "kernel_ms_per_block": kern_ms / blocks_per_launch if blocks_per_launch else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "voices_per_wave": lanes,
                 "pipeline_waves_per_64_voices": eng.pipeline_depth,
-                "bytes_per_voice_sample": bytes_per_launch / float(V * block),
+                "bytes_per_voice_sample": bytes_per_block / float(V * block),
                 "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block; "
                         "see valu_issue for the bound that applies",
                 # The limiter: instruction issue / dependent-instruction latency.  CDNA4 SIMDs are
@@ -377,7 +385,7 @@ def main():
                     "unit": "G wave-instructions/s",
                     "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 2.0),
                     "frac_of_measured_ceiling": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 3.05),
-                    "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block),
+                    "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block * blocks_per_launch),
                     "source": pmc_src,
                 },
             },

@@ -199,10 +199,13 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
  * on the engine's stream. */
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus);
 int og_synchronize(og_engine* e);
-/* Throughput option for streaming callers of og_process_block_async: sum the partial buses of up to `blocks`
- * (1..8) consecutive blocks with ONE reduce launch per tree level instead of one per block.  The bus of an async block
- * is then complete after the last block of its batch, after og_flush() (enqueues the pending reduces, does not wait)
- * or after og_synchronize(); og_process_block / og_render* always deliver complete buses.  Same tree, same bits. */
+/* Throughput option for streaming callers of og_process_block_async: up to `blocks` (1..8) consecutive async blocks
+ * that nothing separates (no value change, no event push, no taps) are rendered by ONE launch of the voice kernel over
+ * their frames back to back -- per-voice state loaded and stored once, one inter-kernel gap, one bus reduce -- instead
+ * of a launch each.  The bus of an async block is then complete after the last block of its batch, after og_flush()
+ * (launches what is queued, does not wait) or og_synchronize(); every call that reads or changes engine state launches
+ * the queue first, and og_process_block / og_render* always deliver complete buses.  Results are those of block-by-block
+ * processing, bit for bit.  Default 1 (a launch per block). */
 int og_set_bus_batching(og_engine* e, uint32_t blocks);
 int og_flush(og_engine* e);
 int og_set_stream(og_engine* e, void* hip_stream);
@@ -255,6 +258,7 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
  * call (HIP events on the engine's stream); returns <0 if timing is off */
 int og_enable_kernel_timing(og_engine* e, int on);
 double og_kernel_time_ms(og_engine* e, uint32_t* n_launches);
+uint64_t og_kernel_blocks_timed(const og_engine* e); /* blocks those launches covered (> launches with og_set_bus_batching) */
 
 /* State snapshot: the DSP state (SoA planes, per-harmonic arrays, post-mix phase, delay lines) followed by a control
  * block -- frame counter, value / ValueRampState of every input, every event that has not fired yet -- so that loading

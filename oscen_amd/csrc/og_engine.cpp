@@ -72,22 +72,6 @@ __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ 
     og_bus_reduce_body(partials, n_rows, frames, out);
 }
 
-// The same for up to OG_RED_BATCH consecutive blocks in one launch (og_set_bus_batching): blockIdx.z = the block.
-// Same tree, same association, same results -- one launch (and one inter-kernel gap) per batch instead of per block.
-#define OG_RED_BATCH 8
-struct OgRedBatch {
-    const float* src[OG_RED_BATCH];
-    float* dst[OG_RED_BATCH];
-    uint32_t frames[OG_RED_BATCH];
-    uint32_t rows;
-};
-__global__ __launch_bounds__(1024) void og_bus_reduce_batch(OgRedBatch B)
-{
-    const uint32_t k = blockIdx.z;
-    if (blockIdx.x * OG_RED_FRAMES >= B.frames[k]) return; // (workgroup-uniform: ragged last block of a batch)
-    og_bus_reduce_body(B.src[k], B.rows, B.frames[k], B.dst[k]);
-}
-
 // Post-mix Tremolo (examples/electric-piano/src/tremolo.rs:40-62) on the summed bus -> Frame<2>.
 // The LFO phase recurrence `phase = fract(phase + rate/sr)` is serial but two ops per frame: lane 0
 // runs it into LDS, then every frame computes its sine (bit-exact libm restatement) in parallel.
@@ -248,19 +232,23 @@ struct og_engine {
     uint32_t* d_ev_cursor = nullptr;
     float* d_partials = nullptr;
     float* d_partials2 = nullptr; // group sums of the multi-pass bus reduce
-    // bus batching (og_set_bus_batching): the voice kernels of up to `bus_batch` consecutive async blocks write their
-    // partial rows into a ring; ONE reduce launch per tree level (plus the post-mix kernels) serves the whole batch
+    // Block queue (og_set_bus_batching): up to `bus_batch` consecutive async blocks that nothing separates (no value
+    // change, no event push, no taps) are rendered by ONE launch of the voice kernel over their frames back to back --
+    // state loaded and stored once, one inter-kernel gap, one bus reduce per tree level -- instead of one launch each.
+    // A queued block has had its ramps ticked and its stream samples captured; anything that touches engine state
+    // launches the queue first.  Results are those of block-by-block processing, bit for bit.
     uint32_t bus_batch = 1;
-    size_t partials_stride = 0, partials2_stride = 0; // floats per ring entry
-    struct PendingBus {
-        const float* partials;
-        float* tmp;      // this entry's scratch for the upper tree levels
-        float* mono;     // this entry's pre-post-mix sum (post-mix graphs)
-        float* dst;      // where the block's bus goes
+    struct QueuedBlock {
+        float* dst; // where the block's bus goes
         uint32_t frames;
         float trem_rate, trem_depth;
     };
-    std::vector<PendingBus> bus_pending;
+    std::vector<QueuedBlock> queue;
+    uint64_t q_frame0 = 0;   // absolute frame of the first queued block
+    uint32_t q_frames = 0;   // frames queued
+    bool q_ramps = false;    // some queued block ticked a ramp (or the graph has stream inputs): table-reading variant
+    int q_ramp_slot = -1;    // staging buffer of the per-frame table being filled
+    float* d_stage_bus = nullptr; // bus of a launch whose blocks' destinations are not contiguous
     float* d_bus = nullptr;
     float* d_ramp[RAMP_RING] = {};
     float* h_ramp[RAMP_RING] = {};
@@ -306,6 +294,7 @@ struct og_engine {
     bool timing = false;
     std::vector<hipEvent_t> t_start, t_stop;
     size_t t_used = 0;
+    size_t t_blocks = 0; // blocks the timed launches covered
 
     ~og_engine()
     {
@@ -323,6 +312,7 @@ struct og_engine {
         (void)hipFree(d_ev_cursor);
         (void)hipFree(d_partials);
         (void)hipFree(d_partials2);
+        (void)hipFree(d_stage_bus);
         (void)hipFree(d_bus);
         (void)hipFree(d_taps);
         (void)hipFree(d_tap_slot);
@@ -601,131 +591,130 @@ struct og_engine {
         if (bulk || !incremental_update()) full_rebuild();
     }
 
-    // sum the partial rows of every pending block (fixed-association tree: groups of 1024 rows, then, for > 1024
-    // waves, the group sums), then the post-mix stage in block order
-    void flush_bus()
-    {
-        if (bus_pending.empty()) return;
-        const bool post_mix = cg->bus_tremolo && bus_stage;
-        const size_t n = bus_pending.size();
-        uint32_t max_frames = 0;
-        for (const auto& pb : bus_pending) max_frames = std::max(max_frames, pb.frames);
-        std::vector<const float*> src(n);
-        std::vector<float*> tmp(n);
-        for (size_t k = 0; k < n; ++k) {
-            src[k] = bus_pending[k].partials;
-            tmp[k] = bus_pending[k].tmp;
-        }
-        uint32_t rows = n_wg;
-        bus_passes = 0;
-        for (;;) {
-            const bool last = rows <= OG_RED_GROUP;
-            const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
-            bus_passes += 1;
-            if (n == 1) {
-                float* dst = last ? (post_mix ? bus_pending[0].mono : bus_pending[0].dst) : tmp[0];
-                hipLaunchKernelGGL(og_bus_reduce, dim3((bus_pending[0].frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0,
-                                   stream, src[0], rows, bus_pending[0].frames, dst);
-            } else {
-                OgRedBatch B;
-                memset(&B, 0, sizeof B);
-                for (size_t k = 0; k < n; ++k) {
-                    B.src[k] = src[k];
-                    B.dst[k] = last ? (post_mix ? bus_pending[k].mono : bus_pending[k].dst) : tmp[k];
-                    B.frames[k] = bus_pending[k].frames;
-                }
-                B.rows = rows;
-                hipLaunchKernelGGL(og_bus_reduce_batch, dim3((max_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups, (uint32_t)n), dim3(1024),
-                                   0, stream, B);
-            }
-            if (last) break;
-            for (size_t k = 0; k < n; ++k) {
-                src[k] = tmp[k];
-                tmp[k] = tmp[k] + (size_t)groups * OG_MAX_BLOCK; // next level writes behind this one
-            }
-            rows = groups;
-        }
-        HIPCK(hipGetLastError());
-        if (post_mix) {
-            for (const auto& pb : bus_pending)
-                hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, pb.mono, pb.frames, pb.trem_rate, pb.trem_depth, sr,
-                                   d_bus_phase, pb.dst);
-            HIPCK(hipGetLastError());
-        }
-        bus_pending.clear();
-    }
-
     void alloc_bus_buffers(uint32_t batch)
     {
         HIPCK(hipStreamSynchronize(stream));
-        if (d_partials) HIPCK(hipFree(d_partials));
-        if (d_partials2) HIPCK(hipFree(d_partials2));
-        if (d_mono) HIPCK(hipFree(d_mono));
-        d_partials = d_partials2 = d_mono = nullptr;
-        partials_stride = (size_t)n_wg * OG_MAX_BLOCK;
-        partials2_stride = ((size_t)n_wg / OG_RED_GROUP + 2 + 64) * OG_MAX_BLOCK;
-        HIPCK(hipMalloc(&d_partials, partials_stride * batch * 4));
-        HIPCK(hipMemset(d_partials, 0, partials_stride * batch * 4));
-        HIPCK(hipMalloc(&d_partials2, partials2_stride * batch * 4));
-        if (cg->bus_tremolo) HIPCK(hipMalloc(&d_mono, (size_t)OG_MAX_BLOCK * batch * 4));
+        for (float** p : {&d_partials, &d_partials2, &d_mono, &d_stage_bus})
+            if (*p) {
+                HIPCK(hipFree(*p));
+                *p = nullptr;
+            }
+        const size_t max_frames = (size_t)OG_MAX_BLOCK * batch;
+        HIPCK(hipMalloc(&d_partials, (size_t)n_wg * max_frames * 4));
+        HIPCK(hipMemset(d_partials, 0, (size_t)n_wg * max_frames * 4));
+        HIPCK(hipMalloc(&d_partials2, ((size_t)n_wg / OG_RED_GROUP + 2 + 64) * max_frames * 4));
+        HIPCK(hipMalloc(&d_stage_bus, max_frames * 2 * 4));
+        if (cg->bus_tremolo) HIPCK(hipMalloc(&d_mono, max_frames * 4));
+        const size_t rows = (size_t)(cg->n_ramps + cg->n_streams);
+        for (int i = 0; i < RAMP_RING && rows; ++i) {
+            if (d_ramp[i]) HIPCK(hipFree(d_ramp[i]));
+            if (h_ramp[i]) HIPCK(hipHostFree(h_ramp[i]));
+            d_ramp[i] = h_ramp[i] = nullptr;
+            HIPCK(hipMalloc(&d_ramp[i], rows * max_frames * 4));
+            HIPCK(hipHostMalloc((void**)&h_ramp[i], rows * max_frames * 4, hipHostMallocDefault));
+            if (!ramp_ev[i]) HIPCK(hipEventCreateWithFlags(&ramp_ev[i], hipEventDisableTiming));
+            ramp_ev_used[i] = false;
+        }
         bus_batch = batch;
     }
 
+    // process_block(frames), asynchronous: the block joins the queue; the queue is launched when it is full or when
+    // something needs its results or is about to change what it would see
     void process_async(uint32_t frames, float* d_out)
     {
         HIPCK(hipSetDevice(device));
+        if (!pending.empty() || ev_rebuild) flush_bus(); // the timeline update below assumes every earlier block has run
         sync_events(frames);
+        if (queue.empty()) {
+            q_frame0 = frame_now;
+            q_frames = 0;
+            q_ramps = cg->n_streams > 0;
+            q_ramp_slot = -1;
+        }
+        // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks.  The same
+        // per-frame table carries the graph's stream inputs (`<stream_in>_block`, one row each, broadcast to every
+        // voice); a graph with stream inputs always runs the table-reading kernel variant.
+        const size_t stride = (size_t)OG_MAX_BLOCK * bus_batch;
+        const bool ramping = active_ramps > 0 && cg->n_ramps > 0;
+        if ((ramping || cg->n_streams > 0 || q_ramps) && cg->n_ramps + cg->n_streams > 0) {
+            if (q_ramp_slot < 0) { // first block of the queue that needs the table: earlier blocks get constant rows
+                q_ramp_slot = ramp_head;
+                ramp_head = (ramp_head + 1) % RAMP_RING;
+                if (ramp_ev_used[q_ramp_slot]) HIPCK(hipEventSynchronize(ramp_ev[q_ramp_slot]));
+                float* tab0 = h_ramp[q_ramp_slot];
+                for (size_t i = 0; i < cg->inputs.size(); ++i) {
+                    const int row = cg->inputs[i].ramp_row;
+                    if (row >= 0) std::fill(tab0 + (size_t)row * stride, tab0 + (size_t)row * stride + q_frames, ramps[i].current);
+                }
+            }
+            q_ramps = true;
+            float* tab = h_ramp[q_ramp_slot];
+            for (uint32_t f = 0; f < frames; ++f) {
+                for (size_t i = 0; i < cg->inputs.size(); ++i) {
+                    const int row = cg->inputs[i].ramp_row;
+                    if (row < 0) continue;
+                    if (active_ramps > 0 && ramps[i].tick()) active_ramps -= 1;
+                    tab[(size_t)row * stride + q_frames + f] = ramps[i].current;
+                }
+            }
+            for (size_t i = 0; i < cg->inputs.size(); ++i) {
+                if (cg->inputs[i].ramp_row >= 0) values[i] = ramps[i].current;
+                const int srow = cg->inputs[i].stream_row;
+                if (srow >= 0) memcpy(tab + (size_t)srow * stride + q_frames, stream_blocks[i].data(), (size_t)frames * 4);
+            }
+        }
+        QueuedBlock qb;
+        qb.dst = d_out ? d_out : d_bus;
+        qb.frames = frames;
+        qb.trem_rate = qb.trem_depth = 0.0f;
+        if (cg->bus_tremolo && bus_stage) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
+            ogc::UEnv ev = env();
+            qb.trem_rate = cg->tremolo_rate(ev);
+            qb.trem_depth = cg->tremolo_depth(ev);
+        }
+        queue.push_back(qb);
+        q_frames += frames;
+        frame_now += frames;
+        last_frames = frames;
+        if (queue.size() >= bus_batch || n_taps > 0) flush_bus();
+    }
 
+    // launch the queued blocks: voice kernel over their frames, bus reduce (fixed-association tree: groups of 1024
+    // rows, then, for > 1024 waves, the group sums), post-mix stage block by block
+    void flush_bus()
+    {
+        if (queue.empty()) return;
         OgBlockArgs A;
         memset(&A, 0, sizeof A);
         A.n_voices = V;
-        A.frames = frames;
+        A.frames = q_frames;
+        A.ramp_stride = (uint32_t)((size_t)OG_MAX_BLOCK * bus_batch);
         A.lanes = lanes;
         A.split = split;
-        A.frame0 = frame_now;
+        A.frame0 = q_frame0;
         A.state = d_state;
         A.lane_state = d_lane_state;
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
-        const size_t slot = bus_pending.size(); // ring entry of this block (0 when batching is off)
-        A.partials = d_partials + slot * partials_stride;
+        A.partials = d_partials;
         A.taps = d_taps;
         A.tap_slot = d_tap_slot;
         for (size_t k = 0; k < cg->rings.size(); ++k) {
             A.rings[k] = d_ring[k];
             A.ring_cap[k] = ring_cap[k];
         }
-
-        // block-uniform slots from the values at block start (ramped: `.current`)
+        // block-uniform slots: the values the queued blocks were queued under (a setter launches the queue before it
+        // changes one; ramped inputs are read from the table whenever a ramp moved inside the queue)
         {
             ogc::UEnv e = env();
             for (const auto& up : cg->uprogs) A.slots[up.dst] = up.fn(e);
         }
-        // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks.  The same
-        // per-frame table carries the graph's stream inputs (`<stream_in>_block`, one row each, broadcast to every
-        // voice); a graph with stream inputs always runs the table-reading kernel variant.
-        const bool ramping = active_ramps > 0 && cg->n_ramps > 0;
-        const bool ramps_on = ramping || cg->n_streams > 0;
+        const bool ramps_on = q_ramps && q_ramp_slot >= 0;
         if (ramps_on) {
-            const int r = ramp_head;
-            ramp_head = (ramp_head + 1) % RAMP_RING;
-            if (ramp_ev_used[r]) HIPCK(hipEventSynchronize(ramp_ev[r]));
-            float* tab = h_ramp[r];
-            for (uint32_t f = 0; f < frames; ++f) {
-                for (size_t i = 0; i < cg->inputs.size(); ++i) {
-                    const int row = cg->inputs[i].ramp_row;
-                    if (row < 0) continue;
-                    if (active_ramps > 0 && ramps[i].tick()) active_ramps -= 1;
-                    tab[(size_t)row * frames + f] = ramps[i].current;
-                }
-            }
-            for (size_t i = 0; i < cg->inputs.size(); ++i) {
-                if (cg->inputs[i].ramp_row >= 0) values[i] = ramps[i].current;
-                const int srow = cg->inputs[i].stream_row;
-                if (srow >= 0) memcpy(tab + (size_t)srow * frames, stream_blocks[i].data(), (size_t)frames * 4);
-            }
-            HIPCK(hipMemcpyAsync(d_ramp[r], tab, (size_t)(cg->n_ramps + cg->n_streams) * frames * 4, hipMemcpyHostToDevice, stream));
+            const int r = q_ramp_slot;
+            const size_t rows = (size_t)(cg->n_ramps + cg->n_streams);
+            HIPCK(hipMemcpyAsync(d_ramp[r], h_ramp[r], rows * A.ramp_stride * 4, hipMemcpyHostToDevice, stream));
             HIPCK(hipEventRecord(ramp_ev[r], stream));
             ramp_ev_used[r] = true;
             A.ramp_table = d_ramp[r];
@@ -749,27 +738,47 @@ struct og_engine {
         if (timed) {
             HIPCK(hipEventRecord(t_stop[t_used], stream));
             ++t_used;
+            t_blocks += queue.size();
         }
         HIPCK(hipGetLastError());
-        float* bus = d_out ? d_out : d_bus;
+        // ---- bus: sum the partial rows ----------------------------------------------------------------
+        const bool post_mix = cg->bus_tremolo && bus_stage;
+        const uint32_t ch = 1; // the summed voices are mono; a post-mix node (Frame<2>) writes the final bus itself
+        bool contiguous = !post_mix;
+        for (size_t k = 1; k < queue.size() && contiguous; ++k)
+            contiguous = queue[k].dst == queue[k - 1].dst + (size_t)queue[k - 1].frames * ch;
+        float* sum_dst = post_mix ? d_mono : (contiguous ? queue[0].dst : d_stage_bus);
         {
-            PendingBus pb;
-            pb.partials = A.partials;
-            pb.tmp = d_partials2 + slot * partials2_stride;
-            pb.mono = d_mono ? d_mono + slot * OG_MAX_BLOCK : nullptr;
-            pb.dst = bus;
-            pb.frames = frames;
-            pb.trem_rate = pb.trem_depth = 0.0f;
-            if (cg->bus_tremolo && bus_stage) { // voices.output -> tremolo.input; tremolo.output -> out (Frame<2>)
-                ogc::UEnv ev = env();
-                pb.trem_rate = cg->tremolo_rate(ev);
-                pb.trem_depth = cg->tremolo_depth(ev);
+            const float* src = d_partials;
+            uint32_t rows = n_wg;
+            float* tmp = d_partials2;
+            bus_passes = 1;
+            while (rows > OG_RED_GROUP) {
+                bus_passes += 1;
+                const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
+                hipLaunchKernelGGL(og_bus_reduce, dim3((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0, stream, src, rows,
+                                   q_frames, tmp);
+                src = tmp;
+                rows = groups;
+                tmp = tmp + (size_t)groups * q_frames; // next level writes behind this one
             }
-            bus_pending.push_back(pb);
+            hipLaunchKernelGGL(og_bus_reduce, dim3((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, 1), dim3(1024), 0, stream, src, rows, q_frames,
+                               sum_dst);
         }
-        if (bus_pending.size() >= bus_batch) flush_bus();
-        frame_now += frames;
-        last_frames = frames;
+        HIPCK(hipGetLastError());
+        size_t off = 0;
+        for (const QueuedBlock& qb : queue) {
+            if (post_mix) {
+                hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, d_mono + off, qb.frames, qb.trem_rate, qb.trem_depth, sr,
+                                   d_bus_phase, qb.dst);
+            } else if (!contiguous) {
+                HIPCK(hipMemcpyAsync(qb.dst, d_stage_bus + off, (size_t)qb.frames * 4, hipMemcpyDeviceToDevice, stream));
+            }
+            off += qb.frames;
+        }
+        HIPCK(hipGetLastError());
+        queue.clear();
+        q_frames = 0;
     }
 };
 
@@ -1150,14 +1159,6 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         e->stream_blocks.resize(cg.inputs.size());
         for (size_t i = 0; i < cg.inputs.size(); ++i)
             if (cg.inputs[i].stream_row >= 0) e->stream_blocks[i].assign(OG_MAX_BLOCK, 0.0f);
-        if (cg.n_ramps + cg.n_streams) {
-            const size_t rows = (size_t)(cg.n_ramps + cg.n_streams);
-            for (int i = 0; i < RAMP_RING; ++i) {
-                HIPCK(hipMalloc(&e->d_ramp[i], rows * OG_MAX_BLOCK * 4));
-                HIPCK(hipHostMalloc((void**)&e->h_ramp[i], rows * OG_MAX_BLOCK * 4, hipHostMallocDefault));
-                HIPCK(hipEventCreateWithFlags(&e->ramp_ev[i], hipEventDisableTiming));
-            }
-        }
         e->upload_initial_state(); // Graph::new(): 44.1 kHz until init()
         *out = e.release();
         return OG_OK;
@@ -1173,7 +1174,8 @@ int og_init(og_engine* e, float sample_rate)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->sr = sample_rate;
-        e->bus_pending.clear();
+        e->queue.clear();
+        e->q_frames = 0;
         e->upload_initial_state();
         e->reset_timeline();
         e->frame_now = 0;
@@ -1194,6 +1196,7 @@ int og_set_value(og_engine* e, uint32_t input, float v)
 {
     int rc = check_value_input(e, input, false);
     if (rc) return rc;
+    if (!e->queue.empty() && (rc = og_flush(e)) != OG_OK) return rc; // queued blocks keep the old value
     if (e->cg->inputs[input].ramp_row < 0) {
         e->values[input] = v;
         return OG_OK;
@@ -1211,6 +1214,7 @@ int og_set_value_ramp(og_engine* e, uint32_t input, float v, uint32_t frames)
 {
     int rc = check_value_input(e, input, false);
     if (rc) return rc;
+    if (!e->queue.empty() && (rc = og_flush(e)) != OG_OK) return rc; // queued blocks keep the old value
     if (e->cg->inputs[input].ramp_row < 0) {
         e->values[input] = v;
         return OG_OK;
@@ -1231,6 +1235,7 @@ int og_set_value_immediate(og_engine* e, uint32_t input, float v)
 {
     int rc = check_value_input(e, input, false);
     if (rc) return rc;
+    if (!e->queue.empty() && (rc = og_flush(e)) != OG_OK) return rc; // queued blocks keep the old value
     if (e->cg->inputs[input].ramp_row >= 0) { // set_<name>_immediate  codegen/mod.rs:957-963
         Ramp& r = e->ramps[input];
         if (r.ramping()) e->active_ramps -= 1;
@@ -1256,6 +1261,7 @@ int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t c
     if (!v || (uint64_t)first + count > e->V) return set_err(OG_E_INVALID, "voice range out of bounds");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         const size_t w = (size_t)e->cg->inputs[input].state_word;
         HIPCK(hipMemcpyAsync(e->d_state + w * e->V + first, v, (size_t)count * 4, hipMemcpyHostToDevice, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
@@ -1313,6 +1319,7 @@ int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
     return guard([&] {
         if (frames == 0) { // process_block(0): no frame runs; events queued for the block are discarded with it
             HIPCK(hipSetDevice(e->device));
+            e->flush_bus();
             e->sync_events(0);
             e->last_frames = 0;
             return OG_OK;
@@ -1336,7 +1343,7 @@ int og_synchronize(og_engine* e)
 int og_set_bus_batching(og_engine* e, uint32_t blocks)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
-    if (blocks == 0 || blocks > OG_RED_BATCH) return set_err(OG_E_INVALID, "bus batching: 1..8 blocks");
+    if (blocks == 0 || blocks > OG_MAX_LAUNCH_BLOCKS) return set_err(OG_E_INVALID, "bus batching: 1..8 blocks");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
@@ -1467,6 +1474,7 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
     if (!e || (n && !voices)) return set_err(OG_E_INVALID, "null argument");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         HIPCK(hipStreamSynchronize(e->stream));
         std::vector<int32_t> slot(e->V, -1);
         for (uint32_t i = 0; i < n; ++i) {
@@ -1491,6 +1499,7 @@ int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames)
     if (n > e->n_taps || frames != e->last_frames) return set_err(OG_E_INVALID, "taps: n/frames do not match the last block");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         HIPCK(hipMemcpyAsync(out, e->d_taps, (size_t)n * frames * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
@@ -1542,15 +1551,19 @@ int og_enable_kernel_timing(og_engine* e, int on)
     if (!e) return set_err(OG_E_INVALID, "null engine");
     e->timing = on != 0;
     e->t_used = 0;
+    e->t_blocks = 0;
     return OG_OK;
 }
+
+uint64_t og_kernel_blocks_timed(const og_engine* e) { return e ? (uint64_t)e->t_blocks : 0; }
 
 double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
 {
     if (!e || !e->timing) return -1.0;
     double total = 0.0;
-    hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->device);
+    (void)og_flush(e);
+    (void)hipStreamSynchronize(e->stream);
     for (size_t i = 0; i < e->t_used; ++i) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e->t_start[i], e->t_stop[i]) == hipSuccess) total += ms;
@@ -1628,6 +1641,7 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
     if (cap < dsp_bytes(e) + control_bytes(e, evs.size())) return set_err(OG_E_INVALID, "buffer too small");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
         HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
         if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
@@ -1666,6 +1680,7 @@ int og_load_state(og_engine* e, const void* src, size_t len)
         return set_err(OG_E_INVALID, "state blob does not belong to this graph / voice count (or is from another version)");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
         HIPCK(hipMemcpyAsync(e->d_state, src, a, hipMemcpyHostToDevice, e->stream));
         if (b) HIPCK(hipMemcpyAsync(e->d_lane_state, (const char*)src + a, b, hipMemcpyHostToDevice, e->stream));

@@ -2513,8 +2513,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     for (auto& nn : out.node_order) src << nn << " ";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
-        << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.frames + f] : og::slot_f(A, (slot)))\n"
-        << "#define ST(row) A.ramp_table[(size_t)(row) * A.frames + f]\n\n"
+        << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.ramp_stride + f] : og::slot_f(A, (slot)))\n"
+        << "#define ST(row) A.ramp_table[(size_t)(row) * A.ramp_stride + f]\n\n"
         << "namespace og_gen_" << hs << " {\n"
         << "constexpr int LPV = " << out.lpv << "; // lanes per voice\n"
         << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n#undef ST\n\n";

@@ -43,6 +43,8 @@ using __hip_internal::uint64_t;
 
 #define OG_WAVE 64
 #define OG_MAX_BLOCK 512
+#define OG_MAX_LAUNCH_BLOCKS 8                             // blocks one launch may cover (og_set_bus_batching)
+#define OG_MAX_LAUNCH_FRAMES (OG_MAX_BLOCK * OG_MAX_LAUNCH_BLOCKS)
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16
 #define OG_NO_EVENT 0xFFFFFFFFu
@@ -58,7 +60,8 @@ struct OgEvent {
 
 struct OgBlockArgs {
     uint32_t n_voices;
-    uint32_t frames;
+    uint32_t frames;           // frames this launch renders: one block (<= 512), or several queued blocks back to back
+    uint32_t ramp_stride;      // row stride of ramp_table in frames
     uint32_t lanes;            // active lanes per wave (64; experiment knob)
     uint32_t split;            // pipeline depth to launch: 0 = ordinary kernel, 2 / 4 = waves per 64 voices (og_graph.cpp)
     uint64_t frame0;
@@ -68,7 +71,7 @@ struct OgBlockArgs {
     const uint32_t* ev_end;    // [n_voices] one past the voice's last event
     uint32_t* ev_cursor;       // [n_voices] next unconsumed event
     float* partials;           // [n_workgroups][frames]
-    const float* ramp_table;   // [n_ramps][frames] per-frame values of ramped inputs
+    const float* ramp_table;   // [n_ramps + n_streams][ramp_stride] per-frame values of ramped / stream inputs
     float* taps;               // [n_taps][frames] per-voice output taps (or null)
     const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
     float* rings[OG_MAX_RINGS];        // delay lines: [capacity][n_voices] each (slot-major, voices contiguous)
@@ -253,7 +256,6 @@ __device__ __forceinline__ void wave_sync()
 // ---- mix bus ---------------------------------------------------------------
 struct BusLds {
     float tile[OG_BUS_CHUNK][OG_WAVE + 1]; // +1 pad: conflict-free transposed read
-    float part[OG_MAX_BLOCK];              // this wave's partial sum per frame
 };
 
 // one sample of one voice into the wave's transpose tile (row j = frame within the chunk)
@@ -269,7 +271,8 @@ __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c,
     }
 }
 
-// after n <= OG_BUS_CHUNK frames starting at `base`: transpose-sum the tile into part[base..base+n)
+// after n <= OG_BUS_CHUNK frames starting at `base`: transpose-sum the tile; 16 lanes append the wave's partial sums
+// for those frames to its row in HBM (64 bytes per chunk; the row is complete when the launch ends, whatever its length)
 __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t base,
                                                  uint32_t n)
 {
@@ -281,16 +284,11 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
     for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.tile[j][q * (OG_WAVE / 4) + i];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (c.lane < OG_BUS_CHUNK && j < n) lds.part[base + j] = s;
+    if (c.lane < OG_BUS_CHUNK && j < n) a.partials[(size_t)blockIdx.x * a.frames + base + j] = s;
     wave_sync();
 }
 
-__device__ __forceinline__ void bus_flush(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds)
-{
-    wave_sync();
-    for (uint32_t f = c.lane; f < a.frames; f += OG_WAVE)
-        a.partials[(size_t)blockIdx.x * a.frames + f] = lds.part[f];
-}
+__device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLds&) {} // (rows are written as they are formed)
 
 } // namespace og
 

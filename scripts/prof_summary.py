@@ -43,6 +43,16 @@ for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
 out["pmc_voice_kernel"] = pmc
 LPV = {"epiano_voice": 8}.get(GRAPH, 1)
 waves = (V * LPV + 63) // 64
+# a launch may render several queued blocks (bench.py --bus-batch, default 8): frames per dispatch = blocks run / launches
+def _arg(name, default):
+    m = re.search(name + r"\s+(\d+)", cmd)
+    return int(m.group(1)) if m else default
+blocks_run = _arg("--steps", 188) + _arg("--warmup", 8)
+for k in out["kernel_stats"]:
+    if k["name"] == out.get("kernel_name"):
+        out["blocks_per_launch"] = blocks_run / float(k["calls"])
+FR = FR * out.get("blocks_per_launch", 1.0)
+out["frames_per_launch"] = FR
 d = {}
 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
     if k in pmc:
@@ -60,8 +70,8 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 with open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
 with open(os.path.join(ROOT, "profiles", tag + "_summary.md"), "w") as f:
-    f.write("# rocprofv3 summary `%s`\n\n`rocprofv3 --kernel-trace --stats -- %s` (+ separate `--pmc` passes), MI355X, %d voices x %d frames per launch\n\n"
-            % (tag, out["command"], V, FR))
+    f.write("# rocprofv3 summary `%s`\n\n`rocprofv3 --kernel-trace --stats -- %s` (+ separate `--pmc` passes), MI355X, %d voices x %.0f frames per launch (%.2f blocks of %d)\n\n"
+            % (tag, out["command"], V, FR, out.get("blocks_per_launch", 1.0), out["frames"]))
     f.write("| kernel | calls | avg us | % |\n|---|---|---|---|\n")
     for k in out["kernel_stats"]:
         f.write("| `%s` | %d | %.3f | %.1f |\n" % (k["name"][:70], k["calls"], k["avg_us"], k["pct"]))
