@@ -361,6 +361,7 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
             {
                 HIPCK(hipSetDevice(e->device));
                 e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS); // shards render up to 8 blocks per launch
+                e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
             }
             c->shard.push_back(e);
             int di = -1;

@@ -237,7 +237,8 @@ struct og_engine {
     // state loaded and stored once, one inter-kernel gap, one bus reduce per tree level -- instead of one launch each.
     // A queued block has had its ramps ticked and its stream samples captured; anything that touches engine state
     // launches the queue first.  Results are those of block-by-block processing, bit for bit.
-    uint32_t bus_batch = 1;
+    uint32_t bus_batch = 1; // queue limit (blocks per launch)
+    uint32_t batch_cap = 1; // what the buffers are sized for
     struct QueuedBlock {
         float* dst; // where the block's bus goes
         uint32_t frames;
@@ -599,6 +600,7 @@ struct og_engine {
                 HIPCK(hipFree(*p));
                 *p = nullptr;
             }
+        batch_cap = batch;
         const size_t max_frames = (size_t)OG_MAX_BLOCK * batch;
         HIPCK(hipMalloc(&d_partials, (size_t)n_wg * max_frames * 4));
         HIPCK(hipMemset(d_partials, 0, (size_t)n_wg * max_frames * 4));
@@ -615,7 +617,6 @@ struct og_engine {
             if (!ramp_ev[i]) HIPCK(hipEventCreateWithFlags(&ramp_ev[i], hipEventDisableTiming));
             ramp_ev_used[i] = false;
         }
-        bus_batch = batch;
     }
 
     // process_block(frames), asynchronous: the block joins the queue; the queue is launched when it is full or when
@@ -634,7 +635,7 @@ struct og_engine {
         // tick_ramps (codegen/mod.rs:878-914): the value seen by frame f is the one after f+1 ticks.  The same
         // per-frame table carries the graph's stream inputs (`<stream_in>_block`, one row each, broadcast to every
         // voice); a graph with stream inputs always runs the table-reading kernel variant.
-        const size_t stride = (size_t)OG_MAX_BLOCK * bus_batch;
+        const size_t stride = (size_t)OG_MAX_BLOCK * batch_cap;
         const bool ramping = active_ramps > 0 && cg->n_ramps > 0;
         if ((ramping || cg->n_streams > 0 || q_ramps) && cg->n_ramps + cg->n_streams > 0) {
             if (q_ramp_slot < 0) { // first block of the queue that needs the table: earlier blocks get constant rows
@@ -688,7 +689,7 @@ struct og_engine {
         memset(&A, 0, sizeof A);
         A.n_voices = V;
         A.frames = q_frames;
-        A.ramp_stride = (uint32_t)((size_t)OG_MAX_BLOCK * bus_batch);
+        A.ramp_stride = (uint32_t)((size_t)OG_MAX_BLOCK * batch_cap);
         A.lanes = lanes;
         A.split = split;
         A.frame0 = q_frame0;
@@ -1347,7 +1348,8 @@ int og_set_bus_batching(og_engine* e, uint32_t blocks)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        if (blocks != e->bus_batch) e->alloc_bus_buffers(blocks);
+        if (blocks > e->batch_cap) e->alloc_bus_buffers(blocks);
+        e->bus_batch = blocks;
         return OG_OK;
     });
 }
@@ -1399,6 +1401,16 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
         const uint32_t ch = e->cg->channels;
         float* d_all = nullptr;
         HIPCK(hipMalloc(&d_all, (size_t)total_frames * ch * 4));
+        // an offline render has nothing between its blocks: several per launch (the caller's setting is restored)
+        e->flush_bus();
+        const uint32_t user_batch = e->bus_batch;
+        if (e->batch_cap < OG_MAX_LAUNCH_BLOCKS) e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS);
+        e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
+        struct Restore {
+            og_engine* e;
+            uint32_t b;
+            ~Restore() { e->bus_batch = b; }
+        } restore{e, user_batch};
         try {
             for (uint64_t f0 = 0; f0 < total_frames; f0 += block) {
                 const uint32_t frames = (uint32_t)std::min<uint64_t>(block, total_frames - f0);
@@ -1448,6 +1460,15 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
         const uint32_t ch = e->cg->channels;
         float* d_all = nullptr;
         HIPCK(hipMalloc(&d_all, (size_t)total * ch * 4));
+        e->flush_bus();
+        const uint32_t user_batch = e->bus_batch;
+        if (e->batch_cap < OG_MAX_LAUNCH_BLOCKS) e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS);
+        e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
+        struct Restore {
+            og_engine* e;
+            uint32_t b;
+            ~Restore() { e->bus_batch = b; }
+        } restore{e, user_batch};
         try {
             for (uint64_t pos = 0; pos < total; pos += OG_MAX_BLOCK) { // chunks of DEFAULT_MAX_BLOCK_SIZE, offline.rs:71-90
                 const uint32_t n = (uint32_t)std::min<uint64_t>(OG_MAX_BLOCK, total - pos);
