@@ -1110,22 +1110,39 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // Measured on MI355X (65 536 fm voices): 64 lanes 0.129 ms, 32 lanes 0.185 ms, 16 lanes
             // 0.325 ms per block -- a wave-instruction costs the same issue time however many of its
             // lanes are active, so narrowing only multiplies instructions.  Kept as an experiment knob.
-            (void)simds;
             uint32_t lanes = OG_WAVE;
             if (const char* ev = getenv("OSCEN_GPU_LANES")) {
                 const int l = atoi(ev);
                 if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
             }
             e->lanes = lanes;
-            // pipelined variants for banks too small to put four ordinary waves on every SIMD.  Measured on
-            // MI355X (fm_voice, 256-frame block, kernel time with one / two / four waves per 64 voices):
-            // 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152: 0.077 / 0.071 /
-            // 0.054; 65 536: 0.080 / 0.066 / 0.086 (the four-wave form issues ~20% more instructions and its
-            // waves move in lockstep); 98 304: 0.104 / 0.084; 114 688 and above: the ordinary kernel.
+            // Pipelined variants for banks too small to put enough ordinary waves on every SIMD.  Which depth (waves per
+            // 64 voices: 1, 2 or 4) is a small cost model, not a table of bank sizes:
+            //   * a wave issues at most one instruction every ~4.8 cycles (dependent-instruction latency; measured with
+            //     one wave per SIMD), so a frame costs a wave 4.8 x its instructions;
+            //   * a SIMD retires one wave-instruction per ~3.05 cycles (the measured scalar-f32 ceiling), and the kernel
+            //     ends with the fullest SIMD: r = ceil(waves / SIMDs) waves share it;
+            //   * cutting the node sequence into d waves adds hand-off work: ~8 instructions per frame for two waves,
+            //     ~12 % + 16 for four (LDS rings, barriers, the per-wave loop and event bookkeeping).
+            // cycles per frame ~ max(4.8 * I_d, 3.05 * r_d * I_d), I_d = instructions per wave.  With the graph's
+            // estimated VALU cost (node weights) this reproduces every measured crossover of fm_voice (256-frame blocks,
+            // one / two / four waves: 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152:
+            // 0.077 / 0.071 / 0.054; 65 536: 0.080 / 0.066 / 0.086; 98 304: 0.104 / 0.084 / -; 131 072: 0.101 / 0.111 /
+            // 0.116) and scales with the graph instead of assuming its cost.
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
+            const double W = (double)std::max(8, e->cg->valu_estimate);
+            auto cycles = [&](int d) {
+                const double I = d == 1 ? W : (d == 2 ? (W + 8.0) / 2.0 : (W * 1.12 + 16.0) / 4.0);
+                const double r = std::ceil((double)waves1 * d / (double)simds);
+                return std::max(4.8 * I, 3.05 * r * I);
+            };
             uint32_t depth = 0;
-            if (e->cg->max_pipeline >= 4 && waves1 * 4 <= 3 * simds) depth = 4;
-            else if (e->cg->max_pipeline >= 2 && waves1 * 2 <= 3 * simds) depth = 2; // <= 98 304 voices (114 688: 0.121 vs 0.103 ms)
+            double best = cycles(1);
+            if (e->cg->max_pipeline >= 2 && cycles(2) < 0.95 * best) { // (a deeper pipeline has to pay for itself clearly)
+                best = cycles(2);
+                depth = 2;
+            }
+            if (e->cg->max_pipeline >= 4 && cycles(4) < 0.95 * best) depth = 4;
             if (const char* ev = getenv("OSCEN_GPU_SPLIT")) {
                 const int want = atoi(ev);
                 depth = (want >= 4 && e->cg->max_pipeline >= 4) ? 4 : ((want >= 2 && e->cg->max_pipeline >= 2) ? 2 : 0);

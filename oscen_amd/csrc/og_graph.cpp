@@ -1,5 +1,6 @@
 // og_graph.cpp -- graph lowering + HIP code generation (see og_graph.h).
 #include "og_graph.h"
+#include "og_rt_digest.h" // OG_RT_DIGEST: digest of the device headers the generated kernels include
 
 #include <algorithm>
 #include <cctype>
@@ -2188,6 +2189,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         graph_weight += node_weight(cg.nodes[ni].decl->type);
         has_env = has_env || cg.nodes[ni].decl->type.rfind("AdsrEnvelope::", 0) == 0;
     }
+    out.valu_estimate = graph_weight + 8; // + the mix bus
     int unroll = (has_env && graph_weight >= 100) ? 1 : 2;
     if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
@@ -2497,7 +2499,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::string user_src;
     for (const auto& kv : cg.user_fns) user_src += kv.second;
     const std::string body_s = user_src + body.str();
-    out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv));
+    out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv) + "|rt" + OG_RT_DIGEST);
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
 
