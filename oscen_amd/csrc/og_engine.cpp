@@ -454,10 +454,12 @@ struct og_engine {
         }
         const size_t n = evs.size();
         if (n > 0xFFFFFFF0ull) throw std::runtime_error("event timeline too long");
-        if (n + EV_STAGE_EVENTS > ev_cap) {
+        if (n + std::min<size_t>(EV_STAGE_EVENTS, 64) > ev_cap || !d_events) {
             if (d_events) HIPCK(hipFree(d_events));
             d_events = nullptr;
-            ev_cap = std::max<size_t>(n + n / 2, 1024) + 64 * EV_STAGE_EVENTS; // head-room for appended segments (32 MB)
+            size_t headroom = 64 * EV_STAGE_EVENTS; // room for appended segments (32 MB) before the next compaction
+            if (const char* hv = getenv("OSCEN_GPU_EV_HEADROOM")) headroom = std::max<size_t>(64, (size_t)atoll(hv)); // (tests: force compactions)
+            ev_cap = std::max<size_t>(n + n / 2, 1024) + headroom;
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
         }
         if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));

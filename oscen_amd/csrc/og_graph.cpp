@@ -2439,13 +2439,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << ind << "}\n";
             };
             const std::string mc = min_cnt(st);
+            const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: a | b | c | ev (timing of one path only)
             auto variants = [&](bool st_flag, const std::string& ind0) {
-                if (mc.empty()) {
+                if (force && force[0] == 'c') {
+                    quiet("true", "true", st_flag, ind0);
+                } else if (mc.empty()) {
                     quiet("true", "true", st_flag, ind0);
                 } else {
                     body << ind0 << "if (__all((int)(" << mc << " > (uint32_t)XCH))) { // no envelope stage ends in this chunk\n"
                          << ind0 << "    if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
-                    quiet("false", "false", st_flag, ind0 + "        ");
+                    quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "        ");
                     body << ind0 << "    } else {\n";
                     quiet("false", "true", st_flag, ind0 + "        ");
                     body << ind0 << "    }\n" << ind0 << "} else {\n";
@@ -2458,7 +2461,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                  << "        if (ch < n_chunks) {\n"
                  << "        const uint32_t base = ch * XCH;\n"
                  << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n"
-                 << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))) {\n";
+                 << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))" << (force && force[0] == 'e' ? " && A.frames == 0u" : "") << ") {\n";
             if (steady.empty()) {
                 variants(false, "            ");
             } else {
