@@ -1439,7 +1439,7 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
             HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total_frames * ch * 4, hipMemcpyDeviceToHost, e->stream));
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {
-            hipFree(d_all);
+            (void)hipFree(d_all);
             throw;
         }
         HIPCK(hipFree(d_all));

@@ -2439,7 +2439,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << ind << "}\n";
             };
             const std::string mc = min_cnt(st);
-            const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: a | b | c | ev (timing of one path only)
+            const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: b | c | ev -- quiet chunks take the release-arithmetic / stage-end-check / event path (results stay valid)
             auto variants = [&](bool st_flag, const std::string& ind0) {
                 if (force && force[0] == 'c') {
                     quiet("true", "true", st_flag, ind0);

@@ -80,7 +80,7 @@ struct JitImpl : OgJitKernel {
     unsigned lpv = 1;
     ~JitImpl() override
     {
-        if (mod) hipModuleUnload(mod);
+        if (mod) (void)hipModuleUnload(mod);
     }
     void launch(const OgBlockArgs& args, bool ramps, bool taps, hipStream_t stream) override
     {
