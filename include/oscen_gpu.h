@@ -104,7 +104,15 @@ typedef struct {
     const char* process_src;               /* body of process() */
     const char* const* event_handler_src;  /* n_inputs entries (or NULL): body of on_<input>() for event inputs */
     uint32_t cost_hint;                    /* estimated VALU instructions per tick; 0 = estimate from the source */
+    /* `#[output(event)]` fields (oscen-macros/src/lib.rs:127-133).  process() and the handlers see each as an
+     * object with `push(float scalar)` (= EventOutput::try_push of a scalar payload at the current frame; at most
+     * OG_NODE_EVENTS_PER_FRAME = 2 per frame and output, further pushes are dropped like try_push on a full queue --
+     * the reference's queue holds 32).  `a.trig -> b.gate` runs b's on_gate for every event a pushed on that frame,
+     * before b.process(); the outputs are cleared once per frame (clear_event_outputs, lib.rs:237-256). */
+    const char* const* event_outputs;
+    uint32_t n_event_outputs;
 } og_node_type;
+#define OG_NODE_EVENTS_PER_FRAME 2
 int og_register_node(const og_node_type* t);
 int og_unregister_node(const char* type_ctor);
 /* A graph description usable as a node of other graphs (`inner = InnerGraph;`, nested graphs:

@@ -953,6 +953,10 @@ int og_register_node(const og_node_type* t)
             st.arg = f.ctor_arg;
             u.state.push_back(st);
         }
+        for (uint32_t i = 0; i < t->n_event_outputs; ++i) {
+            if (!t->event_outputs || !t->event_outputs[i]) throw std::runtime_error("bad event output name");
+            u.ev_outputs.push_back(t->event_outputs[i]);
+        }
         u.process_src = t->process_src;
         u.weight = (int)t->cost_hint;
         ogc::register_user_node(u);

@@ -233,6 +233,7 @@ struct NodeTypeInfo {
     size_t nargs;
     int lpv = 1; // lanes per voice this node type needs (32: per-harmonic arrays)
     const UserNodeType* user = nullptr; // registered through og_register_node (emit_user)
+    std::vector<std::string> ev_outputs; // `#[output(event)]` fields (user node types only)
 };
 
 const NodeTypeInfo* lookup_type(const std::string& type);
@@ -266,7 +267,10 @@ struct NodeInst {
     };
     std::map<std::string, std::vector<Src>> in_edges; // stream/value port -> sources in edge order
     int domain = 0; // 0 = outer before the inner loop, 1 = oversampled inner loop, 2 = outer after it
-    std::map<std::string, std::vector<int>> ev_edges;   // event port -> graph event-input indices
+    // event port -> its source.  An event edge is clear + copy (graph/static_context.rs:84-155), so on fan-in only the
+    // LAST connected source delivers: at most one of the two maps holds the port, ev_edges with a single entry.
+    std::map<std::string, std::vector<int>> ev_edges;                     // ... a graph event input (index)
+    std::map<std::string, std::pair<int, std::string>> ev_node_edges;     // ... an event output of another node (node, port)
 };
 
 struct Codegen {
@@ -316,6 +320,9 @@ struct Codegen {
         std::set<int> users; // consuming stages
     };
     std::vector<XVal> xvals;
+    bool dynamic_events = false; // some node receives events from another node: they arrive unannounced, so the
+                                 // chunk variants that rely on "nothing happens in this chunk" and the pipelines are off
+    std::ostringstream frame_end; // end of every frame: clear_event_outputs()
     bool bus_all_lanes = false; // every lane of a multi-lane voice contributes a share to the mix bus (og::ep_bank_tick)
     // envelopes whose stage-end fix-up has not been emitted yet: (countdown expression, fix-up code).
     // Flushed as ONE wave-uniform check before the next node that is not an envelope (which may read
@@ -565,6 +572,10 @@ struct NodeCtx {
         return ps.def;
     }
     bool connected(const std::string& name) const { return n.in_edges.count(name) > 0; }
+    // Handler of event input `port`: gen(value expression) -> statements.  Events of a graph event input are applied by
+    // the kernel's event loop before the frame's ticks; events another node pushed on this frame are applied right here
+    // (= before this node's process(), after the producer's: process_event_inputs(), oscen-macros/src/lib.rs:265-285).
+    void on_event(const std::string& port, const std::function<std::string(const std::string&)>& gen);
     // resolved value of a stream/value input: constant default, one source, or the sum of sources
     bool lane_ok = false;
     Val in_lane(const std::string& name)
@@ -687,6 +698,30 @@ struct NodeCtx {
 constexpr float ADSR_MIN_TIME = 1.0e-5f;
 constexpr float ADSR_CURVE_K = 4.6051702f;
 
+void NodeCtx::on_event(const std::string& port, const std::function<std::string(const std::string&)>& gen)
+{
+    auto ev = n.ev_edges.find(port);
+    if (ev != n.ev_edges.end())
+        for (int ei : ev->second) cg.S().ev_handlers[ei] << gen("ev.value");
+    auto nv = n.ev_node_edges.find(port);
+    if (nv == n.ev_node_edges.end()) return;
+    const NodeInst& src = cg.nodes[nv->second.first];
+    if (src.domain != n.domain)
+        fail("event edge '" + src.decl->name + "." + nv->second.second + " -> " + n.decl->name + "." + port +
+             "' crosses a rate boundary (cross-rate event drains are not built)");
+    if (cg.stage_of.size() > (size_t)n.id && cg.stage_of[n.id] != cg.stage_of[src.id])
+        fail("internal: event edge across pipeline stages");
+    const std::string q = "n" + std::to_string(src.id) + "_" + nv->second.second;
+    cg.os() << "        if (__any((int)(" << q << ".n != 0u))) { // events '" << src.decl->name << "." << nv->second.second
+            << "' pushed on this frame\n"
+            << "            #pragma unroll\n"
+            << "            for (uint32_t evk = 0; evk < OG_NODE_EVENTS_PER_FRAME; ++evk)\n"
+            << "                if (evk < " << q << ".n) {\n"
+            << "                const float evv = " << q << ".get(evk);\n"
+            << gen("evv") << "                }\n"
+            << "        }\n";
+}
+
 uint32_t rs_as_u32(float x)
 {
     if (!(x > 0.0f)) return 0u;
@@ -733,10 +768,7 @@ void emit_adsr(NodeCtx& x)
                << "        og::st_u(A, c, " << w_rem << ", og::adsr_rem(" << E << "));\n"
                << "        og::st_f(A, c, " << w_level << ", " << E << ".lv);\n"
                << "        og::st_f(A, c, " << w_vel << ", " << E << ".vel);\n";
-    auto ev = x.n.ev_edges.find("gate");
-    if (ev != x.n.ev_edges.end())
-        for (int ei : ev->second)
-            x.cg.S().ev_handlers[ei] << "                og::adsr_gate(" << E << ", ev.value, " << K << ");\n";
+    x.on_event("gate", [&](const std::string& val) { return "                og::adsr_gate(" + E + ", " + val + ", " + K + ");\n"; });
     x.set_out("output", x.n.domain == 1 ? "og::adsr_tick(" + E + ")" : "og::adsr_tick<decltype(chk)::release>(" + E + ")", true);
     const std::string fix = "og::adsr_complete(" + E + ", " + x.sf(s_ac) + ", " + x.sf(s_dc) + ", " + x.su(s_dn) + ", " + x.p +
                             "output);\n";
@@ -1030,11 +1062,10 @@ void emit_ep_amp(NodeCtx& x)
     x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
                    << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
                    << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
-    auto ev = x.n.ev_edges.find("gate");
-    if (ev != x.n.ev_edges.end())
-        for (int ei : ev->second)
-            x.cg.S().ev_handlers[ei] << "                og::ep_amp_gate(" << A << ", c.h * OG_HPL, ev.value, " << br.e << ", " << vs.e
-                                 << ", " << dr.e << ", " << hd.e << ", " << ks.e << ", " << rr.e << ");\n";
+    x.on_event("gate", [&](const std::string& val) {
+        return "                og::ep_amp_gate(" + A + ", c.h * OG_HPL, " + val + ", " + br.e + ", " + vs.e + ", " + dr.e + ", " + hd.e +
+               ", " + ks.e + ", " + rr.e + ");\n";
+    });
     const std::string var = x.p + "amplitudes";
     x.cg.os() << "        const og::HarmV " << var << " = og::ep_amp_tick(" << A << ");\n";
     Val v;
@@ -1058,9 +1089,7 @@ void emit_ep_bank(NodeCtx& x)
     x.cg.S().load << "        " << B << " = og::EpBank{" << re << ", " << im << ", " << mre << ", " << mim << ", " << lf << ", false};\n";
     x.cg.S().pre_store << "        " << re << " = " << B << ".re; " << im << " = " << B << ".im; " << mre << " = " << B << ".mre; "
                    << mim << " = " << B << ".mim; " << lf << " = " << B << ".last_frequency;\n";
-    auto ev = x.n.ev_edges.find("gate");
-    if (ev != x.n.ev_edges.end())
-        for (int ei : ev->second) x.cg.S().ev_handlers[ei] << "                og::ep_bank_gate(" << B << ", ev.value);\n";
+    x.on_event("gate", [&](const std::string& val) { return "                og::ep_bank_gate(" + B + ", " + val + ");\n"; });
     // update_multipliers(): the frequency test of process() can only fire when the frequency changed
     const std::string upd = "og::ep_bank_update(" + B + ", c.h * OG_HPL, " + fr.e + ", " + x.sf(s_sr) + ");\n";
     if (fr.rate <= Rate::VBlock && fr.rate != Rate::UFrame) {
@@ -1218,6 +1247,10 @@ void emit_user(NodeCtx& x)
                     sep();
                     q << "float& " << o;
                 }
+            for (const std::string& o : u.ev_outputs) {
+                sep();
+                q << "og::EvOut& " << o;
+            }
             sep();
             q << "const float sample_rate";
             return q.str();
@@ -1230,24 +1263,35 @@ void emit_user(NodeCtx& x)
               << "\n}\n";
         x.cg.user_fns[u.type] = d.str();
     }
+    // event outputs: one register queue each, visible to the handlers (kernel event loop) and to the tick
+    std::vector<std::string> evo;
+    for (const std::string& o : u.ev_outputs) {
+        evo.push_back(x.p + o);
+        x.cg.S().decl << "    og::EvOut " << x.p << o << ";\n";
+        (x.n.domain == 1 ? x.cg.S().s_cap : x.cg.frame_end) << "        " << x.p << o << ".clear();\n";
+    }
     // event handlers: value inputs must be known when the event fires (before the frame's nodes run)
     for (const auto& h : u.handlers) {
-        auto ev = x.n.ev_edges.find(h.first);
-        if (ev == x.n.ev_edges.end()) continue;
-        std::ostringstream call;
-        call << "                " << fn << "_on_" << h.first << "(ev.value";
+        if (!x.n.ev_edges.count(h.first) && !x.n.ev_node_edges.count(h.first)) continue;
+        const bool from_node = x.n.ev_node_edges.count(h.first) > 0;
+        std::ostringstream args;
         for (size_t i = 0; i < ins.size(); ++i) {
             if (in_ports[i]->kind != Kind::Value) continue;
-            if (ins[i].rate == Rate::Vary || ins[i].rate == Rate::UFrame)
+            if (!from_node && (ins[i].rate == Rate::Vary || ins[i].rate == Rate::UFrame))
                 fail("node '" + x.n.decl->name + "' (" + u.type + "): value input '" + in_ports[i]->name +
                      "' must be constant over the block because the node has an event handler");
-            call << ", " << ins[i].e;
+            args << ", " << ins[i].e;
         }
-        for (const std::string& v : st) call << ", " << v;
-        call << ", " << x.sf(s_sr) << ");\n";
-        for (int ei : ev->second) x.cg.S().ev_handlers[ei] << call.str();
+        for (const std::string& v : st) args << ", " << v;
+        for (const std::string& v : evo) args << ", " << v;
+        args << ", " << x.sf(s_sr) << ");\n";
+        const std::string tail = args.str(), name = fn + "_on_" + h.first;
+        x.on_event(h.first, [&](const std::string& val) { return "                " + name + "(" + val + tail; });
     }
     for (const auto& kv : x.n.ev_edges)
+        if (!u.handlers.count(kv.first))
+            fail("node '" + x.n.decl->name + "' (" + u.type + "): event input '" + kv.first + "' has no on_" + kv.first + " handler");
+    for (const auto& kv : x.n.ev_node_edges)
         if (!u.handlers.count(kv.first))
             fail("node '" + x.n.decl->name + "' (" + u.type + "): event input '" + kv.first + "' has no on_" + kv.first + " handler");
     // the tick
@@ -1270,6 +1314,10 @@ void emit_user(NodeCtx& x)
     for (const std::string& o : u.outputs) {
         sep();
         call << x.p << o;
+    }
+    for (const std::string& v : evo) {
+        sep();
+        call << v;
     }
     sep();
     call << x.sf(s_sr) << ");\n";
@@ -1641,13 +1689,53 @@ uint32_t RingSpec::capacity(float graph_sr) const
 }
 
 
-GraphDesc expand(const GraphDesc& g) { return expand_nested(expand_arrays(g), 0); }
+// `pass = EventPassthrough::new()` (oscen-lib/src/event_passthrough.rs: on_input forwards the event to `output`) is
+// pure routing: `x -> pass.input; pass.output -> d` delivers x's events to d on the same frame.  The node is removed
+// and its consumers are connected to what feeds it (the last source connected to `input`: clear + copy).
+GraphDesc expand_passthrough(const GraphDesc& g)
+{
+    auto strip = [](std::string t) {
+        t.erase(std::remove_if(t.begin(), t.end(), [](char ch) { return isspace((unsigned char)ch); }), t.end());
+        return t;
+    };
+    GraphDesc r = g;
+    for (int guard = 0; guard < 64; ++guard) {
+        size_t pi = r.nodes.size();
+        for (size_t i = 0; i < r.nodes.size(); ++i)
+            if (r.nodes[i].type == "EventPassthrough::new" || r.nodes[i].type == "EventPassthrough") pi = i;
+        if (pi == r.nodes.size()) return r;
+        const std::string nm = r.nodes[pi].name;
+        std::string feed; // the source that ends up in pass.input
+        for (const GEdge& e : r.edges)
+            if (strip(e.dst) == nm + ".input") feed = e.src;
+        if (strip(feed) == nm + ".output") fail("event passthrough '" + nm + "' feeds itself");
+        std::vector<GEdge> edges;
+        for (const GEdge& e : r.edges) {
+            if (strip(e.dst) == nm + ".input") continue;
+            if (strip(e.src) == nm + ".output") {
+                if (feed.empty()) continue; // nothing ever arrives
+                GEdge f = e;
+                f.src = feed;
+                edges.push_back(f);
+            } else {
+                if (strip(e.src).find(nm + ".") == 0 || strip(e.dst).find(nm + ".") == 0)
+                    fail("EventPassthrough '" + nm + "' has the ports 'input' and 'output' only ('" + e.src + " -> " + e.dst + "')");
+                edges.push_back(e);
+            }
+        }
+        r.edges = edges;
+        r.nodes.erase(r.nodes.begin() + (long)pi);
+    }
+    fail("event passthrough chain too long");
+}
+
+GraphDesc expand(const GraphDesc& g) { return expand_passthrough(expand_nested(expand_arrays(g), 0)); }
 
 void register_user_node(const UserNodeType& t)
 {
     if (t.type.empty()) fail("node type needs a name");
     if (registry().count(t.type)) fail("'" + t.type + "' is a built-in node type");
-    if (t.outputs.empty()) fail("node type '" + t.type + "' needs at least one output");
+    if (t.outputs.empty() && t.ev_outputs.empty()) fail("node type '" + t.type + "' needs at least one output");
     std::set<std::string> names;
     auto uniq = [&](const std::string& n) {
         if (!is_ident(n)) fail("node type '" + t.type + "': '" + n + "' is not an identifier");
@@ -1659,6 +1747,7 @@ void register_user_node(const UserNodeType& t)
         if (p.arg >= (int)t.nargs) fail("node type '" + t.type + "': input '" + p.name + "' refers to a missing constructor argument");
     }
     for (const auto& o : t.outputs) uniq(o);
+    for (const auto& o : t.ev_outputs) uniq(o);
     for (const auto& f : t.state) {
         uniq(f.name);
         if (f.arg >= (int)t.nargs) fail("node type '" + t.type + "': field '" + f.name + "' refers to a missing constructor argument");
@@ -1682,6 +1771,7 @@ void register_user_node(const UserNodeType& t)
     }
     for (const auto& p : e->t.inputs) e->info.inputs.push_back({p.name.c_str(), p.kind, p.def, p.arg});
     for (const auto& o : e->t.outputs) e->info.outputs.push_back(o.c_str());
+    e->info.ev_outputs = e->t.ev_outputs;
     e->info.emit = emit_user;
     e->info.variant = 0;
     e->info.nargs = t.nargs;
@@ -1817,7 +1907,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         std::vector<const Expr*> refs;
         collect_refs(src, refs);
         std::set<int> src_nodes;
-        bool src_is_event_input = false;
+        bool src_is_event_input = false, src_is_event_output = false;
         int src_event_input = -1;
         for (const Expr* r : refs) {
             if (r->port.empty()) {
@@ -1831,8 +1921,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 auto it = cg.node_by_name.find(r->node);
                 if (it == cg.node_by_name.end()) fail("unknown node '" + r->node + "' in '" + e.src + "'");
                 src_nodes.insert(it->second);
+                for (const std::string& eo : cg.nodes[it->second].type->ev_outputs)
+                    if (eo == r->port) src_is_event_output = true;
             }
         }
+        if (src_is_event_output && src->t != Expr::Ref) fail("an event output cannot be part of an expression ('" + e.src + "')");
         // destination
         std::string dn = e.dst, dp;
         size_t dot = dn.find('.');
@@ -1851,7 +1944,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         if (dp.empty()) {
             auto oit = cg.output_by_name.find(dn);
             if (oit == cg.output_by_name.end()) fail("unknown destination '" + e.dst + "'");
-            if (src_is_event_input) fail("event outputs are not supported ('" + e.dst + "')");
+            if (src_is_event_input || src_is_event_output)
+                fail("event outputs of the graph are not supported ('" + e.dst + "'): events stay inside the voice");
             out_edges[oit->second].push_back({src, e.policy});
             out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
             continue;
@@ -1864,11 +1958,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (dp == p.name) ps = &p;
         if (!ps) fail("node '" + dn + "' (" + dst.decl->type + ") has no input '" + dp + "'");
         if (ps->kind == Kind::Event) {
-            if (!src_is_event_input || src->t != Expr::Ref)
-                fail("event input '" + e.dst + "' must be fed by a graph event input");
-            dst.ev_edges[dp].push_back(src_event_input);
+            if (!(src_is_event_input || src_is_event_output) || src->t != Expr::Ref)
+                fail("event input '" + e.dst + "' must be fed by a graph event input or by an event output of a node");
+            // clear + copy: a later edge into the same input replaces the earlier source (last write wins)
+            dst.ev_edges.erase(dp);
+            dst.ev_node_edges.erase(dp);
+            if (src_is_event_input) {
+                dst.ev_edges[dp].push_back(src_event_input);
+            } else {
+                if (e.feedback) fail("an event edge cannot be a feedback edge ('" + e.src + "')");
+                dst.ev_node_edges[dp] = {*src_nodes.begin(), src->port};
+            }
         } else {
-            if (src_is_event_input) fail("event source '" + e.src + "' cannot feed '" + e.dst + "'");
+            if (src_is_event_input || src_is_event_output) fail("event source '" + e.src + "' cannot feed '" + e.dst + "'");
             dst.in_edges[dp].push_back({src, e.policy});
             if (e.feedback) { // outgoing leg of `src -> [via] -> dst` (ir/lower.rs:553-570)
                 if (src->t != Expr::Ref || src->port.empty()) fail("a feedback edge must start at a node output ('" + e.src + "')");
@@ -1883,6 +1985,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
         }
     }
+
+    // a node that receives another node's events runs after it (and keeps it alive)
+    for (size_t i = 0; i < g.nodes.size(); ++i)
+        for (const auto& kv : cg.nodes[i].ev_node_edges) deps[i].insert(kv.second.first);
 
     // ---- dead-node removal (ir/passes/dead_nodes.rs:11-62) ------------------------
     if (!g.outputs.empty()) {
@@ -1907,6 +2013,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live) out.lpv = std::max(out.lpv, cg.nodes[i].type->lpv);
     out.lane_width = out.lpv > 1 ? 4 : 1; // OG_HPL
+    for (size_t i = 0; i < g.nodes.size(); ++i)
+        if (cg.nodes[i].live && !cg.nodes[i].ev_node_edges.empty()) cg.dynamic_events = true;
+    if (cg.dynamic_events && out.lpv != 1) fail("node-to-node event edges are not supported in array-valued (several lanes per voice) graphs");
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
     std::vector<int> order;
@@ -1975,7 +2084,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         const char* env_split = getenv("OGC_SPLIT");
         bool any_delay = false; // delay lines are staged per chunk by the ordinary kernel only
         for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
-        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback &&
+        bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback && !cg.dynamic_events &&
                     !any_delay;
         // estimated per-tick VALU cost of every node, in emission order
         int total = 0;
@@ -2257,7 +2366,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         body << "    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)\n";
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
     // min over the countdowns of a group's envelopes, or "" when it has none
-    const bool chunk_chk = !(getenv("OGC_CHUNK_CHK") && atoi(getenv("OGC_CHUNK_CHK")) == 0);
+    // (dynamic_events: a gate from another node can start a Release or a new stage on any frame)
+    const bool chunk_chk = !(getenv("OGC_CHUNK_CHK") && atoi(getenv("OGC_CHUNK_CHK")) == 0) && !cg.dynamic_events;
     auto min_cnt = [&](const std::vector<int>& st) {
         std::string m;
         if (!chunk_chk) return m;
@@ -2273,7 +2383,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     };
     body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> float {\n"
          << group_tick({all_stages}, 0);
-    body << "        return " << bus_expr << ";\n    };\n";
+    if (cg.frame_end.str().empty()) {
+        body << "        return " << bus_expr << ";\n    };\n";
+    } else { // clear_event_outputs(): the frame's node-to-node events have been delivered
+        body << "        const float g_bus = " << bus_expr << ";\n" << cg.frame_end.str() << "        return g_bus;\n    };\n";
+    }
     body << events_code(all_stages);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"

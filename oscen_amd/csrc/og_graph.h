@@ -157,6 +157,7 @@ struct UserNodeType {
     size_t nargs = 0;
     std::vector<UserPort> inputs;
     std::vector<std::string> outputs;
+    std::vector<std::string> ev_outputs; // `#[output(event)]` fields
     std::vector<UserState> state;
     std::string process_src;
     std::map<std::string, std::string> handlers; // event input -> body of on_<input>()

@@ -101,6 +101,22 @@ struct BoolC {
     static constexpr bool steady = S;
 };
 
+// An event output of a node (`#[output(event)]`, EventOutput): the scalar events the node pushed on the current
+// frame.  Lives in registers (no dynamic indexing), cleared at the end of every frame.
+#define OG_NODE_EVENTS_PER_FRAME 2
+struct EvOut {
+    uint32_t n = 0u;
+    float v0 = 0.0f, v1 = 0.0f;
+    __device__ __forceinline__ void push(float x) // try_push: dropped when the frame's queue is full
+    {
+        v1 = (n == 1u) ? x : v1;
+        v0 = (n == 0u) ? x : v0;
+        n = min(n + 1u, (uint32_t)OG_NODE_EVENTS_PER_FRAME);
+    }
+    __device__ __forceinline__ float get(uint32_t k) const { return k == 0u ? v0 : v1; }
+    __device__ __forceinline__ void clear() { n = 0u; }
+};
+
 struct VoiceCtx {
     uint32_t v;     // voice index
     bool valid;     // v < n_voices

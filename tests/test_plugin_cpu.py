@@ -168,3 +168,33 @@ def test_stream_inputs_lower_to_the_per_frame_table():
     src = g.kernel_source()
     assert "ST(0)" in src and "og::sinc_up<4>" in src and "og::sinc_down<4>" in src
     assert g.jit_check("gfx950") > 10000
+
+
+def test_event_outputs_lower_to_in_kernel_event_edges():
+    """`#[output(event)]` fields: the producer's queue lives in registers, the consumer's handler runs in the tick right
+    before its process(); EventPassthrough is removed; graph-level event outputs are refused."""
+    oscen_amd.register_node(
+        "Ticker::new", inputs=[("period", "value", 64.0, 0)], outputs=[], n_ctor_args=1, state=[("count", "u32", 0, -1)],
+        event_outputs=["trig"], process="    count += 1u;\n    if ((float)count >= period) { count = 0u; trig.push(1.0f); }\n")
+    g = oscen_amd.Graph("ev")
+    g.input_event("gate")
+    g.output_stream("out")
+    g.node("t", "Ticker::new", 32.0)
+    g.node("p", "EventPassthrough::new")
+    g.node("env", "AdsrEnvelope::new", 0.01, 0.1, 0.5, 0.2)
+    g.connect("gate", "env.gate")          # replaced by the later edge into the same input (clear + copy)
+    g.connect("t.trig", "p.input")
+    g.connect("p.output", "env.gate")
+    g.connect("env.output", "out")
+    src = g.kernel_source()
+    assert "og::EvOut n0_trig;" in src and "og::adsr_gate(n1_e, evv, A" in src and "n0_trig.clear();" in src
+    assert "EventPassthrough" not in src and "og_k2_" not in src      # no pipeline kernels for node-to-node events
+    assert "ev.target == 0u" not in src                                 # the graph's gate input no longer reaches env
+    assert g.jit_check() > 0
+    bad = oscen_amd.Graph("ev2")
+    bad.output_stream("out")
+    bad.node("t", "Ticker::new", 32.0)
+    bad.connect("t.trig", "out")
+    with pytest.raises(oscen_amd.OscenError, match="event outputs of the graph"):
+        bad.kernel_source()
+    oscen_amd.unregister_node("Ticker::new")
