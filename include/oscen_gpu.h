@@ -84,6 +84,8 @@ typedef struct {
     int kind;            /* OG_KIND_STREAM / OG_KIND_VALUE / OG_KIND_EVENT */
     float default_value; /* field value while the input is unconnected */
     int ctor_arg;        /* index of the constructor argument that sets that value, or -1 */
+    uint32_t channels;   /* stream inputs: 0 or 1 = f32, N (2..4) = Frame<N> (oscen-lib/src/frame.rs): the source sees a
+                          * `const og::Frame<N>` with `.v[i]`, `+`, `-`, `* float` and unary minus */
 } og_node_port;
 typedef struct {
     const char* name;
@@ -111,6 +113,10 @@ typedef struct {
      * before b.process(); the outputs are cleared once per frame (clear_event_outputs, lib.rs:237-256). */
     const char* const* event_outputs;
     uint32_t n_event_outputs;
+    const uint32_t* output_channels;       /* n_outputs entries (or NULL = all f32): N > 1 makes the output a Frame<N>,
+                                            * `og::Frame<N>&` in the source.  Frame edges: copy, element-wise fan-in sum,
+                                            * `frame + frame`, `frame - frame`, `frame * f32`, `-frame` in compound sources;
+                                            * the built-in frame node is TptFilter::<Frame<N>>::new (N = 2, 4). */
 } og_node_type;
 #define OG_NODE_EVENTS_PER_FRAME 2
 int og_register_node(const og_node_type* t);

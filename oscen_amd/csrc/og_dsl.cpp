@@ -236,14 +236,22 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
     const bool is_array = lx.eat('[');
     // path::to::Type::ctor  -> keep the last two segments
     std::vector<std::string> segs;
+    std::string generic;
     for (;;) {
         segs.push_back(lx.ident());
         lx.skip();
         if (lx.i + 1 < lx.s.size() && lx.s[lx.i] == ':' && lx.s[lx.i + 1] == ':') {
             lx.i += 2;
-            if (lx.peek() == '<') { // turbofish `::<f32>`
-                (void)lx.until(">");
-                lx.expect('>');
+            if (lx.peek() == '<') { // turbofish `::<f32>` / `::<Frame<2>>` / `::<Stereo>`: the frame type of the node
+                int depth = 0;
+                generic.clear();
+                do {
+                    if (lx.i >= lx.s.size()) dfail("unterminated `::<...>`", lx.line);
+                    const char ch = lx.s[lx.i++];
+                    depth += ch == '<' ? 1 : (ch == '>' ? -1 : 0);
+                    generic += ch;
+                } while (depth > 0);
+                generic = generic.substr(1, generic.size() - 2);
                 lx.skip();
                 if (lx.i + 1 < lx.s.size() && lx.s[lx.i] == ':' && lx.s[lx.i + 1] == ':') lx.i += 2;
             }
@@ -254,6 +262,7 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
     if (lx.peek() == '(') {
         if (segs.size() < 2) dfail("expected `Type::ctor(...)` for node '" + n.name + "'", lx.line);
         n.type = segs[segs.size() - 2] + "::" + segs.back();
+        if (!generic.empty()) n.type = normalize_type(segs[segs.size() - 2] + "::<" + generic + ">::" + segs.back());
         lx.expect('(');
         if (lx.peek() != ')') {
             for (;;) {
@@ -430,7 +439,11 @@ std::string to_dsl(const GraphDesc& g)
             continue;
         }
         if (n.name.rfind("__inline_delay_", 0) == 0) continue; // printed as `-> [N] ->`
-        o << "    " << n.name << " = " << (n.array_len ? "[" : "") << n.type << "(";
+        std::string ty = normalize_type(n.type); // "TptFilter<2>::new" prints as the Rust path TptFilter::<Frame<2>>::new
+        const size_t lt = ty.find('<'), gt = ty.find(">::");
+        if (lt != std::string::npos && gt != std::string::npos && lt < gt)
+            ty = ty.substr(0, lt) + "::<Frame<" + ty.substr(lt + 1, gt - lt - 1) + ">>" + ty.substr(gt + 1);
+        o << "    " << n.name << " = " << (n.array_len ? "[" : "") << ty << "(";
         for (size_t i = 0; i < n.args.size(); ++i) o << (i ? ", " : "") << num(n.args[i]);
         o << ")";
         if (n.array_len) o << "; " << n.array_len << "]";

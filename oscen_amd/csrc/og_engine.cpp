@@ -935,7 +935,7 @@ int og_register_node(const og_node_type* t)
         for (uint32_t i = 0; i < t->n_inputs; ++i) {
             const og_node_port& p = t->inputs[i];
             if (!p.name || p.kind < 0 || p.kind > 2) throw std::runtime_error("bad input port description");
-            u.inputs.push_back({p.name, (ogc::Kind)p.kind, p.default_value, p.ctor_arg});
+            u.inputs.push_back({p.name, (ogc::Kind)p.kind, p.default_value, p.ctor_arg, p.channels > 1 ? (int)p.channels : 1});
             if (p.kind == OG_KIND_EVENT && t->event_handler_src && t->event_handler_src[i]) u.handlers[p.name] = t->event_handler_src[i];
         }
         for (uint32_t i = 0; i < t->n_outputs; ++i) {
@@ -953,6 +953,7 @@ int og_register_node(const og_node_type* t)
             st.arg = f.ctor_arg;
             u.state.push_back(st);
         }
+        for (uint32_t i = 0; t->output_channels && i < t->n_outputs; ++i) u.out_channels.push_back((int)t->output_channels[i]);
         for (uint32_t i = 0; i < t->n_event_outputs; ++i) {
             if (!t->event_outputs || !t->event_outputs[i]) throw std::runtime_error("bad event output name");
             u.ev_outputs.push_back(t->event_outputs[i]);

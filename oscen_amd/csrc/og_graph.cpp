@@ -14,6 +14,7 @@
 #include <stdexcept>
 
 namespace ogc {
+std::string normalize_type(const std::string& type);
 
 uint64_t fnv1a(const std::string& s)
 {
@@ -70,6 +71,8 @@ struct Val {
     bool inner = false;           // defined inside the oversampled (x N) inner loop
     bool lane = false;            // one value per lane of an LPV > 1 voice (an `[f32; 32]` endpoint)
     bool stream = false;          // a graph-level stream input: voice-uniform, but a signal (resampled across rate domains)
+    std::vector<Val> ch;          // a Frame<N> payload (oscen-lib/src/frame.rs): its N channels, each a scalar value; `e` unused
+    bool is_frame() const { return !ch.empty(); }
 };
 
 Val vconst(float c)
@@ -219,6 +222,7 @@ struct PortSpec {
     Kind kind;
     float def;
     int arg; // ctor argument that overrides the default, or -1
+    int channels = 1; // stream ports: 1 = f32, N = Frame<N>
 };
 
 struct Codegen;
@@ -234,6 +238,7 @@ struct NodeTypeInfo {
     int lpv = 1; // lanes per voice this node type needs (32: per-harmonic arrays)
     const UserNodeType* user = nullptr; // registered through og_register_node (emit_user)
     std::vector<std::string> ev_outputs; // `#[output(event)]` fields (user node types only)
+    std::vector<int> out_channels;       // per output: 1 = f32, N = Frame<N> (empty: all f32)
 };
 
 const NodeTypeInfo* lookup_type(const std::string& type);
@@ -390,6 +395,13 @@ struct Codegen {
     // stream outer -> inner = Up{N, policy}; inner -> outer = Down{N, policy}; default policy Sinc.
     Val cross(Val v, const std::string& policy, bool dst_inner, bool value_port)
     {
+        if (v.is_frame()) {
+            for (const Val& c : v.ch)
+                if (N > 1 && c.inner != dst_inner)
+                    fail("a Frame<N> edge cannot cross a rate boundary in this version (resample the channels separately)");
+            if (!policy.empty()) fail("connection policy [" + policy + "] on a Frame<N> edge");
+            return v;
+        }
         if (N <= 1 || v.inner == dst_inner) {
             if (!policy.empty() && v.rate == Rate::Vary && N <= 1)
                 fail("connection policy [" + policy + "] needs an oversampled (`* N`) node on one side");
@@ -459,13 +471,11 @@ struct Codegen {
         return r;
     }
 
-    Val eval(const ExprP& e)
+    // scalar arithmetic of a compound source (`a.x * b.y`); op 'n' = unary minus of a
+    Val arith(const Val& a, const Val& b, char op)
     {
-        switch (e->t) {
-        case Expr::Num: return vconst(e->num);
-        case Expr::Neg: {
-            Val a = eval(e->a);
-            Val r;
+        Val r;
+        if (op == 'n') {
             r.e = "(-" + a.e + ")";
             r.rate = a.rate;
             r.inner = a.inner;
@@ -477,6 +487,102 @@ struct Codegen {
             }
             return r;
         }
+        r.e = "(" + a.e + " " + op + " " + b.e + ")";
+        r.rate = join(a.rate, b.rate);
+        r.stream = a.stream || b.stream;
+        if (a.inner != b.inner && a.rate == Rate::Vary && b.rate == Rate::Vary)
+            fail("expression mixes outer-rate and oversampled node outputs; connect them through a cross-rate edge");
+        r.inner = a.inner || b.inner;
+        r.voice_inputs = a.voice_inputs;
+        r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
+        if (a.host && b.host && r.rate <= Rate::UBlock) {
+            HostFn ha = a.host, hb = b.host;
+            r.host = [ha, hb, op](const UEnv& env) {
+                float x = ha(env), y = hb(env);
+                switch (op) {
+                case '+': return x + y;
+                case '-': return x - y;
+                case '*': return x * y;
+                default: return x / y;
+                }
+            };
+        }
+        return r;
+    }
+    // Frame<N> arithmetic (oscen-lib/src/frame.rs:104-134): Add / Sub element-wise between frames of one width,
+    // Mul<f32> = frame * scalar, Neg; nothing else exists on the reference's AudioFrame either
+    Val frame_arith(const Val& a, const Val& b, char op, const std::string& what)
+    {
+        Val r;
+        r.rate = Rate::Vary;
+        if (a.is_frame() && b.is_frame()) {
+            if (a.ch.size() != b.ch.size()) fail("frames of different widths in '" + what + "'");
+            if (op != '+' && op != '-') fail("Frame<N> supports frame + frame, frame - frame and frame * f32 ('" + what + "')");
+            for (size_t i = 0; i < a.ch.size(); ++i) r.ch.push_back(arith(a.ch[i], b.ch[i], op));
+        } else if (a.is_frame() && op == '*') {
+            for (const Val& c : a.ch) r.ch.push_back(arith(c, b, '*'));
+        } else {
+            fail("Frame<N> supports frame + frame, frame - frame and frame * f32 ('" + what + "')");
+        }
+        return r;
+    }
+    std::map<std::string, int> node_frame_outputs; // "n<id>.<port>" -> N for Frame<N> outputs (channels live as "<port>#i")
+
+    // one scalar output of a node (a whole f32 output, or channel "<port>#i" of a frame output)
+    Val node_output(int ni, const std::string& node_name, const std::string& port)
+    {
+        const std::string key = "n" + std::to_string(ni) + "." + port;
+        auto vit = node_outputs.find(key);
+        if (vit == node_outputs.end() && fb_sources.count(key) && !emitted[ni] && nodes[ni].live) {
+            // feedback edge whose producer runs later in the frame: the consumer sees the field the
+            // producer wrote on the previous frame (the struct field persists, codegen/emit_node.rs)
+            if ((nodes[ni].domain == 1) != (dom == 1))
+                fail("feedback edge from '" + node_name + "' crosses the oversampled region: both ends of a feedback edge must "
+                     "run at the same rate in this version");
+            auto fit = fb_vars.find(key);
+            if (fit == fb_vars.end()) {
+                const std::string var = "n" + std::to_string(ni) + "_" + port + "_z";
+                int w = new_state(node_name + "." + port, true, [](const UEnv&) { return 0u; });
+                S().decl << "    float " << var << " = 0.0f;\n";
+                S().load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
+                S().store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
+                fit = fb_vars.emplace(key, var).first;
+            }
+            Val v;
+            v.e = fit->second;
+            v.rate = Rate::Vary;
+            v.inner = nodes[ni].domain == 1; // last tick's value, at the producer's rate
+            return v;
+        }
+        if (vit == node_outputs.end())
+            fail("node '" + node_name + "' has no output '" + port + "' (or it is read before it runs)");
+        Val v = vit->second;
+        if (split && cs > stage_of[ni]) { // value crosses a pipeline cut
+            XVal* x = nullptr;
+            for (auto& xv : xvals)
+                if (xv.var == v.e) x = &xv;
+            if (!x) {
+                xvals.push_back({v.e, "x" + std::to_string(xvals.size()) + "_" + v.e, stage_of[ni], {}});
+                x = &xvals.back();
+            }
+            x->users.insert(cs);
+            v.e = x->alias;
+        }
+        return v;
+    }
+
+    Val eval(const ExprP& e)
+    {
+        switch (e->t) {
+        case Expr::Num: return vconst(e->num);
+        case Expr::Neg: {
+            Val a = eval(e->a);
+            if (!a.is_frame()) return arith(a, a, 'n');
+            Val r;
+            r.rate = Rate::Vary;
+            for (const Val& c : a.ch) r.ch.push_back(arith(c, c, 'n'));
+            return r;
+        }
         case Expr::Ref: {
             if (e->port.empty()) {
                 auto it = input_by_name.find(e->node);
@@ -485,70 +591,22 @@ struct Codegen {
             }
             auto nit = node_by_name.find(e->node);
             if (nit == node_by_name.end()) fail("unknown node '" + e->node + "'");
-            const std::string key = "n" + std::to_string(nit->second) + "." + e->port;
-            auto vit = node_outputs.find(key);
-            if (vit == node_outputs.end() && fb_sources.count(key) && !emitted[nit->second] && nodes[nit->second].live) {
-                // feedback edge whose producer runs later in the frame: the consumer sees the field the
-                // producer wrote on the previous frame (the struct field persists, codegen/emit_node.rs)
-                if ((nodes[nit->second].domain == 1) != (dom == 1))
-                    fail("feedback edge from '" + e->node + "' crosses the oversampled region: both ends of a feedback edge must "
-                         "run at the same rate in this version");
-                auto fit = fb_vars.find(key);
-                if (fit == fb_vars.end()) {
-                    const std::string var = "n" + std::to_string(nit->second) + "_" + e->port + "_z";
-                    int w = new_state(e->node + "." + e->port, true, [](const UEnv&) { return 0u; });
-                    S().decl << "    float " << var << " = 0.0f;\n";
-                    S().load << "        " << var << " = og::ld_f(A, c, " << w << ");\n";
-                    S().store << "        og::st_f(A, c, " << w << ", " << var << ");\n";
-                    fit = fb_vars.emplace(key, var).first;
-                }
-                Val v;
-                v.e = fit->second;
-                v.rate = Rate::Vary;
-                v.inner = nodes[nit->second].domain == 1; // last tick's value, at the producer's rate
-                return v;
-            }
-            if (vit == node_outputs.end())
-                fail("node '" + e->node + "' has no output '" + e->port + "' (or it is read before it runs)");
-            Val v = vit->second;
-            if (split && cs > stage_of[nit->second]) { // value crosses a pipeline cut
-                XVal* x = nullptr;
-                for (auto& xv : xvals)
-                    if (xv.var == v.e) x = &xv;
-                if (!x) {
-                    xvals.push_back({v.e, "x" + std::to_string(xvals.size()) + "_" + v.e, stage_of[nit->second], {}});
-                    x = &xvals.back();
-                }
-                x->users.insert(cs);
-                v.e = x->alias;
-            }
-            return v;
+            int width = 1;
+            const NodeTypeInfo* ti = nodes[nit->second].type;
+            for (size_t o = 0; ti && o < ti->outputs.size() && o < ti->out_channels.size(); ++o)
+                if (e->port == ti->outputs[o]) width = ti->out_channels[o];
+            if (width <= 1) return node_output(nit->second, e->node, e->port);
+            if (fb_sources.count("n" + std::to_string(nit->second) + "." + e->port))
+                fail("a feedback edge carries an f32 stream ('" + e->node + "." + e->port + "' is a Frame<" + std::to_string(width) + ">)");
+            Val r;
+            r.rate = Rate::Vary;
+            for (int c = 0; c < width; ++c) r.ch.push_back(node_output(nit->second, e->node, e->port + "#" + std::to_string(c)));
+            return r;
         }
         default: {
             Val a = eval(e->a), b = eval(e->b);
-            Val r;
-            r.e = "(" + a.e + " " + e->op + " " + b.e + ")";
-            r.rate = join(a.rate, b.rate);
-            r.stream = a.stream || b.stream;
-            if (a.inner != b.inner && a.rate == Rate::Vary && b.rate == Rate::Vary)
-                fail("expression mixes outer-rate and oversampled node outputs; connect them through a cross-rate edge");
-            r.inner = a.inner || b.inner;
-            r.voice_inputs = a.voice_inputs;
-            r.voice_inputs.insert(b.voice_inputs.begin(), b.voice_inputs.end());
-            if (a.host && b.host && r.rate <= Rate::UBlock) {
-                HostFn ha = a.host, hb = b.host;
-                char op = e->op;
-                r.host = [ha, hb, op](const UEnv& env) {
-                    float x = ha(env), y = hb(env);
-                    switch (op) {
-                    case '+': return x + y;
-                    case '-': return x - y;
-                    case '*': return x * y;
-                    default: return x / y;
-                    }
-                };
-            }
-            return r;
+            if (a.is_frame() || b.is_frame()) return frame_arith(a, b, e->op, std::string("frame ") + e->op + " ...");
+            return arith(a, b, e->op);
         }
         }
     }
@@ -585,7 +643,33 @@ struct NodeCtx {
         lane_ok = false;
         return v;
     }
+    // a Frame<N> stream input: the N channel values (unconnected: every channel holds the default)
+    Val in_frame(const std::string& name, int width)
+    {
+        frame_ok = width;
+        Val v = in(name);
+        frame_ok = 1;
+        if (!v.is_frame()) {
+            if (n.in_edges.count(name))
+                fail("node '" + n.decl->name + "': input '" + name + "' is a Frame<" + std::to_string(width) + ">, its source is an f32 stream");
+            Val r;
+            r.rate = Rate::Vary;
+            for (int c = 0; c < width; ++c) r.ch.push_back(v);
+            return r;
+        }
+        return v;
+    }
+    int frame_ok = 1;
     Val in(const std::string& name)
+    {
+        Val v = in_any(name);
+        if (v.is_frame() && (int)v.ch.size() != frame_ok)
+            fail("node '" + n.decl->name + "': input '" + name + "' " +
+                 (frame_ok == 1 ? "takes an f32 stream" : "is a Frame<" + std::to_string(frame_ok) + ">") + ", its source is a Frame<" +
+                 std::to_string(v.ch.size()) + ">");
+        return v;
+    }
+    Val in_any(const std::string& name)
     {
         auto it = n.in_edges.find(name);
         if (it == n.in_edges.end()) return vconst(def(name));
@@ -599,6 +683,10 @@ struct NodeCtx {
             fail("node '" + n.decl->name + "': input '" + name + "' cannot take an array-valued ([f32; 32]) source");
         for (size_t i = 1; i < it->second.size(); ++i) { // connect, then accumulate in edge order
             Val b = cg.eval(it->second[i].e);
+            if (acc.is_frame() || b.is_frame()) { // AccumulateEndpoints for Frame<C>: element-wise (static_context.rs:189-194)
+                acc = cg.frame_arith(acc, b, '+', "fan-in of '" + name + "'");
+                continue;
+            }
             if (b.inner != dst_inner && b.rate == Rate::Vary)
                 fail("fan-in summing supports only same-rate sources (input '" + name + "')");
             Val r;
@@ -672,6 +760,7 @@ struct NodeCtx {
     void set_out(const std::string& port, const std::string& expr, bool patched_later = false)
     {
         std::string var = p + port;
+        std::replace(var.begin(), var.end(), '#', '_');
         cg.os() << "        " << (patched_later ? "" : "const ") << "float " << var << " = " << expr << ";\n";
         Val v;
         v.e = var;
@@ -681,6 +770,10 @@ struct NodeCtx {
         cg.node_outputs[key] = v;
         auto fit = cg.fb_vars.find(key); // an earlier node of the frame reads last frame's value
         if (fit != cg.fb_vars.end()) cg.os() << "        " << fit->second << " = " << var << ";\n";
+    }
+    void set_out_frame(const std::string& port, const std::vector<std::string>& exprs)
+    {
+        for (size_t c = 0; c < exprs.size(); ++c) set_out(port + "#" + std::to_string(c), exprs[c]);
     }
     // a value that is constant over the block per voice: computed in derive()
     std::string hoist(const std::string& name, const std::string& expr)
@@ -802,7 +895,10 @@ void emit_fm_operator(NodeCtx& x)
 
 void emit_tpt(NodeCtx& x)
 {
-    Val in = x.in("input"), cutoff = x.in("cutoff"), q = x.in("q"), fmod = x.in("f_mod");
+    // TptFilter<F: AudioFrame> (tpt/mod.rs:104-123): scalar coefficients, one pair of integrators per channel
+    const int width = x.n.type->out_channels.empty() ? 1 : x.n.type->out_channels[0];
+    Val in = width > 1 ? x.in_frame("input", width) : x.in("input");
+    Val cutoff = x.in("cutoff"), q = x.in("q"), fmod = x.in("f_mod");
     const float k = x.rate_sr_factor();
     const float c0 = x.def("cutoff"), q0 = x.def("q");
     int s_two_sr = x.slot_f([k](const UEnv& e) { return 2.0f * (e.sample_rate * k); });
@@ -821,8 +917,13 @@ void emit_tpt(NodeCtx& x)
         const float h = 1.0f / (1.0f + inv_q * f + f * f);
         return which == 0 ? h : (which == 1 ? f : f + inv_q);
     };
-    std::string z0 = x.state_f("z0", [](const UEnv&) { return 0.0f; });
-    std::string z1 = x.state_f("z1", [](const UEnv&) { return 0.0f; });
+    std::vector<std::string> z0s, z1s;
+    for (int c = 0; c < width; ++c) {
+        const std::string sfx = width > 1 ? "_" + std::to_string(c) : "";
+        z0s.push_back(x.state_f("z0" + sfx, [](const UEnv&) { return 0.0f; }));
+        z1s.push_back(x.state_f("z1" + sfx, [](const UEnv&) { return 0.0f; }));
+    }
+    const std::string z0 = z0s[0], z1 = z1s[0];
     std::string cc = x.state_f("current_cutoff", [c0](const UEnv&) { return c0; });
     std::string cq = x.state_f("current_q", [q0](const UEnv&) { return q0; });
     std::string h = x.state_f("h", [coef](const UEnv& e) { return coef(e, 0); });
@@ -851,7 +952,14 @@ void emit_tpt(NodeCtx& x)
     } else {
         x.cg.os() << "        og::tpt_params_mod(" << cutoff.e << ", " << q.e << ", " << fmod.e << ", " << tail;
     }
-    x.set_out("output", "og::tpt_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + h + ", " + g + ", " + kk + ")");
+    if (width == 1) {
+        x.set_out("output", "og::tpt_tick(" + in.e + ", " + z0 + ", " + z1 + ", " + h + ", " + g + ", " + kk + ")");
+        return;
+    }
+    std::vector<std::string> outs;
+    for (int c = 0; c < width; ++c)
+        outs.push_back("og::tpt_tick(" + in.ch[c].e + ", " + z0s[c] + ", " + z1s[c] + ", " + h + ", " + g + ", " + kk + ")");
+    x.set_out_frame("output", outs);
 }
 
 void emit_polyblep(NodeCtx& x)
@@ -1131,6 +1239,12 @@ const std::map<std::string, NodeTypeInfo>& registry()
                                 {"output"}, emit_fm_operator, 0, 0};
         r["TptFilter::new"] = {{{"input", S, 0, -1}, {"cutoff", S, 0, 0}, {"q", V, 0, 1}, {"f_mod", S, 0, -1}},
                                {"output"}, emit_tpt, 0, 2};
+        for (int w : {2, 4}) { // TptFilter::<Frame<N>>::new (Stereo / Quad)
+            NodeTypeInfo t = r["TptFilter::new"];
+            t.inputs[0].channels = w;
+            t.out_channels = {w};
+            r["TptFilter<" + std::to_string(w) + ">::new"] = t;
+        }
         const char* pbn[4] = {"sine", "saw", "square", "triangle"};
         for (int w = 0; w < 4; ++w)
             r[std::string("PolyBlepOscillator::") + pbn[w]] = {
@@ -1203,7 +1317,12 @@ void emit_user(NodeCtx& x)
     for (const UserPort& p : u.inputs) {
         if (p.kind == Kind::Event) continue;
         // (one statement per input: resolving an input can allocate cut-crossing channels, whose numbering must be deterministic)
-        const Val v = x.in(p.name);
+        Val v = p.channels > 1 ? x.in_frame(p.name, p.channels) : x.in(p.name);
+        if (v.is_frame()) { // handed over as one og::Frame<N> object
+            std::string init;
+            for (const Val& c : v.ch) init += (init.empty() ? "" : ", ") + c.e;
+            v.e = "og::Frame<" + std::to_string(p.channels) + ">{{" + init + "}}";
+        }
         ins.push_back(v);
         in_ports.push_back(&p);
     }
@@ -1236,16 +1355,19 @@ void emit_user(NodeCtx& x)
                 if (p.kind == Kind::Event) continue;
                 if (handler && p.kind != Kind::Value) continue; // a handler runs before the frame's streams exist
                 sep();
-                q << "const float " << p.name;
+                if (p.channels > 1) q << "const og::Frame<" << p.channels << "> " << p.name;
+                else q << "const float " << p.name;
             }
             for (const UserState& f : u.state) {
                 sep();
                 q << (f.is_uint ? "uint32_t& " : "float& ") << f.name;
             }
             if (!handler)
-                for (const std::string& o : u.outputs) {
+                for (size_t oi = 0; oi < u.outputs.size(); ++oi) {
                     sep();
-                    q << "float& " << o;
+                    const int w = oi < u.out_channels.size() ? u.out_channels[oi] : 1;
+                    if (w > 1) q << "og::Frame<" << w << ">& " << u.outputs[oi];
+                    else q << "float& " << u.outputs[oi];
                 }
             for (const std::string& o : u.ev_outputs) {
                 sep();
@@ -1296,7 +1418,11 @@ void emit_user(NodeCtx& x)
             fail("node '" + x.n.decl->name + "' (" + u.type + "): event input '" + kv.first + "' has no on_" + kv.first + " handler");
     // the tick
     std::ostringstream call;
-    for (const std::string& o : u.outputs) x.cg.os() << "        float " << x.p << o << " = 0.0f;\n";
+    auto out_width = [&](size_t oi) { return oi < u.out_channels.size() ? u.out_channels[oi] : 1; };
+    for (size_t oi = 0; oi < u.outputs.size(); ++oi) {
+        if (out_width(oi) > 1) x.cg.os() << "        og::Frame<" << out_width(oi) << "> " << x.p << u.outputs[oi] << " = {};\n";
+        else x.cg.os() << "        float " << x.p << u.outputs[oi] << " = 0.0f;\n";
+    }
     call << "        " << fn << "_process(";
     bool first = true;
     auto sep = [&]() {
@@ -1322,7 +1448,15 @@ void emit_user(NodeCtx& x)
     sep();
     call << x.sf(s_sr) << ");\n";
     x.cg.os() << call.str();
-    for (const std::string& o : u.outputs) {
+    for (size_t oi = 0; oi < u.outputs.size(); ++oi)
+        if (out_width(oi) > 1) { // the channels of a Frame<N> output continue as scalar values "<port>#i"
+            std::vector<std::string> chans;
+            for (int c = 0; c < out_width(oi); ++c) chans.push_back(x.p + u.outputs[oi] + ".v[" + std::to_string(c) + "]");
+            x.set_out_frame(u.outputs[oi], chans);
+        }
+    for (size_t oi = 0; oi < u.outputs.size(); ++oi) {
+        if (out_width(oi) > 1) continue;
+        const std::string& o = u.outputs[oi];
         Val v;
         v.e = x.p + o;
         v.rate = Rate::Vary;
@@ -1334,8 +1468,9 @@ void emit_user(NodeCtx& x)
     }
 }
 
-const NodeTypeInfo* lookup_type(const std::string& type)
+const NodeTypeInfo* lookup_type(const std::string& type_in)
 {
+    const std::string type = normalize_type(type_in);
     auto it = registry().find(type);
     if (it != registry().end()) return &it->second;
     auto ut = user_registry().find(type);
@@ -1677,6 +1812,26 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
 
 } // namespace
 
+// `TptFilter::<Frame<2>>::new` / `::<Stereo>` / `::<Quad>` / `::<f32>` / `::<Mono>` -> "TptFilter<2>::new" (f32: "TptFilter::new")
+std::string normalize_type(const std::string& type)
+{
+    const size_t a = type.find("::<");
+    if (a == std::string::npos) return type;
+    const size_t b = type.rfind(">::");
+    if (b == std::string::npos || b < a) return type;
+    std::string g = type.substr(a + 3, b - (a + 3));
+    g.erase(std::remove_if(g.begin(), g.end(), [](char ch) { return isspace((unsigned char)ch); }), g.end());
+    int w = 0;
+    if (g == "f32") w = 1;
+    else if (g == "Mono") w = 1;
+    else if (g == "Stereo") w = 2;
+    else if (g == "Quad") w = 4;
+    else if (g.rfind("Frame<", 0) == 0 && g.size() >= 8 && g.back() == '>') w = atoi(g.c_str() + 6);
+    if (w <= 0) return type;
+    return type.substr(0, a) + (w == 1 ? std::string() : "<" + std::to_string(w) + ">") + type.substr(b + 1);
+}
+
+
 uint32_t RingSpec::capacity(float graph_sr) const
 {
     const float want = 2.0f * (graph_sr * rate_factor); // delay/mod.rs:62-66: (2.0 * sr) as usize, capped at 88200
@@ -1769,8 +1924,17 @@ void register_user_node(const UserNodeType& t)
         }
         e->t.weight = std::max(1, w);
     }
-    for (const auto& p : e->t.inputs) e->info.inputs.push_back({p.name.c_str(), p.kind, p.def, p.arg});
+    for (const auto& p : e->t.inputs) {
+        if (p.channels > 1 && p.kind != Kind::Stream) fail("node type '" + t.type + "': only stream inputs can be Frame<N> ('" + p.name + "')");
+        if (p.channels > 4) fail("node type '" + t.type + "': Frame<N> ports support N <= 4 ('" + p.name + "')");
+        e->info.inputs.push_back({p.name.c_str(), p.kind, p.def, p.arg, std::max(1, p.channels)});
+    }
     for (const auto& o : e->t.outputs) e->info.outputs.push_back(o.c_str());
+    for (size_t oi = 0; oi < e->t.outputs.size(); ++oi) {
+        const int w = oi < e->t.out_channels.size() ? std::max(1, e->t.out_channels[oi]) : 1;
+        if (w > 4) fail("node type '" + t.type + "': Frame<N> ports support N <= 4 ('" + e->t.outputs[oi] + "')");
+        e->info.out_channels.push_back(w);
+    }
     e->info.ev_outputs = e->t.ev_outputs;
     e->info.emit = emit_user;
     e->info.variant = 0;
@@ -2227,6 +2391,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (it->second.size() > 1 && !it->second[k].policy.empty())
                     fail("fan-in summing supports only same-rate sources (graph output)");
                 Val v = cg.cross(cg.eval(it->second[k].src), it->second[k].policy, false, false);
+                if (v.is_frame())
+                    fail("graph output '" + g.outputs[oi].name + "' is fed a Frame<" + std::to_string(v.ch.size()) +
+                         ">: the voice output summed on the mix bus is an f32 stream (take the channels apart in a node; a "
+                         "stereo bus comes from a post-mix node, og_graph_add_bus_node)");
                 if (it->second.size() > 1 && v.inner) fail("fan-in summing supports only same-rate sources (graph output)");
                 acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
             }

@@ -144,6 +144,7 @@ struct UserPort {
     Kind kind = Kind::Stream;
     float def = 0.0f;
     int arg = -1; // constructor argument that initialises the field, or -1
+    int channels = 1; // stream inputs: 1 = f32, N = Frame<N>
 };
 struct UserState {
     std::string name;
@@ -157,6 +158,7 @@ struct UserNodeType {
     size_t nargs = 0;
     std::vector<UserPort> inputs;
     std::vector<std::string> outputs;
+    std::vector<int> out_channels;       // per output: 1 = f32, N = Frame<N> (empty: all f32)
     std::vector<std::string> ev_outputs; // `#[output(event)]` fields
     std::vector<UserState> state;
     std::string process_src;
@@ -171,6 +173,8 @@ void register_graph_type(const std::string& name, const GraphDesc& g);
 bool unregister_graph_type(const std::string& name);
 // node arrays and nested graphs are desugared before lowering; exposed for tests / to_dsl of the expansion
 GraphDesc expand(const GraphDesc& g);
+// `TptFilter::<Frame<2>>::new` / `::<Stereo>` -> "TptFilter<2>::new"; `::<f32>` -> "TptFilter::new"
+std::string normalize_type(const std::string& type);
 
 uint64_t fnv1a(const std::string& s);
 

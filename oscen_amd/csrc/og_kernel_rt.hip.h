@@ -101,6 +101,48 @@ struct BoolC {
     static constexpr bool steady = S;
 };
 
+// Frame<N> stream payload (oscen-lib/src/frame.rs): N f32 channels of one sample instant, with the arithmetic the
+// reference's AudioFrame has.  Only indexed with constants by the generated code, so it lives in registers.
+template <int N>
+struct Frame {
+    float v[N];
+    __device__ __forceinline__ Frame operator+(const Frame& o) const
+    {
+        Frame r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = v[i] + o.v[i];
+        return r;
+    }
+    __device__ __forceinline__ Frame operator-(const Frame& o) const
+    {
+        Frame r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = v[i] - o.v[i];
+        return r;
+    }
+    __device__ __forceinline__ Frame operator*(float s) const
+    {
+        Frame r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = v[i] * s;
+        return r;
+    }
+    __device__ __forceinline__ Frame operator-() const
+    {
+        Frame r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = -v[i];
+        return r;
+    }
+    static __device__ __forceinline__ Frame splat(float s) // From<f32>: one sample on every channel
+    {
+        Frame r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = s;
+        return r;
+    }
+};
+
 // An event output of a node (`#[output(event)]`, EventOutput): the scalar events the node pushed on the current
 // frame.  Lives in registers (no dynamic indexing), cleared at the end of every frame.
 #define OG_NODE_EVENTS_PER_FRAME 2

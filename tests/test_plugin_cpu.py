@@ -198,3 +198,49 @@ def test_event_outputs_lower_to_in_kernel_event_edges():
     with pytest.raises(oscen_amd.OscenError, match="event outputs of the graph"):
         bad.kernel_source()
     oscen_amd.unregister_node("Ticker::new")
+
+
+def test_frame_ports_lower_to_channel_values():
+    """Frame<N> edges: the channels travel as scalar values (so they cross pipeline cuts like any other value), user code
+    sees og::Frame<N>; width mismatches and frames on the mono mix bus are compile-time errors."""
+    oscen_amd.register_node("Wide::new", inputs=[("input", "stream", 0.0, -1)], outputs=[("output", 2)],
+                            process="    output = og::Frame<2>::splat(input);\n")
+    oscen_amd.register_node("Narrow::new", inputs=[("input", "stream", 0.0, -1, 2)], outputs=["output"],
+                            process="    output = input.v[0] + input.v[1];\n")
+    g = oscen_amd.Graph("fr")
+    g.output_stream("out")
+    g.node("osc", "Oscillator::sine", 330.0, 1.0)
+    g.node("w", "Wide::new")
+    g.node("f", "TptFilter::<Frame<2>>::new", 900.0, 0.7)
+    g.node("n", "Narrow::new")
+    g.connect("osc.output", "w.input")
+    g.connect("w.output * osc.output", "f.input")
+    g.connect("-w.output", "f.input")
+    g.connect("f.output", "n.input")
+    g.connect("n.output", "out")
+    assert "TptFilter::<Frame<2>>::new(900.0" in g.to_dsl()
+    src = g.kernel_source()
+    assert "og::Frame<2>& output" in src and "const og::Frame<2> input" in src
+    assert "n2_z0_0" in src and "n2_z1_1" in src  # one integrator pair per channel
+    assert g.jit_check() > 0
+
+    def bad(wire, msg):
+        h = oscen_amd.Graph("bad")
+        h.output_stream("out")
+        h.node("osc", "Oscillator::sine", 330.0, 1.0)
+        h.node("w", "Wide::new")
+        h.node("f", "TptFilter::<Frame<2>>::new", 900.0, 0.7)
+        h.node("m", "TptFilter::new", 900.0, 0.7)
+        h.node("n", "Narrow::new")
+        h.connect("osc.output", "w.input")
+        wire(h)
+        with pytest.raises(oscen_amd.OscenError, match=msg):
+            h.kernel_source()
+
+    bad(lambda h: (h.connect("w.output", "m.input"), h.connect("m.output", "out")), "takes an f32 stream")
+    bad(lambda h: (h.connect("osc.output", "f.input"), h.connect("f.output", "n.input"), h.connect("n.output", "out")),
+        "its source is an f32 stream")
+    bad(lambda h: h.connect("w.output", "out"), "the voice output summed on the mix bus is an f32 stream")
+    bad(lambda h: (h.connect("w.output * w.output", "n.input"), h.connect("n.output", "out")), "frame \\* f32")
+    oscen_amd.unregister_node("Wide::new")
+    oscen_amd.unregister_node("Narrow::new")
