@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,17 +102,31 @@ __global__ __launch_bounds__(512) void og_bus_tremolo(const float* __restrict__ 
     }
 }
 
-// Incremental event path: point the listed voices at their freshly appended timeline segments.
-// upd = n x {voice, cursor, end}
-__global__ void og_apply_event_updates(const uint32_t* __restrict__ upd, uint32_t n, uint32_t* __restrict__ cursor,
+// Incremental event path: append the staged segments to the timeline and point the listed voices at them.
+// `staged` and `upd` are PINNED HOST buffers read by the kernel itself: a kernel launch never waits for the stream,
+// whereas hipMemcpyAsync of a small pinned buffer was measured to block until the stream had drained (~290 us with a
+// batch of blocks in flight), which serialised the host's event preparation with the GPU.  upd = n x {voice, cursor, end}
+__global__ void og_apply_event_updates(const uint4* __restrict__ staged, uint32_t n_ev, uint4* __restrict__ timeline_tail,
+                                       const uint32_t* __restrict__ upd, uint32_t n, uint32_t* __restrict__ cursor,
                                        uint32_t* __restrict__ end)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ev) timeline_tail[i] = staged[i]; // (OgEvent = 16 bytes)
     if (i < n) {
         const uint32_t v = upd[3 * i];
         cursor[v] = upd[3 * i + 1];
         end[v] = upd[3 * i + 2];
     }
+}
+
+// Stream progress marker: launched after every batch of blocks, writes the batch number into a word of pinned host
+// memory.  The host checks it before it reuses a staging buffer (event segments, ramp tables): hipEventSynchronize on an
+// event recorded many launches earlier was measured to block until the whole stream had drained (~350 us per call with
+// a batch in flight), which serialised the host's preparation of the next batch with the GPU.
+__global__ void og_stream_mark(volatile uint64_t* host_word, uint64_t seq)
+{
+    __threadfence_system();
+    *host_word = seq;
 }
 
 // ---- registry ---------------------------------------------------------------
@@ -201,7 +216,37 @@ struct og_graph_desc {
     ogc::GraphDesc g;
 };
 
+// OSCEN_GPU_HOST_PROF=1: wall time of the host-side phases of the live path, printed when the engine is destroyed
+struct HostProf {
+    enum { SYNC_EVENTS, INCREMENTAL, REBUILD, LAUNCH, RAMPS, EV_WAIT, EV_COMMIT, N };
+    double t[N] = {};
+    uint64_t n[N] = {};
+    bool on = getenv("OSCEN_GPU_HOST_PROF") != nullptr;
+    struct Scope {
+        HostProf& p;
+        int k;
+        std::chrono::steady_clock::time_point t0;
+        Scope(HostProf& p_, int k_) : p(p_), k(k_) { if (p.on) t0 = std::chrono::steady_clock::now(); }
+        ~Scope()
+        {
+            if (!p.on) return;
+            p.t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            p.n[k] += 1;
+        }
+    };
+    void report() const
+    {
+        if (!on) return;
+        static const char* names[N] = {"sync_events", "incremental_update", "full_rebuild", "flush_bus (launches)", "ramp table",
+                                        "  staging-slot wait", "  commit + launch"};
+        for (int k = 0; k < N; ++k)
+            if (n[k]) fprintf(stderr, "[oscen_gpu host prof] %-22s %9llu calls %10.1f us total %8.2f us/call\n", names[k],
+                              (unsigned long long)n[k], t[k] * 1e6, t[k] * 1e6 / (double)n[k]);
+    }
+};
+
 struct og_engine {
+    HostProf prof;
     std::unique_ptr<ogc::CompiledGraph> cg;
     OgLaunchFn launch = nullptr;
     std::unique_ptr<OgJitKernel> jit;
@@ -253,8 +298,7 @@ struct og_engine {
     float* d_bus = nullptr;
     float* d_ramp[RAMP_RING] = {};
     float* h_ramp[RAMP_RING] = {};
-    hipEvent_t ramp_ev[RAMP_RING] = {};
-    bool ramp_ev_used[RAMP_RING] = {};
+    uint64_t ramp_seq[RAMP_RING] = {}; // batch whose launch copied ramp table i to the device (0 = never)
     int ramp_head = 0;
     float* d_taps = nullptr;
     int32_t* d_tap_slot = nullptr;
@@ -280,11 +324,21 @@ struct og_engine {
     OgEvent* h_stage_ev[EV_RING] = {};   // pinned
     uint32_t* h_stage_upd[EV_RING] = {}; // pinned, n x {voice, cursor, end}
     uint32_t* d_stage_upd[EV_RING] = {};
-    hipEvent_t stage_done[EV_RING] = {};
-    bool stage_used[EV_RING] = {};
+    uint64_t stage_seq[EV_RING] = {};         // batch (flush_seq) whose launch read staging slot i (0 = never used)
+    uint64_t flush_seq = 0;                    // batches launched so far
+    bool batch_staged = false;                 // the batch being assembled reads a host staging buffer
+    volatile uint64_t* h_progress = nullptr;  // pinned: number of the last batch the stream has finished (og_stream_mark)
+    bool batch_done(uint64_t seq)
+    {
+        if (seq == 0 || (h_progress && *h_progress >= seq)) return true;
+        if (seq > flush_seq) return true; // (staged for a batch that was never launched: nothing read it)
+        HIPCK(hipStreamSynchronize(stream)); // (a ring slot that is still in flight: never seen in practice)
+        return true;
+    }
     int stage_head = 0;
     uint64_t n_full_rebuilds = 0, n_incremental = 0;
     size_t n_block_local = 0; // events pushed with try_push semantics for the next block
+    size_t local_from = 0;    // index in `pending` of the first push since the previous block was queued
     uint64_t seq = 0;
     uint32_t bus_passes = 0; // og_bus_reduce launches of the last block (1 + levels of the multi-pass tree)
     uint64_t frame_now = 0;
@@ -299,6 +353,7 @@ struct og_engine {
 
     ~og_engine()
     {
+        prof.report();
         (void)hipSetDevice(device);
         // a borrowed stream (og_set_stream) may already be gone: wait for the device instead of touching it
         if (own_stream && stream) (void)hipStreamSynchronize(stream);
@@ -320,14 +375,13 @@ struct og_engine {
         for (int i = 0; i < RAMP_RING; ++i) {
             (void)hipFree(d_ramp[i]);
             if (h_ramp[i]) (void)hipHostFree(h_ramp[i]);
-            if (ramp_ev[i]) (void)hipEventDestroy(ramp_ev[i]);
         }
         for (int i = 0; i < EV_RING; ++i) {
             if (h_stage_ev[i]) (void)hipHostFree(h_stage_ev[i]);
             if (h_stage_upd[i]) (void)hipHostFree(h_stage_upd[i]);
             (void)hipFree(d_stage_upd[i]);
-            if (stage_done[i]) (void)hipEventDestroy(stage_done[i]);
         }
+        if (h_progress) (void)hipHostFree((void*)h_progress);
         for (auto ev : t_start) (void)hipEventDestroy(ev);
         for (auto ev : t_stop) (void)hipEventDestroy(ev);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -378,6 +432,7 @@ struct og_engine {
     void reset_timeline()
     {
         pending.clear();
+        local_from = 0;
         h_events.clear();
         seg_begin.clear();
         seg_end.clear();
@@ -396,12 +451,17 @@ struct og_engine {
         local_touched.clear();
     }
 
+    // Everything before this frame has been consumed on the device by the time an update issued now takes effect:
+    // launched blocks run before it in stream order; blocks still in the queue have not seen their events yet.
+    uint64_t consumed_horizon() const { return queue.empty() ? frame_now : q_frame0; }
     // unconsumed events of voice v on the device timeline (a block consumes everything before its end)
+    bool has_old_events(uint32_t v) const { return !seg_begin.empty() && seg_begin[v] != seg_end[v] && seg_last[v] >= consumed_horizon(); }
     void old_events(uint32_t v, std::vector<OgEvent>& out) const
     {
-        if (seg_begin.empty() || seg_begin[v] == seg_end[v] || seg_last[v] < frame_now) return; // (no look at h_events: cold memory)
+        if (!has_old_events(v)) return; // (no look at h_events: cold memory)
+        const uint64_t hz = consumed_horizon();
         for (uint32_t i = seg_begin[v]; i < seg_end[v]; ++i)
-            if (h_events[i].frame >= frame_now) out.push_back(h_events[i]);
+            if (h_events[i].frame >= hz) out.push_back(h_events[i]);
     }
 
     static bool push_order(const HostEvent& a, const HostEvent& b)
@@ -428,6 +488,7 @@ struct og_engine {
 
     void full_rebuild()
     {
+        HostProf::Scope ps(prof, HostProf::REBUILD);
         std::stable_sort(pending.begin(), pending.end(), push_order);
         std::vector<OgEvent> evs;
         std::vector<uint32_t> cursor(V), end(V);
@@ -472,6 +533,7 @@ struct og_engine {
         seg_last.swap(last);
         ev_tail = n;
         pending.clear();
+        local_from = 0;
         ev_rebuild = false;
         n_full_rebuilds += 1;
     }
@@ -480,13 +542,12 @@ struct og_engine {
     // (staging buffer, tail of d_events): the caller falls back to full_rebuild().
     bool incremental_update()
     {
+        HostProf::Scope ps(prof, HostProf::INCREMENTAL);
         if (pending.size() > EV_STAGE_EVENTS) return false;
         if (!h_stage_ev[0]) {
             for (int i = 0; i < EV_RING; ++i) {
                 HIPCK(hipHostMalloc((void**)&h_stage_ev[i], EV_STAGE_EVENTS * sizeof(OgEvent), hipHostMallocDefault));
                 HIPCK(hipHostMalloc((void**)&h_stage_upd[i], EV_STAGE_EVENTS * 3 * 4, hipHostMallocDefault));
-                HIPCK(hipMalloc(&d_stage_upd[i], EV_STAGE_EVENTS * 3 * 4));
-                HIPCK(hipEventCreateWithFlags(&stage_done[i], hipEventDisableTiming));
             }
         }
         if (seg_begin.empty()) {
@@ -515,7 +576,10 @@ struct og_engine {
             grp_tail[v] = (uint32_t)i;
         }
         const int r = stage_head;
-        if (stage_used[r]) HIPCK(hipEventSynchronize(stage_done[r])); // (EV_RING blocks ago: long done)
+        {
+            HostProf::Scope pw(prof, HostProf::EV_WAIT);
+            batch_done(stage_seq[r]); // (EV_RING batches ago: long done)
+        }
         OgEvent* sev = h_stage_ev[r];
         uint32_t* upd = h_stage_upd[r];
         std::vector<OgEvent> old, merged;
@@ -523,6 +587,28 @@ struct og_engine {
         size_t n_ev = 0, n_upd = 0;
         bool fits = true;
         for (const uint32_t v : grp_voices) {
+            // the usual live case: nothing of this voice is waiting on the device and its pushes arrived in frame order
+            // (a note-on is a frequency value and a gate on one frame) -- straight into the staging buffer
+            if (fits && !has_old_events(v)) {
+                size_t k = 0;
+                uint64_t last = 0;
+                bool ordered = true;
+                for (uint32_t i = grp_head[v]; i != NONE; i = grp_next[i], ++k) {
+                    const HostEvent& h = pending[i];
+                    ordered = ordered && h.frame >= last;
+                    last = h.frame;
+                    if (n_ev + k < EV_STAGE_EVENTS) sev[n_ev + k] = OgEvent{h.frame, h.target, h.value};
+                }
+                if (ordered && n_ev + k <= EV_STAGE_EVENTS && ev_tail + n_ev + k <= ev_cap) {
+                    grp_head[v] = NONE;
+                    upd[3 * n_upd] = v;
+                    upd[3 * n_upd + 1] = (uint32_t)(ev_tail + n_ev);
+                    upd[3 * n_upd + 2] = (uint32_t)(ev_tail + n_ev + k);
+                    n_ev += k;
+                    n_upd += 1;
+                    continue;
+                }
+            }
             mine.clear();
             for (uint32_t i = grp_head[v]; i != NONE; i = grp_next[i]) mine.push_back(pending[i]);
             grp_head[v] = NONE; // (left clean for the next batch, also on the early exit below)
@@ -553,6 +639,7 @@ struct og_engine {
         }
         if (!fits) return false;
         // commit: host mirror, then the device
+        HostProf::Scope pc(prof, HostProf::EV_COMMIT);
         h_events.resize(ev_tail + n_ev);
         memcpy(h_events.data() + ev_tail, sev, n_ev * sizeof(OgEvent));
         for (size_t i = 0; i < n_upd; ++i) {
@@ -560,35 +647,45 @@ struct og_engine {
             seg_end[upd[3 * i]] = upd[3 * i + 2];
             seg_last[upd[3 * i]] = sev[upd[3 * i + 2] - 1 - ev_tail].frame;
         }
-        if (n_ev) HIPCK(hipMemcpyAsync(d_events + ev_tail, sev, n_ev * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
-        HIPCK(hipMemcpyAsync(d_stage_upd[r], upd, n_upd * 3 * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(og_apply_event_updates, dim3((uint32_t)((n_upd + 255) / 256)), dim3(256), 0, stream, d_stage_upd[r],
-                           (uint32_t)n_upd, d_ev_cursor, d_ev_end);
-        HIPCK(hipEventRecord(stage_done[r], stream));
-        stage_used[r] = true;
+        static_assert(sizeof(OgEvent) == sizeof(uint4), "og_apply_event_updates copies events as 16-byte words");
+        const uint32_t n_wg_upd = (uint32_t)((std::max(n_upd, n_ev) + 255) / 256);
+        hipLaunchKernelGGL(og_apply_event_updates, dim3(n_wg_upd), dim3(256), 0, stream, (const uint4*)sev, (uint32_t)n_ev,
+                           (uint4*)(d_events + ev_tail), (const uint32_t*)upd, (uint32_t)n_upd, d_ev_cursor, d_ev_end);
+        HIPCK(hipGetLastError());
+        stage_seq[r] = flush_seq + 1; // read in stream order before the batch that is about to be launched
+        batch_staged = true;
         stage_head = (stage_head + 1) % EV_RING;
         ev_tail += n_ev;
         pending.clear();
+        local_from = 0;
         n_incremental += 1;
         return true;
     }
 
-    // bring the device timeline up to date before a block of `frames` frames
-    void sync_events(uint32_t frames)
+    // a block of `frames` frames is about to be queued: a try_push'ed event whose frame_offset >= frames is never
+    // delivered (the reference clears the queues at the end of the block)
+    void drop_late_local(uint32_t frames)
     {
-        // reference: a try_push'ed event whose frame_offset >= frames is never delivered (the queues are
-        // cleared at the end of the block)
-        if (n_block_local) {
-            const uint64_t lim = frame_now + frames;
-            const size_t before = pending.size();
-            pending.erase(std::remove_if(pending.begin(), pending.end(),
-                                         [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
-                          pending.end());
-            dropped += before - pending.size();
-            n_block_local = 0;
-            clear_local_counts();
-        }
+        const size_t from = std::min(local_from, pending.size()); // pushes since the previous block sit behind this index
+        local_from = pending.size();
+        if (!n_block_local) return;
+        const uint64_t lim = frame_now + frames;
+        const size_t before = pending.size();
+        pending.erase(std::remove_if(pending.begin() + (long)from, pending.end(),
+                                     [&](const HostEvent& h) { return h.block_local && h.frame >= lim; }),
+                      pending.end());
+        dropped += before - pending.size();
+        for (size_t i = from; i < pending.size(); ++i) pending[i].block_local = false; // (delivered: part of the timeline from here on)
+        local_from = pending.size();
+        n_block_local = 0;
+        clear_local_counts();
+    }
+    // bring the device timeline up to date: right before the queued blocks are launched (their events may have arrived
+    // over several blocks: one staging copy and one cursor update for all of them)
+    void upload_events()
+    {
         if (pending.empty() && !ev_rebuild) return;
+        HostProf::Scope ps(prof, HostProf::SYNC_EVENTS);
         // many voices touched at once (bulk scheduling): one compact CSR rebuild beats per-voice segments
         const bool bulk = ev_rebuild || pending.size() > EV_STAGE_EVENTS || pending.size() > (size_t)V / 2 + 64 || !d_events;
         if (bulk || !incremental_update()) full_rebuild();
@@ -616,8 +713,7 @@ struct og_engine {
             d_ramp[i] = h_ramp[i] = nullptr;
             HIPCK(hipMalloc(&d_ramp[i], rows * max_frames * 4));
             HIPCK(hipHostMalloc((void**)&h_ramp[i], rows * max_frames * 4, hipHostMallocDefault));
-            if (!ramp_ev[i]) HIPCK(hipEventCreateWithFlags(&ramp_ev[i], hipEventDisableTiming));
-            ramp_ev_used[i] = false;
+            ramp_seq[i] = 0;
         }
     }
 
@@ -626,8 +722,10 @@ struct og_engine {
     void process_async(uint32_t frames, float* d_out)
     {
         HIPCK(hipSetDevice(device));
-        if (!pending.empty() || ev_rebuild) flush_bus(); // the timeline update below assumes every earlier block has run
-        sync_events(frames);
+        drop_late_local(frames);
+        // events wait on the host until the queue is launched: launch it before they outgrow the staging buffers (or the
+        // size up to which per-voice segments beat a rebuild of the whole timeline)
+        if (!queue.empty() && pending.size() > std::min<size_t>(EV_STAGE_EVENTS / 2, (size_t)V / 4 + 32)) flush_bus();
         if (queue.empty()) {
             q_frame0 = frame_now;
             q_frames = 0;
@@ -643,7 +741,7 @@ struct og_engine {
             if (q_ramp_slot < 0) { // first block of the queue that needs the table: earlier blocks get constant rows
                 q_ramp_slot = ramp_head;
                 ramp_head = (ramp_head + 1) % RAMP_RING;
-                if (ramp_ev_used[q_ramp_slot]) HIPCK(hipEventSynchronize(ramp_ev[q_ramp_slot]));
+                batch_done(ramp_seq[q_ramp_slot]);
                 float* tab0 = h_ramp[q_ramp_slot];
                 for (size_t i = 0; i < cg->inputs.size(); ++i) {
                     const int row = cg->inputs[i].ramp_row;
@@ -687,6 +785,8 @@ struct og_engine {
     void flush_bus()
     {
         if (queue.empty()) return;
+        upload_events(); // (before the launch arguments are formed: a rebuild may move the timeline)
+        HostProf::Scope ps(prof, HostProf::LAUNCH);
         OgBlockArgs A;
         memset(&A, 0, sizeof A);
         A.n_voices = V;
@@ -718,8 +818,8 @@ struct og_engine {
             const int r = q_ramp_slot;
             const size_t rows = (size_t)(cg->n_ramps + cg->n_streams);
             HIPCK(hipMemcpyAsync(d_ramp[r], h_ramp[r], rows * A.ramp_stride * 4, hipMemcpyHostToDevice, stream));
-            HIPCK(hipEventRecord(ramp_ev[r], stream));
-            ramp_ev_used[r] = true;
+            ramp_seq[r] = flush_seq + 1;
+            batch_staged = true;
             A.ramp_table = d_ramp[r];
         }
         const bool taps_on = n_taps > 0;
@@ -780,6 +880,16 @@ struct og_engine {
             off += qb.frames;
         }
         HIPCK(hipGetLastError());
+        flush_seq += 1;
+        if (batch_staged) { // this batch read a host staging buffer: tell the host when the stream is past it
+            if (!h_progress) {
+                HIPCK(hipHostMalloc((void**)&h_progress, 64, hipHostMallocDefault));
+                *h_progress = 0;
+            }
+            hipLaunchKernelGGL(og_stream_mark, dim3(1), dim3(1), 0, stream, h_progress, flush_seq);
+            HIPCK(hipGetLastError());
+            batch_staged = false;
+        }
         queue.clear();
         q_frames = 0;
     }
@@ -1345,7 +1455,7 @@ int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
         if (frames == 0) { // process_block(0): no frame runs; events queued for the block are discarded with it
             HIPCK(hipSetDevice(e->device));
             e->flush_bus();
-            e->sync_events(0);
+            e->drop_late_local(0);
             e->last_frames = 0;
             return OG_OK;
         }

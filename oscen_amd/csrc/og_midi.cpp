@@ -8,6 +8,9 @@
 // queued with their frame offset and applied in frame order when the next block starts, like the
 // generated process_block sorts its staged events (codegen/mod.rs:782-799).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -187,7 +190,22 @@ struct og_midi {
     // frames: length of the block the messages are for.  A `midi_in` event whose frame_offset >= frames never
     // reaches the parser (the generated loop only visits frames < frames and the queue is cleared with the
     // block, codegen/mod.rs:782-871), so it must not touch the allocator either.
+    // OSCEN_GPU_HOST_PROF=1: time spent parsing / allocating / pushing (printed by og_midi_destroy)
+    bool prof_on = getenv("OSCEN_GPU_HOST_PROF") != nullptr;
+    double prof_t = 0.0;
+    uint64_t prof_msgs = 0, prof_calls = 0;
     void flush(uint32_t frames = 0xFFFFFFFFu)
+    {
+        std::chrono::steady_clock::time_point t0;
+        if (prof_on) {
+            t0 = std::chrono::steady_clock::now();
+            prof_msgs += queue.size();
+            prof_calls += 1;
+        }
+        flush_impl(frames);
+        if (prof_on) prof_t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void flush_impl(uint32_t frames)
     {
         if (!queue_sorted) std::stable_sort(queue.begin(), queue.end(), [](const Msg& a, const Msg& b) { return a.frame < b.frame; });
         queue_sorted = true;
@@ -230,7 +248,14 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
     return OG_OK;
 }
 
-void og_midi_destroy(og_midi* m) { delete m; }
+void og_midi_destroy(og_midi* m)
+{
+    if (m && m->prof_on && m->prof_calls)
+        fprintf(stderr, "[oscen_gpu host prof] midi flush (parse+allocate+push) %llu calls %llu msgs %.1f us total %.2f us/call %.1f ns/msg\n",
+                (unsigned long long)m->prof_calls, (unsigned long long)m->prof_msgs, m->prof_t * 1e6, m->prof_t * 1e6 / (double)m->prof_calls,
+                m->prof_msgs ? m->prof_t * 1e9 / (double)m->prof_msgs : 0.0);
+    delete m;
+}
 
 float og_midi_note_to_freq(uint8_t note) { return og_midi::note_to_freq(note); }
 
