@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def pmc_profile(voices, block, graph, kernel_hash):
+def pmc_profile(voices, block, graph, kernel_hash, blocks_per_launch=None):
     """The committed rocprofv3 PMC summary (profiles/*_summary.json, scripts/prof_summary.py) of THIS kernel:
     same graph, bank size, block and kernel hash.  FETCH_SIZE / WRITE_SIZE / SQ_* come from separate --pmc
     runs, so they cannot be measured in-process; a summary of another kernel build is never mixed in --
@@ -44,15 +44,20 @@ def pmc_profile(voices, block, graph, kernel_hash):
         if d.get("voices") != voices or d.get("frames") != block or d.get("graph", "fm_voice") != graph:
             continue
         if d.get("kernel_hash") == kernel_hash and "hbm_traffic" in d:
-            match = (path, d)
+            # several summaries of this kernel: the one whose command queued the same number of blocks per launch
+            def off(x):
+                return abs(x.get("blocks_per_launch", 1.0) - (blocks_per_launch or x.get("blocks_per_launch", 1.0)))
+            if match is None or off(d) <= off(match[1]):
+                match = (path, d)
         else:
             stale = path
     if match:
         d = match[1]
         valu = d.get("pmc_voice_kernel", {}).get("SQ_INSTS_VALU", {}).get("avg_per_dispatch")
-        return {"bytes": d["hbm_traffic"]["total_bytes_corrected"], "valu": valu,
+        return {"bytes": d["hbm_traffic"]["total_bytes_corrected"], "valu": valu, "blocks_per_launch": d.get("blocks_per_launch", 1.0),
                 "source": os.path.relpath(match[0], ROOT), "stale": None}
-    return {"bytes": None, "valu": None, "source": None, "stale": os.path.relpath(stale, ROOT) if stale else None}
+    return {"bytes": None, "valu": None, "blocks_per_launch": None, "source": None,
+            "stale": os.path.relpath(stale, ROOT) if stale else None}
 
 
 def cpu_baseline(block, seed, frames, span):
@@ -150,8 +155,9 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bus-batch", type=int, default=8,
-                    help="blocks per bus-reduce launch (og_set_bus_batching; 1 = a reduce after every block)")
+    ap.add_argument("--bus-batch", type=int, default=32,
+                    help="blocks the engine may render per kernel launch (og_set_bus_batching, 1..32; 1 = a launch and a bus "
+                         "reduce per block)")
     ap.add_argument("--sparse-events", action="store_true",
                     help="keep the 1 s note plan as is even when the run is shorter (default: every voice plays a slice "
                          "of its cyclic plan, so that note-on, note-off and retrigger all fall inside the timed region at "
@@ -222,7 +228,7 @@ def main():
         n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if "gate" in eng.input_names else 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    if args.bus_batch > 1:  # one bus-reduce launch per 8 blocks; every bus is complete before the timed region closes (flush below)
+    if args.bus_batch > 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
         eng.set_bus_batching(args.bus_batch)
     ch = eng.channels
     bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
@@ -286,7 +292,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kern_ms, n_launch = eng.kernel_time_ms()       # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
-    n_blocks_timed = eng.kernel_blocks_timed         # blocks those launches rendered (8 per launch with --bus-batch 8)
+    n_blocks_timed = eng.kernel_blocks_timed         # blocks those launches rendered (up to --bus-batch per launch)
     eng.enable_kernel_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
@@ -311,8 +317,16 @@ def main():
         blocks_per_launch = n_blocks_timed / float(max(1, n_launch))
         bytes_per_launch = bytes_per_block * blocks_per_launch
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        prof = pmc_profile(V, block, args.graph, eng.kernel_hash)
+        prof = pmc_profile(V, block, args.graph, eng.kernel_hash, blocks_per_launch)
         pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
+        pmc_note = None
+        if pmc_src and abs(prof["blocks_per_launch"] - blocks_per_launch) > 0.02 * blocks_per_launch:
+            # the profiled command queued a different number of blocks per launch: instruction counts scale with the frames
+            # rendered; HBM traffic does not (the state planes are touched once per launch) and is not extrapolated
+            pmc_note = ("profile has %.2f blocks per launch, this run %.2f: VALU count scaled by the ratio, traffic omitted"
+                        % (prof["blocks_per_launch"], blocks_per_launch))
+            pmc_valu = pmc_valu * blocks_per_launch / prof["blocks_per_launch"] if pmc_valu else None
+            pmc_bytes = None
         traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
         line = {
             "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
@@ -361,6 +375,7 @@ def main():
                 "traffic_bytes_per_launch": pmc_bytes,
                 "traffic_source": pmc_src,
                 "stale_profile": prof["stale"],  # newest summary of this configuration taken on ANOTHER kernel build
+                "profile_note": pmc_note,
                 "kernel_hash": eng.kernel_hash,
                 "kernel_variant": eng.kernel_variant,
                 "kernel_ms_avg": kern_ms,

@@ -78,7 +78,7 @@ extern "C" {
 // ---- round 2: bulk scheduling, stream inputs / render(inputs, tail), node arrays, custom nodes, nested graphs,
 // ---- multi-GPU clusters, async MIDI ----
 #[repr(C)] pub struct og_cluster { _p: [u8; 0] }
-#[repr(C)] pub struct og_node_port { pub name: *const c_char, pub kind: c_int, pub default_value: c_float, pub ctor_arg: c_int }
+#[repr(C)] pub struct og_node_port { pub name: *const c_char, pub kind: c_int, pub default_value: c_float, pub ctor_arg: c_int, pub channels: u32 }
 #[repr(C)] pub struct og_node_field { pub name: *const c_char, pub is_uint: c_int, pub init: c_float, pub init_uint: u32, pub ctor_arg: c_int }
 #[repr(C)] pub struct og_node_type {
     pub type_ctor: *const c_char, pub n_ctor_args: u32,
@@ -86,6 +86,8 @@ extern "C" {
     pub outputs: *const *const c_char, pub n_outputs: u32,
     pub state: *const og_node_field, pub n_state: u32,
     pub process_src: *const c_char, pub event_handler_src: *const *const c_char, pub cost_hint: u32,
+    pub event_outputs: *const *const c_char, pub n_event_outputs: u32,
+    pub output_channels: *const u32,
 }
 extern "C" {
     pub fn og_graph_add_node_array(g: *mut og_graph_desc, name: *const c_char, type_ctor: *const c_char,

@@ -213,13 +213,14 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
  * on the engine's stream. */
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus);
 int og_synchronize(og_engine* e);
-/* Throughput option for streaming callers of og_process_block_async: up to `blocks` (1..8) consecutive async blocks
- * that nothing separates (no value change, no event push, no taps) are rendered by ONE launch of the voice kernel over
+/* Throughput option for streaming callers of og_process_block_async: up to `blocks` (1..32) consecutive async blocks
+ * that nothing but event pushes separates (no value change, no taps) are rendered by ONE launch of the voice kernel over
  * their frames back to back -- per-voice state loaded and stored once, one inter-kernel gap, one bus reduce -- instead
  * of a launch each.  The bus of an async block is then complete after the last block of its batch, after og_flush()
  * (launches what is queued, does not wait) or og_synchronize(); every call that reads or changes engine state launches
  * the queue first, and og_process_block / og_render* always deliver complete buses.  Results are those of block-by-block
- * processing, bit for bit.  Default 1 (a launch per block). */
+ * processing, bit for bit.  Default 1 (a launch per block).  (Measured, fm_voice at 65 536 voices: 1 -> 8 blocks +30 %,
+ * 8 -> 32 another +3.5 %; the partial-sum rows grow with it: workgroups x 512 x blocks x 4 bytes.) */
 int og_set_bus_batching(og_engine* e, uint32_t blocks);
 int og_flush(og_engine* e);
 int og_set_stream(og_engine* e, void* hip_stream);

@@ -1478,7 +1478,7 @@ int og_synchronize(og_engine* e)
 int og_set_bus_batching(og_engine* e, uint32_t blocks)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
-    if (blocks == 0 || blocks > OG_MAX_LAUNCH_BLOCKS) return set_err(OG_E_INVALID, "bus batching: 1..8 blocks");
+    if (blocks == 0 || blocks > OG_MAX_LAUNCH_BLOCKS) return set_err(OG_E_INVALID, "bus batching: 1..OG_MAX_LAUNCH_BLOCKS blocks");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();

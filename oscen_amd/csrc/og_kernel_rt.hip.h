@@ -43,7 +43,7 @@ using __hip_internal::uint64_t;
 
 #define OG_WAVE 64
 #define OG_MAX_BLOCK 512
-#define OG_MAX_LAUNCH_BLOCKS 8                             // blocks one launch may cover (og_set_bus_batching)
+#define OG_MAX_LAUNCH_BLOCKS 32                            // blocks one launch may cover (og_set_bus_batching)
 #define OG_MAX_LAUNCH_FRAMES (OG_MAX_BLOCK * OG_MAX_LAUNCH_BLOCKS)
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16

@@ -31,26 +31,38 @@ for k in out["kernel_stats"]:
         out["kernel_hash"] = m.group(1)
         out["kernel_name"] = k["name"]
         break
+LPV = {"epiano_voice": 8}.get(GRAPH, 1)
+waves = (V * LPV + 63) // 64
+# A launch renders the blocks queued since the previous one (bench.py --bus-batch, default 32).  The timed region of
+# bench.py starts with a fresh queue, so the first ceil(warmup / batch) launches of the voice kernel are warm-up and the
+# rest are the launches bench.py times: the per-launch figures below are of THOSE, like bench.py's own HIP-event average.
+def _arg(name, default):
+    m = re.search(name + r"\s+(\d+)", cmd)
+    return int(m.group(1)) if m else default
+steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), max(1, _arg("--bus-batch", 32))
+warm_launches = (warm + batch - 1) // batch
+timed_launches = (steps + batch - 1) // batch
+out["warmup_launches"], out["timed_launches"] = warm_launches, timed_launches
+out["blocks_per_launch"] = steps / float(timed_launches)
+durs = [r[0] for r in con.execute("select (end - start) from kernels where name = ? order by start", (out.get("kernel_name", ""),))]
+if len(durs) == warm_launches + timed_launches:
+    out["timed_avg_us"] = sum(durs[warm_launches:]) / 1e3 / max(1, timed_launches)
+else:
+    out["launch_count_note"] = "expected %d + %d launches of the voice kernel, the trace has %d" % (warm_launches, timed_launches, len(durs))
 pmc = {}
 for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
     c = sqlite3.connect(db)
-    for name, cnt, avg in c.execute("select counter_name, count(*), avg(value) from counters_collection "
-                                    "where kernel_name like 'og_k_%' group by counter_name"):
-        pmc[name] = {"dispatches": cnt, "avg_per_dispatch": avg}
+    rows = {}
+    for name, value in c.execute("select counter_name, value from counters_collection where kernel_name like 'og_k_%' "
+                                 "order by dispatch_id"):
+        rows.setdefault(name, []).append(value)
+    for name, vals in rows.items():
+        timed = vals[warm_launches:] if len(vals) == warm_launches + timed_launches else vals
+        pmc[name] = {"dispatches": len(timed), "avg_per_dispatch": sum(timed) / max(1, len(timed))}
     for row in c.execute("select distinct vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, scratch_size, "
                          "workgroup_size, grid_size from counters_collection where kernel_name like 'og_k_%' limit 1"):
         out["dispatch"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "workgroup", "grid"], row))
 out["pmc_voice_kernel"] = pmc
-LPV = {"epiano_voice": 8}.get(GRAPH, 1)
-waves = (V * LPV + 63) // 64
-# a launch may render several queued blocks (bench.py --bus-batch, default 8): frames per dispatch = blocks run / launches
-def _arg(name, default):
-    m = re.search(name + r"\s+(\d+)", cmd)
-    return int(m.group(1)) if m else default
-blocks_run = _arg("--steps", 188) + _arg("--warmup", 8)
-for k in out["kernel_stats"]:
-    if k["name"] == out.get("kernel_name"):
-        out["blocks_per_launch"] = blocks_run / float(k["calls"])
 FR = FR * out.get("blocks_per_launch", 1.0)
 out["frames_per_launch"] = FR
 d = {}
@@ -72,6 +84,9 @@ with open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w") as f:
 with open(os.path.join(ROOT, "profiles", tag + "_summary.md"), "w") as f:
     f.write("# rocprofv3 summary `%s`\n\n`rocprofv3 --kernel-trace --stats -- %s` (+ separate `--pmc` passes), MI355X, %d voices x %.0f frames per launch (%.2f blocks of %d)\n\n"
             % (tag, out["command"], V, FR, out.get("blocks_per_launch", 1.0), out["frames"]))
+    if "timed_avg_us" in out:
+        f.write("voice kernel, the %d launches of the timed region (after %d warm-up launches): %.3f us per launch = %.3f us per block\n\n"
+                % (out["timed_launches"], out["warmup_launches"], out["timed_avg_us"], out["timed_avg_us"] / out["blocks_per_launch"]))
     f.write("| kernel | calls | avg us | % |\n|---|---|---|---|\n")
     for k in out["kernel_stats"]:
         f.write("| `%s` | %d | %.3f | %.1f |\n" % (k["name"][:70], k["calls"], k["avg_us"], k["pct"]))
