@@ -155,9 +155,9 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bus-batch", type=int, default=32,
-                    help="blocks the engine may render per kernel launch (og_set_bus_batching, 1..32; 1 = a launch and a bus "
-                         "reduce per block)")
+    ap.add_argument("--bus-batch", type=int, default=0,
+                    help="blocks the engine may render per kernel launch (og_set_bus_batching: 0 = the engine's choice, 8..32 "
+                         "by bank size; 1 = a launch and a bus reduce per block)")
     ap.add_argument("--sparse-events", action="store_true",
                     help="keep the 1 s note plan as is even when the run is shorter (default: every voice plays a slice "
                          "of its cyclic plan, so that note-on, note-off and retrigger all fall inside the timed region at "
@@ -228,7 +228,7 @@ def main():
         n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if "gate" in eng.input_names else 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    if args.bus_batch > 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
+    if args.bus_batch != 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
         eng.set_bus_batching(args.bus_batch)
     ch = eng.channels
     bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
@@ -357,7 +357,7 @@ def main():
                 "parallelism": "voice-shard x%d" % world_size,
                 "events_in_timed_region": n_events_timed,
                 "note_plan_span_frames": span if span else 48000,
-                "bus_reduce_batch_blocks": args.bus_batch,
+                "blocks_per_launch_limit": args.bus_batch if args.bus_batch else "engine's choice (8..32 by bank size)",
                 "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
                                ("og_midi_process_block, blocking" if args.midi_blocking else "og_midi_process_block_async"))
                               if midi is not None

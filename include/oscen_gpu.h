@@ -219,8 +219,9 @@ int og_synchronize(og_engine* e);
  * of a launch each.  The bus of an async block is then complete after the last block of its batch, after og_flush()
  * (launches what is queued, does not wait) or og_synchronize(); every call that reads or changes engine state launches
  * the queue first, and og_process_block / og_render* always deliver complete buses.  Results are those of block-by-block
- * processing, bit for bit.  Default 1 (a launch per block).  (Measured, fm_voice at 65 536 voices: 1 -> 8 blocks +30 %,
- * 8 -> 32 another +3.5 %; the partial-sum rows grow with it: workgroups x 512 x blocks x 4 bytes.) */
+ * processing, bit for bit.  Default 1 (a launch per block); blocks = 0 picks 8..32 from the bank size (what og_render*
+ * and cluster shards use: as many blocks as keep one launch's partial-sum rows within 32 MB).  Measured, fm_voice at
+ * 65 536 voices: 1 -> 8 blocks +30 %, 8 -> 32 another +3.5 %. */
 int og_set_bus_batching(og_engine* e, uint32_t blocks);
 int og_flush(og_engine* e);
 int og_set_stream(og_engine* e, void* hip_stream);

@@ -268,7 +268,7 @@ struct og_cluster {
                         const uint32_t frames = (uint32_t)std::min<size_t>(block, nf - g);
                         e->process_async(frames, buf + g);
                     }
-                    e->flush_bus(); // (shards queue up to OG_MAX_LAUNCH_BLOCKS blocks per launch: og_cluster_create)
+                    e->flush_bus(); // (shards queue 8..32 blocks per launch: og_cluster_create)
                     HIPCK(hipEventRecord(done, e->stream));
                 });
             }
@@ -360,8 +360,8 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
             e->bus_stage = false; // shards hand over the mono voice sum; the post-mix node runs once, on the root
             {
                 HIPCK(hipSetDevice(e->device));
-                e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS); // shards render up to 32 blocks per launch
-                e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
+                e->alloc_bus_buffers(e->auto_batch()); // shards render 8..32 blocks per launch
+                e->bus_batch = e->auto_batch();
             }
             c->shard.push_back(e);
             int di = -1;

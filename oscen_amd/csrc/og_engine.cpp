@@ -34,6 +34,7 @@
 // and 16 -> 1 through LDS.  History: 4 waves walking all rows 40 us; 16 slices x 64 frames 6.5 us.
 #define OG_RED_SLICES 64
 #define OG_RED_FRAMES 16
+static_assert(OG_RED_FRAMES == OG_BUS_CHUNK, "og_bus_reduce reads the chunks og::bus_chunk_reduce writes");
 #define OG_RED_GROUP 1024 // rows per workgroup; larger banks take a second pass over the group sums
 __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ partials, uint32_t n_rows, uint32_t frames,
                                                    float* __restrict__ out)
@@ -46,13 +47,15 @@ __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ par
     const uint32_t row0 = blockIdx.y * OG_RED_GROUP;
     const uint32_t row1 = min(n_rows, row0 + OG_RED_GROUP);
     float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // rows are chunk-major, [chunk][row][OG_RED_FRAMES] (og::bus_chunk_reduce): this workgroup's chunk is contiguous
+    const float* __restrict__ chunk = partials + (size_t)blockIdx.x * n_rows * OG_RED_FRAMES;
     if (f < frames) {
         uint32_t r = row0 + slice;
         for (; r + 7 * OG_RED_SLICES < row1; r += 8 * OG_RED_SLICES) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += partials[(size_t)(r + i * OG_RED_SLICES) * frames + f];
+            for (int i = 0; i < 8; ++i) acc[i] += chunk[(size_t)(r + i * OG_RED_SLICES) * OG_RED_FRAMES + fx];
         }
-        for (int i = 0; r < row1; r += OG_RED_SLICES, ++i) acc[i] += partials[(size_t)r * frames + f];
+        for (int i = 0; r < row1; r += OG_RED_SLICES, ++i) acc[i] += chunk[(size_t)r * OG_RED_FRAMES + fx];
     }
     part[slice][fx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
@@ -63,7 +66,8 @@ __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ par
         float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < OG_RED_SLICES / 4; ++i) s[i & 3] += quad[i][fx];
-        out[(size_t)blockIdx.y * frames + f] = (s[0] + s[1]) + (s[2] + s[3]);
+        // group sums in the same layout, [chunk][group][OG_RED_FRAMES]; with one group that is the bus itself
+        out[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * OG_RED_FRAMES + fx] = (s[0] + s[1]) + (s[2] + s[3]);
     }
 }
 
@@ -453,6 +457,16 @@ struct og_engine {
 
     // Everything before this frame has been consumed on the device by the time an update issued now takes effect:
     // launched blocks run before it in stream order; blocks still in the queue have not seen their events yet.
+    // Blocks per launch for throughput callers (og_render*, cluster shards, og_set_bus_batching(e, 0)): as many as the
+    // launch overhead still pays for while the launch's partial-sum rows stay modest.  Measured: fm_voice at 65 536 voices
+    // gains 30 % from 1 -> 8 blocks and 3.5 % more from 8 -> 32 (32 MB of rows); sat4x_voice at 131 072 voices and sub_voice
+    // at 262 144 LOSE 10-25 % once the rows of one launch pass ~64 MB, with either row layout (not understood further).
+    uint32_t auto_batch() const
+    {
+        const size_t per_block = (size_t)std::max<uint32_t>(n_wg, 1u) * 256u * 4u; // rows of one 256-frame block
+        const size_t b = ((size_t)32 << 20) / per_block;
+        return (uint32_t)std::min<size_t>(OG_MAX_LAUNCH_BLOCKS, std::max<size_t>(8, b));
+    }
     uint64_t consumed_horizon() const { return queue.empty() ? frame_now : q_frame0; }
     // unconsumed events of voice v on the device timeline (a block consumes everything before its end)
     bool has_old_events(uint32_t v) const { return !seg_begin.empty() && seg_begin[v] != seg_end[v] && seg_last[v] >= consumed_horizon(); }
@@ -863,7 +877,7 @@ struct og_engine {
                                    q_frames, tmp);
                 src = tmp;
                 rows = groups;
-                tmp = tmp + (size_t)groups * q_frames; // next level writes behind this one
+                tmp = tmp + (size_t)groups * ((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES) * OG_RED_FRAMES; // next level writes behind this one
             }
             hipLaunchKernelGGL(og_bus_reduce, dim3((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, 1), dim3(1024), 0, stream, src, rows, q_frames,
                                sum_dst);
@@ -1478,7 +1492,8 @@ int og_synchronize(og_engine* e)
 int og_set_bus_batching(og_engine* e, uint32_t blocks)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
-    if (blocks == 0 || blocks > OG_MAX_LAUNCH_BLOCKS) return set_err(OG_E_INVALID, "bus batching: 1..OG_MAX_LAUNCH_BLOCKS blocks");
+    if (blocks > OG_MAX_LAUNCH_BLOCKS) return set_err(OG_E_INVALID, "bus batching: 0 (automatic) or 1..32 blocks");
+    if (blocks == 0) blocks = e->auto_batch();
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
@@ -1538,8 +1553,8 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
         // an offline render has nothing between its blocks: several per launch (the caller's setting is restored)
         e->flush_bus();
         const uint32_t user_batch = e->bus_batch;
-        if (e->batch_cap < OG_MAX_LAUNCH_BLOCKS) e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS);
-        e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
+        if (e->batch_cap < e->auto_batch()) e->alloc_bus_buffers(e->auto_batch());
+        e->bus_batch = e->auto_batch();
         struct Restore {
             og_engine* e;
             uint32_t b;
@@ -1596,8 +1611,8 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
         HIPCK(hipMalloc(&d_all, (size_t)total * ch * 4));
         e->flush_bus();
         const uint32_t user_batch = e->bus_batch;
-        if (e->batch_cap < OG_MAX_LAUNCH_BLOCKS) e->alloc_bus_buffers(OG_MAX_LAUNCH_BLOCKS);
-        e->bus_batch = OG_MAX_LAUNCH_BLOCKS;
+        if (e->batch_cap < e->auto_batch()) e->alloc_bus_buffers(e->auto_batch());
+        e->bus_batch = e->auto_batch();
         struct Restore {
             og_engine* e;
             uint32_t b;

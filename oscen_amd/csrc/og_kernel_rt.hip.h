@@ -70,7 +70,7 @@ struct OgBlockArgs {
     const OgEvent* events;     // sorted by (voice, frame, push order)
     const uint32_t* ev_end;    // [n_voices] one past the voice's last event
     uint32_t* ev_cursor;       // [n_voices] next unconsumed event
-    float* partials;           // [n_workgroups][frames]
+    float* partials;           // [ceil(frames / 16)][n_workgroups][16]: per-workgroup partial sums of the mix bus
     const float* ramp_table;   // [n_ramps + n_streams][ramp_stride] per-frame values of ramped / stream inputs
     float* taps;               // [n_taps][frames] per-voice output taps (or null)
     const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
@@ -342,7 +342,11 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
     for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.tile[j][q * (OG_WAVE / 4) + i];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (c.lane < OG_BUS_CHUNK && j < n) a.partials[(size_t)blockIdx.x * a.frames + base + j] = s;
+    // chunk-major rows: [chunk][workgroup][OG_BUS_CHUNK].  All waves of the bank are at about the same chunk, so what is
+    // written (and what one workgroup of og_bus_reduce reads) at any moment is one compact region instead of one cache
+    // line in each of thousands of rows a whole launch apart (row-major rows of 32 blocks: -25 % on sat4x_voice).
+    if (c.lane < OG_BUS_CHUNK && j < n)
+        a.partials[((size_t)(base / OG_BUS_CHUNK) * gridDim.x + blockIdx.x) * OG_BUS_CHUNK + j] = s;
     wave_sync();
 }
 

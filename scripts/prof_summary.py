@@ -39,7 +39,9 @@ waves = (V * LPV + 63) // 64
 def _arg(name, default):
     m = re.search(name + r"\s+(\d+)", cmd)
     return int(m.group(1)) if m else default
-steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), max(1, _arg("--bus-batch", 32))
+# (--bus-batch 0 / absent: the engine's own choice, og_engine::auto_batch)
+auto_batch = min(32, max(8, (32 << 20) // (max(1, waves) * 256 * 4)))
+steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), (_arg("--bus-batch", 0) or auto_batch)
 warm_launches = (warm + batch - 1) // batch
 timed_launches = (steps + batch - 1) // batch
 out["warmup_launches"], out["timed_launches"] = warm_launches, timed_launches
