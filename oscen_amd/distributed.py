@@ -8,8 +8,9 @@ the voices are evaluated, and the per-rank partial buses of a whole batch of
 blocks are combined by ONE reduce (RCCL over xGMI when the backend is "nccl";
 a [blocks x frames] f32 message is latency-bound, so it is batched rather than
 issued per 1 KB block).  The fm-synth bus is mono and the hosts duplicate it
-to L/R after the sum (examples/fm-synth/src/lib.rs:269-274); the e-piano's
-stereo Tremolo runs after the reduce on the root.
+to L/R after the sum (examples/fm-synth/src/lib.rs:269-274).  In this torch-level path an engine with a post-mix
+node (the e-piano's stereo Tremolo) applies it per rank before the reduce -- the node is linear in its input, so the
+reduced bus is the same; the C-ABI cluster (og_cluster_*) reduces the mono sums and runs it once on the root.
 """
 import os
 

@@ -42,7 +42,7 @@ def _arg(name, default):
 # (--bus-batch 0 / absent: the engine's own choice, og_engine::auto_batch)
 auto_batch = min(32, max(8, (32 << 20) // (max(1, waves) * 256 * 4)))
 steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), (_arg("--bus-batch", 0) or auto_batch)
-warm_launches = (warm + batch - 1) // batch
+warm_launches = ((warm - 1 + batch - 1) // batch if warm > 1 else 0) + (1 if warm > 0 else 0)  # bench.py: W - 1 blocks, barrier, the last block
 timed_launches = (steps + batch - 1) // batch
 out["warmup_launches"], out["timed_launches"] = warm_launches, timed_launches
 out["blocks_per_launch"] = steps / float(timed_launches)
