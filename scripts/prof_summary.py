@@ -42,15 +42,16 @@ def _arg(name, default):
 # (--bus-batch 0 / absent: the engine's own choice, og_engine::auto_batch)
 auto_batch = min(32, max(8, (32 << 20) // (max(1, waves) * 256 * 4)))
 steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), (_arg("--bus-batch", 0) or auto_batch)
-warm_launches = ((warm - 1 + batch - 1) // batch if warm > 1 else 0) + (1 if warm > 0 else 0)  # bench.py: W - 1 blocks, barrier, the last block
 timed_launches = (steps + batch - 1) // batch
-out["warmup_launches"], out["timed_launches"] = warm_launches, timed_launches
+out["timed_launches"] = timed_launches
 out["blocks_per_launch"] = steps / float(timed_launches)
+# the timed region comes last: its launches are the last `timed_launches` dispatches of the voice kernel (the warm-up
+# blocks in front of it take 2-3 launches: a bulk-scheduled score is uploaded after the first block, and bench.py runs
+# the last warm-up block after the barrier)
 durs = [r[0] for r in con.execute("select (end - start) from kernels where name = ? order by start", (out.get("kernel_name", ""),))]
-if len(durs) == warm_launches + timed_launches:
-    out["timed_avg_us"] = sum(durs[warm_launches:]) / 1e3 / max(1, timed_launches)
-else:
-    out["launch_count_note"] = "expected %d + %d launches of the voice kernel, the trace has %d" % (warm_launches, timed_launches, len(durs))
+out["warmup_launches"] = max(0, len(durs) - timed_launches)
+if len(durs) >= timed_launches:
+    out["timed_avg_us"] = sum(durs[-timed_launches:]) / 1e3 / max(1, timed_launches)
 pmc = {}
 for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
     c = sqlite3.connect(db)
@@ -59,7 +60,7 @@ for db in sorted(glob.glob(os.path.join(base, "pmc_*", "pmc_results.db"))):
                                  "order by dispatch_id"):
         rows.setdefault(name, []).append(value)
     for name, vals in rows.items():
-        timed = vals[warm_launches:] if len(vals) == warm_launches + timed_launches else vals
+        timed = vals[-timed_launches:]
         pmc[name] = {"dispatches": len(timed), "avg_per_dispatch": sum(timed) / max(1, len(timed))}
     for row in c.execute("select distinct vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, scratch_size, "
                          "workgroup_size, grid_size from counters_collection where kernel_name like 'og_k_%' limit 1"):
