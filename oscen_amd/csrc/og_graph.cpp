@@ -2061,6 +2061,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             } else if (port == "rate" || port == "depth") {
                 Val v = cg.eval(Parser(e.src).parse());
                 if (!v.host) fail("bus node parameter '" + e.dst + "' must be a block-uniform value");
+                if (v.rate == Rate::UFrame) // (the reference would move it every frame; the post-mix kernel takes one value per block)
+                    fail("bus node parameter '" + e.dst + "' cannot be driven by a [ramp: N] input: it is applied once per block");
                 (port == "rate" ? out.tremolo_rate : out.tremolo_depth) = v.host;
             } else {
                 fail("bus node has no input '" + port + "'");
