@@ -332,6 +332,21 @@ struct og_engine {
     uint64_t flush_seq = 0;                    // batches launched so far
     bool batch_staged = false;                 // the batch being assembled reads a host staging buffer
     volatile uint64_t* h_progress = nullptr;  // pinned: number of the last batch the stream has finished (og_stream_mark)
+    float* h_bus_pinned = nullptr; // pinned + device-visible: destination of a blocking block's bus (og_process_block)
+    void wait_progress(uint64_t seq)
+    {
+        // the batch is tens of microseconds long: spin on the marker word (a runtime wait costs more than the block)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !h_progress || *h_progress < seq; ++spins) {
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                HIPCK(hipStreamSynchronize(stream)); // (something much slower than a block is in front of it)
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
     bool batch_done(uint64_t seq)
     {
         if (seq == 0 || (h_progress && *h_progress >= seq)) return true;
@@ -386,6 +401,7 @@ struct og_engine {
             (void)hipFree(d_stage_upd[i]);
         }
         if (h_progress) (void)hipHostFree((void*)h_progress);
+        if (h_bus_pinned) (void)hipHostFree(h_bus_pinned);
         for (auto ev : t_start) (void)hipEventDestroy(ev);
         for (auto ev : t_stop) (void)hipEventDestroy(ev);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -1513,15 +1529,35 @@ int og_flush(og_engine* e)
     });
 }
 
+// The blocking drop-in entry (the reference's process_block + reading the output field): the bus of this one block is
+// written by the device straight into pinned host memory, and completion is a word of pinned memory the stream marker
+// writes -- no hipMemcpy, no hipStreamSynchronize (both cost tens of microseconds of runtime latency per block).
 int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
 {
-    int rc = og_process_block_async(e, frames, nullptr);
-    if (rc) return rc;
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
+    if (frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 0..512");
+    if (frames == 0 || !out_bus || e->n_taps > 0 || getenv("OSCEN_GPU_BLOCKING_MEMCPY")) { // (taps are read with a stream sync anyway)
+        int rc = og_process_block_async(e, frames, nullptr);
+        if (rc) return rc;
+        return guard([&] {
+            e->flush_bus();
+            if (out_bus && frames)
+                HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(hipStreamSynchronize(e->stream));
+            return OG_OK;
+        });
+    }
     return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->flush_bus(); // earlier async blocks keep their own destinations
+        if (!e->h_bus_pinned) HIPCK(hipHostMalloc((void**)&e->h_bus_pinned, (size_t)OG_MAX_BLOCK * 2 * 4, hipHostMallocDefault));
+        e->process_async(frames, e->h_bus_pinned);
+        e->batch_staged = true; // ask for the stream marker behind this launch
+        const uint64_t seq = e->flush_seq + 1;
         e->flush_bus();
-        if (out_bus && frames)
-            HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
+        e->wait_progress(seq);
+        memcpy(out_bus, e->h_bus_pinned, (size_t)frames * e->cg->channels * 4);
         return OG_OK;
     });
 }
