@@ -196,17 +196,21 @@ int og_push_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint32_t f
 int og_schedule_voice_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float scalar);
 int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64_t abs_frame, float v);
 /* Bulk form of the two calls above (a whole score at once): `input` is an event input (values = scalar
- * payloads) or a per-voice value input (values = new values).  Events land on the device timeline
- * when the next block starts.  How they get there: a large batch rebuilds the timeline (O(V) upload,
- * one stream sync); a small one (live playing: og_push_voice_event, og_midi_*) appends per-voice
- * segments with one async copy and no synchronisation. */
+ * payloads) or a per-voice value input (values = new values).  Events wait on the host until the
+ * blocks they belong to are launched (with og_set_bus_batching several blocks share a launch and
+ * one timeline update).  How they get to the device: a large batch rebuilds the timeline (O(V)
+ * upload, one stream sync); a small one (live playing: og_push_voice_event, og_midi_*) appends
+ * per-voice segments that the update kernel reads from pinned host memory -- no copy call, no
+ * synchronisation. */
 int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uint32_t* voices,
                              const uint64_t* abs_frames, const float* values);
 
 /* process_block(frames)  codegen/mod.rs:755-873, frames <= 512, then copies
  * <out>_block[..frames] (the sum over voices, `voices.out -> out`) to host
- * memory: out_bus[frames * channels].  Blocking.  frames == 0 runs no frame and discards the
- * events pushed for the block (their frame_offset >= frames), like the generated loop. */
+ * memory: out_bus[frames * channels].  Blocking (the device writes the block's bus into pinned host
+ * memory; the call spins on a completion word instead of synchronising the stream).  frames == 0
+ * runs no frame and discards the events pushed for the block (their frame_offset >= frames), like
+ * the generated loop. */
 int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
 /* Same, but the bus stays in device memory (d_out_bus[frames*channels], may be
  * NULL to keep it in the engine's own buffer) and the call only enqueues work
