@@ -103,6 +103,7 @@ extern "C" {
     pub fn og_render_inputs(e: *mut og_engine, inputs: *const *const c_float, input_lens: *const u64, n_inputs: u32,
                             tail: u64, out_bus: *mut c_float, frames_rendered: *mut u64) -> c_int;
     pub fn og_kernel_hash(e: *const og_engine) -> u64;
+    pub fn og_voice_channels(e: *const og_engine) -> u32;
     pub fn og_midi_send_batch(m: *mut og_midi, bytes3: *const u8, frame_offsets: *const u32, n: u32) -> c_int;
     pub fn og_midi_set_queue_capacity(m: *mut og_midi, capacity: u32) -> c_int;
     pub fn og_midi_process_block_async(m: *mut og_midi, frames: u32, d_out_bus: *mut c_float) -> c_int;

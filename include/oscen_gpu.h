@@ -251,6 +251,10 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n);
 int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames);
 
 uint32_t og_channels(const og_engine* e);
+/* 1: every voice contributes an f32 sample per frame; 2: the graph's stream output is fed a Frame<2> (e.g. a per-voice
+ * pan): both channels are summed over the voices, the bus is interleaved L R and og_read_voice_taps delivers
+ * [tap][frame][2].  (og_channels is also 2 for a mono voice sum with a stereo post-mix node.) */
+uint32_t og_voice_channels(const og_engine* e);
 uint32_t og_num_voices(const og_engine* e);
 uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
 uint64_t og_frames_processed(const og_engine* e);

@@ -357,6 +357,10 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
                 if (rc == OG_E_DEVICE) throw HipError(g_err);
                 throw std::runtime_error(g_err);
             }
+            if (e->cg->voice_channels != 1) {
+                og_destroy(e);
+                throw std::runtime_error("clusters sum mono voice outputs: a Frame<2> graph output is not supported here yet");
+            }
             e->bus_stage = false; // shards hand over the mono voice sum; the post-mix node runs once, on the root
             {
                 HIPCK(hipSetDevice(e->device));

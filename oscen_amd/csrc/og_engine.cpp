@@ -36,8 +36,9 @@
 #define OG_RED_FRAMES 16
 static_assert(OG_RED_FRAMES == OG_BUS_CHUNK, "og_bus_reduce reads the chunks og::bus_chunk_reduce writes");
 #define OG_RED_GROUP 1024 // rows per workgroup; larger banks take a second pass over the group sums
+// out_stride / out_off: the last pass of a stereo bus writes channel out_off of interleaved Frame<2> samples
 __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ partials, uint32_t n_rows, uint32_t frames,
-                                                   float* __restrict__ out)
+                                                   float* __restrict__ out, uint32_t out_stride, uint32_t out_off)
 {
     __shared__ float part[OG_RED_SLICES][OG_RED_FRAMES];
     __shared__ float quad[OG_RED_SLICES / 4][OG_RED_FRAMES];
@@ -67,14 +68,14 @@ __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ par
 #pragma unroll
         for (int i = 0; i < OG_RED_SLICES / 4; ++i) s[i & 3] += quad[i][fx];
         // group sums in the same layout, [chunk][group][OG_RED_FRAMES]; with one group that is the bus itself
-        out[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * OG_RED_FRAMES + fx] = (s[0] + s[1]) + (s[2] + s[3]);
+        out[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * OG_RED_FRAMES + fx) * out_stride + out_off] = (s[0] + s[1]) + (s[2] + s[3]);
     }
 }
 
 __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
-                                                      uint32_t frames, float* __restrict__ out)
+                                                      uint32_t frames, float* __restrict__ out, uint32_t out_stride, uint32_t out_off)
 {
-    og_bus_reduce_body(partials, n_rows, frames, out);
+    og_bus_reduce_body(partials, n_rows, frames, out, out_stride, out_off);
 }
 
 // Post-mix Tremolo (examples/electric-piano/src/tremolo.rs:40-62) on the summed bus -> Frame<2>.
@@ -731,8 +732,9 @@ struct og_engine {
             }
         batch_cap = batch;
         const size_t max_frames = (size_t)OG_MAX_BLOCK * batch;
-        HIPCK(hipMalloc(&d_partials, (size_t)n_wg * max_frames * 4));
-        HIPCK(hipMemset(d_partials, 0, (size_t)n_wg * max_frames * 4));
+        const size_t vc = cg->voice_channels; // a Frame<2> voice output: two planes of partial rows
+        HIPCK(hipMalloc(&d_partials, (size_t)n_wg * max_frames * 4 * vc));
+        HIPCK(hipMemset(d_partials, 0, (size_t)n_wg * max_frames * 4 * vc));
         HIPCK(hipMalloc(&d_partials2, ((size_t)n_wg / OG_RED_GROUP + 2 + 64) * max_frames * 4));
         HIPCK(hipMalloc(&d_stage_bus, max_frames * 2 * 4));
         if (cg->bus_tremolo) HIPCK(hipMalloc(&d_mono, max_frames * 4));
@@ -831,6 +833,8 @@ struct og_engine {
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
         A.partials = d_partials;
+        const uint32_t n_chunks16 = (q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES;
+        A.partial_plane = (uint32_t)((size_t)n_chunks16 * n_wg * OG_RED_FRAMES);
         A.taps = d_taps;
         A.tap_slot = d_tap_slot;
         for (size_t k = 0; k < cg->rings.size(); ++k) {
@@ -876,27 +880,25 @@ struct og_engine {
         HIPCK(hipGetLastError());
         // ---- bus: sum the partial rows ----------------------------------------------------------------
         const bool post_mix = cg->bus_tremolo && bus_stage;
-        const uint32_t ch = 1; // the summed voices are mono; a post-mix node (Frame<2>) writes the final bus itself
+        const uint32_t ch = cg->voice_channels; // summed voices: mono, or Frame<2> voices (a post-mix node writes its Frame<2> bus itself)
         bool contiguous = !post_mix;
         for (size_t k = 1; k < queue.size() && contiguous; ++k)
             contiguous = queue[k].dst == queue[k - 1].dst + (size_t)queue[k - 1].frames * ch;
         float* sum_dst = post_mix ? d_mono : (contiguous ? queue[0].dst : d_stage_bus);
-        {
-            const float* src = d_partials;
+        for (uint32_t c = 0; c < ch; ++c) { // one tree per channel plane; the last pass interleaves Frame<2> samples
+            const float* src = d_partials + (size_t)c * A.partial_plane;
             uint32_t rows = n_wg;
             float* tmp = d_partials2;
             bus_passes = 1;
             while (rows > OG_RED_GROUP) {
                 bus_passes += 1;
                 const uint32_t groups = (rows + OG_RED_GROUP - 1) / OG_RED_GROUP;
-                hipLaunchKernelGGL(og_bus_reduce, dim3((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, groups), dim3(1024), 0, stream, src, rows,
-                                   q_frames, tmp);
+                hipLaunchKernelGGL(og_bus_reduce, dim3(n_chunks16, groups), dim3(1024), 0, stream, src, rows, q_frames, tmp, 1u, 0u);
                 src = tmp;
                 rows = groups;
-                tmp = tmp + (size_t)groups * ((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES) * OG_RED_FRAMES; // next level writes behind this one
+                tmp = tmp + (size_t)groups * n_chunks16 * OG_RED_FRAMES; // next level writes behind this one
             }
-            hipLaunchKernelGGL(og_bus_reduce, dim3((q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES, 1), dim3(1024), 0, stream, src, rows, q_frames,
-                               sum_dst);
+            hipLaunchKernelGGL(og_bus_reduce, dim3(n_chunks16, 1), dim3(1024), 0, stream, src, rows, q_frames, sum_dst, ch, c);
         }
         HIPCK(hipGetLastError());
         size_t off = 0;
@@ -905,7 +907,7 @@ struct og_engine {
                 hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, stream, d_mono + off, qb.frames, qb.trem_rate, qb.trem_depth, sr,
                                    d_bus_phase, qb.dst);
             } else if (!contiguous) {
-                HIPCK(hipMemcpyAsync(qb.dst, d_stage_bus + off, (size_t)qb.frames * 4, hipMemcpyDeviceToDevice, stream));
+                HIPCK(hipMemcpyAsync(qb.dst, d_stage_bus + off * ch, (size_t)qb.frames * ch * 4, hipMemcpyDeviceToDevice, stream));
             }
             off += qb.frames;
         }
@@ -1691,8 +1693,9 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
         if (e->d_taps) HIPCK(hipFree(e->d_taps));
         e->d_taps = nullptr;
         if (n) {
-            HIPCK(hipMalloc(&e->d_taps, (size_t)n * OG_MAX_BLOCK * 4));
-            HIPCK(hipMemset(e->d_taps, 0, (size_t)n * OG_MAX_BLOCK * 4));
+            // (a Frame<2> voice output: [tap][frame][2])
+            HIPCK(hipMalloc(&e->d_taps, (size_t)n * OG_MAX_BLOCK * 4 * e->cg->voice_channels));
+            HIPCK(hipMemset(e->d_taps, 0, (size_t)n * OG_MAX_BLOCK * 4 * e->cg->voice_channels));
         }
         e->n_taps = n;
         return OG_OK;
@@ -1706,13 +1709,14 @@ int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        HIPCK(hipMemcpyAsync(out, e->d_taps, (size_t)n * frames * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipMemcpyAsync(out, e->d_taps, (size_t)n * frames * 4 * e->cg->voice_channels, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
 }
 
 uint32_t og_channels(const og_engine* e) { return e ? e->cg->channels : 0; }
+uint32_t og_voice_channels(const og_engine* e) { return e ? e->cg->voice_channels : 0; }
 uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }

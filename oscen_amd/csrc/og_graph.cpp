@@ -2246,12 +2246,28 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     // group of all stages.
     cg.stage_of.assign(g.nodes.size(), 0);
     cg.n_stages = 1;
+    bool stereo_out = false;
     {
         const char* env_split = getenv("OGC_SPLIT");
         bool any_delay = false; // delay lines are staged per chunk by the ordinary kernel only
         for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
+        // a Frame<2> voice output (two bus tiles) is summed by the ordinary kernel only
+        std::function<int(const ExprP&)> width_of = [&](const ExprP& e) -> int {
+            if (!e) return 1;
+            if (e->t == Expr::Ref && !e->port.empty()) {
+                auto nit = cg.node_by_name.find(e->node);
+                if (nit == cg.node_by_name.end()) return 1;
+                const NodeTypeInfo* ti = cg.nodes[nit->second].type;
+                for (size_t o = 0; o < ti->outputs.size() && o < ti->out_channels.size(); ++o)
+                    if (e->port == ti->outputs[o]) return ti->out_channels[o];
+                return 1;
+            }
+            return std::max(width_of(e->a), width_of(e->b));
+        };
+        for (auto& kv : out_edges)
+            for (auto& src : kv.second) stereo_out = stereo_out || width_of(src.src) == 2;
         bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback && !cg.dynamic_events &&
-                    !any_delay;
+                    !any_delay && !stereo_out;
         // estimated per-tick VALU cost of every node, in emission order
         int total = 0;
         std::vector<int> w;
@@ -2388,19 +2404,34 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (it == out_edges.end()) continue;
             if ((int)oi == bus_final_output) fail("graph output fed by the post-mix node cannot have other sources");
             if (++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
-            std::string acc;
+            std::string acc, acc_r;
+            bool stereo = false;
             for (size_t k = 0; k < it->second.size(); ++k) {
                 if (it->second.size() > 1 && !it->second[k].policy.empty())
                     fail("fan-in summing supports only same-rate sources (graph output)");
                 Val v = cg.cross(cg.eval(it->second[k].src), it->second[k].policy, false, false);
-                if (v.is_frame())
+                if (v.is_frame() && v.ch.size() != 2)
                     fail("graph output '" + g.outputs[oi].name + "' is fed a Frame<" + std::to_string(v.ch.size()) +
-                         ">: the voice output summed on the mix bus is an f32 stream (take the channels apart in a node; a "
-                         "stereo bus comes from a post-mix node, og_graph_add_bus_node)");
+                         ">: the mix bus carries f32 or Frame<2> voices");
+                if (k > 0 && v.is_frame() != stereo) fail("graph output '" + g.outputs[oi].name + "' mixes f32 and Frame<2> sources");
+                stereo = v.is_frame();
+                if (stereo) { // a Frame<2> voice: both channels summed over the voices, bus interleaved (BlockRender<Frame<2>>)
+                    if (out.lpv != 1 || out.bus_tremolo || cg.N > 1)
+                        fail("a Frame<2> graph output is not supported in array-valued, multirate or post-mix graphs yet");
+                    acc = (k == 0) ? v.ch[0].e : "(" + acc + " + " + v.ch[0].e + ")";
+                    acc_r = (k == 0) ? v.ch[1].e : "(" + acc_r + " + " + v.ch[1].e + ")";
+                    continue;
+                }
                 if (it->second.size() > 1 && v.inner) fail("fan-in summing supports only same-rate sources (graph output)");
                 acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
             }
-            cg.os() << "        const float g_out = " << acc << ";\n";
+            if (stereo) {
+                cg.os() << "        const og::Out2 g_out = {" << acc << ", " << acc_r << "};\n";
+                out.voice_channels = 2;
+                out.channels = 2;
+            } else {
+                cg.os() << "        const float g_out = " << acc << ";\n";
+            }
             bus_expr = "g_out";
         }
     }
@@ -2520,7 +2551,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::ostringstream body;
     body << "template <bool RAMPS, bool TAPS>\n"
          << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
-         << "    __shared__ og::BusLds bus;\n"
+         << "    __shared__ og::" << (stereo_out ? "BusLds2" : "BusLds") << " bus;\n"
          << (out.rings.empty() ? std::string()
                                : "    __shared__ float ring_lds[" + std::to_string(out.rings.size()) +
                                      "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
@@ -2551,12 +2582,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (const auto& r : cg.sec[k].env_rs) m = m.empty() ? r : "(" + m + " + " + r + ")";
         return m;
     };
-    body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> float {\n"
+    body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> " << (stereo_out ? "og::Out2" : "float") << " {\n"
          << group_tick({all_stages}, 0);
     if (cg.frame_end.str().empty()) {
         body << "        return " << bus_expr << ";\n    };\n";
     } else { // clear_event_outputs(): the frame's node-to-node events have been delivered
-        body << "        const float g_bus = " << bus_expr << ";\n" << cg.frame_end.str() << "        return g_bus;\n    };\n";
+        body << "        const auto g_bus = " << bus_expr << ";\n" << cg.frame_end.str() << "        return g_bus;\n    };\n";
     }
     body << events_code(all_stages);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"

@@ -125,6 +125,7 @@ struct CompiledGraph {
     int n_streams = 0; // graph-level stream inputs (`<stream_in>_block`): rows n_ramps.. of the per-frame table
     int n_event_inputs = 0;
     uint32_t channels = 1;
+    uint32_t voice_channels = 1; // 2: the voice graph's stream output is fed a Frame<2> (summed per channel, bus interleaved)
     uint32_t latency_samples = 0;
     std::vector<std::string> node_order; // topological order actually emitted (introspection/tests)
     int find_input(const std::string& n) const;

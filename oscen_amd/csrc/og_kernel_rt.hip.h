@@ -63,6 +63,7 @@ struct OgBlockArgs {
     uint32_t frames;           // frames this launch renders: one block (<= 512), or several queued blocks back to back
     uint32_t ramp_stride;      // row stride of ramp_table in frames
     uint32_t lanes;            // active lanes per wave (64; experiment knob)
+    uint32_t partial_plane;    // floats between the channel planes of `partials` (stereo voice output)
     uint32_t split;            // pipeline depth to launch: 0 = ordinary kernel, 2 / 4 = waves per 64 voices (og_graph.cpp)
     uint64_t frame0;
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
@@ -71,6 +72,7 @@ struct OgBlockArgs {
     const uint32_t* ev_end;    // [n_voices] one past the voice's last event
     uint32_t* ev_cursor;       // [n_voices] next unconsumed event
     float* partials;           // [ceil(frames / 16)][n_workgroups][16]: per-workgroup partial sums of the mix bus
+                               // (a Frame<2> voice output: two such planes, `partial_plane` floats apart)
     const float* ramp_table;   // [n_ramps + n_streams][ramp_stride] per-frame values of ramped / stream inputs
     float* taps;               // [n_taps][frames] per-voice output taps (or null)
     const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
@@ -351,6 +353,47 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
 }
 
 __device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLds&) {} // (rows are written as they are formed)
+
+// ---- a Frame<2> voice output (the graph's stream output is fed a stereo frame): two tiles, two planes of partial
+// rows, taps [tap][frame][2] -- same calls, picked by overload
+struct Out2 {
+    float l, r;
+};
+struct BusLds2 {
+    BusLds ch[2];
+};
+template <bool TAPS, bool ALL_LANES = false>
+__device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds2& lds, uint32_t f, uint32_t j, Out2 out)
+{
+    const bool on = c.valid && (ALL_LANES || c.lead);
+    const float yl = on ? out.l : 0.0f, yr = on ? out.r : 0.0f;
+    lds.ch[0].tile[j][c.lane] = yl;
+    lds.ch[1].tile[j][c.lane] = yr;
+    if (TAPS) {
+        if (c.tap >= 0 && c.lead) {
+            a.taps[((size_t)c.tap * a.frames + f) * 2] = yl;
+            a.taps[((size_t)c.tap * a.frames + f) * 2 + 1] = yr;
+        }
+    }
+}
+__device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLds2& lds, uint32_t base, uint32_t n)
+{
+    wave_sync();
+    const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
+    const uint32_t q = c.lane / OG_BUS_CHUNK;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.ch[k].tile[j][q * (OG_WAVE / 4) + i];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (c.lane < OG_BUS_CHUNK && j < n)
+            a.partials[(size_t)k * a.partial_plane + ((size_t)(base / OG_BUS_CHUNK) * gridDim.x + blockIdx.x) * OG_BUS_CHUNK + j] = s;
+    }
+    wave_sync();
+}
+__device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLds2&) {}
 
 } // namespace og
 

@@ -132,3 +132,72 @@ def test_stereo_filter_channels_are_independent():
         eng = oscen_amd.Engine(g, 1, sample_rate=SR)
         out = eng.process_block(8)[:, 0]
         assert np.allclose(out, want, atol=1e-6), (which, out)
+
+
+def test_frame2_voice_output_gives_a_stereo_bus():
+    """the graph's stream output fed a Frame<2> (a per-voice pan): both channels are summed over the voices, the bus is
+    interleaved L R, taps are [tap][frame][2]; also across the multi-pass bus reduce (> 1024 workgroups) and with
+    several blocks per launch"""
+    oscen_amd.register_node(
+        "Pan::new", inputs=[("input", "stream", 0.0, -1), ("pan", "value", 0.5, -1)], outputs=[("output", 2)],
+        process="    output.v[0] = input * (1.0f - pan);\n    output.v[1] = input * pan;\n")
+    g = oscen_amd.Graph("panned")
+    g.input_value("frequency", 220.0, per_voice=True)
+    g.input_value("pan", 0.5, per_voice=True)
+    g.input_event("gate")
+    g.output_stream("out")
+    g.node("osc", "PolyBlepOscillator::saw", 220.0, 0.25)
+    g.node("env", "AdsrEnvelope::new", 0.005, 0.05, 0.7, 0.05)
+    g.node("p", "Pan::new")
+    g.connect("frequency", "osc.frequency")
+    g.connect("gate", "env.gate")
+    g.connect("pan", "p.pan")
+    g.connect("osc.output * env.output", "p.input")
+    g.connect("p.output", "out")
+    lib = ol.load()
+    for n, blocks in ((200, (256, 300, 212)), (70000, (256, 256, 256))):
+        freqs = (55.0 * (1.0 + np.arange(n) % 97)).astype(np.float32)
+        pans = ((np.arange(n) * 37 % 101) / 100.0).astype(np.float32)
+        probe = np.unique(np.linspace(0, n - 1, 40).astype(np.uint32))
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        assert eng.channels == 2 and eng.lib.og_voice_channels(eng.h) == 2 and eng.pipeline_depth == 1
+        eng.set_voice_values("frequency", freqs)
+        eng.set_voice_values("pan", pans)
+        eng.schedule_voice_events("gate", np.arange(n), 3 + np.arange(n) % 50, np.full(n, 0.8, np.float32))
+        eng.set_voice_taps(probe)
+        bus, taps = [], []
+        for b in blocks:
+            bus.append(eng.process_block(b))
+            taps.append(eng.read_voice_taps(b))
+        bus, taps = np.concatenate(bus), np.concatenate(taps, axis=1)
+        frames = sum(blocks)
+        assert bus.shape == (frames, 2) and taps.shape == (len(probe), frames, 2)
+        # per-voice model over the oracle's nodes (all voices for the small bank, the probed ones for the big one)
+        voices = range(n) if n <= 1000 else [int(v) for v in probe]
+        ref = {}
+        for v in voices:
+            osc = _make(lib, f32(SR), "PolyBlepOscillator::saw", [220.0, 0.25])
+            env = _make(lib, f32(SR), "AdsrEnvelope::new", [0.005, 0.05, 0.7, 0.05])
+            osc.set("frequency", freqs[v])
+            y = np.zeros((frames, 2), dtype=np.float32)
+            for f in range(frames):
+                osc.process()
+                if f == 3 + v % 50:
+                    env.gate(0.8)
+                env.process()
+                x = f32(osc.get("output") * env.get("output"))
+                y[f, 0], y[f, 1] = f32(x * f32(f32(1.0) - pans[v])), f32(x * pans[v])
+            ref[v] = y
+        for i, v in enumerate(probe):
+            r = ref[int(v)]
+            assert float(np.max(np.abs(taps[i] - r) / np.maximum(1.0, np.abs(r)))) <= 1e-5
+        if n <= 1000:
+            want = np.sum([ref[v].astype(np.float64) for v in voices], axis=0)
+            scale = np.sum([np.abs(ref[v]).astype(np.float64) for v in voices], axis=0)
+            assert np.all(np.abs(bus - want) <= 2e-6 * np.maximum(scale, 1e-3)) and np.abs(want).max() > 1.0
+        # several blocks per launch give the same bits as a launch per block
+        e2 = oscen_amd.Engine(g, n, sample_rate=SR)
+        e2.set_voice_values("frequency", freqs)
+        e2.set_voice_values("pan", pans)
+        e2.schedule_voice_events("gate", np.arange(n), 3 + np.arange(n) % 50, np.full(n, 0.8, np.float32))
+        assert np.array_equal(e2.render(frames, block=256)[: blocks[0]], bus[: blocks[0]])

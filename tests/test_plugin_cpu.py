@@ -202,7 +202,7 @@ def test_event_outputs_lower_to_in_kernel_event_edges():
 
 def test_frame_ports_lower_to_channel_values():
     """Frame<N> edges: the channels travel as scalar values (so they cross pipeline cuts like any other value), user code
-    sees og::Frame<N>; width mismatches and frames on the mono mix bus are compile-time errors."""
+    sees og::Frame<N>; width mismatches are compile-time errors; a Frame<2> at the graph output makes the mix bus stereo."""
     oscen_amd.register_node("Wide::new", inputs=[("input", "stream", 0.0, -1)], outputs=[("output", 2)],
                             process="    output = og::Frame<2>::splat(input);\n")
     oscen_amd.register_node("Narrow::new", inputs=[("input", "stream", 0.0, -1, 2)], outputs=["output"],
@@ -240,7 +240,17 @@ def test_frame_ports_lower_to_channel_values():
     bad(lambda h: (h.connect("w.output", "m.input"), h.connect("m.output", "out")), "takes an f32 stream")
     bad(lambda h: (h.connect("osc.output", "f.input"), h.connect("f.output", "n.input"), h.connect("n.output", "out")),
         "its source is an f32 stream")
-    bad(lambda h: h.connect("w.output", "out"), "the voice output summed on the mix bus is an f32 stream")
+    bad(lambda h: (h.connect("w.output", "out"), h.connect("osc.output", "out")), "mixes f32 and Frame<2> sources")
+    # a Frame<2> straight to the graph output: a stereo mix bus (two tiles, the ordinary kernel only)
+    st = oscen_amd.Graph("st")
+    st.output_stream("out")
+    st.node("osc", "Oscillator::sine", 330.0, 1.0)
+    st.node("w", "Wide::new")
+    st.connect("osc.output", "w.input")
+    st.connect("w.output", "out")
+    src = st.kernel_source()
+    assert "og::BusLds2 bus;" in src and "-> og::Out2 {" in src and "og_k2_" not in src
+    assert st.jit_check() > 0
     bad(lambda h: (h.connect("w.output * w.output", "n.input"), h.connect("n.output", "out")), "frame \\* f32")
     oscen_amd.unregister_node("Wide::new")
     oscen_amd.unregister_node("Narrow::new")
