@@ -12,6 +12,7 @@
 //   nodes { NAME = GraphType; }  /  GraphType::new()      a registered graph type used as a node (nested graph)
 // Not handled (diagnosed): `external`.  `src -> [N] -> dst` and `src -> [delay_node] -> dst` expand into the two edges of
 // ir/lower.rs:342-347 (the second one a feedback edge).
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -223,9 +224,18 @@ void parse_output(Lexer& lx, GraphDesc& g)
         kind = first;
         name = lx.ident();
     }
-    if (lx.eat(':')) (void)lx.until(";");
+    GOutput o{name, kind_of(kind, lx.line)};
+    if (lx.eat(':')) { // `output out: stream: Frame<2>;` (examples/electric-piano/src/main.rs:51)
+        std::string ty = lx.until(";");
+        ty.erase(std::remove_if(ty.begin(), ty.end(), [](char ch) { return isspace((unsigned char)ch); }), ty.end());
+        if (ty == "Stereo") o.channels = 2;
+        else if (ty == "Quad") o.channels = 4;
+        else if (ty == "f32" || ty == "Mono") o.channels = 1;
+        else if (ty.rfind("Frame<", 0) == 0) o.channels = atoi(ty.c_str() + 6);
+        else dfail("output '" + name + "': unknown stream type '" + ty + "'", lx.line);
+    }
     lx.expect(';');
-    g.outputs.push_back({name, kind_of(kind, lx.line)});
+    g.outputs.push_back(o);
 }
 
 void parse_node_decl(Lexer& lx, GraphDesc& g)
@@ -431,7 +441,9 @@ std::string to_dsl(const GraphDesc& g)
         }
         o << ";" << (in.per_voice ? "  // per voice" : "") << "\n";
     }
-    for (const auto& out : g.outputs) o << "output " << out.name << ": " << kn[(int)out.kind] << ";\n";
+    for (const auto& out : g.outputs)
+        o << "output " << out.name << ": " << kn[(int)out.kind] << (out.channels > 1 ? ": Frame<" + std::to_string(out.channels) + ">" : std::string())
+          << ";\n";
     o << "\nnodes {\n";
     for (const auto& n : g.nodes) {
         if (n.bus) {

@@ -2425,6 +2425,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (it->second.size() > 1 && v.inner) fail("fan-in summing supports only same-rate sources (graph output)");
                 acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
             }
+            const int declared = g.outputs[oi].channels; // `output out: stream: Frame<2>;` (0: not declared)
+            if (declared > 2) fail("graph output '" + g.outputs[oi].name + "': the mix bus carries f32 or Frame<2> voices");
+            if (declared && (declared == 2) != stereo)
+                fail("graph output '" + g.outputs[oi].name + "' is declared " + (declared == 2 ? "Frame<2>" : "f32") + " but fed " +
+                     (stereo ? "a Frame<2>" : "an f32 stream"));
             if (stereo) {
                 cg.os() << "        const og::Out2 g_out = {" << acc << ", " << acc_r << "};\n";
                 out.voice_channels = 2;

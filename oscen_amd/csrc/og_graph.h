@@ -52,6 +52,7 @@ struct GInput {
 struct GOutput {
     std::string name;
     Kind kind = Kind::Stream;
+    int channels = 0; // `output out: stream: Frame<2>;`: the declared frame width (0 = not declared: taken from what feeds it)
 };
 struct GNode {
     std::string name;

@@ -251,6 +251,14 @@ def test_frame_ports_lower_to_channel_values():
     src = st.kernel_source()
     assert "og::BusLds2 bus;" in src and "-> og::Out2 {" in src and "og_k2_" not in src
     assert st.jit_check() > 0
+    # the DSL's typed output (`output out: stream: Frame<2>;`, examples/electric-piano/src/main.rs:51) is kept and checked
+    typed = st.to_dsl().replace("output out: stream;", "output out: stream: Frame<2>;")
+    g2 = oscen_amd.Graph(dsl=typed)
+    assert "output out: stream: Frame<2>;" in g2.to_dsl() and "og::BusLds2 bus;" in g2.kernel_source()
+    with pytest.raises(oscen_amd.OscenError, match="declared Frame<2> but fed an f32 stream"):
+        oscen_amd.Graph(dsl=typed.replace("w.output -> out", "osc.output -> out")).kernel_source()
+    with pytest.raises(oscen_amd.OscenError, match="declared f32 but fed a Frame<2>"):
+        oscen_amd.Graph(dsl=typed.replace("stream: Frame<2>", "stream: f32")).kernel_source()
     bad(lambda h: (h.connect("w.output * w.output", "n.input"), h.connect("n.output", "out")), "frame \\* f32")
     oscen_amd.unregister_node("Wide::new")
     oscen_amd.unregister_node("Narrow::new")
