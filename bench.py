@@ -10,6 +10,14 @@ no torch.distributed environment the script launches itself under torch.distribu
 per GPU, RCCL); the driver's own `python -m torch.distributed.run ... bench.py --gpus N` works too.
 Rank 0 prints ONE JSON line.
 
+The K-step timed region (barrier + synchronize on both sides) is run --repeats times (default 5); `value` is the
+MEDIAN region, every region's time is in the line (`regions_ms`).  After the timed regions rank 0 of a one-GPU run
+also measures the REAL-TIME entry (`realtime`: blocking og_midi_process_block, one launch per 256-frame block, live
+MIDI, p50 / p99 / max wall latency against the 5.333 ms deadline) and the CPU baseline (`cpu_baseline`).
+
+`--gpus N --cluster` runs the same workload through the C-ABI cluster (og_cluster_*: ONE process, one engine per GPU,
+one batched ncclReduce per launch batch) instead of one torch.distributed rank per GPU.
+
 Other modes (not the headline): --midi-live (events arrive through og_midi_send + the blocking
 og_process_block every block instead of a resident timeline), --graph <built-in> for the other
 BASELINE configurations.
@@ -93,8 +101,10 @@ def cpu_baseline(block, seed, frames, span):
         cand.append(t)
         t *= 2
     cand.append(cores)
+    probe = {"1": single}
     for t in cand:
         r = max(timed(64 * t, pf, t, 8), timed(64 * t, pf, t, 8))
+        probe[str(t)] = r
         if r > best_rate:
             best_t, best_rate = t, r
     threads = best_t
@@ -112,7 +122,23 @@ def cpu_baseline(block, seed, frames, span):
 
     v8, t8, _ = run(8, 4.0, best_rate)  # (a throttled container sustains less than the probe burst: lands at 10-20 s)
     vw, tw, _ = run(0, 1.5, best_rate * 0.5)
+    # the reference's own criterion shapes (oscen-lib/benches/static_vs_runtime.rs:68-116) + BASELINE config 1, one thread
+    shapes = (C.c_double * 4)()
+    lib.oo_criterion_shapes.argtypes = [C.c_double, C.POINTER(C.c_double)]
+    lib.oo_criterion_shapes.restype = None
+    lib.oo_criterion_shapes(0.3, shapes)
     return {
+        "criterion_shapes": {
+            "simple_graph/static_ns_per_process": shapes[0],
+            "complex_graph/static_ns_per_process": shapes[1],
+            "batch_processing/static_graph_512_ns": shapes[2],
+            "config1_fm_voice_1voice_1s_block256_seconds": shapes[3],
+            "config1_voices_samples_per_s": 48000.0 / shapes[3] if shapes[3] > 0 else None,
+            "source": "C oracle (port) of StaticSimpleGraph / StaticComplexGraph process() at 44.1 kHz and of the FMVoice "
+                      "graph (1 voice, 48 000 frames, note-on frame 0, note-off frame 24 000), single thread, ~0.3 s each",
+        },
+        "host": host_facts(),
+        "scaling_probe": probe,
         "value": v8 * frames / t8,
         "unit": "voices*samples/s",
         "cores": threads,
@@ -132,6 +158,120 @@ def cpu_baseline(block, seed, frames, span):
     }
 
 
+def host_facts():
+    """What the box really gives this process: CPUs reported, CPUs in the affinity mask, the cgroup CPU quota and the
+    CPU model -- so that `cores` and the per-thread rate of the CPU baseline can be read against evidence."""
+    facts = {"os_cpu_count": os.cpu_count()}
+    try:
+        facts["sched_affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        facts["sched_affinity_cpus"] = None
+    quota = None
+    try:  # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+        facts["cgroup_cpu_max"] = "%s %s" % (q, per)
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / float(per)
+            facts["cgroup_cpu_max"] = "%d %d" % (q, per)
+        except Exception:
+            facts["cgroup_cpu_max"] = None
+    facts["cgroup_cpu_quota_cores"] = quota
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                facts["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        out = subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5).stdout
+        keep = {}
+        for ln in out.splitlines():
+            k, _, v = ln.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)", "CPU max MHz"):
+                keep[k.strip()] = v.strip()
+        facts["lscpu"] = keep
+    except Exception:
+        facts["lscpu"] = None
+    try:
+        facts["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except Exception:
+        pass
+    return facts
+
+
+def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device):
+    """The real-time entry, measured as a host would call it: one blocking og_midi_process_block per 256-frame block
+    (the reference's audio callback: drain the MIDI queue, process_block, copy the bus out --
+    examples/fm-synth/src/main.rs:148-215, 512-frame callback :273-277), one kernel launch per block, nothing
+    queued ahead, `midi_per_block` live MIDI messages per block.  Wall latency per block against the deadline
+    block / 48 kHz."""
+    import numpy as np
+
+    import oscen_amd
+
+    deadline_ms = block / 48000.0 * 1e3
+    out = []
+    for V in voices_list:
+        eng = oscen_amd.Engine(graph, V, device=device, sample_rate=48000.0)
+        plans = oscen_amd.note_plans(V)
+        eng.set_voice_values("frequency", plans["frequency"])
+        midi = oscen_amd.Midi(eng)
+        midi.set_queue_capacity(max(32, midi_per_block))
+        rng = np.random.default_rng(0x05CE2026)
+        n_pat = 64  # message patterns built once: the loop pays for the engine's live path, not for numpy
+        notes = rng.integers(36, 97, size=(n_pat, midi_per_block)).astype(np.uint8)
+        frames = np.sort(rng.integers(0, block, size=(n_pat, midi_per_block)), axis=1).astype(np.uint32)
+        packed = [midi.pack_messages(notes[i - (i % 2)], frames[i], on=(i % 2 == 0)) for i in range(n_pat)]
+        warm = 50
+        lat = np.empty(n_blocks, dtype=np.float64)
+        peak = 0.0
+        for i in range(warm + n_blocks):
+            t0 = time.perf_counter()
+            if midi_per_block:
+                midi.send_packed(packed[i % n_pat])
+            bus = midi.process_block(block)
+            t1 = time.perf_counter()
+            if i >= warm:
+                lat[i - warm] = t1 - t0
+                peak = max(peak, float(np.abs(bus).max()))
+        calls, timeouts = eng.blocking_stats
+        lat_ms = lat * 1e3
+        rec = {
+            "voices": V,
+            "blocks": n_blocks,
+            "midi_messages_per_block": midi_per_block,
+            "latency_ms": {"p50": float(np.percentile(lat_ms, 50)), "p99": float(np.percentile(lat_ms, 99)),
+                           "p999": float(np.percentile(lat_ms, 99.9)), "max": float(lat_ms.max()), "mean": float(lat_ms.mean())},
+            "deadline_ms": deadline_ms,
+            "deadline_misses": int(np.count_nonzero(lat_ms > deadline_ms)),
+            "value_blocking": V * block / float(lat.mean()),
+            "marker_timeouts": timeouts,
+            "bus_peak": peak,
+            "kernel_variant": eng.kernel_variant,
+        }
+        out.append(rec)
+        del midi
+        eng.close()
+    ok = [r for r in out if r["deadline_misses"] == 0 and r["bus_peak"] > 0.0]
+    return {
+        "entry": "og_midi_send_batch + og_midi_process_block (blocking: bus in host memory when the call returns), "
+                 "one launch per block, default batching",
+        "block": block,
+        "runs": out,
+        # the largest bank measured here whose EVERY block met the deadline (not an extrapolation)
+        "realtime_voices_at_48k": max([r["voices"] for r in ok]) if ok else 0,
+        # p99-latency-scaled estimate from the largest such bank (how many voices would still fit the deadline if the
+        # block time scaled linearly): an upper bound, not a measurement
+        "realtime_voices_at_48k_extrapolated": (max(ok, key=lambda r: r["voices"])["voices"] * deadline_ms /
+                                                max(ok, key=lambda r: r["voices"])["latency_ms"]["p99"]) if ok else 0,
+    }
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torch.distributed environment: one rank per GPU over RCCL."""
     s = socket.socket()
@@ -145,16 +285,208 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed):
+    """The HBM roofline object of the contract for the voice kernel of `eng` (one shard of V voices)."""
+    words = eng.state_words_per_voice
+    lanes = eng.voices_per_wave * eng.lanes_per_voice
+    n_wg = eng.partial_rows
+    # SURVEY 8(d)'s per-unit figure (state read + written once per 256-frame block, event cursors, one partial row per
+    # workgroup) x the units one launch processes: a launch that renders several queued blocks is charged that many
+    # blocks' worth, although it touches the state planes only once -- so `achieved` is an ACCOUNTING rate, not a DRAM
+    # bandwidth; `dram_gbs` (PMC bytes / kernel time) is the bandwidth
+    bytes_per_block = V * (4 * (words + eng.state_words_written_per_voice) + 8) + n_wg * block * 4
+    # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
+    bytes_per_block += V * block * 8 * {"echo_voice": 1}.get(graph, 0)
+    blocks_per_launch = n_blocks_timed / float(max(1, n_launch))
+    bytes_per_launch = bytes_per_block * blocks_per_launch
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    prof = pmc_profile(V, block, graph, eng.kernel_hash, blocks_per_launch)
+    pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
+    pmc_note = None
+    if pmc_src and abs(prof["blocks_per_launch"] - blocks_per_launch) > 0.02 * blocks_per_launch:
+        # the profiled command queued a different number of blocks per launch: instruction counts scale with the frames
+        # rendered; HBM traffic does not (the state planes are touched once per launch) and is not extrapolated
+        pmc_note = ("profile has %.2f blocks per launch, this run %.2f: VALU count scaled by the ratio, traffic omitted"
+                    % (prof["blocks_per_launch"], blocks_per_launch))
+        pmc_valu = pmc_valu * blocks_per_launch / prof["blocks_per_launch"] if pmc_valu else None
+        pmc_bytes = None
+    traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "achieved_is": "charged bytes (SURVEY 8d per-block accounting x blocks per launch) / kernel time -- an accounting "
+                       "rate; the DRAM bandwidth is dram_gbs",
+        "charged_gbs": achieved,
+        "traffic": traffic,
+        "dram_gbs": traffic,
+        "dram_frac": traffic / HBM_PEAK_GBS if traffic else None,
+        "traffic_bytes_per_launch": pmc_bytes,
+        "traffic_source": pmc_src,
+        "stale_profile": prof["stale"],  # newest summary of this configuration taken on ANOTHER kernel build
+        "profile_note": pmc_note,
+        "kernel_hash": eng.kernel_hash,
+        "kernel_variant": eng.kernel_variant,
+        "kernel_ms_avg": kern_ms,
+        "kernel_launches": n_launch,
+        "blocks_per_launch": blocks_per_launch,
+        "kernel_ms_per_block": kern_ms / blocks_per_launch if blocks_per_launch else None,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "voices_per_wave": lanes,
+        "pipeline_waves_per_64_voices": eng.pipeline_depth,
+        "bytes_per_voice_sample": bytes_per_block / float(V * block),
+        "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per launch; "
+                "see valu_issue for the bound that applies",
+        # The limiter (DESIGN.md 4.1): instruction issue / dependent-instruction latency.  peak = the nominal rate
+        # MI355X_MICROARCH.md gives (a wave64 VALU instruction every 2 cycles per SIMD: 1024 SIMDs x 2.4 GHz / 2 = the
+        # 157 TF vector peak); measured_ceiling = the plain-FMA stream ceiling cdna_hip_programming.md quotes (103 TF
+        # of v_fma_f32 = 3.05 cycles per instruction; scripts/pk_probe reaches 3.2 with eight waves per SIMD).
+        # achieved = SQ_INSTS_VALU per launch (committed PMC pass of the SAME kernel hash) / the kernel duration
+        # measured in this run.
+        "valu_issue": None if not (pmc_valu and kern_ms > 0) else {
+            "achieved": pmc_valu / (kern_ms * 1e-3) / 1e9,
+            "peak": 1024 * 2.4 / 2.0,
+            "measured_ceiling": 1024 * 2.4 / 3.05,
+            "unit": "G wave-instructions/s",
+            "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 2.0),
+            "frac_of_measured_ceiling": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 3.05),
+            "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block * blocks_per_launch),
+            "source": pmc_src,
+        },
+    }
+
+
+def region_stats(times, total_voices, K, block):
+    import numpy as np
+
+    t = np.asarray(times, dtype=np.float64)
+    med = float(np.median(t))
+    return med, {
+        "repeats": len(times),
+        "regions_ms": [x * 1e3 for x in times],
+        "value_median": total_voices * K * block / med,
+        "value_min": total_voices * K * block / float(t.max()),
+        "value_max": total_voices * K * block / float(t.min()),
+        "value_first_region": total_voices * K * block / float(t[0]),
+    }
+
+
+def run_cluster(args):
+    """--cluster: ONE process drives every GPU through the C-ABI cluster (og_cluster_create over devices 0..N-1,
+    og_cluster_render of the K blocks inside the timed region: per-shard host threads, one batched ncclReduce over
+    xGMI).  This is what a Rust / C caller of liboscen_gpu.so gets on a multi-GPU node."""
+    import numpy as np
+    import torch
+
+    import oscen_amd
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    N = args.gpus
+    devices = [0] * N if args.single_device else list(range(N))
+    if not args.single_device and n_dev < N:
+        sys.exit("bench.py --cluster --gpus %d: only %d device(s) visible" % (N, n_dev))
+    V, block, K, W, R = args.voices_per_gpu, args.block, args.steps, args.warmup, max(1, args.repeats)
+    total_voices = V * N
+    total_frames = (W + R * K) * block
+    span = 0 if args.sparse_events else min(total_frames, 48000)
+    cl = oscen_amd.Cluster(args.graph, total_voices, devices, sample_rate=48000.0)
+    plans = oscen_amd.note_plans(total_voices, span=span, fold="slice")
+    cl.set_voice_values("frequency", plans["frequency"])
+    ev_v, ev_f, ev_x = plans["events"]
+    keep = ev_f < total_frames
+    has_gate = True
+    try:
+        cl.schedule_voice_events("gate", ev_v[keep], ev_f[keep], ev_x[keep])
+    except oscen_amd.OscenError:
+        has_gate = False
+    n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if has_gate else 0
+    shard0 = cl.shard(0)
+    if W > 0:
+        cl.render(W * block, block)
+    torch.cuda.synchronize()
+    shard0.enable_kernel_timing(True)
+    times = []
+    mix = None
+    for r in range(R):
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        mix = cl.render(K * block, block)  # blocks until the reduced bus of all K blocks is in host memory
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        times.append(time.perf_counter() - t0)
+    kern_ms, n_launch = shard0.kernel_time_ms()
+    n_blocks_timed = shard0.kernel_blocks_timed
+    shard0.enable_kernel_timing(False)
+    assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
+    elapsed, stats = region_stats(times, total_voices, K, block)
+    line = {
+        "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
+        "value": total_voices * K * block / elapsed,
+        "unit": "voices*samples/s",
+        "n_gpus": N,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "fm-synth voice bank (FMVoice graph) through the C-ABI cluster (og_cluster_render), %d voices/GPU on %d "
+                        "device(s), block=%d frames, 48 kHz, f32; synthetic note streams splitmix64(0x05CE2026 ^ voice) "
+                        "resident in HBM; %d note events inside the timed regions; %s"
+                        % (V, len(set(devices)), block, n_events_timed,
+                           "mix bus of each launch batch summed with one ncclReduce over xGMI" if cl.rccl_reduces
+                           else "one device: no collective on the data path"),
+            "graph": args.graph,
+            "voices_per_gpu": V,
+            "total_voices": total_voices,
+            "block": block,
+            "sample_rate": 48000,
+            "parallelism": "cluster voice-shard x%d (one process, one host thread per shard)" % N,
+            "events_in_timed_region": n_events_timed,
+            "note_plan_span_frames": span if span else 48000,
+            "event_path": "resident timeline (og_cluster_schedule_voice_events)",
+        },
+        "timing": stats,
+        "rccl_ranks": cl.num_devices if cl.rccl_reduces else None,
+        "cluster": {"shards": cl.num_shards, "devices": cl.num_devices, "rccl_reduces": cl.rccl_reduces},
+        "offline_voices_at_48k": total_voices * K * block / elapsed / 48000.0,
+        "roofline": roofline_record(shard0, V, block, args.graph, kern_ms, n_launch, n_blocks_timed),
+        "cpu_baseline": None,
+    }
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=188)   # 188 x 256 frames = 1 s of audio
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how many times the K-step timed region is run (value = the median region)")
     ap.add_argument("--voices-per-gpu", type=int, default=65536,
                     help="65536 = BASELINE configs[1]; 262144 with --gpus 8 = configs[3] (2 097 152 voices)")
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-realtime", action="store_true", help="skip the blocking-path real-time latency record")
+    ap.add_argument("--rt-blocks", type=int, default=2000, help="blocks per bank size of the real-time record")
+    ap.add_argument("--rt-voices", default="65536,131072,1048576",
+                    help="bank sizes of the real-time record (comma separated)")
+    ap.add_argument("--rt-midi", type=int, default=1000, help="live MIDI messages per block in the real-time record")
+    ap.add_argument("--cluster", action="store_true",
+                    help="multi-GPU through the C-ABI cluster (og_cluster_*, one process) instead of one rank per GPU; "
+                         "with --gpus 1 the plain engine path runs (identical to the default)")
     ap.add_argument("--bus-batch", type=int, default=0,
                     help="blocks the engine may render per kernel launch (og_set_bus_batching: 0 = the engine's choice, 8..32 "
                          "by bank size; 1 = a launch and a bus reduce per block)")
@@ -169,12 +501,16 @@ def main():
                     help="with --midi-live: the blocking drop-in entry og_midi_process_block (= process_block + bus to host)")
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    ap.add_argument("--single-device", action="store_true", help="map every rank onto GPU 0")
+    ap.add_argument("--single-device", action="store_true", help="map every rank / shard onto GPU 0")
     ap.add_argument("--dist-single", action="store_true",
                     help="run the RCCL leg (process group, reduce, barrier) with a one-rank communicator: RCCL refuses two "
                          "ranks on one GPU ('Duplicate GPU detected'), so this is how a one-GPU box exercises it")
     args = ap.parse_args()
 
+    if args.cluster and args.gpus > 1:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            sys.exit("bench.py --cluster is a single-process mode: start it as `python bench.py --gpus N --cluster`")
+        return run_cluster(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
@@ -209,37 +545,48 @@ def main():
     V = args.voices_per_gpu
     total_voices = V * world_size
     lo, hi = ogd.shard_range(rank, world_size, total_voices)
-    block, K, W = args.block, args.steps, args.warmup
-    total_frames = (K + W) * block
+    block, K, W, R = args.block, args.steps, args.warmup, max(1, args.repeats)
+    # block sequence: W warm-up blocks (the last one runs after the barrier, see below), then R regions of K timed
+    # blocks, regions 1.. each preceded by ONE untimed block that plays the same role as that last warm-up block
+    n_blocks = W + R * K + (R - 1)
+    total_frames = n_blocks * block
     span = 0 if args.sparse_events else min(total_frames, 48000)
 
     eng = oscen_amd.Engine(args.graph, hi - lo, device=local_rank, sample_rate=48000.0)
     # global voice ids keep their note streams; a run shorter than the 1 s score sees a slice of it at its real density
     plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="slice")
     midi = None
+    timed_blocks = np.zeros(n_blocks, dtype=bool)
+    for r in range(R):
+        b0 = W + r * (K + 1)
+        timed_blocks[b0:b0 + K] = True
     if args.midi_live:
         eng.set_voice_values("frequency", plans["frequency"])
         midi = oscen_amd.Midi(eng)
         midi.set_queue_capacity(max(32, args.midi_live))
-        n_events_timed = args.midi_live * K
+        n_events_timed = args.midi_live * K * R
     else:
         oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
         ev_f = plans["events"][1]
-        n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if "gate" in eng.input_names else 0
+        if "gate" in eng.input_names:
+            inside = ev_f < total_frames
+            n_events_timed = int(np.count_nonzero(timed_blocks[(ev_f[inside] // block).astype(np.int64)]))
+        else:
+            n_events_timed = 0
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     if args.bus_batch != 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
         eng.set_bus_batching(args.bus_batch)
     ch = eng.channels
-    bus = torch.zeros((K + W, block * ch), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((n_blocks, block * ch), dtype=torch.float32, device="cuda")
     base = bus.data_ptr()
-    host_bus = np.zeros((K + W, block * ch), dtype=np.float32)
+    host_bus = np.zeros((n_blocks, block * ch), dtype=np.float32)
     rng = np.random.default_rng(0x05CE2026 + rank)
     live = []
     if midi is not None:  # messages built once: the timed loop pays for the engine's live path, not for numpy
-        live_notes = rng.integers(36, 97, size=(K + W, args.midi_live)).astype(np.uint8)
-        live_frames = np.sort(rng.integers(0, block, size=(K + W, args.midi_live)), axis=1).astype(np.uint32)
-        for i in range(K + W):  # even blocks play notes, odd blocks release the notes of the block before
+        live_notes = rng.integers(36, 97, size=(n_blocks, args.midi_live)).astype(np.uint8)
+        live_frames = np.sort(rng.integers(0, block, size=(n_blocks, args.midi_live)), axis=1).astype(np.uint32)
+        for i in range(n_blocks):  # even blocks play notes, odd blocks release the notes of the block before
             live.append(midi.pack_messages(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0)))
 
     def step(i):
@@ -279,64 +626,49 @@ def main():
         ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(ones)  # every rank of the communicator took part
         rccl_ranks = int(round(float(ones.item())))
-    torch.cuda.synchronize()
-    if dist is not None:
-        barrier()
-    torch.cuda.synchronize()
-    if W > 0:
-        step(W - 1)
-        eng.flush()
+    times = []
+    kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
+    for r in range(R):
+        first = W + r * (K + 1)        # first timed block of this region
         torch.cuda.synchronize()
-    eng.enable_kernel_timing(True)
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
-    if dist is not None:
-        reduce_bus(bus[W:])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
-    torch.cuda.synchronize()
-    if dist is not None:
-        barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kern_ms, n_launch = eng.kernel_time_ms()       # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
-    n_blocks_timed = eng.kernel_blocks_timed         # blocks those launches rendered (up to --bus-batch per launch)
-    eng.enable_kernel_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if dist is not None:
+            barrier()
+        torch.cuda.synchronize()
+        if first > 0 and (r > 0 or W > 0):  # the untimed block right in front of the region
+            step(first - 1)
+            eng.flush()
+            torch.cuda.synchronize()
+        eng.enable_kernel_timing(True)  # (per region: the untimed block in front of it is not part of the launch average)
+        t0 = time.perf_counter()
+        for i in range(first, first + K):
+            step(i)
+        eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
+        if dist is not None:
+            reduce_bus(bus[first:first + K])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
+        torch.cuda.synchronize()
+        if dist is not None:
+            barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times.append(elapsed)
+        ms, n = eng.kernel_time_ms()               # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
+        kern_total_ms += ms * n
+        n_launch += n
+        n_blocks_timed += eng.kernel_blocks_timed  # blocks those launches rendered (up to --bus-batch per launch)
+        eng.enable_kernel_timing(False)
+    kern_ms = kern_total_ms / max(1, n_launch)
 
     if rank == 0:
-        mix = host_bus[W:] if (midi is not None and args.midi_blocking) else bus[W:].float().cpu().numpy()
+        sel = torch.from_numpy(timed_blocks)
+        mix = host_bus[timed_blocks] if (midi is not None and args.midi_blocking) else bus[sel.to(bus.device)].float().cpu().numpy()
         assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
+        elapsed, stats = region_stats(times, total_voices, K, block)
         value = total_voices * K * block / elapsed
-        words = eng.state_words_per_voice
-        lanes = eng.voices_per_wave * eng.lanes_per_voice
-        # algorithmic HBM bytes of one launch: state planes read once + written once,
-        # the two event-cursor words read per voice, one partial-bus row written per workgroup
-        n_wg = eng.partial_rows
-        # SURVEY 8(d)'s per-unit figure (state read + written once per 256-frame block, event cursors, one partial row per
-        # workgroup) x the units one launch processes: a launch that renders several queued blocks is charged that many
-        # blocks' worth, although it touches the state planes only once
-        bytes_per_block = V * (4 * (words + eng.state_words_written_per_voice) + 8) + n_wg * block * 4
-        # graphs with a Delay: every voice-sample reads one and writes one 4-byte slot of its HBM ring
-        bytes_per_block += V * block * 8 * {"echo_voice": 1}.get(args.graph, 0)
-        blocks_per_launch = n_blocks_timed / float(max(1, n_launch))
-        bytes_per_launch = bytes_per_block * blocks_per_launch
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        prof = pmc_profile(V, block, args.graph, eng.kernel_hash, blocks_per_launch)
-        pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
-        pmc_note = None
-        if pmc_src and abs(prof["blocks_per_launch"] - blocks_per_launch) > 0.02 * blocks_per_launch:
-            # the profiled command queued a different number of blocks per launch: instruction counts scale with the frames
-            # rendered; HBM traffic does not (the state planes are touched once per launch) and is not extrapolated
-            pmc_note = ("profile has %.2f blocks per launch, this run %.2f: VALU count scaled by the ratio, traffic omitted"
-                        % (prof["blocks_per_launch"], blocks_per_launch))
-            pmc_valu = pmc_valu * blocks_per_launch / prof["blocks_per_launch"] if pmc_valu else None
-            pmc_bytes = None
-        traffic = pmc_bytes / (kern_ms * 1e-3) / 1e9 if (pmc_bytes and kern_ms > 0) else None
         line = {
             "metric": "voices*samples/sec (fm-synth graph, 48 kHz)",
             "value": value,
@@ -353,18 +685,20 @@ def main():
             "config": {
                 "workload": "fm-synth voice bank (FMVoice graph), %d voices/GPU, block=%d frames, 48 kHz, f32; "
                             "synthetic note streams splitmix64(0x05CE2026 ^ voice) resident in HBM%s; "
-                            "%d note events (on / off / retrigger) fall inside the timed region; "
-                            "mix bus reduced once per run over RCCL"
+                            "%d note events (on / off / retrigger) fall inside the %d timed regions; %s"
                             % (V, block, "" if not span or span >= 48000 else
                                ", the %d-frame run shows a per-voice slice of the cyclic 1 s note plan at its real event density" % span,
-                               n_events_timed),
+                               n_events_timed, R,
+                               "one GPU: no collective on the data path" if dist is None else
+                               "the [K x block] mix bus of a region reduced once over %s (%d rank%s)"
+                               % ("RCCL" if args.backend == "nccl" else "gloo", world_size, "" if world_size == 1 else "s")),
                 "graph": args.graph,
                 "voices_per_gpu": V,
                 "total_voices": total_voices,
                 "block": block,
                 "sample_rate": 48000,
                 "parallelism": "voice-shard x%d" % world_size,
-                "events_in_timed_region": n_events_timed,
+                "events_in_timed_region": n_events_timed // R,
                 "note_plan_span_frames": span if span else 48000,
                 "blocks_per_launch_limit": args.bus_batch if args.bus_batch else "engine's choice (8..32 by bank size)",
                 "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
@@ -372,61 +706,33 @@ def main():
                               if midi is not None
                               else "resident timeline (og_schedule_voice_events)",
             },
+            "timing": stats,
             "rccl_ranks": rccl_ranks,
-            "realtime_voices_at_48k": value / 48000.0,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_bytes_per_launch": pmc_bytes,
-                "traffic_source": pmc_src,
-                "stale_profile": prof["stale"],  # newest summary of this configuration taken on ANOTHER kernel build
-                "profile_note": pmc_note,
-                "kernel_hash": eng.kernel_hash,
-                "kernel_variant": eng.kernel_variant,
-                "kernel_ms_avg": kern_ms,
-                "kernel_launches": n_launch,
-                "blocks_per_launch": blocks_per_launch,
-                "kernel_ms_per_block": kern_ms / blocks_per_launch if blocks_per_launch else None,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "voices_per_wave": lanes,
-                "pipeline_waves_per_64_voices": eng.pipeline_depth,
-                "bytes_per_voice_sample": bytes_per_block / float(V * block),
-                "note": "path is VALU/transcendental-bound (SURVEY F8): HBM is touched once per block; "
-                        "see valu_issue for the bound that applies",
-                # The limiter: instruction issue / dependent-instruction latency.  CDNA4 SIMDs are
-                # 32 wide: a wave64 VALU instruction issues in 2 cycles (1024 SIMDs x 2.4 GHz / 2 = the 157 TF
-                # vector peak); the measured ceiling for scalar f32 streams is ~3.05 cycles (103 TF,
-                # MI355X_MICROARCH.md; scripts/pk_probe: 3.2 with 8 waves per SIMD).  achieved = SQ_INSTS_VALU per
-                # launch (committed PMC pass of the SAME kernel hash) / the kernel duration measured in this run.
-                "valu_issue": None if not (pmc_valu and kern_ms > 0) else {
-                    "achieved": pmc_valu / (kern_ms * 1e-3) / 1e9,
-                    "peak": 1024 * 2.4 / 2.0,
-                    "measured_ceiling": 1024 * 2.4 / 3.05,
-                    "unit": "G wave-instructions/s",
-                    "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 2.0),
-                    "frac_of_measured_ceiling": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 3.05),
-                    "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block * blocks_per_launch),
-                    "source": pmc_src,
-                },
-            },
+            # throughput of the QUEUED path (blocks known ahead, up to 32 per launch) expressed in 48 kHz voices: an
+            # offline-render rate.  The real-time figure comes from the blocking entry: realtime.realtime_voices_at_48k
+            "offline_voices_at_48k": value / 48000.0,
+            "roofline": roofline_record(eng, V, block, args.graph, kern_ms, n_launch, n_blocks_timed),
         }
         if midi is not None:
             line["config"]["midi_messages_per_block"] = args.midi_live
             line["event_stats"] = eng.event_stats
-        if world_size == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span)
-        else:
-            line["cpu_baseline"] = None
     else:
         line = None
     if dist is not None:
         barrier()
         dist.destroy_process_group()
     if line is not None:
+        if world_size == 1 and not args.no_realtime and "gate" in eng.input_names and args.graph == "fm_voice":
+            torch.cuda.synchronize()
+            rt_voices = [int(x) for x in args.rt_voices.split(",") if x.strip()]
+            line["realtime"] = realtime_record(args.graph, block, rt_voices, args.rt_blocks, args.rt_midi, local_rank)
+            line["realtime_voices_at_48k"] = line["realtime"]["realtime_voices_at_48k"]
+        else:
+            line["realtime"] = None
+        if world_size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span)
+        else:
+            line["cpu_baseline"] = None
         # RCCL writes a version banner through C stdio: push it out first, so that the JSON is the LAST line of stdout
         import ctypes
 

@@ -278,6 +278,9 @@ uint32_t og_partial_rows(const og_engine* e);   /* partial bus rows one launch w
 uint32_t og_bus_reduce_passes(const og_engine* e);
 /* event-path counters: full timeline rebuilds, incremental (per-voice segment) updates, events resident */
 int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* incremental_updates, uint64_t* resident_events);
+/* the blocking entry (og_process_block / og_midi_process_block): calls that waited on the completion word, and how
+ * many of those waits ran into the 20 ms fallback (a stream synchronise) -- 0 unless a block is slower than that */
+int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_timeouts);
 /* average device time of the voice kernel over the launches since the last
  * call (HIP events on the engine's stream); returns <0 if timing is off */
 int og_enable_kernel_timing(og_engine* e, int on);

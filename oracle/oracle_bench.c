@@ -153,3 +153,91 @@ double oo_bank_render_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint
 {
     return run_mt(kind, first_voice, n_voices, frames_total, block, n_threads, group, seed, span, mono64, abs64, NULL);
 }
+
+/* ---- the reference's own criterion shapes (oscen-lib/benches/static_vs_runtime.rs:68-116), single thread ----
+ * out[0]: ns per StaticSimpleGraph::process()        ("simple_graph/static",   :68-82,  init(44100))
+ * out[1]: ns per StaticComplexGraph::process()       ("complex_graph/static",  :84-98)
+ * out[2]: ns per 512 x StaticSimpleGraph::process()  ("batch_processing/static_graph_512", :100-116)
+ * out[3]: seconds for BASELINE config 1: one FMVoice bank of 1 voice, 48 000 frames at 48 kHz in blocks of 256,
+ *         note-on at frame 0 (velocity 100/127, 440 Hz), note-off at frame 24 000
+ * Each shape loops for about `budget_s` seconds; a volatile sink stands in for criterion's black_box. */
+static volatile float g_sink;
+void oo_criterion_shapes(double budget_s, double *out)
+{
+    if (!(budget_s > 0.0)) budget_s = 0.2;
+    {
+        oo_static_simple g;
+        oo_static_simple_new(&g);
+        oo_static_simple_init(&g, 44100.0f);
+        uint64_t it = 0;
+        const double t0 = now_s();
+        double t1 = t0;
+        while (t1 - t0 < budget_s) {
+            for (int k = 0; k < 4096; ++k) {
+                oo_static_simple_process(&g);
+                g_sink = g.gain.output;
+            }
+            it += 4096;
+            t1 = now_s();
+        }
+        out[0] = (t1 - t0) * 1e9 / (double)it;
+    }
+    {
+        oo_static_complex g;
+        oo_static_complex_new(&g);
+        oo_static_complex_init(&g, 44100.0f);
+        uint64_t it = 0;
+        const double t0 = now_s();
+        double t1 = t0;
+        while (t1 - t0 < budget_s) {
+            for (int k = 0; k < 4096; ++k) {
+                oo_static_complex_process(&g);
+                g_sink = g.vca.output;
+            }
+            it += 4096;
+            t1 = now_s();
+        }
+        out[1] = (t1 - t0) * 1e9 / (double)it;
+    }
+    {
+        oo_static_simple g;
+        oo_static_simple_new(&g);
+        oo_static_simple_init(&g, 44100.0f);
+        uint64_t it = 0;
+        const double t0 = now_s();
+        double t1 = t0;
+        while (t1 - t0 < budget_s) {
+            for (int r = 0; r < 16; ++r) {
+                for (int k = 0; k < 512; ++k) {
+                    oo_static_simple_process(&g);
+                    g_sink = g.gain.output;
+                }
+                it += 1;
+            }
+            t1 = now_s();
+        }
+        out[2] = (t1 - t0) * 1e9 / (double)it;
+    }
+    {
+        double best = 1e30;
+        const double t_begin = now_s();
+        do {
+            oo_bank *b = oo_bank_create(OO_BANK_FM, 1);
+            oo_bank_init(b, 48000.0f);
+            oo_bank_set_voice_frequency(b, 0, 440.0f);
+            float bus[OO_MAX_BLOCK * 2];
+            const double t0 = now_s();
+            for (uint32_t f0 = 0; f0 < 48000; f0 += 256) {
+                const uint32_t frames = 48000 - f0 < 256 ? 48000 - f0 : 256;
+                if (f0 == 0) oo_bank_push_event(b, 0, 0, OO_EV_GATE, 100.0f / 127.0f);
+                if (24000 >= f0 && 24000 < f0 + frames) oo_bank_push_event(b, 0, 24000 - f0, OO_EV_GATE, 0.0f);
+                oo_bank_process_block(b, frames, bus, NULL, 0, NULL);
+                g_sink = bus[frames - 1];
+            }
+            const double dt = now_s() - t0;
+            if (dt < best) best = dt;
+            oo_bank_destroy(b);
+        } while (now_s() - t_begin < budget_s);
+        out[3] = best;
+    }
+}

@@ -116,7 +116,8 @@ struct Worker {
     }
     void run(std::function<void()> j)
     {
-        std::lock_guard<std::mutex> lk(m);
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; }); // (never overwrite a job that is still running: its error would be lost)
         job = std::move(j);
         busy = true;
         err.clear();
@@ -145,6 +146,7 @@ struct og_cluster {
     std::vector<std::unique_ptr<Worker>> workers;
     uint64_t total = 0;
     uint32_t channels = 1;
+    uint32_t vch = 1; // channels of the voice sum the shards hand over (og_voice_channels)
     bool tremolo = false;
     bool inited = false;
     // per shard: two batch buffers of mono partial buses + "buffer filled" events
@@ -215,7 +217,7 @@ struct og_cluster {
             for (int b = 0; b < 2; ++b) {
                 if (sh_buf[b][s]) HIPCK(hipFree(sh_buf[b][s]));
                 sh_buf[b][s] = nullptr;
-                HIPCK(hipMalloc(&sh_buf[b][s], frames * sizeof(float)));
+                HIPCK(hipMalloc(&sh_buf[b][s], frames * vch * sizeof(float)));
             }
         }
         HIPCK(hipSetDevice(devs[0]));
@@ -229,6 +231,27 @@ struct og_cluster {
             if (!host_ready[b]) HIPCK(hipEventCreateWithFlags(&host_ready[b], hipEventDisableTiming));
         }
         cap_frames = frames;
+    }
+
+    // every shard thread has finished its job; the FIRST error is rethrown only after all of them are idle (a thread
+    // that is still issuing launches holds raw engine pointers and events)
+    void wait_all()
+    {
+        std::string first;
+        bool dev = false;
+        for (auto& w : workers) {
+            try {
+                w->wait();
+            } catch (const HipError& ex) {
+                if (first.empty()) { first = ex.what(); dev = true; }
+            } catch (const std::exception& ex) {
+                if (first.empty()) first = ex.what();
+            }
+        }
+        if (!first.empty()) {
+            if (dev) throw HipError(first);
+            throw std::runtime_error(first);
+        }
     }
 
     void sync_all()
@@ -249,6 +272,7 @@ struct og_cluster {
         const size_t batch_frames = (size_t)std::min<uint64_t>(total_frames, (uint64_t)CL_BATCH_BLOCKS * block);
         ensure_buffers(batch_frames);
         const size_t n_sh = shard.size();
+        const size_t vc = vch; // floats per frame of a shard's voice sum: 1, or 2 for Frame<2> voice outputs (interleaved)
         int b = 0;
         bool have_prev = false;
         uint64_t prev_f0 = 0;
@@ -266,13 +290,13 @@ struct og_cluster {
                     HIPCK(hipStreamWaitEvent(e->stream, free_ev, 0)); // the reduce that last read this buffer is over
                     for (size_t g = 0; g < nf; g += block) {
                         const uint32_t frames = (uint32_t)std::min<size_t>(block, nf - g);
-                        e->process_async(frames, buf + g);
+                        e->process_async(frames, buf + g * vc);
                     }
                     e->flush_bus(); // (shards queue 8..32 blocks per launch: og_cluster_create)
                     HIPCK(hipEventRecord(done, e->stream));
                 });
             }
-            for (size_t s = 0; s < n_sh; ++s) workers[s]->wait();
+            wait_all();
             // (2) per device: add the buffers of the other shards on that device into the first one's
             for (size_t d = 0; d < devs.size(); ++d) {
                 HIPCK(hipSetDevice(devs[d]));
@@ -283,8 +307,8 @@ struct og_cluster {
                     if (!acc) {
                         acc = sh_buf[b][s];
                     } else {
-                        hipLaunchKernelGGL(og_bus_accumulate, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, dev_stream[d], acc,
-                                           sh_buf[b][s], nf);
+                        hipLaunchKernelGGL(og_bus_accumulate, dim3((uint32_t)((nf * vc + 255) / 256)), dim3(256), 0, dev_stream[d], acc,
+                                           sh_buf[b][s], nf * vc);
                     }
                 }
                 dev_acc[b][d] = acc;
@@ -294,7 +318,7 @@ struct og_cluster {
                 Rccl& R = rccl();
                 R.ck(R.GroupStart(), "ncclGroupStart");
                 for (size_t d = 0; d < devs.size(); ++d)
-                    R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
+                    R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf * vc, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
                 R.ck(R.GroupEnd(), "ncclGroupEnd");
                 n_reduces += 1;
             }
@@ -312,7 +336,7 @@ struct og_cluster {
                 }
                 HIPCK(hipMemcpyAsync(h_pin[b], d_out, nf * 2 * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
             } else {
-                HIPCK(hipMemcpyAsync(h_pin[b], mono, nf * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
+                HIPCK(hipMemcpyAsync(h_pin[b], mono, nf * vc * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0])); // (Frame<2> voices: interleaved L R)
             }
             HIPCK(hipEventRecord(host_ready[b], dev_stream[0]));
             // buffer b may be rewritten once every reader on its device is done
@@ -351,23 +375,21 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
         for (uint32_t s = 0; s < n_shards; ++s) {
             const uint64_t nv = c->lo[s + 1] - c->lo[s];
             if (nv > 0xFFFFFFFFull) throw std::runtime_error("more than 2^32 voices in one shard");
-            og_engine* e = nullptr;
-            const int rc = og_create(g, (uint32_t)nv, device_ids[s], &e);
+            og_engine* raw = nullptr;
+            const int rc = og_create(g, (uint32_t)nv, device_ids[s], &raw);
             if (rc != OG_OK) {
                 if (rc == OG_E_DEVICE) throw HipError(g_err);
                 throw std::runtime_error(g_err);
             }
-            if (e->cg->voice_channels != 1) {
-                og_destroy(e);
-                throw std::runtime_error("clusters sum mono voice outputs: a Frame<2> graph output is not supported here yet");
-            }
-            e->bus_stage = false; // shards hand over the mono voice sum; the post-mix node runs once, on the root
+            std::unique_ptr<og_engine> e(raw); // (owned here until the cluster has it: alloc_bus_buffers may throw)
+            e->bus_stage = false; // shards hand over the voice sum; the post-mix node runs once, on the root
             {
                 HIPCK(hipSetDevice(e->device));
                 e->alloc_bus_buffers(e->auto_batch()); // shards render 8..32 blocks per launch
                 e->bus_batch = e->auto_batch();
             }
-            c->shard.push_back(e);
+            c->shard.push_back(e.get());
+            e.release();
             int di = -1;
             for (size_t d = 0; d < c->devs.size(); ++d)
                 if (c->devs[d] == device_ids[s]) di = (int)d;
@@ -379,6 +401,7 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
             c->workers.emplace_back(new Worker);
         }
         c->channels = c->shard[0]->cg->channels;
+        c->vch = c->shard[0]->cg->voice_channels;
         c->tremolo = c->shard[0]->cg->bus_tremolo;
         const size_t nd = c->devs.size();
         c->dev_stream.assign(nd, nullptr);

@@ -334,19 +334,21 @@ struct og_engine {
     bool batch_staged = false;                 // the batch being assembled reads a host staging buffer
     volatile uint64_t* h_progress = nullptr;  // pinned: number of the last batch the stream has finished (og_stream_mark)
     float* h_bus_pinned = nullptr; // pinned + device-visible: destination of a blocking block's bus (og_process_block)
-    void wait_progress(uint64_t seq)
+    uint64_t blocking_waits = 0, blocking_timeouts = 0; // og_process_block calls / calls whose marker wait timed out
+    bool wait_progress(uint64_t seq) // false: the marker did not arrive within 20 ms (fell back to a stream sync)
     {
         // the batch is tens of microseconds long: spin on the marker word (a runtime wait costs more than the block)
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spins = 0; !h_progress || *h_progress < seq; ++spins) {
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
                 HIPCK(hipStreamSynchronize(stream)); // (something much slower than a block is in front of it)
-                break;
+                return false;
             }
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
         }
+        return true;
     }
     bool batch_done(uint64_t seq)
     {
@@ -715,6 +717,28 @@ struct og_engine {
     // over several blocks: one staging copy and one cursor update for all of them)
     void upload_events()
     {
+        if (pending.empty() && !ev_rebuild) return;
+        // try_push'ed events of the block that is still being assembled (pushed since the last block was queued) stay
+        // on the host: drop_late_local() has not judged them against that block's length yet.  A flush in between --
+        // og_process_block launches earlier async blocks, the setters launch the queue -- must not turn an event whose
+        // frame_offset >= frames into one that fires in a later block.
+        std::vector<HostEvent> held;
+        if (n_block_local > 0) {
+            const size_t from = std::min(local_from, pending.size());
+            auto mid = std::stable_partition(pending.begin() + (long)from, pending.end(), [](const HostEvent& h) { return !h.block_local; });
+            held.assign(mid, pending.end());
+            pending.erase(mid, pending.end());
+        }
+        struct PutBack {
+            og_engine* e;
+            std::vector<HostEvent>& held;
+            ~PutBack()
+            {
+                if (held.empty()) return;
+                e->local_from = std::min(e->local_from, e->pending.size());
+                e->pending.insert(e->pending.end(), held.begin(), held.end());
+            }
+        } put_back{this, held};
         if (pending.empty() && !ev_rebuild) return;
         HostProf::Scope ps(prof, HostProf::SYNC_EVENTS);
         // many voices touched at once (bulk scheduling): one compact CSR rebuild beats per-voice segments
@@ -1554,11 +1578,15 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
         HIPCK(hipSetDevice(e->device));
         e->flush_bus(); // earlier async blocks keep their own destinations
         if (!e->h_bus_pinned) HIPCK(hipHostMalloc((void**)&e->h_bus_pinned, (size_t)OG_MAX_BLOCK * 2 * 4, hipHostMallocDefault));
-        e->process_async(frames, e->h_bus_pinned);
-        e->batch_staged = true; // ask for the stream marker behind this launch
+        // ask for the stream marker behind this block's launch BEFORE the block is queued: with one block per launch
+        // (the default) process_async launches it itself, and a marker requested afterwards would never be written
+        // (the wait then ran into its 20 ms timeout on every call -- ADVICE r2)
+        e->batch_staged = true;
         const uint64_t seq = e->flush_seq + 1;
+        e->process_async(frames, e->h_bus_pinned);
         e->flush_bus();
-        e->wait_progress(seq);
+        e->blocking_waits += 1;
+        if (!e->wait_progress(seq)) e->blocking_timeouts += 1;
         memcpy(out_bus, e->h_bus_pinned, (size_t)frames * e->cg->channels * 4);
         return OG_OK;
     });
@@ -1756,6 +1784,14 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
     return OG_OK;
 }
 
+int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_timeouts)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (calls) *calls = e->blocking_waits;
+    if (marker_timeouts) *marker_timeouts = e->blocking_timeouts;
+    return OG_OK;
+}
+
 int og_enable_kernel_timing(og_engine* e, int on)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
@@ -1815,16 +1851,23 @@ size_t dsp_bytes(const og_engine* e)
     return (e->cg->state.size() + e->cg->lane_state.size() * e->cg->lpv * e->cg->lane_width) * (size_t)e->V * 4 +
            (e->cg->bus_tremolo ? 4 : 0) + e->ring_bytes();
 }
+// Every event that has not fired by frame_now.  Blocks that are still queued (og_set_bus_batching) consume the events
+// in [q_frame0, frame_now) when they are launched, and the snapshot header stores the post-queue frame_now: those
+// events must not be saved (they would fire a second time after a load -- ADVICE r2), so the horizon is frame_now,
+// not consumed_horizon().  og_save_state launches the queue first; og_state_bytes only counts.
 void collect_unconsumed(const og_engine* e, std::vector<SnapEvent>& out)
 {
-    std::vector<OgEvent> old;
+    const uint64_t hz = e->frame_now;
     if (!e->seg_begin.empty())
         for (uint32_t v = 0; v < e->V; ++v) {
-            old.clear();
-            e->old_events(v, old);
-            for (const OgEvent& ev : old) out.push_back(SnapEvent{v, ev.target, ev.frame, ev.value, 0u});
+            if (e->seg_begin[v] == e->seg_end[v] || e->seg_last[v] < hz) continue;
+            for (uint32_t i = e->seg_begin[v]; i < e->seg_end[v]; ++i) {
+                const OgEvent& ev = e->h_events[i];
+                if (ev.frame >= hz) out.push_back(SnapEvent{v, ev.target, ev.frame, ev.value, 0u});
+            }
         }
-    for (const HostEvent& h : e->pending) out.push_back(SnapEvent{h.voice, h.target, h.frame, h.value, h.block_local ? 1u : 0u});
+    for (const HostEvent& h : e->pending)
+        if (h.frame >= hz) out.push_back(SnapEvent{h.voice, h.target, h.frame, h.value, h.block_local ? 1u : 0u});
 }
 size_t control_bytes(const og_engine* e, size_t n_events)
 {
@@ -1846,12 +1889,12 @@ size_t og_state_bytes(const og_engine* e)
 int og_save_state(og_engine* e, void* dst, size_t cap)
 {
     if (!e || !dst) return set_err(OG_E_INVALID, "null argument");
-    std::vector<SnapEvent> evs;
-    collect_unconsumed(e, evs);
-    if (cap < dsp_bytes(e) + control_bytes(e, evs.size())) return set_err(OG_E_INVALID, "buffer too small");
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
-        e->flush_bus();
+        e->flush_bus(); // queued blocks consume their events first: what is collected below is what frame_now has not reached
+        std::vector<SnapEvent> evs;
+        collect_unconsumed(e, evs);
+        if (cap < dsp_bytes(e) + control_bytes(e, evs.size())) throw std::runtime_error("buffer too small");
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
         HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
         if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
@@ -1886,8 +1929,27 @@ int og_load_state(og_engine* e, const void* src, size_t len)
     if (len < dsp + sizeof(SnapHeader)) return set_err(OG_E_INVALID, "state blob size mismatch");
     SnapHeader h;
     memcpy(&h, (const char*)src + dsp, sizeof h);
-    if (h.magic != SNAP_MAGIC || h.version != 2u || h.n_inputs != e->cg->inputs.size() || len != dsp + control_bytes(e, (size_t)h.n_events))
+    // (n_events is checked against the bytes that are there BEFORE it enters any size arithmetic: a crafted count must
+    //  not wrap control_bytes() around to a matching length)
+    const size_t fixed = control_bytes(e, 0);
+    if (h.magic != SNAP_MAGIC || h.version != 2u || h.n_inputs != e->cg->inputs.size() || len < dsp + fixed ||
+        h.n_events > (uint64_t)((len - dsp - fixed) / sizeof(SnapEvent)) || len != dsp + control_bytes(e, (size_t)h.n_events))
         return set_err(OG_E_INVALID, "state blob does not belong to this graph / voice count (or is from another version)");
+    { // validate the events before anything is changed: the kernel indexes handlers / per-voice inputs by `target`
+        const char* q = (const char*)src + dsp + fixed;
+        for (uint64_t i = 0; i < h.n_events; ++i, q += sizeof(SnapEvent)) {
+            SnapEvent ev;
+            memcpy(&ev, q, sizeof ev);
+            bool ok = ev.voice < e->V;
+            if (ev.target & OG_EV_SETVALUE) {
+                const uint32_t in = ev.target & ~OG_EV_SETVALUE;
+                ok = ok && in < e->cg->inputs.size() && e->cg->inputs[in].decl.kind == ogc::Kind::Value && e->cg->inputs[in].decl.per_voice;
+            } else {
+                ok = ok && (int)ev.target < e->cg->n_event_inputs;
+            }
+            if (!ok) return set_err(OG_E_INVALID, "state blob: event " + std::to_string(i) + " addresses a voice or input this graph does not have");
+        }
+    }
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
@@ -1921,9 +1983,18 @@ int og_load_state(og_engine* e, const void* src, size_t len)
             SnapEvent ev;
             memcpy(&ev, p, sizeof ev);
             p += sizeof ev;
-            if (ev.voice >= e->V) throw std::runtime_error("state blob: event voice out of range");
-            e->pending.push_back(HostEvent{ev.voice, ev.frame, ev.target, ev.value, e->seq++, ev.block_local != 0u});
-            if (ev.block_local) e->n_block_local += 1;
+            const bool local = ev.block_local != 0u;
+            e->pending.push_back(HostEvent{ev.voice, std::max(ev.frame, h.frame_now), ev.target, ev.value, e->seq++, local});
+            if (local) {
+                e->n_block_local += 1;
+                if (!(ev.target & OG_EV_SETVALUE)) { // the try_push capacity count of the block being assembled
+                    const size_t ne = (size_t)std::max(1, e->cg->n_event_inputs);
+                    if (e->local_cnt.empty()) e->local_cnt.assign((size_t)e->V * ne, 0);
+                    const size_t k = (size_t)ev.voice * ne + ev.target;
+                    if (e->local_cnt[k] == 0) e->local_touched.push_back((uint32_t)k);
+                    if (e->local_cnt[k] < 255) e->local_cnt[k] += 1;
+                }
+            }
         }
         return OG_OK;
     });

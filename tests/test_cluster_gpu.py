@@ -81,3 +81,119 @@ def test_cluster_routes_per_voice_calls_by_global_voice_id():
         assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max()))
     assert np.abs(b).max() > 1e-2
     assert cl.push_voice_event("gate", n, 0, 1.0) == oscen_amd.OG_E_INVALID
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 through the product path, the moment the box has more than one GPU: a cluster over REAL devices
+# (one engine per GPU, RCCL communicator with one rank per device, one ncclReduce per launch batch) at config 4's
+# per-GPU shard size.  Skips cleanly on a one-GPU box; needs nothing but more devices to run.
+# ---------------------------------------------------------------------------------------------------------------
+def device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("graph", ["fm_voice", "epiano_voice"])
+def test_multi_device_cluster_at_the_config4_shard_size(graph):
+    n_dev = device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two GPUs (the driver's multi-GPU node)")
+    from tests import oracle_lib as ol
+    from tests.test_fullsize_gpu import oracle_taps, sample_voices
+
+    kind = ol.BANK_FM if graph == "fm_voice" else ol.BANK_EPIANO
+    devs = list(range(min(n_dev, 8)))
+    per_gpu = 262144
+    n, total, block = per_gpu * len(devs), 512, 256
+    cl = oscen_amd.Cluster(graph, n, devs, sample_rate=SR)
+    assert cl.num_shards == len(devs) and cl.num_devices == len(devs)
+    plans = oscen_amd.note_plans(n, span=total)
+    oscen_amd.schedule_note_plans(cl, plans, total_frames=total)
+    # taps: sampled GLOBAL voices, set on the shard that owns each
+    voices = sample_voices(n, 96)
+    shards = [cl.shard(s) for s in range(cl.num_shards)]
+    owned = []
+    for sh in shards:
+        mine = voices[(voices >= sh.first_voice) & (voices < sh.first_voice + sh.n_voices)]
+        sh.set_voice_taps((mine - sh.first_voice).astype(np.uint32))
+        owned.append(mine)
+    bus, taps = [], [[] for _ in shards]
+    for _ in range(total // block):
+        bus.append(cl.process_block(block).copy())
+        for k, sh in enumerate(shards):
+            if len(owned[k]):
+                taps[k].append(sh.read_voice_taps(block))
+    bus = np.concatenate(bus, axis=0)
+    assert cl.rccl_reduces > 0  # the RCCL leg really ran: one reduce per launch batch over the devices' communicator
+    # (1) sampled voices of every shard against the oracle
+    got = np.concatenate([np.concatenate(t, axis=1) for t in taps if t], axis=0)
+    ref = oracle_taps(kind, np.concatenate([o for o in owned if len(o)]), total, block)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert float(err.max()) <= 1e-5, float(err.max())
+    # (2) the reduced bus against the oracle's f64 sum over ALL voices (the e-piano through the Tremolo pan sequence,
+    #     which runs once on the root after the reduce)
+    mono, abs_sum, _ = ol.render_mt(kind, 0, n, total, block=block, group=8, seed=oscen_amd.SYNTH_SEED, span=total)
+    if graph == "epiano_voice":
+        pan = ol.tremolo_pan(total, 5.0, 0.3, SR).astype(np.float64)
+        want, scale = mono[:, None] * pan, abs_sum[:, None] * np.ones((1, 2))
+    else:
+        want, scale = mono[:, None], abs_sum[:, None]
+    assert bus.shape == want.shape
+    diff = np.abs(bus.astype(np.float64) - want)
+    assert np.all(diff <= 2e-6 * scale + 1e-5), float((diff / (scale + 1e-30)).max())
+    assert np.abs(want).max() > 1.0
+    # (3) the batched render (one ncclReduce for all blocks) gives the same bus as block by block
+    cl2 = oscen_amd.Cluster(graph, n, devs, sample_rate=SR)
+    oscen_amd.schedule_note_plans(cl2, plans, total_frames=total)
+    bus2 = cl2.render(total, block=block)
+    assert cl2.rccl_reduces == 1
+    assert np.array_equal(bus2, bus)
+
+
+def test_stereo_voice_outputs_through_the_cluster(monkeypatch):
+    """a graph whose stream output is fed a Frame<2> (per-voice pan): the shards hand over interleaved L R sums, the
+    reduce covers both channels"""
+    monkeypatch.setenv("OSCEN_GPU_FORCE_RCCL", "1")
+    n, total, block = 1500, 768, 256
+    oscen_amd.register_node(
+        "ClPan::new", inputs=[("input", "stream", 0.0, -1), ("pan", "value", 0.5, -1)], outputs=[("output", 2)],
+        process="    output.v[0] = input * (1.0f - pan);\n    output.v[1] = input * pan;\n")
+    try:
+        g = oscen_amd.Graph("cl_panned")
+        g.input_value("frequency", 220.0, per_voice=True)
+        g.input_value("pan", 0.5, per_voice=True)
+        g.input_event("gate")
+        g.output_stream("out")
+        g.node("osc", "PolyBlepOscillator::saw", 220.0, 0.25)
+        g.node("env", "AdsrEnvelope::new", 0.005, 0.05, 0.7, 0.05)
+        g.node("p", "ClPan::new")
+        g.connect("frequency", "osc.frequency")
+        g.connect("gate", "env.gate")
+        g.connect("pan", "p.pan")
+        g.connect("osc.output * env.output", "p.input")
+        g.connect("p.output", "out")
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        cl = oscen_amd.Cluster(g, n, [0, 0, 0], sample_rate=SR)
+        assert cl.channels == 2 and eng.channels == 2
+        f = np.linspace(110.0, 1760.0, n).astype(np.float32)
+        pan = np.linspace(0.0, 1.0, n).astype(np.float32)
+        for x in (eng, cl):
+            x.set_voice_values("frequency", f)
+            x.set_voice_values("pan", pan)
+            x.schedule_voice_events("gate", np.arange(n), 3 + np.arange(n) % 50, np.full(n, 0.8, np.float32))
+        want = eng.render(total, block=block)
+        got = cl.render(total, block=block)
+        assert cl.rccl_reduces == 1
+        assert got.shape == want.shape == (total, 2)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.max(np.abs(got - want)) <= 1e-4 * scale
+        assert np.abs(want[:, 0]).max() > 1e-2 and np.abs(want[:, 0] - want[:, 1]).max() > 1e-3
+        per_block = oscen_amd.Cluster(g, n, [0, 0], sample_rate=SR)
+        per_block.set_voice_values("frequency", f)
+        per_block.set_voice_values("pan", pan)
+        per_block.schedule_voice_events("gate", np.arange(n), 3 + np.arange(n) % 50, np.full(n, 0.8, np.float32))
+        pb = np.concatenate([per_block.process_block(block) for _ in range(total // block)], axis=0)
+        assert np.max(np.abs(pb - want)) <= 1e-4 * scale
+    finally:
+        oscen_amd.unregister_node("ClPan::new")

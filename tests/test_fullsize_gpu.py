@@ -145,3 +145,100 @@ def test_every_kernel_variant_is_bit_identical_at_full_size(graph, n, total):
     assert np.array_equal(tp_a, tp_0) and np.array_equal(tp_a, tp_2)
     assert np.array_equal(bus_a, bus_0) and np.array_equal(bus_a, bus_2)
     assert np.abs(bus_a).max() > 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The path bench.py TIMES (og_process_block_async into a device buffer, the engine's own blocks-per-launch pick,
+# og_flush) against the path the oracle comparisons above use (blocking og_process_block with taps, one launch per
+# block): the bus bit for bit, and -- taps would force a launch per block -- the complete DSP state after the run bit
+# for bit (every state word of every voice: two voices that end a render in the same state after producing the same
+# bus took the same trajectory), plus the bus against the oracle's f64 sum.
+# ---------------------------------------------------------------------------------------------------------------
+def dsp_state(eng):
+    import ctypes as C
+
+    blob = eng.save_state()
+    words = eng.state_words_per_voice
+    return blob[: words * eng.n_voices * 4].copy()
+
+
+def render_as_bench_does(graph, n, total, block, batch, env=None):
+    """bench.py:step/flush: async blocks into one device tensor on torch's current stream, `batch` blocks per launch
+    (0 = the engine's pick), flushed once at the end"""
+    import torch
+
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        eng = oscen_amd.Engine(graph, n, sample_rate=SR)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    plans = oscen_amd.note_plans(n, span=total)
+    oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if batch != 1:
+        eng.set_bus_batching(batch)
+    ch = eng.channels
+    nb = total // block
+    bus = torch.zeros((nb, block * ch), dtype=torch.float32, device="cuda")
+    eng.enable_kernel_timing(True)
+    for i in range(nb):
+        eng.process_block_async(block, bus.data_ptr() + i * block * ch * 4)
+    eng.flush()
+    torch.cuda.synchronize()
+    _, launches = eng.kernel_time_ms()
+    out = bus.cpu().numpy().reshape(total, ch)
+    state = dsp_state(eng)
+    info = {"launches": launches, "depth": eng.pipeline_depth, "variant": eng.kernel_variant}
+    eng.close()
+    return out, state, info
+
+
+def render_blocking_with_taps(graph, n, total, block, taps):
+    eng = oscen_amd.Engine(graph, n, sample_rate=SR)
+    plans = oscen_amd.note_plans(n, span=total)
+    oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+    eng.set_voice_taps(taps)
+    bus, tp = [], []
+    for _ in range(total // block):
+        bus.append(eng.process_block(block).copy())
+        tp.append(eng.read_voice_taps(block))
+    state = dsp_state(eng)
+    eng.close()
+    return np.concatenate(bus, axis=0), np.concatenate(tp, axis=1), state
+
+
+@pytest.mark.parametrize("graph,kind,n,blocks,expect_batch", [("fm_voice", ol.BANK_FM, 65536, 40, 32), ("fm_voice", ol.BANK_FM, 262144, 20, 8)],
+                         ids=["fm65536", "fm262144"])
+def test_the_timed_path_equals_the_checked_path_bit_for_bit(graph, kind, n, blocks, expect_batch):
+    block = 256
+    total = blocks * block
+    taps = sample_voices(n, 64)
+    # the checked path: blocking, one launch per block, sampled voices against the oracle
+    bus_ref, tp, state_ref = render_blocking_with_taps(graph, n, total, block, taps)
+    ref = oracle_taps(kind, taps, total, block)
+    err = np.abs(tp - ref) / np.maximum(1.0, np.abs(ref))
+    assert float(err.max()) <= TOL, float(err.max())
+    # the timed path: the engine's own blocks-per-launch pick, the pick's pipelined kernel and the ordinary kernel
+    for env, want_depth in ((None, None), ({"OSCEN_GPU_SPLIT": "0"}, 1), ({"OSCEN_GPU_SPLIT": "2"}, 2)):
+        bus, state, info = render_as_bench_does(graph, n, total, block, 0, env=env)
+        assert info["launches"] == -(-blocks // expect_batch), info   # ceil(blocks / the engine's pick)
+        if want_depth is not None:
+            assert info["depth"] == want_depth, info
+        assert np.array_equal(bus, bus_ref), (info, float(np.abs(bus - bus_ref).max()))
+        assert np.array_equal(state, state_ref), info
+    # and a launch per block through the async entry
+    bus1, state1, info1 = render_as_bench_does(graph, n, total, block, 1)
+    assert info1["launches"] == blocks
+    assert np.array_equal(bus1, bus_ref) and np.array_equal(state1, state_ref)
+    # the whole bus of the timed path against the oracle's f64 sum
+    mono, abs_sum, _ = ol.render_mt(kind, 0, n, total, block=block, group=8, seed=oscen_amd.SYNTH_SEED, span=total)
+    diff = np.abs(bus_ref[:, 0].astype(np.float64) - mono)
+    assert np.all(diff <= 2e-6 * abs_sum + 1e-5), float((diff / (abs_sum + 1e-30)).max())
+    assert np.abs(mono).max() > 1.0
