@@ -241,6 +241,7 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device)
                 peak = max(peak, float(np.abs(bus).max()))
         calls, timeouts = eng.blocking_stats
         lat_ms = lat * 1e3
+        worst = np.argsort(lat_ms)[-5:][::-1]
         rec = {
             "voices": V,
             "blocks": n_blocks,
@@ -251,6 +252,8 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device)
             "deadline_misses": int(np.count_nonzero(lat_ms > deadline_ms)),
             "value_blocking": V * block / float(lat.mean()),
             "marker_timeouts": timeouts,
+            "worst_blocks": [[int(i), float(lat_ms[i])] for i in worst],
+            "event_stats": eng.event_stats,
             "bus_peak": peak,
             "kernel_variant": eng.kernel_variant,
         }

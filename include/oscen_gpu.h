@@ -278,6 +278,9 @@ uint32_t og_partial_rows(const og_engine* e);   /* partial bus rows one launch w
 uint32_t og_bus_reduce_passes(const og_engine* e);
 /* event-path counters: full timeline rebuilds, incremental (per-voice segment) updates, events resident */
 int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* incremental_updates, uint64_t* resident_events);
+/* times the live path's append pointer wrapped around the device event buffer (a ring: the space of consumed /
+ * superseded segments is reused, so steady live playing never needs the O(V) timeline rebuild) */
+uint64_t og_event_ring_wraps(const og_engine* e);
 /* the blocking entry (og_process_block / og_midi_process_block): calls that waited on the completion word, and how
  * many of those waits ran into the 20 ms fallback (a stream synchronise) -- 0 unless a block is slower than that */
 int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_timeouts);
@@ -340,6 +343,10 @@ og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice);
  * object runs detached over n_voices and logs what the voices would receive (og_midi_pop_output). */
 typedef struct og_midi og_midi;
 int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input, const char* gate_input, og_midi** out);
+/* The same front end in front of a multi-GPU bank: one allocator over the cluster's GLOBAL voice ids (N = the whole
+ * bank, the decisions of voice_allocator.rs:57-136 for a single bank of that size), every per-voice message routed
+ * to the shard that owns the voice; og_midi_process_block = flush + og_cluster_process_block. */
+int og_midi_create_cluster(og_cluster* c, const char* frequency_input, const char* gate_input, og_midi** out);
 void og_midi_destroy(og_midi* m);
 /* MidiVoiceHandler::midi_note_to_freq (midi.rs:69-72): 440 * 2^((note - 69) / 12) in f32 through the platform powf */
 float og_midi_note_to_freq(uint8_t note);

@@ -22,6 +22,7 @@
 
 struct og_midi {
     og_engine* engine = nullptr;
+    og_cluster* cluster = nullptr; // or: a multi-GPU bank (voices = GLOBAL voice ids, routed to their shard by the cluster)
     uint32_t n = 0;
     int freq_input = -1, gate_input = -1;
     struct Voice {
@@ -159,6 +160,12 @@ struct og_midi {
             const int rc2 = og_push_voice_event(engine, (uint32_t)gate_input, voice, frame, gate);
             if (rc == OG_OK) rc = rc2;
             if (rc != OG_OK && last_rc == OG_OK) last_rc = rc;
+        } else if (cluster) {
+            int rc = OG_OK;
+            if (has_f) rc = og_cluster_push_voice_value(cluster, (uint32_t)freq_input, voice, frame, f);
+            const int rc2 = og_cluster_push_voice_event(cluster, (uint32_t)gate_input, voice, frame, gate);
+            if (rc == OG_OK) rc = rc2;
+            if (rc != OG_OK && last_rc == OG_OK) last_rc = rc;
         } else {
             log.push_back(Out{voice, frame, f, gate, has_f ? 1 : 0});
             if (log.size() > 65536) log.pop_front();
@@ -248,6 +255,27 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
     return OG_OK;
 }
 
+// The same front end over a multi-GPU bank: ONE allocator over the cluster's global voice ids (the LRU / stealing
+// decisions are those of a single bank of that size), every voice message routed to the shard that owns the voice.
+int og_midi_create_cluster(og_cluster* c, const char* frequency_input, const char* gate_input, og_midi** out)
+{
+    if (!out || !c) return OG_E_INVALID;
+    if (og_cluster_num_voices(c) > 0xFFFFFFFFull) return OG_E_UNSUPPORTED; // (voice ids of the allocator are 32-bit)
+    og_midi* m = new og_midi;
+    m->cluster = c;
+    m->n = (uint32_t)og_cluster_num_voices(c);
+    m->freq_input = og_cluster_input_index(c, frequency_input ? frequency_input : "frequency");
+    m->gate_input = og_cluster_input_index(c, gate_input ? gate_input : "gate");
+    if (m->freq_input < 0 || m->gate_input < 0 || m->n == 0) {
+        delete m;
+        return OG_E_INVALID;
+    }
+    m->voices.resize(m->n);
+    m->queue_cap = 32u * ((m->n + 23u) / 24u);
+    *out = m;
+    return OG_OK;
+}
+
 void og_midi_destroy(og_midi* m)
 {
     if (m && m->prof_on && m->prof_calls)
@@ -307,15 +335,16 @@ int og_midi_flush(og_midi* m)
 
 int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus)
 {
-    if (!m || !m->engine) return OG_E_INVALID;
+    if (!m || (!m->engine && !m->cluster)) return OG_E_INVALID;
     m->last_rc = OG_OK;
     m->flush(frames);
-    const int rc = og_process_block(m->engine, frames, out_bus);
+    const int rc = m->engine ? og_process_block(m->engine, frames, out_bus) : og_cluster_process_block(m->cluster, frames, out_bus);
     return rc != OG_OK ? rc : m->last_rc; // the block was rendered; a non-zero code reports a dropped event
 }
 
 int og_midi_process_block_async(og_midi* m, uint32_t frames, float* d_out_bus)
 {
+    if (m && m->cluster) return OG_E_UNSUPPORTED; // (a cluster's bus is complete only after the cross-device reduce)
     if (!m || !m->engine) return OG_E_INVALID;
     m->last_rc = OG_OK;
     m->flush(frames);

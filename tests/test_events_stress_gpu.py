@@ -1,6 +1,6 @@
 """The live event path under stress: the same score reaches three engines in three ways -- (A) scheduled in bulk up
 front (one timeline rebuild), (B) pushed block by block with try_push semantics plus events scheduled a few blocks
-ahead (incremental per-voice segments, with the head-room shrunk so that the timeline is compacted many times), (C) as
+ahead (incremental per-voice segments, with the head-room shrunk so that the event ring wraps many times), (C) as
 (B) on the asynchronous entry with the block queue on (pushes force queue launches).  All three must agree bit for bit
 with each other (state snapshot and final bus) and with the CPU oracle."""
 import os
@@ -81,11 +81,14 @@ def test_bulk_incremental_and_queued_event_paths_agree(n, monkeypatch):
                 e.process_block(block)
         return e.process_block(64), e.save_state()
 
-    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "4096")  # many compactions (full rebuilds that merge old + new)
+    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "4096")  # a small ring: many wraps (and merges of old + new events)
     bmode = engine()
     bus_b, state_b = live(bmode, queued=False)
     stats = bmode.event_stats
-    assert stats["incremental_updates"] > blocks // 2 and stats["full_rebuilds"] >= (2 if n > 1000 else 1), stats
+    # the device event buffer is a ring: with the head-room shrunk the append pointer wraps into the space of consumed /
+    # superseded segments instead of rebuilding the whole timeline
+    assert stats["incremental_updates"] > blocks // 2 and stats["full_rebuilds"] >= 1, stats
+    assert stats["ring_wraps"] >= (1 if n > 1000 else 0), stats
     c = engine()
     bus_c, state_c = live(c, queued=True)
     monkeypatch.delenv("OSCEN_GPU_EV_HEADROOM")

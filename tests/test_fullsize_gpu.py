@@ -228,7 +228,9 @@ def test_the_timed_path_equals_the_checked_path_bit_for_bit(graph, kind, n, bloc
     # the timed path: the engine's own blocks-per-launch pick, the pick's pipelined kernel and the ordinary kernel
     for env, want_depth in ((None, None), ({"OSCEN_GPU_SPLIT": "0"}, 1), ({"OSCEN_GPU_SPLIT": "2"}, 2)):
         bus, state, info = render_as_bench_does(graph, n, total, block, 0, env=env)
-        assert info["launches"] == -(-blocks // expect_batch), info   # ceil(blocks / the engine's pick)
+        # ceil(blocks / the engine's pick) launches, + 1: the bulk score waiting on the host makes the first block
+        # launch on its own (og_engine.cpp process_async: pending events are uploaded before they outgrow the staging)
+        assert -(-blocks // expect_batch) <= info["launches"] <= -(-blocks // expect_batch) + 1, info
         if want_depth is not None:
             assert info["depth"] == want_depth, info
         assert np.array_equal(bus, bus_ref), (info, float(np.abs(bus - bus_ref).max()))
