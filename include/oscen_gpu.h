@@ -145,6 +145,19 @@ int og_graph_connect_via(og_graph_desc* g, const char* src_expr, const char* via
  * per_voice_inputs: comma-separated value inputs the poly wrapper feeds per voice
  * (e.g. "frequency"); may be NULL. */
 int og_graph_parse(const char* dsl_text, const char* per_voice_inputs, og_graph_desc** out);
+/* POLY WRAPPER graphs (examples/fm-synth/src/lib.rs:22-131, examples/electric-piano/src/main.rs:33-97) go through
+ * og_graph_parse / og_create as written: `midi_parser = MidiParser::new(); voice_allocator = VoiceAllocator::<N>::new();
+ * voice_handlers = [MidiVoiceHandler::new(); N]; voices = [Voice::new(); N];` plus an optional node fed by the voice
+ * sum.  The three MIDI node kinds are this library's host-side front end (og_midi_*), `voices` is the bank (its size
+ * is og_create's n_voices, not the N of the text), `voices.out -> out` the mix bus, the node after the sum the
+ * post-mix stage.  The engine's inputs are: the voice input MidiVoiceHandler.frequency feeds (per voice), the one its
+ * gate feeds (event), then the wrapper's value inputs with their defaults and [ramp: N] specs; the raw-MIDI event
+ * input is served by og_midi_send.  The voice type must be a graph type: registered with og_register_graph_type, or
+ * one of the built-in FMVoice / ElectricPianoVoiceNode.  Event outputs fed by the MIDI nodes (`midi_parser.note_on ->
+ * note_on_out`) are host-side events and are not lowered.
+ * og_graph_poly_info: 1 if `g` is such a wrapper (0 if not, < 0 on a malformed one), the N it declares, and the names
+ * of the per-voice frequency and gate inputs to hand to og_midi_create. */
+int og_graph_poly_info(const og_graph_desc* g, uint32_t* declared_voices, char* frequency_input, char* gate_input, size_t cap);
 /* Print a description back as DSL text; returns the length, copies at most cap-1 bytes. */
 int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap);
 void og_graph_free(og_graph_desc* g);

@@ -1,6 +1,7 @@
 // og_builtin.cpp -- builder-form descriptions of the reference graphs in scope.
 // These are the graphs whose kernels are compiled ahead of time into the
 // library; any other description goes through the same compiler at og_create().
+#include <map>
 #include <stdexcept>
 
 #include "og_graph.h"
@@ -230,6 +231,40 @@ GraphDesc epiano_voice()
 }
 
 } // namespace
+
+// The voice graphs by themselves, as the example crates declare them (no wrapper: `frequency` is an ordinary value
+// input, nothing is ramped, no post-mix stage) -- what `voices = [FMVoice::new(); 8]` names.
+std::map<std::string, GraphDesc> builtin_voice_graph_types()
+{
+    std::map<std::string, GraphDesc> R;
+    {
+        GraphDesc v = fm_voice();
+        v.name = "FMVoice";
+        for (GInput& in : v.inputs) {
+            in.per_voice = false;
+            in.ramp_frames = 0;
+        }
+        R["FMVoice"] = v;
+    }
+    {
+        GraphDesc w = epiano_voice(), v;
+        v.name = "ElectricPianoVoiceNode";
+        for (GInput in : w.inputs) {
+            if (in.name == "vibrato_intensity" || in.name == "vibrato_speed") continue; // (the wrapper's Tremolo parameters)
+            in.per_voice = false;
+            v.inputs.push_back(in);
+        }
+        v.outputs.push_back({"output", Kind::Stream});
+        for (const GNode& n : w.nodes)
+            if (!n.bus) v.nodes.push_back(n);
+        for (const GEdge& e : w.edges)
+            if (e.src.find("tremolo") == std::string::npos && e.dst.find("tremolo") == std::string::npos && e.src != "output" &&
+                e.src != "vibrato_intensity" && e.src != "vibrato_speed")
+                v.edges.push_back(e);
+        R["ElectricPianoVoiceNode"] = v;
+    }
+    return R;
+}
 
 std::vector<std::string> builtin_graph_names() { return {"fm_voice", "sub_voice", "sat4x_voice", "sat1x_voice", "epiano_voice", "echo_voice"}; }
 

@@ -232,6 +232,7 @@ void parse_output(Lexer& lx, GraphDesc& g)
         else if (ty == "Quad") o.channels = 4;
         else if (ty == "f32" || ty == "Mono") o.channels = 1;
         else if (ty.rfind("Frame<", 0) == 0) o.channels = atoi(ty.c_str() + 6);
+        else if (ty.rfind("[f32;", 0) == 0 && ty.back() == ']') o.channels = atoi(ty.c_str() + 5); // `[f32; N]` = N channels
         else dfail("output '" + name + "': unknown stream type '" + ty + "'", lx.line);
     }
     lx.expect(';');
@@ -264,6 +265,7 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
                 generic = generic.substr(1, generic.size() - 2);
                 lx.skip();
                 if (lx.i + 1 < lx.s.size() && lx.s[lx.i] == ':' && lx.s[lx.i + 1] == ':') lx.i += 2;
+                else break; // `VoiceAllocator::<4>;`: a bare generic type (= Type::<4>::new())
             }
             continue;
         }
@@ -276,13 +278,56 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
         lx.expect('(');
         if (lx.peek() != ')') {
             for (;;) {
-                n.args.push_back(lx.number());
+                // one argument: a number; `Frame([a, b, ..])` (a frame literal: its channels, in order); or any other
+                // Rust expression, kept as text
+                std::string raw = lx.until(",");
+                Lexer al(raw);
+                std::vector<float> vals;
+                bool numeric = false;
+                try {
+                    if (al.peek_ident("Frame")) {
+                        al.ident();
+                        al.expect('(');
+                        al.expect('[');
+                        for (;;) {
+                            vals.push_back(al.number());
+                            if (al.eat(';')) { // `[x; N]`
+                                const float rep = al.number();
+                                const float x = vals.back();
+                                vals.pop_back();
+                                for (int k = 0; k < (int)rep; ++k) vals.push_back(x);
+                                break;
+                            }
+                            if (!al.eat(',')) break;
+                        }
+                        al.expect(']');
+                        al.expect(')');
+                        numeric = al.eof();
+                    } else {
+                        vals.push_back(al.number());
+                        numeric = al.eof();
+                    }
+                } catch (const std::exception&) {
+                    numeric = false;
+                }
+                if (numeric) {
+                    for (float v : vals) {
+                        n.args.push_back(v);
+                        if (!n.raw_args.empty()) n.raw_args.push_back("");
+                    }
+                } else {
+                    if (raw.empty()) dfail("empty constructor argument", lx.line);
+                    if (n.raw_args.empty()) n.raw_args.assign(n.args.size(), "");
+                    n.args.push_back(0.0f);
+                    n.raw_args.push_back(raw);
+                }
                 if (!lx.eat(',')) break;
             }
         }
         lx.expect(')');
     } else { // bare `Type` (a unit struct or a nested graph type: `inner = InnerGraph;`) = Type::new()
         n.type = segs.back() + "::new";
+        if (!generic.empty()) n.type = normalize_type(segs.back() + "::<" + generic + ">::new");
     }
     if (is_array) {
         lx.expect(';');
@@ -456,7 +501,8 @@ std::string to_dsl(const GraphDesc& g)
         if (lt != std::string::npos && gt != std::string::npos && lt < gt)
             ty = ty.substr(0, lt) + "::<Frame<" + ty.substr(lt + 1, gt - lt - 1) + ">>" + ty.substr(gt + 1);
         o << "    " << n.name << " = " << (n.array_len ? "[" : "") << ty << "(";
-        for (size_t i = 0; i < n.args.size(); ++i) o << (i ? ", " : "") << num(n.args[i]);
+        for (size_t i = 0; i < n.args.size(); ++i)
+            o << (i ? ", " : "") << (i < n.raw_args.size() && !n.raw_args[i].empty() ? n.raw_args[i] : num(n.args[i]));
         o << ")";
         if (n.array_len) o << "; " << n.array_len << "]";
         if (n.rate_factor > 1) o << " * " << n.rate_factor;

@@ -1267,6 +1267,28 @@ int og_graph_parse(const char* dsl_text, const char* per_voice_inputs, og_graph_
     });
 }
 
+int og_graph_poly_info(const og_graph_desc* g, uint32_t* declared_voices, char* frequency_input, char* gate_input, size_t cap)
+{
+    if (!g) return set_err(OG_E_INVALID, "null graph");
+    int is_wrapper = 0;
+    int rc = guard([&] {
+        ogc::PolyInfo pi;
+        (void)ogc::lower_poly_wrapper(g->g, &pi);
+        is_wrapper = pi.is_wrapper ? 1 : 0;
+        if (declared_voices) *declared_voices = pi.declared_voices;
+        auto put = [&](char* dst, const std::string& s) {
+            if (!dst || !cap) return;
+            const size_t n = std::min(cap - 1, s.size());
+            memcpy(dst, s.data(), n);
+            dst[n] = 0;
+        };
+        put(frequency_input, pi.frequency_input);
+        put(gate_input, pi.gate_input);
+        return OG_OK;
+    });
+    return rc == OG_OK ? is_wrapper : rc;
+}
+
 int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap)
 {
     if (!g) return set_err(OG_E_INVALID, "null graph");

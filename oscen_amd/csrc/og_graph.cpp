@@ -283,6 +283,7 @@ struct Codegen {
     CompiledGraph& out;
     std::vector<NodeInst> nodes;
     std::map<std::string, int> node_by_name, input_by_name, output_by_name;
+    std::map<std::string, Val> output_vals; // graph outputs that other outputs read: their value on the current frame
     std::map<std::string, Val> node_outputs; // "n<id>.<port>" -> value
     std::set<std::string> fb_sources;            // "n<id>.<port>" fed into a feedback edge
     std::map<std::string, std::string> fb_vars;  // ... -> state variable holding last frame's value
@@ -396,11 +397,20 @@ struct Codegen {
     Val cross(Val v, const std::string& policy, bool dst_inner, bool value_port)
     {
         if (v.is_frame()) {
-            for (const Val& c : v.ch)
-                if (N > 1 && c.inner != dst_inner)
-                    fail("a Frame<N> edge cannot cross a rate boundary in this version (resample the channels separately)");
-            if (!policy.empty()) fail("connection policy [" + policy + "] on a Frame<N> edge");
-            return v;
+            // The reference's resamplers are generic over F: AudioFrame and work channel by channel with one state per
+            // channel (resample/sinc_fir.rs:96-144; `Frame<2>` == scalar per channel, tests/resample_kernels.rs:475-626):
+            // a frame edge crosses a rate boundary as its channels do.  The edge's latency counts once.
+            Val r;
+            r.rate = Rate::Vary;
+            const uint32_t lat0 = out.latency_samples;
+            uint32_t lat1 = lat0;
+            for (const Val& c : v.ch) {
+                out.latency_samples = lat0;
+                r.ch.push_back(cross(c, policy, dst_inner, value_port));
+                lat1 = std::max(lat1, out.latency_samples);
+            }
+            out.latency_samples = lat1;
+            return r;
         }
         if (N <= 1 || v.inner == dst_inner) {
             if (!policy.empty() && v.rate == Rate::Vary && N <= 1)
@@ -586,8 +596,14 @@ struct Codegen {
         case Expr::Ref: {
             if (e->port.empty()) {
                 auto it = input_by_name.find(e->node);
-                if (it == input_by_name.end()) fail("unknown source '" + e->node + "'");
-                return input_val(it->second);
+                if (it != input_by_name.end()) return input_val(it->second);
+                // a graph OUTPUT read as a source (`out_a + out_b -> out`, tests/multirate_graph.rs:444-458): the value
+                // this frame's edges put into it
+                auto ov = output_vals.find(e->node);
+                if (ov != output_vals.end()) return ov->second;
+                if (output_by_name.count(e->node))
+                    fail("graph output '" + e->node + "' is read before it is formed (only another graph output may read it)");
+                fail("unknown source '" + e->node + "'");
             }
             auto nit = node_by_name.find(e->node);
             if (nit == node_by_name.end()) fail("unknown node '" + e->node + "'");
@@ -1486,7 +1502,9 @@ int user_weight(const std::string& type)
 // ---- node arrays and nested graphs: desugared before lowering ------------------------------------------
 std::map<std::string, GraphDesc>& graph_types()
 {
-    static std::map<std::string, GraphDesc> R;
+    // starts out with the reference's own voice graphs (og_builtin.cpp), so that the example crates' poly wrappers
+    // (`voices = [FMVoice::new(); 8]`) lower without registration; og_register_graph_type may replace them
+    static std::map<std::string, GraphDesc> R = builtin_voice_graph_types();
     return R;
 }
 
@@ -1695,8 +1713,14 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
     for (const GNode& n : g.nodes) {
         const GraphDesc* t = type_of(n);
         if (!t) continue;
-        if (n.rate_factor != 1) fail("nested graph '" + n.name + "' cannot be oversampled as a whole; mark its nodes instead");
         subs[n.name].g = expand_nested(expand_arrays(*t), depth + 1);
+        if (n.rate_factor != 1) { // `inner = InnerGraph::new() * 2`: every node of the nested graph runs at that rate
+            for (GNode& in : subs[n.name].g.nodes) {
+                if (in.rate_factor != 1)
+                    fail("nested graph '" + n.name + "' is oversampled as a whole and has oversampled nodes of its own ('" + in.name + "')");
+                in.rate_factor = n.rate_factor;
+            }
+        }
     }
     // outer edges into sub-graph inputs
     std::vector<GEdge> outer;
@@ -1720,7 +1744,7 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
             continue;
         }
         Sub& sb = sit->second;
-        const std::string pre = n.name + "_";
+        const std::string pre = n.inline_bare ? std::string() : n.name + "_";
         std::map<std::string, const GInput*> inner_in;
         for (const GInput& in : sb.g.inputs) inner_in[in.name] = &in;
         std::map<std::string, bool> inner_node;
@@ -1884,7 +1908,207 @@ GraphDesc expand_passthrough(const GraphDesc& g)
     fail("event passthrough chain too long");
 }
 
-GraphDesc expand(const GraphDesc& g) { return expand_passthrough(expand_nested(expand_arrays(g), 0)); }
+// ---- poly wrapper graphs -----------------------------------------------------------------------------------
+// `midi_parser = MidiParser::new(); voice_allocator = VoiceAllocator::<N>::new(); voice_handlers =
+// [MidiVoiceHandler::new(); N]; voices = [Voice::new(); N]; [tremolo = Tremolo::new();]` with the wiring of
+// examples/fm-synth/src/lib.rs:68-131 / examples/electric-piano/src/main.rs:52-96.  On this engine the three MIDI
+// node kinds are the host-side front end (og_midi_*: same parser / allocator / handler decisions, N = the bank size),
+// the voice array IS the bank, `voices.out -> out` is the mix bus and a node fed by the voice sum is the post-mix
+// stage.  The description is rewritten into the voice-bank graph the engine runs:
+//   inputs   <handler.frequency target> (per voice), <handler.gate target> (event), then the wrapper's value inputs
+//            (defaults and [ramp: N] kept); the raw-MIDI event input is dropped (og_midi_send takes its place)
+//   nodes    the voice graph's own nodes under their own names (prefixed with `<array>_` only if a name collides),
+//            wrapper parameters wired to the voice inputs exactly as `param -> voices.param` says
+//   outputs  the wrapper's stream outputs; with a post-mix node also the voice graph's output (the summed voices)
+namespace {
+std::string strip_ws(std::string t)
+{
+    t.erase(std::remove_if(t.begin(), t.end(), [](char ch) { return isspace((unsigned char)ch); }), t.end());
+    return t;
+}
+bool type_is(const GNode& n, const char* base)
+{
+    const std::string t = n.type;
+    const size_t len = strlen(base);
+    return t.compare(0, len, base) == 0 && (t.size() == len || t[len] == ':' || t[len] == '<');
+}
+} // namespace
+
+GraphDesc lower_poly_wrapper(const GraphDesc& g, PolyInfo* info)
+{
+    const GNode *parser = nullptr, *alloc = nullptr, *handlers = nullptr;
+    for (const GNode& n : g.nodes) {
+        if (type_is(n, "MidiParser")) parser = &n;
+        else if (type_is(n, "VoiceAllocator")) alloc = &n;
+        else if (type_is(n, "MidiVoiceHandler")) handlers = &n;
+    }
+    if (!parser && !alloc && !handlers) return g;
+    if (!handlers) fail("poly wrapper: MidiParser / VoiceAllocator without a [MidiVoiceHandler::new(); N] array");
+    std::set<std::string> control;
+    for (const GNode* n : {parser, alloc, handlers})
+        if (n) control.insert(n->name);
+    auto root = [](const std::string& s) {
+        const std::string t = strip_ws(s);
+        return t.substr(0, t.find_first_of(".[("));
+    };
+    auto port = [](const std::string& s) {
+        const std::string t = strip_ws(s);
+        const size_t d = t.find('.');
+        if (d == std::string::npos) return std::string();
+        std::string p = t.substr(d + 1);
+        const size_t par = p.find('(');
+        return par == std::string::npos ? p : p.substr(0, par);
+    };
+    // the voice array: what the handlers' frequency / gate outputs feed
+    std::string voices, freq_in, gate_in;
+    for (const GEdge& e : g.edges) {
+        if (root(e.src) != handlers->name) continue;
+        const std::string sp = port(e.src), dn = root(e.dst), dp = port(e.dst);
+        if (control.count(dn)) continue;
+        if (sp == "frequency") {
+            voices = voices.empty() ? dn : voices;
+            freq_in = dp;
+        } else if (sp == "gate") {
+            voices = voices.empty() ? dn : voices;
+            gate_in = dp;
+        } else {
+            fail("poly wrapper: MidiVoiceHandler has the outputs 'frequency' and 'gate' ('" + e.src + "')");
+        }
+        if (dn != voices) fail("poly wrapper: the voice handlers feed more than one node array ('" + dn + "' and '" + voices + "')");
+    }
+    if (voices.empty() || gate_in.empty())
+        fail("poly wrapper: `" + handlers->name + ".gate -> <voices>.<gate input>` is missing");
+    const GNode* varr = nullptr;
+    for (const GNode& n : g.nodes)
+        if (n.name == voices) varr = &n;
+    if (!varr) fail("poly wrapper: unknown node '" + voices + "'");
+    std::string vtype = varr->type;
+    if (vtype.size() > 5 && vtype.compare(vtype.size() - 5, 5, "::new") == 0) vtype.erase(vtype.size() - 5);
+    auto git = graph_types().find(vtype);
+    if (git == graph_types().end())
+        fail("poly wrapper: the voice type '" + vtype + "' is not a graph type (register the voice graph with og_register_graph_type, "
+             "or use the built-in FMVoice / ElectricPianoVoiceNode)");
+    const GraphDesc& vt = git->second;
+    if (handlers->array_len && varr->array_len && handlers->array_len != varr->array_len)
+        fail("poly wrapper: " + std::to_string(handlers->array_len) + " voice handlers for " + std::to_string(varr->array_len) + " voices");
+    const GInput *vfreq = nullptr, *vgate = nullptr;
+    for (const GInput& in : vt.inputs) {
+        if (in.name == freq_in) vfreq = &in;
+        if (in.name == gate_in) vgate = &in;
+    }
+    if (!vgate || vgate->kind != Kind::Event) fail("poly wrapper: '" + vtype + "." + gate_in + "' is not an event input");
+    if (!freq_in.empty() && (!vfreq || vfreq->kind != Kind::Value)) fail("poly wrapper: '" + vtype + "." + freq_in + "' is not a value input");
+
+    GraphDesc o;
+    o.name = g.name;
+    PolyInfo pi;
+    pi.is_wrapper = true;
+    pi.declared_voices = varr->array_len ? varr->array_len : 1;
+    pi.voice_type = vtype;
+    pi.frequency_input = freq_in;
+    pi.gate_input = gate_in;
+    // inputs
+    std::set<std::string> taken;
+    if (vfreq) {
+        GInput f = *vfreq;
+        f.per_voice = true;
+        f.ramp_frames = 0;
+        o.inputs.push_back(f);
+        taken.insert(f.name);
+    }
+    {
+        GInput ev = *vgate;
+        o.inputs.push_back(ev);
+        taken.insert(ev.name);
+    }
+    for (const GInput& in : g.inputs) {
+        if (in.kind == Kind::Event) { // the raw MIDI input: every use must be the parser's
+            for (const GEdge& e : g.edges)
+                if (root(e.src) == in.name && !(parser && root(e.dst) == parser->name))
+                    fail("poly wrapper: event input '" + in.name + "' may only feed the MidiParser");
+            pi.midi_input = in.name;
+            continue;
+        }
+        if (taken.count(in.name)) fail("poly wrapper: input '" + in.name + "' collides with the per-voice input of the same name");
+        o.inputs.push_back(in);
+        taken.insert(in.name);
+    }
+    // the voice graph as ONE nested node, inlined under its own node names unless one collides with a wrapper name
+    bool bare = true;
+    for (const GNode& vn : vt.nodes) {
+        if (taken.count(vn.name)) bare = false;
+        for (const GNode& wn : g.nodes)
+            if (!control.count(wn.name) && wn.name != voices && wn.name == vn.name) bare = false;
+        for (const GOutput& wo : g.outputs)
+            if (wo.name == vn.name) bare = false;
+    }
+    GNode vnode;
+    vnode.name = voices;
+    vnode.type = vtype + "::new";
+    vnode.rate_factor = varr->rate_factor;
+    vnode.inline_bare = bare;
+    // a node fed by the voice sum = the post-mix stage
+    std::set<std::string> post;
+    for (const GEdge& e : g.edges)
+        if (root(e.src) == voices && !port(e.dst).empty() && !control.count(root(e.dst)) && root(e.dst) != voices) post.insert(root(e.dst));
+    // outputs: the wrapper's stream outputs; event outputs fed by the MIDI nodes stay on the host
+    std::string sum_output; // graph output that carries the summed voices into the post-mix node
+    std::set<std::string> dropped;
+    for (const GOutput& out : g.outputs) {
+        if (out.kind == Kind::Event) {
+            dropped.insert(out.name);
+            pi.dropped_event_outputs.push_back(out.name);
+        }
+    }
+    for (const GEdge& e : g.edges)
+        if (dropped.count(strip_ws(e.dst)) && !control.count(root(e.src)))
+            fail("poly wrapper: event output '" + e.dst + "' is fed by '" + e.src + "' (only the MIDI nodes' events are kept on the host)");
+    if (!post.empty()) {
+        std::string vout;
+        for (const GEdge& e : g.edges)
+            if (root(e.src) == voices && post.count(root(e.dst))) vout = port(e.src);
+        sum_output = vout;
+        for (const GOutput& out : g.outputs)
+            if (out.name == sum_output) sum_output = "__voice_sum";
+        for (const GNode& vn : vt.nodes)
+            if (bare && vn.name == sum_output) sum_output = "__voice_sum";
+        GOutput so;
+        so.name = sum_output;
+        so.kind = Kind::Stream;
+        o.outputs.push_back(so);
+    }
+    for (const GOutput& out : g.outputs)
+        if (!dropped.count(out.name)) o.outputs.push_back(out);
+    o.nodes.push_back(vnode);
+    for (const GNode& n : g.nodes) {
+        if (control.count(n.name) || n.name == voices) continue;
+        GNode c = n;
+        if (post.count(n.name)) c.bus = true;
+        o.nodes.push_back(c);
+    }
+    // edges
+    if (vfreq) o.edges.push_back({freq_in, voices + "." + freq_in, ""});
+    o.edges.push_back({gate_in, voices + "." + gate_in, ""});
+    bool summed = false;
+    for (const GEdge& e : g.edges) {
+        const std::string sr = root(e.src), dr = root(e.dst);
+        if (control.count(sr) || control.count(dr)) continue;      // MIDI plumbing: host side
+        if (!pi.midi_input.empty() && sr == pi.midi_input) continue;
+        if (dropped.count(strip_ws(e.dst))) continue;
+        GEdge x = e;
+        if (sr == voices && post.count(dr)) { // voices.output -> tremolo.input  ==>  voices.output -> <sum>; <sum> -> tremolo.input
+            if (!summed) o.edges.push_back({strip_ws(e.src), sum_output, e.policy});
+            summed = true;
+            x.src = sum_output;
+            x.policy.clear();
+        }
+        o.edges.push_back(x);
+    }
+    if (info) *info = pi;
+    return o;
+}
+
+GraphDesc expand(const GraphDesc& g) { return expand_passthrough(expand_nested(expand_arrays(lower_poly_wrapper(g)), 0)); }
 
 void register_user_node(const UserNodeType& t)
 {
@@ -1950,7 +2174,16 @@ void register_graph_type(const std::string& name, const GraphDesc& g)
     if (!is_ident(name)) fail("graph type name '" + name + "' is not an identifier");
     graph_types()[name] = g;
 }
-bool unregister_graph_type(const std::string& name) { return graph_types().erase(name) > 0; }
+bool unregister_graph_type(const std::string& name)
+{
+    auto it = graph_types().find(name);
+    if (it == graph_types().end()) return false;
+    const auto builtin = builtin_voice_graph_types(); // a replaced built-in voice type comes back
+    auto b = builtin.find(name);
+    if (b != builtin.end()) it->second = b->second;
+    else graph_types().erase(it);
+    return true;
+}
 
 std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
 {
@@ -1998,6 +2231,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             fail("duplicate name '" + nd.name + "'");
         const NodeTypeInfo* nti = lookup_type(nd.type);
         if (!nti) fail("unknown node type '" + nd.type + "' (node '" + nd.name + "'); custom nodes are added with og_register_node");
+        for (size_t a = 0; a < nd.raw_args.size(); ++a)
+            if (!nd.raw_args[a].empty())
+                fail("node '" + nd.name + "': constructor argument '" + nd.raw_args[a] + "' of " + nd.type + " is not a number");
         if (nd.args.size() != nti->nargs)
             fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(nti->nargs) + " arguments");
         if (nd.rate_factor != 1) { // `* N`, N in {2,4,8} (parse.rs:460-488)
@@ -2031,6 +2267,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::map<int, std::vector<OutEdge>> out_edges; // graph output index -> sources
     std::vector<std::set<int>> deps(g.nodes.size()); // node -> nodes it reads
     std::vector<std::set<int>> out_deps(g.outputs.size());
+    std::vector<std::set<int>> out_reads(g.outputs.size()); // output -> outputs its sources read (`out_a + out_b -> out`)
     std::vector<std::set<int>> fb_deps(g.nodes.size()); // feedback edges: liveness only, no ordering
     bool any_feedback = false;
     cg.emitted.assign(g.nodes.size(), 0);
@@ -2072,13 +2309,18 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         ExprP src = Parser(e.src).parse();
         std::vector<const Expr*> refs;
         collect_refs(src, refs);
-        std::set<int> src_nodes;
+        std::set<int> src_nodes, src_outputs;
         bool src_is_event_input = false, src_is_event_output = false;
         int src_event_input = -1;
         for (const Expr* r : refs) {
             if (r->port.empty()) {
                 auto it = cg.input_by_name.find(r->node);
-                if (it == cg.input_by_name.end()) fail("unknown source '" + r->node + "' in '" + e.src + "'");
+                if (it == cg.input_by_name.end()) {
+                    auto oit = cg.output_by_name.find(r->node);
+                    if (oit == cg.output_by_name.end()) fail("unknown source '" + r->node + "' in '" + e.src + "'");
+                    src_outputs.insert(oit->second);
+                    continue;
+                }
                 if (g.inputs[it->second].kind == Kind::Event) {
                     src_is_event_input = true;
                     src_event_input = out.inputs[it->second].event_index;
@@ -2114,8 +2356,14 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 fail("event outputs of the graph are not supported ('" + e.dst + "'): events stay inside the voice");
             out_edges[oit->second].push_back({src, e.policy});
             out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
+            for (int so : src_outputs) {
+                if (so == oit->second) fail("graph output '" + dn + "' reads itself");
+                out_reads[oit->second].insert(so);
+            }
             continue;
         }
+        if (!src_outputs.empty())
+            fail("a graph output can only be read by another graph output ('" + e.src + " -> " + e.dst + "')");
         auto nit = cg.node_by_name.find(dn);
         if (nit == cg.node_by_name.end()) fail("unknown destination node '" + dn + "'");
         NodeInst& dst = cg.nodes[nit->second];
@@ -2398,12 +2646,34 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     cg.cs = cg.n_stages - 1;
     {
         int n_stream = 0;
-        for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
+        // outputs that other outputs read come first (`[sinc] a.output -> out_a; out_a + out_b -> out`); such an output
+        // is a named per-frame value of the voice, the output nobody reads is the one that goes onto the mix bus
+        std::vector<int> consumed(g.outputs.size(), 0);
+        for (const auto& rd : out_reads)
+            for (int so : rd) consumed[so] = 1;
+        std::vector<size_t> oorder;
+        {
+            std::vector<int> done(g.outputs.size(), 0);
+            for (size_t pass = 0; pass <= g.outputs.size() && oorder.size() < g.outputs.size(); ++pass)
+                for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
+                    if (done[oi]) continue;
+                    bool ready = true;
+                    for (int so : out_reads[oi]) ready = ready && done[so];
+                    if (!ready) continue;
+                    done[oi] = 1;
+                    oorder.push_back(oi);
+                }
+            if (oorder.size() < g.outputs.size()) fail("graph outputs read each other in a cycle");
+        }
+        for (size_t oi : oorder) {
             if (g.outputs[oi].kind == Kind::Event) fail("event outputs are not supported");
             auto it = out_edges.find((int)oi);
-            if (it == out_edges.end()) continue;
+            if (it == out_edges.end()) {
+                if (consumed[oi]) fail("graph output '" + g.outputs[oi].name + "' is read but nothing feeds it");
+                continue;
+            }
             if ((int)oi == bus_final_output) fail("graph output fed by the post-mix node cannot have other sources");
-            if (++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
+            if (!consumed[oi] && ++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
             std::string acc, acc_r;
             bool stereo = false;
             for (size_t k = 0; k < it->second.size(); ++k) {
@@ -2430,6 +2700,24 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (declared && (declared == 2) != stereo)
                 fail("graph output '" + g.outputs[oi].name + "' is declared " + (declared == 2 ? "Frame<2>" : "f32") + " but fed " +
                      (stereo ? "a Frame<2>" : "an f32 stream"));
+            if (consumed[oi]) { // read by another output: a named value of this frame, not the bus
+                const std::string var = "go" + std::to_string(oi);
+                Val ov;
+                ov.rate = Rate::Vary;
+                if (stereo) {
+                    cg.os() << "        const float " << var << "_l = " << acc << ", " << var << "_r = " << acc_r << ";\n";
+                    Val l, r;
+                    l.rate = r.rate = Rate::Vary;
+                    l.e = var + "_l";
+                    r.e = var + "_r";
+                    ov.ch = {l, r};
+                } else {
+                    cg.os() << "        const float " << var << " = " << acc << ";\n";
+                    ov.e = var;
+                }
+                cg.output_vals[g.outputs[oi].name] = ov;
+                continue;
+            }
             if (stereo) {
                 cg.os() << "        const og::Out2 g_out = {" << acc << ", " << acc_r << "};\n";
                 out.voice_channels = 2;

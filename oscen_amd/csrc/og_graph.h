@@ -61,6 +61,11 @@ struct GNode {
     uint32_t rate_factor = 1; // `* N`
     bool bus = false;         // post-mix node of the wrapper graph (runs once on the summed bus, e.g. Tremolo)
     uint32_t array_len = 0;   // `name = [Type::ctor(..); N]` (parse.rs:447-520): a node array of N elements; 0 = a single node
+    // constructor arguments that are not numbers (`Voice::new(sample_rate)`, `Convolver::with_ir(reverb_ir())`): raw text,
+    // parallel to `args` ("" where the argument is a number; empty vector = all numeric).  A node type that needs the
+    // value of such an argument is diagnosed at lowering; nested graph types ignore their constructor arguments.
+    std::vector<std::string> raw_args;
+    bool inline_bare = false; // nested graph inlined WITHOUT the `<name>_` prefix (the voice graph of a lowered poly wrapper)
 };
 struct GEdge {
     std::string src; // endpoint or compound expression: "env.output", "a.x * b.y", "gate"
@@ -78,6 +83,24 @@ struct GraphDesc {
     std::vector<GNode> nodes;
     std::vector<GEdge> edges;
 };
+
+// What lowering a poly WRAPPER graph (MidiParser -> VoiceAllocator<N> -> [MidiVoiceHandler; N] -> [Voice; N] -> sum
+// [-> post-mix node], examples/fm-synth/src/lib.rs:22-131) found: the control-rate MIDI nodes run on the host
+// (og_midi_*), the voice array is the bank.  `declared_voices` is the reference's N (the bank size is og_create's).
+struct PolyInfo {
+    bool is_wrapper = false;
+    uint32_t declared_voices = 0;
+    std::string voice_type;      // "FMVoice"
+    std::string frequency_input; // per-voice value input of the lowered graph fed by MidiVoiceHandler.frequency
+    std::string gate_input;      // event input fed by MidiVoiceHandler.gate
+    std::string midi_input;      // the wrapper's raw-MIDI event input (`midi_in`), served by og_midi_send
+    std::vector<std::string> dropped_event_outputs; // `midi_parser.note_on -> note_on_out`: host-side events, not lowered
+};
+// The voice-bank graph a poly wrapper lowers to (identity for any other description).
+GraphDesc lower_poly_wrapper(const GraphDesc& g, PolyInfo* info = nullptr);
+// the reference's example voice graphs as graph TYPES (usable as nested nodes and as the voice of a poly wrapper):
+// "FMVoice" (examples/fm-synth/src/fm_voice.rs:6-156), "ElectricPianoVoiceNode" (electric_piano_voice.rs:362-402)
+std::map<std::string, GraphDesc> builtin_voice_graph_types();
 
 // ---- compiled form ---------------------------------------------------------
 struct InputInfo {
