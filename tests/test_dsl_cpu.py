@@ -92,8 +92,8 @@ def test_old_style_syntax_policies_and_rates():
 def test_dsl_diagnostics():
     # node arrays parse (round 2); an element type nobody registered is diagnosed when the graph is lowered
     with pytest.raises(oscen_amd.OscenError) as e:
-        oscen_amd.Graph(dsl="name: X; nodes { voices = [FMVoice::new(); 8]; }").kernel_source()
-    assert "unknown node type 'FMVoice::new'" in str(e.value)
+        oscen_amd.Graph(dsl="name: X; nodes { voices = [NobodysVoice::new(); 8]; }").kernel_source()
+    assert "unknown node type 'NobodysVoice::new'" in str(e.value)
     with pytest.raises(oscen_amd.OscenError) as e:
         oscen_amd.Graph(dsl="name: X;\ninput a: value = 1.0;\nbogus;")
     assert "line 3" in str(e.value)
