@@ -484,7 +484,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true", help="skip the blocking-path real-time latency record")
     ap.add_argument("--rt-blocks", type=int, default=2000, help="blocks per bank size of the real-time record")
-    ap.add_argument("--rt-voices", default="65536,131072,1048576",
+    ap.add_argument("--rt-voices", default="65536,131072,1048576,4194304",
                     help="bank sizes of the real-time record (comma separated)")
     ap.add_argument("--rt-midi", type=int, default=1000, help="live MIDI messages per block in the real-time record")
     ap.add_argument("--cluster", action="store_true",

@@ -1707,6 +1707,7 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
     struct Sub {
         GraphDesc g;                                      // expanded inner graph
         std::map<std::string, std::vector<std::string>> in_src; // inner input -> outer source expressions (edge order)
+        std::map<std::string, std::string> in_policy;           // inner input -> connection policy of the outer edge(s)
         std::map<std::string, std::string> out_expr;      // inner output -> expression over (prefixed) inner nodes
     };
     std::map<std::string, Sub> subs;
@@ -1730,8 +1731,14 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
         for (const Tok& t : dst)
             if (t.k == Tok::Ident) d = d ? d : &t;
         if (d && subs.count(d->text) && !d->port.empty()) {
-            if (!e.policy.empty() || e.feedback) fail("connection policies / feedback edges cannot target a nested graph input ('" + e.dst + "')");
+            if (e.feedback) fail("feedback edges cannot target a nested graph input ('" + e.dst + "')");
             subs[d->text].in_src[d->port].push_back(e.src);
+            // `[policy] src -> inner.x` (an oversampled nested graph): the policy goes to the inner edges that read x
+            if (!e.policy.empty()) {
+                std::string& pol = subs[d->text].in_policy[d->port];
+                if (!pol.empty() && pol != e.policy) fail("nested graph input '" + e.dst + "' is fed with different connection policies");
+                pol = e.policy;
+            }
             continue;
         }
         outer.push_back(e);
@@ -1757,8 +1764,10 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
             o.nodes.push_back(in);
         }
         // rewrite an inner expression: nodes get the prefix, inputs become the outer sources (or the default)
+        std::string carried_policy; // policy of the outer edge into the input the expression being rewritten reads
         auto rewrite = [&](const std::string& expr, bool& is_event, std::string& event_src) {
             std::vector<Tok> t = scan(expr);
+            carried_policy.clear();
             for (Tok& k : t) {
                 if (k.k != Tok::Ident) continue;
                 if (inner_node.count(k.text)) {
@@ -1768,6 +1777,22 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
                 auto iit = inner_in.find(k.text);
                 if (iit == inner_in.end()) continue;
                 const GInput& gi = *iit->second;
+                {
+                    auto pit = sb.in_policy.find(gi.name);
+                    if (pit != sb.in_policy.end()) {
+                        size_t idents = 0;
+                        bool plain = true;
+                        for (const Tok& q : t) {
+                            if (q.k == Tok::Ident) ++idents;
+                            else
+                                for (char ch : q.text) plain = plain && isspace((unsigned char)ch);
+                        }
+                        if (idents != 1 || !plain)
+                            fail("nested graph input '" + n.name + "." + gi.name + "' is fed through [" + pit->second +
+                                 "] but read inside a compound expression ('" + expr + "')");
+                        carried_policy = pit->second;
+                    }
+                }
                 auto src = sb.in_src.find(gi.name);
                 if (gi.kind == Kind::Event) {
                     is_event = true;
@@ -1799,6 +1824,11 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
             std::string event_src;
             GEdge x = ie;
             x.src = rewrite(ie.src, is_event, event_src);
+            if (!carried_policy.empty()) {
+                if (!x.policy.empty() && x.policy != carried_policy)
+                    fail("nested graph '" + n.name + "': edge '" + ie.src + " -> " + ie.dst + "' already has a connection policy");
+                x.policy = carried_policy;
+            }
             if (is_event) {
                 if (event_src.empty()) continue; // unconnected event input: the inner handlers never fire
                 x.src = event_src;

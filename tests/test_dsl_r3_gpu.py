@@ -1,0 +1,227 @@
+"""Round-3 front-end features on the GPU, each against a per-voice model composed from the ORACLE's nodes and resampler
+kernels (tolerance 1e-5 * max(1, |ref|), BASELINE.json north_star):
+
+* graph outputs read as connection sources (`[sinc] a.output -> out_a; [linear] b.output -> out_b; out_a + out_b -> out`,
+  the shape of oscen-lib/tests/multirate_graph.rs:444-458);
+* a Frame<2> edge across a rate boundary, up and down (oscen-lib/tests/frame_resampler_graph.rs:103-114): channel by
+  channel, one resampler state per channel (resample/sinc_fir.rs:96-144 is generic over F: AudioFrame);
+* a nested graph oversampled as a whole (`inner = Inner * 4`) with connection policies on the edges into and out of it;
+* `Frame([l, r])` constructor arguments of a registered node.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+f32 = np.float32
+
+
+def rel_err(got, ref):
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+
+
+def polyblep(lib, freq, amp, wave, sr):
+    o = ol.PolyBlep()
+    lib.oo_polyblep_new(C.byref(o), float(freq), float(amp), wave)
+    o.sample_rate = sr
+    return o
+
+
+def render_taps(eng, n, frames, blocks):
+    eng.set_voice_taps(list(range(n)))
+    got = []
+    for _ in range(blocks):
+        eng.process_block(frames)
+        got.append(eng.read_voice_taps(frames))
+    return np.concatenate(got, axis=1)
+
+
+def test_graph_outputs_as_connection_sources_with_two_policies():
+    lib = ol.load()
+    text = """
+        name: TwoOut;
+        input frequency: value = 220.0;
+        output out_a: stream;
+        output out_b: stream;
+        output out: stream;
+        nodes {
+            a = PolyBlepOscillator::saw(220.0, 0.5) * 2;
+            b = PolyBlepOscillator::sine(330.0, 0.4) * 2;
+        }
+        connections {
+            frequency -> a.frequency;
+            frequency * 1.5 -> b.frequency;
+            [sinc] a.output -> out_a;
+            [linear] b.output -> out_b;
+            out_a + out_b -> out;
+        }
+    """
+    g = oscen_amd.Graph(dsl=text, per_voice=["frequency"])
+    n, frames, blocks = 6, 200, 3
+    freqs = np.array([55.0, 220.0, 441.0, 1234.5, 3000.0, 7000.0], dtype=f32)
+    eng = oscen_amd.Engine(g, n, sample_rate=SR)
+    eng.set_voice_values("frequency", freqs)
+    got = render_taps(eng, n, frames, blocks)
+    worst = 0.0
+    for v in range(n):
+        a = polyblep(lib, freqs[v], 0.5, ol.PB_SAW, SR * 2)
+        b = polyblep(lib, f32(freqs[v]) * f32(1.5), 0.4, ol.PB_SINE, SR * 2)
+        dn = ol.SincDown()
+        lib.oo_sinc_down_new(C.byref(dn), 2)
+        ref = np.zeros(frames * blocks, dtype=f32)
+        xa, xb = np.zeros(2, dtype=f32), np.zeros(2, dtype=f32)
+        for i in range(len(ref)):
+            for j in range(2):
+                lib.oo_polyblep_process(C.byref(a))
+                lib.oo_polyblep_process(C.byref(b))
+                xa[j], xb[j] = a.output, b.output
+            out_a = f32(lib.oo_sinc_down_process(C.byref(dn), ol.fptr(xa)))
+            out_b = f32(lib.oo_linear_down_process(2, ol.fptr(xb)))
+            ref[i] = out_a + out_b
+        worst = max(worst, rel_err(got[v], ref))
+        assert np.abs(ref).max() > 0.2
+    assert worst <= 1e-5, worst
+    assert eng.latency_samples == 5  # the sinc edge: 11 * (2 - 1) / 2 (emit_struct.rs:534-570); linear adds (2 - 1) / 2 / 2 = 0
+
+
+def test_frame_edge_across_a_rate_boundary_up_and_down():
+    lib = ol.load()
+    oscen_amd.register_node(
+        "R3Spread::new", inputs=[("input", "stream", 0.0, -1), ("pan", "value", 0.5, 0)], outputs=[("output", 2)], n_ctor_args=1,
+        process="    output.v[0] = input * (1.0f - pan);\n    output.v[1] = input * pan;\n")
+    oscen_amd.register_node(
+        "R3StereoClip::new", inputs=[("inp", "stream", 0.0, -1, 2)], outputs=[("out", 2)],
+        process="    out.v[0] = og::clampf(inp.v[0] * 3.0f, -0.4f, 0.4f);\n    out.v[1] = og::clampf(inp.v[1] * 3.0f, -0.4f, 0.4f);\n")
+    oscen_amd.register_node(
+        "R3Diff::new", inputs=[("inp", "stream", 0.0, -1, 2)], outputs=["out"],
+        process="    out = inp.v[0] - inp.v[1] * 0.5f;\n")
+    try:
+        text = """
+            name: StereoCross;
+            input frequency: value = 220.0;
+            output out: stream;
+            nodes {
+                osc = PolyBlepOscillator::saw(220.0, 0.5);
+                sp = R3Spread::new(0.3);
+                inner = R3StereoClip::new() * 2;
+                mix = R3Diff::new();
+            }
+            connections {
+                frequency -> osc.frequency;
+                osc.output -> sp.input;
+                [linear] sp.output -> inner.inp;
+                [sinc] inner.out -> mix.inp;
+                mix.out -> out;
+            }
+        """
+        g = oscen_amd.Graph(dsl=text, per_voice=["frequency"])
+        n, frames, blocks = 5, 192, 3
+        freqs = np.array([82.4, 220.0, 523.25, 1500.0, 4000.0], dtype=f32)
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        eng.set_voice_values("frequency", freqs)
+        got = render_taps(eng, n, frames, blocks)
+        worst = 0.0
+        for v in range(n):
+            osc = polyblep(lib, freqs[v], 0.5, ol.PB_SAW, SR)
+            ups = [ol.LinearUp(), ol.LinearUp()]
+            dns = [ol.SincDown(), ol.SincDown()]
+            for u, d in zip(ups, dns):
+                lib.oo_linear_up_new(C.byref(u), 2)
+                lib.oo_sinc_down_new(C.byref(d), 2)
+            ref = np.zeros(frames * blocks, dtype=f32)
+            buf, cl = np.zeros(2, dtype=f32), np.zeros(2, dtype=f32)
+            for i in range(len(ref)):
+                lib.oo_polyblep_process(C.byref(osc))
+                x = f32(osc.output)
+                chans = (f32(x * f32(f32(1.0) - f32(0.3))), f32(x * f32(0.3)))
+                outs = []
+                for c in range(2):  # one resampler pair PER CHANNEL
+                    lib.oo_linear_up_process(C.byref(ups[c]), float(chans[c]), ol.fptr(buf))
+                    for j in range(2):
+                        cl[j] = min(max(f32(buf[j] * f32(3.0)), f32(-0.4)), f32(0.4))
+                    outs.append(f32(lib.oo_sinc_down_process(C.byref(dns[c]), ol.fptr(cl))))
+                ref[i] = f32(outs[0] - f32(outs[1] * f32(0.5)))
+            worst = max(worst, rel_err(got[v], ref))
+            assert np.abs(ref).max() > 0.05
+        assert worst <= 1e-5, worst
+    finally:
+        for t in ("R3Spread::new", "R3StereoClip::new", "R3Diff::new"):
+            oscen_amd.unregister_node(t)
+
+
+def test_nested_graph_oversampled_as_a_whole():
+    from tests.test_multirate_gpu import _oracle_chain
+
+    lib = ol.load()
+    inner = oscen_amd.Graph(dsl="""
+        name: R3ClipInner;
+        input x: stream;
+        output y: stream;
+        nodes { clip = HardClip::new(); }
+        connections { x -> clip.input; clip.output -> y; }
+    """)
+    oscen_amd.register_graph_type("R3ClipInner", inner)
+    try:
+        nested = oscen_amd.Graph(dsl="""
+            name: NestedOs;
+            input frequency: value = 440.0;
+            output out: stream;
+            nodes {
+                src = PolyBlepOscillator::sine(440.0, 0.9);
+                inner = R3ClipInner::new() * 4;
+            }
+            connections {
+                frequency -> src.frequency;
+                [sinc] src.output -> inner.x;
+                [sinc] inner.y -> out;
+            }
+        """, per_voice=["frequency"])
+        flat = oscen_amd.Graph("flat_os")
+        flat.input_value("frequency", 440.0, per_voice=True)
+        flat.output_stream("out")
+        flat.node("src", "PolyBlepOscillator::sine", 440.0, 0.9)
+        flat.node("clip", "HardClip::new", rate=4)
+        flat.connect("frequency", "src.frequency")
+        flat.connect("src.output", "clip.input", "sinc")
+        flat.connect("clip.output", "out", "sinc")
+        n, frames, blocks = 4, 256, 2
+        freqs = np.array([110.0, 997.0, 4800.0, 9600.0], dtype=f32)
+        outs = []
+        for g in (nested, flat):
+            eng = oscen_amd.Engine(g, n, sample_rate=SR)
+            eng.set_voice_values("frequency", freqs)
+            assert eng.latency_samples == 8
+            outs.append(render_taps(eng, n, frames, blocks))
+        assert np.array_equal(outs[0], outs[1])  # the nested form is the flat graph
+        worst = max(rel_err(outs[0][v], _oracle_chain(lib, frames * blocks, float(freqs[v]), "sinc", "sinc", 4)) for v in range(n))
+        assert worst <= 1e-5, worst
+    finally:
+        oscen_amd.unregister_graph_type("R3ClipInner")
+
+
+def test_frame_literal_constructor_argument():
+    """`StereoConstSrc::new(Frame([0.3, -0.7]))` (frame_resampler_graph.rs:105): a frame literal hands its channels to
+    the constructor arguments of a registered node, in order"""
+    oscen_amd.register_node(
+        "R3ConstSrc::new", inputs=[], outputs=[("out", 2)], n_ctor_args=2,
+        state=[("l", "f32", 0.0, 0), ("r", "f32", 0.0, 1)],
+        process="    out.v[0] = l;\n    out.v[1] = r;\n")
+    try:
+        g = oscen_amd.Graph(dsl="""
+            name: ConstStereo;
+            output out: stream: Frame<2>;
+            nodes { src = R3ConstSrc::new(Frame([0.3, -0.7])); }
+            connections { src.out -> out; }
+        """)
+        n = 70
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        bus = eng.process_block(64)
+        assert bus.shape == (64, 2)
+        assert np.allclose(bus[:, 0], n * f32(0.3), rtol=1e-6) and np.allclose(bus[:, 1], n * f32(-0.7), rtol=1e-6)
+    finally:
+        oscen_amd.unregister_node("R3ConstSrc::new")
