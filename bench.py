@@ -400,6 +400,9 @@ def run_cluster(args):
     plans = oscen_amd.note_plans(total_voices, span=span, fold="slice")
     cl.set_voice_values("frequency", plans["frequency"])
     ev_v, ev_f, ev_x = plans["events"]
+    if total_frames > 48000:  # a run longer than the 1 s score plays it again and again
+        reps = -(-total_frames // 48000)
+        ev_v, ev_f, ev_x = np.tile(ev_v, reps), np.concatenate([ev_f + 48000 * k for k in range(reps)]), np.tile(ev_x, reps)
     keep = ev_f < total_frames
     has_gate = True
     try:
@@ -569,6 +572,10 @@ def main():
         midi.set_queue_capacity(max(32, args.midi_live))
         n_events_timed = args.midi_live * K * R
     else:
+        if total_frames > 48000:  # a run longer than the 1 s score plays it again and again (same density throughout)
+            ev_v, ev_f0, ev_x = plans["events"]
+            reps = -(-total_frames // 48000)
+            plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
         oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
         ev_f = plans["events"][1]
         if "gate" in eng.input_names:

@@ -3077,7 +3077,58 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << ind << "}\n";
             };
             const std::string mc = min_cnt(st);
+            // ---- events in the pipelined kernels -----------------------------------------------------------------
+            // (1) A wave only has to leave the straight-line path for events IT handles.  Every wave of the pipeline
+            //     walks the voice's event list, but e.g. FMVoice's second wave (operators 2 and 1, filter) has no
+            //     handler for `gate` -- only the envelope wave has -- and used to run the chunk frame by frame for
+            //     nothing.  Events without a handler in this wave's stages are consumed at the top of the chunk.
+            // (2) A chunk that does hold an event (or an envelope stage end) runs the UNROLLED body with one
+            //     wave-uniform `any lane has an event on this frame` test per frame, instead of a rolled frame loop
+            //     that serialises the frames (measured: the rolled event chunk costs twice a quiet one, and the launch
+            //     ends with the wave that met the most events).  It replaces the stage-end-check variant of the quiet
+            //     chunk, so the kernel does not grow.
+            // OGC_EVSKIP=0 / OGC_EVUNROLL=0 restore the round-2 form.
+            const bool ev_skip = !(getenv("OGC_EVSKIP") && atoi(getenv("OGC_EVSKIP")) == 0);
+            const bool ev_unroll = !(getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) == 0);
+            std::string relevant; // condition on `tgt`: this wave has a handler for the event
+            {
+                const std::string code = cat(st, &Codegen::Sect::derive) + group_tick(groups, gi) + cat(st, &Codegen::Sect::decl);
+                for (size_t i = 0; i < out.inputs.size(); ++i) {
+                    const InputInfo& in = out.inputs[i];
+                    if (!(in.decl.kind == Kind::Value && in.decl.per_voice)) continue;
+                    const std::string var = "vin_" + std::to_string(i);
+                    bool used = false;
+                    for (size_t p = code.find(var); p != std::string::npos && !used; p = code.find(var, p + 1)) {
+                        const size_t e = p + var.size();
+                        used = e >= code.size() || !isdigit((unsigned char)code[e]);
+                    }
+                    // (the first wave stores the per-voice inputs back: it applies every SETVALUE)
+                    if (used || gi == 0) relevant += (relevant.empty() ? "" : " || ") + ("tgt == (OG_EV_SETVALUE | " + std::to_string(i) + "u)");
+                }
+                std::set<int> handled;
+                for (int k : st)
+                    for (auto& kv : cg.sec[k].ev_handlers)
+                        if (!kv.second.str().empty()) handled.insert(kv.first);
+                for (int h : handled) relevant += (relevant.empty() ? "" : " || ") + ("tgt == " + std::to_string(h) + "u");
+                if (relevant.empty()) relevant = "false";
+            }
             const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: b | c | ev -- quiet chunks take the release-arithmetic / stage-end-check / event path (results stay valid)
+            // the checked chunk: unrolled, stage-end checks and release arithmetic on, events applied on their frame
+            auto checked = [&](const std::string& ind) {
+                const bool pre = !reads.empty();
+                if (pre) {
+                    body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
+                    for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
+                    body << ind << "}\n";
+                }
+                const std::string flag = std::string("true, true, ") + (pre ? "true" : "false") + ", false";
+                body << ind << "#pragma unroll\n"
+                     << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n"
+                     << ind << "    const uint32_t f = base + j;\n"
+                     << ind << "    if (__any((int)(f == c.next_ev))) events(f); // (wave-uniform: rare)\n"
+                     << ind << "    " << call(flag) << "\n"
+                     << ind << "}\n";
+            };
             auto variants = [&](bool st_flag, const std::string& ind0) {
                 if (force && force[0] == 'c') {
                     quiet("true", "true", st_flag, ind0);
@@ -3090,7 +3141,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     body << ind0 << "    } else {\n";
                     quiet("false", "true", st_flag, ind0 + "        ");
                     body << ind0 << "    }\n" << ind0 << "} else {\n";
-                    quiet("true", "true", st_flag, ind0 + "    ");
+                    if (ev_unroll) checked(ind0 + "    ");
+                    else quiet("true", "true", st_flag, ind0 + "    ");
                     body << ind0 << "}\n";
                 }
             };
@@ -3098,8 +3150,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                  << "        const uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"
                  << "        const uint32_t base = ch * XCH;\n"
-                 << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n"
-                 << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))" << (force && force[0] == 'e' ? " && A.frames == 0u" : "") << ") {\n";
+                 << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n";
+            if (ev_skip && relevant != "true")
+                body << "        if (!__all((int)(c.next_ev >= base + XCH))) { // consume the events this wave has no handler for\n"
+                     << "            while (c.next_ev < base + XCH) {\n"
+                     << "                const uint32_t tgt = A.events[c.ev_cur].target;\n"
+                     << "                if (" << relevant << ") break;\n"
+                     << "                og::ev_advance(A, c);\n"
+                     << "            }\n"
+                     << "        }\n";
+            body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))" << (force && force[0] == 'e' ? " && A.frames == 0u" : "") << ") {\n";
             if (steady.empty()) {
                 variants(false, "            ");
             } else {
@@ -3109,6 +3169,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 body << "            } else {\n";
                 variants(false, "                ");
                 body << "            }\n";
+            }
+            if (ev_unroll && !mc.empty() && !(force && force[0] == 'e')) {
+                body << "        } else if (n == XCH) { // a chunk with an event: the checked, unrolled body\n";
+                checked("            ");
             }
             body << "        } else {\n"
                  << "            for (uint32_t j = 0; j < n; ++j) {\n"

@@ -89,9 +89,12 @@ def test_cluster_routes_per_voice_calls_by_global_voice_id():
 # per-GPU shard size.  Skips cleanly on a one-GPU box; needs nothing but more devices to run.
 # ---------------------------------------------------------------------------------------------------------------
 def device_count():
-    import torch
+    import ctypes as C
 
-    return torch.cuda.device_count()
+    oscen_amd.load_library()
+    n = C.c_int(0)
+    hip = C.CDLL("libamdhip64.so")  # the runtime liboscen_gpu.so is linked against
+    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
 
 
 @pytest.mark.parametrize("graph", ["fm_voice", "epiano_voice"])

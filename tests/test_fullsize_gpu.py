@@ -162,10 +162,36 @@ def dsp_state(eng):
     return blob[: words * eng.n_voices * 4].copy()
 
 
+class DeviceBuffer:
+    """device memory from the HIP runtime liboscen_gpu.so is linked against (already mapped into the process): the
+    test needs a destination for og_process_block_async like bench.py's torch tensor, without bringing a second
+    framework's runtime initialisation order into play"""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+        assert self.hip.hipMemset(self.ptr, 0, C.c_size_t(nbytes)) == 0
+
+    def to_host(self):
+        out = np.empty(self.nbytes // 4, dtype=np.float32)
+        assert self.hip.hipDeviceSynchronize() == 0
+        assert self.hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(self.nbytes), 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip.hipFree(self.ptr)
+            self.ptr = None
+
+
 def render_as_bench_does(graph, n, total, block, batch, env=None):
-    """bench.py:step/flush: async blocks into one device tensor on torch's current stream, `batch` blocks per launch
-    (0 = the engine's pick), flushed once at the end"""
-    import torch
+    """bench.py:step/flush: async blocks into one device buffer, `batch` blocks per launch (0 = the engine's pick),
+    flushed once at the end"""
 
     old = {}
     for k, v in (env or {}).items():
@@ -181,19 +207,19 @@ def render_as_bench_does(graph, n, total, block, batch, env=None):
                 os.environ[k] = v
     plans = oscen_amd.note_plans(n, span=total)
     oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if batch != 1:
         eng.set_bus_batching(batch)
     ch = eng.channels
     nb = total // block
-    bus = torch.zeros((nb, block * ch), dtype=torch.float32, device="cuda")
+    bus = DeviceBuffer(nb * block * ch * 4)
     eng.enable_kernel_timing(True)
     for i in range(nb):
-        eng.process_block_async(block, bus.data_ptr() + i * block * ch * 4)
+        eng.process_block_async(block, bus.ptr.value + i * block * ch * 4)
     eng.flush()
-    torch.cuda.synchronize()
+    eng.synchronize()
     _, launches = eng.kernel_time_ms()
-    out = bus.cpu().numpy().reshape(total, ch)
+    out = bus.to_host().reshape(total, ch)
+    bus.free()
     state = dsp_state(eng)
     info = {"launches": launches, "depth": eng.pipeline_depth, "variant": eng.kernel_variant}
     eng.close()
