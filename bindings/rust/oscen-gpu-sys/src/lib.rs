@@ -121,4 +121,10 @@ extern "C" {
     pub fn og_cluster_process_block(c: *mut og_cluster, frames: u32, out_bus: *mut c_float) -> c_int;
     pub fn og_cluster_render(c: *mut og_cluster, total_frames: u64, block: u32, out_bus: *mut c_float) -> c_int;
     pub fn og_cluster_channels(c: *const og_cluster) -> u32;
+    pub fn og_graph_poly_info(g: *const og_graph_desc, declared_voices: *mut u32, frequency_input: *mut c_char,
+                              gate_input: *mut c_char, cap: usize) -> c_int;
+    pub fn og_midi_create_cluster(c: *mut og_cluster, frequency_input: *const c_char, gate_input: *const c_char,
+                                  out: *mut *mut og_midi) -> c_int;
+    pub fn og_blocking_stats(e: *const og_engine, calls: *mut u64, marker_timeouts: *mut u64) -> c_int;
+    pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
 }

@@ -4,13 +4,16 @@
 // oscen-gpu: the public surface of a `graph!`-generated struct (oscen-graph-compiler/src/codegen/mod.rs:1292-1392)
 // over the MI355X engine, for ANY graph: the `graph! { ... }` body text goes to the engine's DSL front end.
 //
-//   let mut g = GpuGraph::from_dsl(include_str!("fm_voice.graph"), &["frequency"], 65_536)?;   // Graph::new()
+//   let mut g = GpuGraph::<0>::from_dsl(include_str!("fm_voice.graph"), &["frequency"], [], 65_536)?;   // Graph::new()
+//   (the const parameter is the number of STREAM INPUTS of the graph -- BlockRender::NUM_STREAM_INPUTS, a compile-time
+//    constant in the reference too -- and the array names them in declaration order; a poly wrapper such as
+//    examples/fm-synth/src/lib.rs `FMGraph` goes in as written: GpuGraph::<0>::from_dsl(FM_GRAPH_BODY, &[], [], 65_536))
 //   g.init(48_000.0);                                                                          // init(sr)
 //   let cutoff = g.value("filter_cutoff")?;               // input handles are resolved ONCE (no per-call lookup)
 //   g.set(cutoff, 3_000.0); g.set_with_ramp(cutoff, 6_000.0, 2_205); g.set_immediate(cutoff, 1_000.0);
 //   g.try_push(gate, voice, EventInstance { frame_offset: 17, payload: 0.8 })?;
 //   g.process_block(256);  let bus = &g.out_block[..256 * g.channels()];
-//   let rendered: Vec<Vec<f32>> = BlockRender::render(&mut g, &[&input[..]], tail);            // offline.rs:46-90
+//   let rendered: Vec<Vec<f32>> = BlockRender::render(&mut g1, &[&input[..]], tail);  // g1: GpuGraph<1>, offline.rs:46-90
 //
 // `gpu_graph!` below generates a struct with the reference's own method names (set_<name>, set_<name>_with_ramp,
 // set_<name>_immediate) for a fixed list of inputs, so existing call sites compile unchanged.
@@ -36,42 +39,52 @@ pub struct InputId(pub u32);
 #[derive(Clone, Copy, Debug)]
 pub struct EventInstance { pub frame_offset: u32, pub payload: f32 }
 
-pub struct GpuGraph {
+/// `IN` = the graph's number of stream inputs (`BlockRender::NUM_STREAM_INPUTS`, offline.rs:23): a compile-time
+/// constant of a generated graph, so a const parameter here; `from_dsl` / `builtin` check it against the engine.
+pub struct GpuGraph<const IN: usize = 0> {
     e: *mut sys::og_engine,
     channels: usize,
-    stream_inputs: Vec<InputId>,
-    stream_in_blocks: Vec<[f32; MAX_BLOCK_SIZE]>,          // `pub <stream_in>_block: [f32; 512]`
+    stream_inputs: [InputId; IN],
+    pub stream_in_blocks: [[f32; MAX_BLOCK_SIZE]; IN],     // `pub <stream_in>_block: [f32; 512]`
     /// `<out>_block`: interleaved when the graph ends in a Frame<2> post-mix node
     pub out_block: [f32; 2 * MAX_BLOCK_SIZE],
     /// `pub <out>: F`: the last frame of the last block
     pub out: [f32; 2],
 }
-unsafe impl Send for GpuGraph {} // SignalProcessor: Send (traits.rs:27); one `&mut self` caller at a time
+unsafe impl<const IN: usize> Send for GpuGraph<IN> {} // SignalProcessor: Send (traits.rs:27); one `&mut self` caller at a time
 
-impl GpuGraph {
+impl<const IN: usize> GpuGraph<IN> {
     /// Graph::new(): `voices = [Voice::new(); N]` with N = n_voices, 44.1 kHz until init().  `per_voice` names the value
-    /// inputs the poly wrapper feeds per voice (MidiVoiceHandler.frequency).  Fails loudly without a GPU.
-    pub fn from_dsl(graph_body: &str, per_voice: &[&str], n_voices: u32) -> Result<Self, GpuError> {
+    /// inputs the poly wrapper feeds per voice (MidiVoiceHandler.frequency; empty for a poly-wrapper body, which names
+    /// them itself); `stream_inputs` names the graph's stream inputs in declaration order.  Fails loudly without a GPU.
+    pub fn from_dsl(graph_body: &str, per_voice: &[&str], stream_inputs: [&str; IN], n_voices: u32) -> Result<Self, GpuError> {
         let text = CString::new(graph_body).unwrap();
         let pv = CString::new(per_voice.join(",")).unwrap();
         let mut g = std::ptr::null_mut();
         ck(unsafe { sys::og_graph_parse(text.as_ptr(), pv.as_ptr(), &mut g) })?;
-        Self::from_desc(g, n_voices)
+        Self::from_desc(g, stream_inputs, n_voices)
     }
-    pub fn builtin(name: &str, n_voices: u32) -> Result<Self, GpuError> {
+    pub fn builtin(name: &str, stream_inputs: [&str; IN], n_voices: u32) -> Result<Self, GpuError> {
         let n = CString::new(name).unwrap();
         let mut g = std::ptr::null_mut();
         ck(unsafe { sys::og_graph_builtin(n.as_ptr(), &mut g) })?;
-        Self::from_desc(g, n_voices)
+        Self::from_desc(g, stream_inputs, n_voices)
     }
-    fn from_desc(g: *mut sys::og_graph_desc, n_voices: u32) -> Result<Self, GpuError> {
+    fn from_desc(g: *mut sys::og_graph_desc, stream_inputs: [&str; IN], n_voices: u32) -> Result<Self, GpuError> {
         let mut e = std::ptr::null_mut();
         let rc = unsafe { sys::og_create(g, n_voices, 0, &mut e) };
         unsafe { sys::og_graph_free(g) };
         ck(rc)?;
         let channels = unsafe { sys::og_channels(e) } as usize;
-        Ok(Self { e, channels, stream_inputs: Vec::new(), stream_in_blocks: Vec::new(),
-                  out_block: [0.0; 2 * MAX_BLOCK_SIZE], out: [0.0; 2] })
+        let mut me = Self { e, channels, stream_inputs: [InputId(0); IN], stream_in_blocks: [[0.0; MAX_BLOCK_SIZE]; IN],
+                            out_block: [0.0; 2 * MAX_BLOCK_SIZE], out: [0.0; 2] };
+        // NUM_STREAM_INPUTS is a type-level constant: it must be the engine's count (assert_eq! in the default render)
+        let have = unsafe { sys::og_num_stream_inputs(e) } as usize;
+        if have != IN {
+            return Err(GpuError(-1, format!("graph has {} stream inputs, GpuGraph::<{}> was asked for", have, IN)));
+        }
+        for k in 0..IN { me.stream_inputs[k] = me.id(stream_inputs[k])?; }
+        Ok(me)
     }
     pub fn init(&mut self, sample_rate: f32) { unsafe { sys::og_init(self.e, sample_rate); } }
     pub fn set_sample_rate(&mut self, sample_rate: f32) { self.init(sample_rate) }
@@ -84,13 +97,8 @@ impl GpuGraph {
     }
     pub fn value(&self, name: &str) -> Result<InputId, GpuError> { self.id(name) }
     pub fn event(&self, name: &str) -> Result<InputId, GpuError> { self.id(name) }
-    /// declares `name` as stream input number `stream_inputs.len()` (declaration order = BlockRender order)
-    pub fn stream(&mut self, name: &str) -> Result<InputId, GpuError> {
-        let id = self.id(name)?;
-        self.stream_inputs.push(id);
-        self.stream_in_blocks.push([0.0; MAX_BLOCK_SIZE]);
-        Ok(id)
-    }
+    /// handle of stream input k (declaration order = BlockRender order)
+    pub fn stream(&self, k: usize) -> InputId { self.stream_inputs[k] }
 
     // generated setters  codegen/mod.rs:917-976
     pub fn set(&mut self, i: InputId, v: f32) { unsafe { sys::og_set_value(self.e, i.0, v); } }
@@ -125,21 +133,24 @@ impl GpuGraph {
     pub fn process(&mut self) { self.process_block(1) }
     pub fn get_stream_output(&self, i: usize) -> Option<f32> { if i < self.channels { Some(self.out[i]) } else { None } }
 }
-impl Drop for GpuGraph { fn drop(&mut self) { unsafe { sys::og_destroy(self.e) } } }
+impl<const IN: usize> Drop for GpuGraph<IN> { fn drop(&mut self) { unsafe { sys::og_destroy(self.e) } } }
 
-/// oscen::graph::offline::BlockRender<f32> (offline.rs:19-113) for a mono graph; the trait's default `render` /
-/// `render_mono` then work unchanged (chunks of 512, silence padding, `tail`).
-impl oscen::BlockRender<f32> for GpuGraph {
-    const NUM_STREAM_INPUTS: usize = usize::MAX;  // see num_stream_inputs(): the count is a run-time property here
+/// oscen::graph::offline::BlockRender<f32> (offline.rs:19-113) for a graph with a mono bus.  NUM_STREAM_INPUTS is the
+/// const parameter, so the trait's default `render` (`assert_eq!(inputs.len(), Self::NUM_STREAM_INPUTS)`, the loop
+/// `for i in 0..Self::NUM_STREAM_INPUTS`, offline.rs:46-75) and `render_mono` (`assert_eq!(.., 1)`, :96-101) work
+/// as they do for a generated graph: chunks of 512, silence padding, `tail`.
+impl<const IN: usize> oscen::BlockRender<f32> for GpuGraph<IN> {
+    const NUM_STREAM_INPUTS: usize = IN;
     const NUM_STREAM_OUTPUTS: usize = 1;
-    fn run_block(&mut self, frames: usize) { self.process_block(frames) }
+    fn run_block(&mut self, frames: usize) { debug_assert!(self.channels == 1); self.process_block(frames) }
     fn stream_input_block_mut(&mut self, index: usize) -> &mut [f32] { &mut self.stream_in_blocks[index][..] }
     fn stream_output_block(&self, _index: usize) -> &[f32] { &self.out_block[..MAX_BLOCK_SIZE] }
 }
-impl GpuGraph {
+impl<const IN: usize> GpuGraph<IN> {
     pub fn num_stream_inputs(&self) -> usize { unsafe { sys::og_num_stream_inputs(self.e) as usize } }
-    /// render(inputs, tail) in one call into the library (the device keeps the whole output until the end)
-    pub fn render(&mut self, inputs: &[&[f32]], tail: usize) -> Vec<f32> {
+    /// render(inputs, tail) in one call into the library (the device keeps the whole output until the end); interleaved
+    /// when the bus is a Frame<2>
+    pub fn render_all(&mut self, inputs: &[&[f32]; IN], tail: usize) -> Vec<f32> {
         let ptrs: Vec<*const f32> = inputs.iter().map(|s| s.as_ptr()).collect();
         let lens: Vec<u64> = inputs.iter().map(|s| s.len() as u64).collect();
         let total = lens.iter().copied().max().unwrap_or(0) as usize + tail;
@@ -159,10 +170,10 @@ impl GpuGraph {
 macro_rules! gpu_graph {
     ($name:ident, dsl = $dsl:expr, per_voice = [$($pv:ident),*], values = [$($v:ident),*], events = [$($ev:ident),*]) => {
         paste::paste! {
-            pub struct $name { pub g: $crate::GpuGraph, $($v: $crate::InputId,)* $($ev: $crate::InputId,)* }
+            pub struct $name { pub g: $crate::GpuGraph<0>, $($v: $crate::InputId,)* $($ev: $crate::InputId,)* }
             impl $name {
                 pub fn new(n_voices: u32) -> Result<Self, $crate::GpuError> {
-                    let g = $crate::GpuGraph::from_dsl($dsl, &[$(stringify!($pv)),*], n_voices)?;
+                    let g = $crate::GpuGraph::<0>::from_dsl($dsl, &[$(stringify!($pv)),*], [], n_voices)?;
                     Ok(Self { $($v: g.value(stringify!($v))?,)* $($ev: g.event(stringify!($ev))?,)* g })
                 }
                 pub fn init(&mut self, sr: f32) { self.g.init(sr) }

@@ -3087,9 +3087,14 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             //     that serialises the frames (measured: the rolled event chunk costs twice a quiet one, and the launch
             //     ends with the wave that met the most events).  It replaces the stage-end-check variant of the quiet
             //     chunk, so the kernel does not grow.
-            // OGC_EVSKIP=0 / OGC_EVUNROLL=0 restore the round-2 form.
+            // Measured (scripts/dbg_event_cost.py, fm_voice, 65 536 voices, kernel ms per 256-frame block, round-2 form ->
+            // both): one retrigger per voice in 5 120 frames 0.0641 -> 0.0623, two 0.0714 -> 0.0677 (the cost of an
+            // event falls by a third, nearly all of it from (1)) -- but (2) inlines the handlers into every frame of the
+            // checked body (two-wave kernel 26.8 -> 35.9 KB) and the QUIET path pays for it: idle bank 0.0514 -> 0.0528,
+            // sustaining 0.0536 -> 0.0553.  At the benchmark's event density the two cancel (2.73e11 either way), so
+            // (1) is on and (2) is off by default: OGC_EVUNROLL=1 turns it on, OGC_EVSKIP=0 turns (1) off.
             const bool ev_skip = !(getenv("OGC_EVSKIP") && atoi(getenv("OGC_EVSKIP")) == 0);
-            const bool ev_unroll = !(getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) == 0);
+            const bool ev_unroll = getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) != 0;
             std::string relevant; // condition on `tgt`: this wave has a handler for the event
             {
                 const std::string code = cat(st, &Codegen::Sect::derive) + group_tick(groups, gi) + cat(st, &Codegen::Sect::decl);
@@ -3141,10 +3146,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     body << ind0 << "    } else {\n";
                     quiet("false", "true", st_flag, ind0 + "        ");
                     body << ind0 << "    }\n" << ind0 << "} else {\n";
-                    if (ev_unroll) checked(ind0 + "    ");
-                    else quiet("true", "true", st_flag, ind0 + "    ");
+                    quiet("true", "true", st_flag, ind0 + "    ");
                     body << ind0 << "}\n";
                 }
+            };
+            // the two straight-line variants only (the caller has established that no countdown ends in the chunk)
+            auto fast_variants = [&](bool st_flag, const std::string& ind0) {
+                body << ind0 << "if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // no lane is in Release\n";
+                quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "    ");
+                body << ind0 << "} else {\n";
+                quiet("false", "true", st_flag, ind0 + "    ");
+                body << ind0 << "}\n";
             };
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
                  << "        const uint32_t ch = t - " << gi << "u;\n"
@@ -3159,19 +3171,28 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << "                og::ev_advance(A, c);\n"
                      << "            }\n"
                      << "        }\n";
-            body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))" << (force && force[0] == 'e' ? " && A.frames == 0u" : "") << ") {\n";
+            const bool one_checked = ev_unroll && !mc.empty() && !force; // events and stage ends share ONE unrolled, checked body
+            if (one_checked)
+                body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH)) && __all((int)(" << mc
+                     << " > (uint32_t)XCH))) { // nothing happens in this chunk: no event, no envelope stage end\n";
+            else
+                body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH))" << (force && force[0] == 'e' ? " && A.frames == 0u" : "") << ") {\n";
+            auto pick = [&](bool st_flag, const std::string& ind) {
+                if (one_checked) fast_variants(st_flag, ind);
+                else variants(st_flag, ind);
+            };
             if (steady.empty()) {
-                variants(false, "            ");
+                pick(false, "            ");
             } else {
                 body << "            constexpr uint32_t CHUNK = XCH;\n"
                      << "            if (__all((int)(!c.valid || (" << steady << ")))) { // node steady states hold for the whole chunk\n";
-                variants(true, "                ");
+                pick(true, "                ");
                 body << "            } else {\n";
-                variants(false, "                ");
+                pick(false, "                ");
                 body << "            }\n";
             }
-            if (ev_unroll && !mc.empty() && !(force && force[0] == 'e')) {
-                body << "        } else if (n == XCH) { // a chunk with an event: the checked, unrolled body\n";
+            if (one_checked) {
+                body << "        } else if (n == XCH) { // an event or a stage end in this chunk: the checked, unrolled body\n";
                 checked("            ");
             }
             body << "        } else {\n"

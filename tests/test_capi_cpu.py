@@ -258,3 +258,30 @@ def test_note_event_streams_match_the_oracle_generator_in_both_fold_modes():
         if fold == "slice" and 0 < span < 48000:  # all three kinds of event inside a short window
             win = ev_f < span
             assert (ev_x[win] > 0).sum() > 0 and (ev_x[win] == 0).sum() > 0
+
+
+def test_rust_shim_block_render_constants_and_calls():
+    """bindings/rust/oscen-gpu (source only: no rustc here): BlockRender::NUM_STREAM_INPUTS must be a real constant --
+    the trait's default render() asserts `inputs.len() == NUM_STREAM_INPUTS` and loops over it
+    (oscen-lib/src/graph/offline.rs:46-75; round 2 had usize::MAX there, which panics) -- and every `sys::og_*` the
+    shim calls must be declared by the sys crate and by include/oscen_gpu.h."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "bindings", "rust", "oscen-gpu", "src", "lib.rs")).read()
+    code = "\n".join(ln for ln in shim.splitlines() if not ln.lstrip().startswith("//"))
+    assert "usize::MAX" not in code
+    assert re.search(r"impl<const IN: usize> oscen::BlockRender<f32> for GpuGraph<IN>", code)
+    assert re.search(r"const NUM_STREAM_INPUTS: usize = IN;", code)
+    assert re.search(r"stream_in_blocks: \[\[f32; MAX_BLOCK_SIZE\]; IN\]", code)
+    assert "og_num_stream_inputs(e) } as usize" in code and "have != IN" in code  # checked against the engine at construction
+    sys_rs = open(os.path.join(root, "bindings", "rust", "oscen-gpu-sys", "src", "lib.rs")).read()
+    bound = set(re.findall(r"pub fn (og_\w+)\s*\(", sys_rs))
+    hdr = open(os.path.join(root, "include", "oscen_gpu.h")).read()
+    called = set(re.findall(r"sys::(og_\w+)\s*\(", code))
+    assert len(called) >= 20
+    for name in called:
+        assert name in bound, name + " is called by the shim but not bound by oscen-gpu-sys"
+        assert re.search(r"\b%s\s*\(" % name, hdr), name + " is not declared in include/oscen_gpu.h"
+    for ty in re.findall(r"sys::(og_\w+)\b(?!\s*\()", code):
+        assert re.search(r"pub struct %s\b" % ty, sys_rs), ty
