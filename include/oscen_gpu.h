@@ -109,7 +109,7 @@ typedef struct {
     /* `#[output(event)]` fields (oscen-macros/src/lib.rs:127-133).  process() and the handlers see each as an
      * object with `push(float scalar)` (= EventOutput::try_push of a scalar payload at the current frame; at most
      * OG_NODE_EVENTS_PER_FRAME = 2 per frame and output, further pushes are dropped like try_push on a full queue --
-     * the reference's queue holds 32).  `a.trig -> b.gate` runs b's on_gate for every event a pushed on that frame,
+     * the reference's queue holds 32 -- and counted in og_events_dropped).  `a.trig -> b.gate` runs b's on_gate for every event a pushed on that frame,
      * before b.process(); the outputs are cleared once per frame (clear_event_outputs, lib.rs:237-256). */
     const char* const* event_outputs;
     uint32_t n_event_outputs;
@@ -280,7 +280,26 @@ uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 8 for graphs with per-
 int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched kernel: 0 = one wave per 64 voices,
                                                  2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
+/* events that were never delivered: try_push overflows and late block-local events (host side) + pushes the in-voice
+ * event queues of user nodes could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output; counted on the device) */
 uint64_t og_events_dropped(const og_engine* e);
+
+/* ---- event OUTPUTS of the graph (`output x: event;` fed by a node's #[output(event)] field: EventOutput,
+ * oscen-lib/src/graph/types.rs:137-241; in the reference the caller iterates `graph.x` after process_block).
+ * With N voices the events of all voices go to one device log; og_read_output_events moves what has arrived since the
+ * last call to the host, ordered by (frame, voice, push order).  `frame` is absolute (frames since og_init):
+ * frame_offset within the last block = frame - (og_frames_processed() - frames of that block).  The log holds
+ * max(65 536, 4 x voices) events between two reads; what does not fit is counted in *n_overflowed. */
+typedef struct {
+    uint32_t voice;
+    uint32_t output; /* og_event_output_index */
+    uint64_t frame;
+    float value;     /* scalar payload */
+    uint32_t reserved;
+} og_out_event;
+uint32_t og_num_event_outputs(const og_engine* e);
+int og_event_output_index(const og_engine* e, const char* name);
+int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_t* n, uint64_t* n_overflowed);
 /* which voice kernel runs: FNV-1a hash of the generated kernel body (the `<hash>` in the kernel names
  * og_k_<hash>_*, og_k2_<hash>_*, ... that rocprofv3 reports), and whether it came from hiprtc */
 uint64_t og_kernel_hash(const og_engine* e);

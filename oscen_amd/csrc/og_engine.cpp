@@ -306,6 +306,12 @@ struct og_engine {
     float* h_ramp[RAMP_RING] = {};
     uint64_t ramp_seq[RAMP_RING] = {}; // batch whose launch copied ramp table i to the device (0 = never)
     int ramp_head = 0;
+    // events leaving the voices (graph event outputs) and pushes the in-voice queues dropped: device log / counter
+    OgOutEvent* d_out_ev = nullptr;
+    uint32_t* d_out_ev_count = nullptr; // [0] = events appended, [1] = in-voice pushes lost
+    uint32_t out_ev_cap = 0;
+    uint64_t out_ev_overflow = 0;       // events that did not fit the log (reported by og_read_output_events)
+    uint64_t ev_lost_total = 0;         // in-voice pushes lost, read back so far
     float* d_taps = nullptr;
     int32_t* d_tap_slot = nullptr;
     uint32_t n_taps = 0;
@@ -431,6 +437,8 @@ struct og_engine {
         (void)hipFree(d_bus);
         (void)hipFree(d_taps);
         (void)hipFree(d_tap_slot);
+        (void)hipFree(d_out_ev);
+        (void)hipFree(d_out_ev_count);
         for (int i = 0; i < RAMP_RING; ++i) {
             (void)hipFree(d_ramp[i]);
             if (h_ramp[i]) (void)hipHostFree(h_ramp[i]);
@@ -912,6 +920,10 @@ struct og_engine {
         A.partial_plane = (uint32_t)((size_t)n_chunks16 * n_wg * OG_RED_FRAMES);
         A.taps = d_taps;
         A.tap_slot = d_tap_slot;
+        A.out_ev = d_out_ev;
+        A.out_ev_cap = out_ev_cap;
+        A.out_ev_count = d_out_ev ? d_out_ev_count : nullptr;
+        A.ev_lost = d_out_ev_count ? d_out_ev_count + 1 : nullptr;
         for (size_t k = 0; k < cg->rings.size(); ++k) {
             A.rings[k] = d_ring[k];
             A.ring_cap[k] = ring_cap[k];
@@ -1420,6 +1432,16 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
+        if (!cg.event_outputs.empty() || cg.has_node_event_outputs) {
+            HIPCK(hipMalloc(&e->d_out_ev_count, 2 * sizeof(uint32_t)));
+            HIPCK(hipMemset(e->d_out_ev_count, 0, 2 * sizeof(uint32_t)));
+        }
+        if (!cg.event_outputs.empty()) { // room for four events per voice between two reads (OSCEN_GPU_OUT_EVENTS overrides)
+            size_t cap = std::max<size_t>(65536, (size_t)n_voices * 4);
+            if (const char* ev = getenv("OSCEN_GPU_OUT_EVENTS")) cap = std::max<size_t>(16, (size_t)atoll(ev));
+            e->out_ev_cap = (uint32_t)std::min<size_t>(cap, 0x7FFFFFFFu);
+            HIPCK(hipMalloc(&e->d_out_ev, (size_t)e->out_ev_cap * sizeof(OgOutEvent)));
+        }
         e->stream_blocks.resize(cg.inputs.size());
         for (size_t i = 0; i < cg.inputs.size(); ++i)
             if (cg.inputs[i].stream_row >= 0) e->stream_blocks[i].assign(OG_MAX_BLOCK, 0.0f);
@@ -1442,6 +1464,9 @@ int og_init(og_engine* e, float sample_rate)
         e->q_frames = 0;
         e->upload_initial_state();
         e->reset_timeline();
+        if (e->d_out_ev_count) HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, 2 * sizeof(uint32_t), e->stream));
+        e->out_ev_overflow = 0;
+        e->ev_lost_total = 0;
         e->frame_now = 0;
         e->inited = true;
         return OG_OK;
@@ -1836,7 +1861,72 @@ uint32_t og_state_words_written_per_voice(const og_engine* e)
 uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lpv : 0; }
 int og_uses_split_kernel(const og_engine* e) { return e ? (int)e->split : 0; }
 uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes / (uint32_t)e->cg->lpv : 0; }
-uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped : 0; }
+uint64_t og_events_dropped(const og_engine* ce)
+{
+    if (!ce) return 0;
+    og_engine* e = const_cast<og_engine*>(ce);
+    // in-voice event queues (#[output(event)] fields of user nodes) hold OG_NODE_EVENTS_PER_FRAME events per frame and
+    // output; what they could not hold is counted on the device and read back here (one small copy, graphs with such
+    // nodes only)
+    if (e->d_out_ev_count && e->cg->has_node_event_outputs && e->inited) {
+        try {
+            HIPCK(hipSetDevice(e->device));
+            e->flush_bus();
+            uint32_t lost = 0;
+            HIPCK(hipMemcpyAsync(&lost, e->d_out_ev_count + 1, sizeof lost, hipMemcpyDeviceToHost, e->stream));
+            HIPCK(hipMemsetAsync(e->d_out_ev_count + 1, 0, sizeof(uint32_t), e->stream));
+            HIPCK(hipStreamSynchronize(e->stream));
+            e->ev_lost_total += lost;
+        } catch (const std::exception&) {
+        }
+    }
+    return e->dropped + e->ev_lost_total;
+}
+
+uint32_t og_num_event_outputs(const og_engine* e) { return e ? (uint32_t)e->cg->event_outputs.size() : 0; }
+int og_event_output_index(const og_engine* e, const char* name)
+{
+    if (!e || !name) return set_err(OG_E_INVALID, "null argument");
+    for (size_t i = 0; i < e->cg->event_outputs.size(); ++i)
+        if (e->cg->event_outputs[i] == name) return (int)i;
+    return set_err(OG_E_INVALID, std::string("no event output named '") + name + "'");
+}
+
+int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_t* n_out, uint64_t* n_overflowed)
+{
+    if (!e || (cap && !buf) || !n_out) return set_err(OG_E_INVALID, "null argument");
+    *n_out = 0;
+    if (n_overflowed) *n_overflowed = 0;
+    if (!e->d_out_ev) return OG_OK; // (a graph without event outputs: nothing ever arrives)
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
+        uint32_t count = 0;
+        HIPCK(hipMemcpyAsync(&count, e->d_out_ev_count, sizeof count, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        const uint32_t have = std::min(count, e->out_ev_cap);
+        std::vector<OgOutEvent> ev(have);
+        if (have) HIPCK(hipMemcpyAsync(ev.data(), e->d_out_ev, (size_t)have * sizeof(OgOutEvent), hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, sizeof(uint32_t), e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        e->out_ev_overflow += count - have;
+        // frame order; within a frame voice order; a voice's events of one frame in push order (the append index of
+        // one lane grows in program order)
+        std::sort(ev.begin(), ev.end(), [](const OgOutEvent& a, const OgOutEvent& b) {
+            if (a.frame != b.frame) return a.frame < b.frame;
+            if (a.voice != b.voice) return a.voice < b.voice;
+            return a.seq < b.seq;
+        });
+        const uint32_t give = std::min(have, cap);
+        for (uint32_t i = 0; i < give; ++i) buf[i] = og_out_event{ev[i].voice, ev[i].output, ev[i].frame, ev[i].value, 0u};
+        *n_out = give;
+        if (n_overflowed) {
+            *n_overflowed = e->out_ev_overflow + (have - give);
+            e->out_ev_overflow = 0;
+        }
+        return OG_OK;
+    });
+}
 uint64_t og_kernel_hash(const og_engine* e) { return e ? e->cg->hash : 0; }
 int og_kernel_is_jit(const og_engine* e) { return e ? (e->launch ? 0 : 1) : 0; }
 uint32_t og_bus_reduce_passes(const og_engine* e) { return e ? e->bus_passes : 0; }

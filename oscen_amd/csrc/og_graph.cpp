@@ -329,6 +329,7 @@ struct Codegen {
     bool dynamic_events = false; // some node receives events from another node: they arrive unannounced, so the
                                  // chunk variants that rely on "nothing happens in this chunk" and the pipelines are off
     std::ostringstream frame_end; // end of every frame: clear_event_outputs()
+    std::ostringstream frame_log; // ... right before it: events of the graph's event outputs go to the host log
     bool bus_all_lanes = false; // every lane of a multi-lane voice contributes a share to the mix bus (og::ep_bank_tick)
     // envelopes whose stage-end fix-up has not been emitted yet: (countdown expression, fix-up code).
     // Flushed as ONE wave-uniform check before the next node that is not an envelope (which may read
@@ -1406,7 +1407,10 @@ void emit_user(NodeCtx& x)
     for (const std::string& o : u.ev_outputs) {
         evo.push_back(x.p + o);
         x.cg.S().decl << "    og::EvOut " << x.p << o << ";\n";
-        (x.n.domain == 1 ? x.cg.S().s_cap : x.cg.frame_end) << "        " << x.p << o << ".clear();\n";
+        (x.n.domain == 1 ? x.cg.S().s_cap : x.cg.frame_end)
+            << "        if (__any((int)(" << x.p << o << ".lost != 0u))) og::ev_report_lost(A, c, " << x.p << o << ");\n"
+            << "        " << x.p << o << ".clear();\n";
+        x.cg.out.has_node_event_outputs = true;
     }
     // event handlers: value inputs must be known when the event fires (before the frame's nodes run)
     for (const auto& h : u.handlers) {
@@ -2298,6 +2302,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::vector<std::set<int>> deps(g.nodes.size()); // node -> nodes it reads
     std::vector<std::set<int>> out_deps(g.outputs.size());
     std::vector<std::set<int>> out_reads(g.outputs.size()); // output -> outputs its sources read (`out_a + out_b -> out`)
+    std::map<int, std::pair<int, std::string>> ev_out_edges; // graph EVENT output -> (node, event-output port) feeding it
     std::vector<std::set<int>> fb_deps(g.nodes.size()); // feedback edges: liveness only, no ordering
     bool any_feedback = false;
     cg.emitted.assign(g.nodes.size(), 0);
@@ -2382,8 +2387,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         if (dp.empty()) {
             auto oit = cg.output_by_name.find(dn);
             if (oit == cg.output_by_name.end()) fail("unknown destination '" + e.dst + "'");
+            if (g.outputs[oit->second].kind == Kind::Event) {
+                // `node.trig -> x` with `output x: event;` (EventOutput, graph/types.rs:137-241): the events leave the
+                // voice through the device log.  clear + copy: the LAST connected source delivers.
+                if (!src_is_event_output || src->t != Expr::Ref)
+                    fail("event output '" + e.dst + "' must be fed by an event output of a node ('" + e.src + "')");
+                ev_out_edges[oit->second] = {*src_nodes.begin(), src->port};
+                out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
+                continue;
+            }
             if (src_is_event_input || src_is_event_output)
-                fail("event outputs of the graph are not supported ('" + e.dst + "'): events stay inside the voice");
+                fail("'" + e.dst + "' is a stream output: an event source cannot feed it");
             out_edges[oit->second].push_back({src, e.policy});
             out_deps[oit->second].insert(src_nodes.begin(), src_nodes.end());
             for (int so : src_outputs) {
@@ -2459,6 +2473,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     out.lane_width = out.lpv > 1 ? 4 : 1; // OG_HPL
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live && !cg.nodes[i].ev_node_edges.empty()) cg.dynamic_events = true;
+    if (!ev_out_edges.empty()) cg.dynamic_events = true; // (the per-frame log / clear lives in the ordinary kernel's tick)
+    if (!ev_out_edges.empty() && out.lpv != 1) fail("graph event outputs are not supported in array-valued (several lanes per voice) graphs");
     if (cg.dynamic_events && out.lpv != 1) fail("node-to-node event edges are not supported in array-valued (several lanes per voice) graphs");
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
@@ -2695,8 +2711,18 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 }
             if (oorder.size() < g.outputs.size()) fail("graph outputs read each other in a cycle");
         }
+        for (size_t oi = 0; oi < g.outputs.size(); ++oi) { // event outputs: one log call per frame each, before the clears
+            if (g.outputs[oi].kind != Kind::Event) continue;
+            auto eo = ev_out_edges.find((int)oi);
+            if (eo == ev_out_edges.end()) continue; // declared, never fed: nothing ever arrives
+            const NodeInst& src = cg.nodes[eo->second.first];
+            if (src.domain == 1) fail("event output '" + g.outputs[oi].name + "' is fed from an oversampled node (cross-rate event drains are not built)");
+            const std::string q = "n" + std::to_string(src.id) + "_" + eo->second.second;
+            cg.frame_log << "        if (__any((int)(" << q << ".n != 0u))) og::ev_out_log(A, c, " << out.event_outputs.size() << "u, f, " << q << ");\n";
+            out.event_outputs.push_back(g.outputs[oi].name);
+        }
         for (size_t oi : oorder) {
-            if (g.outputs[oi].kind == Kind::Event) fail("event outputs are not supported");
+            if (g.outputs[oi].kind == Kind::Event) continue;
             auto it = out_edges.find((int)oi);
             if (it == out_edges.end()) {
                 if (consumed[oi]) fail("graph output '" + g.outputs[oi].name + "' is read but nothing feeds it");
@@ -2909,8 +2935,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
          << group_tick({all_stages}, 0);
     if (cg.frame_end.str().empty()) {
         body << "        return " << bus_expr << ";\n    };\n";
-    } else { // clear_event_outputs(): the frame's node-to-node events have been delivered
-        body << "        const auto g_bus = " << bus_expr << ";\n" << cg.frame_end.str() << "        return g_bus;\n    };\n";
+    } else { // clear_event_outputs(): the frame's node-to-node events have been delivered (and the graph's event outputs logged)
+        body << "        const auto g_bus = " << bus_expr << ";\n" << cg.frame_log.str() << cg.frame_end.str() << "        return g_bus;\n    };\n";
     }
     body << events_code(all_stages);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"

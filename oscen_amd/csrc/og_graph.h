@@ -148,6 +148,8 @@ struct CompiledGraph {
     int n_ramps = 0;
     int n_streams = 0; // graph-level stream inputs (`<stream_in>_block`): rows n_ramps.. of the per-frame table
     int n_event_inputs = 0;
+    std::vector<std::string> event_outputs; // the graph's event outputs that a node feeds, in declaration order (og_read_output_events)
+    bool has_node_event_outputs = false;    // some live node has an #[output(event)] field (drops are counted on the device)
     uint32_t channels = 1;
     uint32_t voice_channels = 1; // 2: the voice graph's stream output is fed a Frame<2> (summed per channel, bus interleaved)
     uint32_t latency_samples = 0;

@@ -58,6 +58,14 @@ struct OgEvent {
 
 #define OG_MAX_RINGS 4
 
+struct OgOutEvent { // one event of a graph event output (og_read_output_events)
+    uint32_t voice;
+    uint32_t output; // index among the graph's event outputs
+    uint64_t frame;  // absolute frame since og_init
+    float value;     // scalar payload
+    uint32_t seq;    // append order (ties of one voice on one frame keep their push order)
+};
+
 struct OgBlockArgs {
     uint32_t n_voices;
     uint32_t frames;           // frames this launch renders: one block (<= 512), or several queued blocks back to back
@@ -76,6 +84,12 @@ struct OgBlockArgs {
     const float* ramp_table;   // [n_ramps + n_streams][ramp_stride] per-frame values of ramped / stream inputs
     float* taps;               // [n_taps][frames] per-voice output taps (or null)
     const int32_t* tap_slot;   // [n_voices] tap row or -1 (or null)
+    // events that leave the voice (`output x: event;` fed by a node's #[output(event)] field): appended to a device log
+    uint32_t* out_ev_count;    // events logged so far (may run past out_ev_cap: the excess is counted as dropped)
+    struct OgOutEvent* out_ev; // [out_ev_cap]
+    uint32_t out_ev_cap;
+    uint32_t _pad0;
+    uint32_t* ev_lost;         // pushes an in-voice event queue could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output)
     float* rings[OG_MAX_RINGS];        // delay lines: [capacity][n_voices] each (slot-major, voices contiguous)
     uint32_t ring_cap[OG_MAX_RINGS];   // capacity in samples (a power of two, ring_buffer/mod.rs:35-41)
     uint32_t slots[OG_MAX_SLOTS]; // block-uniform values (f32 or u32 bits)
@@ -150,15 +164,17 @@ struct Frame {
 #define OG_NODE_EVENTS_PER_FRAME 2
 struct EvOut {
     uint32_t n = 0u;
+    uint32_t lost = 0u; // pushes past the capacity on this frame (reported through OgBlockArgs::ev_lost, og_events_dropped)
     float v0 = 0.0f, v1 = 0.0f;
     __device__ __forceinline__ void push(float x) // try_push: dropped when the frame's queue is full
     {
         v1 = (n == 1u) ? x : v1;
         v0 = (n == 0u) ? x : v0;
+        lost += (n >= (uint32_t)OG_NODE_EVENTS_PER_FRAME) ? 1u : 0u;
         n = min(n + 1u, (uint32_t)OG_NODE_EVENTS_PER_FRAME);
     }
     __device__ __forceinline__ float get(uint32_t k) const { return k == 0u ? v0 : v1; }
-    __device__ __forceinline__ void clear() { n = 0u; }
+    __device__ __forceinline__ void clear() { n = 0u; lost = 0u; }
 };
 
 struct VoiceCtx {
@@ -230,6 +246,23 @@ __device__ __forceinline__ void voice_begin_split(const OgBlockArgs& a, VoiceCtx
 __device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
 {
     if (c.valid && c.lead && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
+}
+
+// end of a frame, before the queues are cleared: count the pushes an event output had to drop ...
+__device__ __forceinline__ void ev_report_lost(const OgBlockArgs& a, const VoiceCtx& c, const EvOut& q)
+{
+    if (c.valid && c.lead && q.lost != 0u && a.ev_lost) atomicAdd(a.ev_lost, q.lost);
+}
+// ... and hand the events of a GRAPH event output (`node.trig -> x` with `output x: event`) to the host log
+__device__ __forceinline__ void ev_out_log(const OgBlockArgs& a, const VoiceCtx& c, uint32_t output, uint32_t f, const EvOut& q)
+{
+    if (!(c.valid && c.lead) || !a.out_ev_count) return;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++k)
+        if (k < q.n) {
+            const uint32_t idx = atomicAdd(a.out_ev_count, 1u);
+            if (idx < a.out_ev_cap) a.out_ev[idx] = OgOutEvent{c.v, output, a.frame0 + (uint64_t)f, q.get(k), idx};
+        }
 }
 
 // pop the current event and arm the next one

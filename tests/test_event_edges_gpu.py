@@ -167,3 +167,87 @@ def test_passthrough_between_a_graph_event_input_and_a_node_is_free():
         for v in range(64):
             e.schedule_voice_event("gate", v, 3 * v, 0.9)
     assert np.array_equal(a.process_block(256), b.process_block(256))
+
+
+def test_graph_event_outputs_reach_the_host_in_frame_voice_push_order():
+    """`output ticks: event;` fed by a node's #[output(event)] field (EventOutput, oscen-lib/src/graph/types.rs:137-241;
+    the reference's caller iterates `graph.ticks` after process_block): the events of every voice leave through the
+    device log with their exact frame; a third push on one frame is dropped and counted (the in-voice queue holds
+    OG_NODE_EVENTS_PER_FRAME = 2)."""
+    oscen_amd.register_node(
+        "Burst::new", inputs=[("period", "value", 100.0, 0), ("pushes", "value", 1.0, 1)], outputs=["level"], n_ctor_args=2,
+        state=[("count", "u32", 0, -1), ("fired", "f32", 0.0, -1)], event_outputs=["tick"],
+        process="""
+    count += 1u;
+    if ((float)count >= period) {
+        count = 0u;
+        fired += 1.0f;
+        for (int k = 0; k < (int)pushes; ++k) tick.push(fired * 10.0f + (float)k);
+    }
+    level = fired;
+""")
+    try:
+        g = oscen_amd.Graph("bursts")
+        g.input_value("period", 100.0, per_voice=True)
+        g.input_value("pushes", 1.0, per_voice=True)
+        g.output_stream("out")
+        g.output_event("ticks")
+        g.node("b", "Burst::new", 100.0, 1.0)
+        g.connect("period", "b.period")
+        g.connect("pushes", "b.pushes")
+        g.connect("b.level", "out")
+        g.connect("b.tick", "ticks")
+        n = 200
+        periods = (37 + (np.arange(n) * 7) % 90).astype(np.float32)
+        pushes = (1 + np.arange(n) % 3).astype(np.float32)  # 1, 2 or 3 pushes per firing: the third is dropped
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        assert eng.lib.og_num_event_outputs(eng.h) == 1 and eng.event_output_index("ticks") == 0
+        eng.set_voice_values("period", periods)
+        eng.set_voice_values("pushes", pushes)
+        got = []
+        blocks = (256, 100, 412, 256)
+        for i, b in enumerate(blocks):
+            eng.process_block(b)
+            if i % 2 == 1:  # drained every other block: events of two blocks arrive together, still ordered
+                ev, over = eng.read_output_events()
+                assert over == 0
+                got.append(ev)
+        ev, over = eng.read_output_events()
+        assert over == 0 and len(ev) == 0
+        got = np.concatenate(got)
+        # model
+        want, lost = [], 0
+        total = sum(blocks)
+        for v in range(n):
+            count, fired = 0, 0.0
+            for f in range(total):
+                count += 1
+                if np.float32(count) >= periods[v]:
+                    count = 0
+                    fired += 1.0
+                    for k in range(int(pushes[v])):
+                        if k < 2:
+                            want.append((f, v, np.float32(np.float32(fired * 10.0) + np.float32(k))))
+                        else:
+                            lost += 1
+        want.sort(key=lambda t: (t[0], t[1]))  # (stable: a voice's two pushes of one frame keep their order)
+        assert len(got) == len(want) and len(want) > 1000
+        assert np.array_equal(got["frame"], np.array([w[0] for w in want], dtype=np.uint64))
+        assert np.array_equal(got["voice"], np.array([w[1] for w in want], dtype=np.uint32))
+        assert np.array_equal(got["value"], np.array([w[2] for w in want], dtype=np.float32))
+        assert np.all(got["output"] == 0)
+        assert eng.events_dropped == lost and lost > 50
+        # a log too small for what arrives between two reads: the excess is counted, not lost silently
+        import os
+        os.environ["OSCEN_GPU_OUT_EVENTS"] = "64"
+        try:
+            small = oscen_amd.Engine(g, n, sample_rate=SR)
+        finally:
+            del os.environ["OSCEN_GPU_OUT_EVENTS"]
+        small.set_voice_values("period", periods)
+        small.set_voice_values("pushes", np.ones(n, dtype=np.float32))
+        small.process_block(512)
+        ev, over = small.read_output_events()
+        assert len(ev) == 64 and over > 0
+    finally:
+        oscen_amd.unregister_node("Burst::new")
