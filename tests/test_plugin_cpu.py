@@ -195,8 +195,20 @@ def test_event_outputs_lower_to_in_kernel_event_edges():
     bad.output_stream("out")
     bad.node("t", "Ticker::new", 32.0)
     bad.connect("t.trig", "out")
-    with pytest.raises(oscen_amd.OscenError, match="event outputs of the graph"):
+    with pytest.raises(oscen_amd.OscenError, match="is a stream output: an event source cannot feed it"):
         bad.kernel_source()
+    # round 3: an EVENT output of the graph takes the node's events out of the voice (device log, og_read_output_events)
+    ok = oscen_amd.Graph("ev3")
+    ok.output_stream("out")
+    ok.output_event("ticks")
+    ok.node("t", "Ticker::new", 32.0)
+    ok.node("osc", "Oscillator::sine", 220.0, 0.5)
+    ok.connect("osc.output", "out")
+    ok.connect("t.trig", "ticks")
+    src = ok.kernel_source()
+    assert "og::ev_out_log(A, c, 0u, f, n0_trig);" in src and "og::ev_report_lost(A, c, n0_trig);" in src
+    assert src.index("og::ev_out_log(") < src.index("n0_trig.clear();") and "og_k2_" not in src
+    assert ok.jit_check() > 0
     oscen_amd.unregister_node("Ticker::new")
 
 
