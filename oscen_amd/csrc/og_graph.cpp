@@ -2470,7 +2470,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         fail("the post-mix node must be wired `<voice output> -> node.input` and `node.output -> <graph output>`");
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live) out.lpv = std::max(out.lpv, cg.nodes[i].type->lpv);
-    out.lane_width = out.lpv > 1 ? 4 : 1; // OG_HPL
+    // harmonics per lane of an array-valued voice (OG_HPL): 4 = eight lanes per 32-harmonic voice.  OGC_HPL=2|8 builds the
+    // 16 x 2 / 4 x 8 forms for comparison (profiles/r03_epiano_lanes.md); the state layout [voice][32] does not change.
+    int hpl = 4;
+    if (const char* eh = getenv("OGC_HPL")) {
+        const int h = atoi(eh);
+        if (h == 2 || h == 4 || h == 8) hpl = h;
+    }
+    if (out.lpv > 1) out.lpv = 32 / hpl;
+    out.lane_width = out.lpv > 1 ? hpl : 1; // OG_HPL
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live && !cg.nodes[i].ev_node_edges.empty()) cg.dynamic_events = true;
     if (!ev_out_edges.empty()) cg.dynamic_events = true; // (the per-frame log / clear lives in the ordinary kernel's tick)
@@ -3265,6 +3273,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << ".\n"
         << "// Node order: ";
     for (auto& nn : out.node_order) src << nn << " ";
+    if (out.lpv > 1 && out.lane_width != 4) src << "\n#define OG_HPL " << out.lane_width << " // harmonics per lane (OGC_HPL)";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
         << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.ramp_stride + f] : og::slot_f(A, (slot)))\n"
@@ -3274,8 +3283,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n#undef ST\n\n";
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
+    // register budget of the ordinary kernel: 4 waves per SIMD = 128 VGPRs.  The 4-lanes-per-voice e-piano form
+    // (OGC_HPL=8) keeps twice the harmonics per lane and needs the 256-VGPR budget (2 waves per SIMD)
+    int waves_eu = (out.lpv > 1 && out.lane_width == 8) ? 2 : 4;
+    if (const char* ew = getenv("OGC_WAVES_EU")) waves_eu = std::max(1, std::min(8, atoi(ew)));
     for (auto& v : variants)
-        src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void og_k_" << hs << "_" << v[0]
+        src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(" << waves_eu << "))) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";
     std::vector<std::pair<int, int>> depths; // (tag: what OgBlockArgs::split selects, waves per workgroup)
     if (!cg.groups2.empty()) depths.push_back({2, (int)cg.groups2.size()});

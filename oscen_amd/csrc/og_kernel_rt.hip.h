@@ -290,20 +290,42 @@ __device__ __forceinline__ void st_u(const OgBlockArgs& a, const VoiceCtx& c, in
 }
 
 // Array-valued state of an LPV > 1 voice (`[f32; 32]` fields: the electric piano's per-harmonic arrays): a lane
-// owns OG_HPL consecutive elements, h = c.h * OG_HPL + j, kept in registers as one HarmV and moved as one 16-byte
-// access -- the 64 lanes of a wave read 1 KB of consecutive bytes per array.
-// The four elements sit in two 2-vectors so that the per-element arithmetic (identical and independent across
-// elements) runs on packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations per issue, each
-// rounded exactly like its scalar form).
-#define OG_HPL 4
+// owns OG_HPL consecutive elements, h = c.h * OG_HPL + j, kept in registers as one HarmV and moved with 16-byte
+// accesses -- the 64 lanes of a wave read consecutive bytes per array.
+// The elements sit in 2-vectors so that the per-element arithmetic (identical and independent across elements) runs
+// on packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations per issue, each rounded exactly
+// like its scalar form).
+#ifndef OG_HPL
+#define OG_HPL 4 // harmonics per lane (2, 4 or 8: 16, 8 or 4 lanes per 32-harmonic voice); a generated source may pre-define it
+#endif
+#define OG_HPAIRS (OG_HPL / 2)
 typedef float og_f2 __attribute__((ext_vector_type(2)));
 struct HarmV {
-    og_f2 a, b; // elements 0,1 and 2,3
+    og_f2 p[OG_HPAIRS]; // elements (0,1), (2,3), ...
 };
 // (a value select: `c ? x : y` on two HarmV lvalues would select ADDRESSES and pin both to scratch memory)
-__device__ __forceinline__ HarmV harm_select(bool c, const HarmV& x, const HarmV& y)
+// (by VALUE, element by element through scalars: a select between two loads is turned into a load from a selected
+//  address, which takes the addresses of both operands and moves whole node structs into scratch -- seen again in
+//  round 3 when the elements became an array: 96-byte EpAmp stores/loads around every chunk)
+__device__ __forceinline__ og_f2 f2_select(bool c, og_f2 x, og_f2 y)
 {
-    return HarmV{og_f2{c ? x.a.x : y.a.x, c ? x.a.y : y.a.y}, og_f2{c ? x.b.x : y.b.x, c ? x.b.y : y.b.y}};
+    const float x0 = x.x, x1 = x.y, y0 = y.x, y1 = y.y;
+    return og_f2{c ? x0 : y0, c ? x1 : y1};
+}
+__device__ __forceinline__ HarmV harm_select(bool c, HarmV x, HarmV y)
+{
+    HarmV r;
+#if OG_HPAIRS >= 1
+    r.p[0] = f2_select(c, x.p[0], y.p[0]);
+#endif
+#if OG_HPAIRS >= 2
+    r.p[1] = f2_select(c, x.p[1], y.p[1]);
+#endif
+#if OG_HPAIRS >= 4
+    r.p[2] = f2_select(c, x.p[2], y.p[2]);
+    r.p[3] = f2_select(c, x.p[3], y.p[3]);
+#endif
+    return r;
 }
 // element-wise helpers; OG_EP_SCALAR (experiment switch) forces one scalar instruction per element
 #ifdef OG_EP_SCALAR
@@ -321,19 +343,49 @@ __device__ __forceinline__ og_f2 f2_add(og_f2 x, og_f2 y) { return x + y; }
 __device__ __forceinline__ og_f2 f2_sub(og_f2 x, og_f2 y) { return x - y; }
 #endif
 __device__ __forceinline__ og_f2 f2_mul(og_f2 x, float y) { return f2_mul(x, og_f2{y, y}); }
-__device__ __forceinline__ HarmV harm_splat(float x) { return HarmV{og_f2{x, x}, og_f2{x, x}}; }
-__device__ __forceinline__ HarmV harm_make(const float (&t)[OG_HPL]) { return HarmV{og_f2{t[0], t[1]}, og_f2{t[2], t[3]}}; }
+__device__ __forceinline__ HarmV harm_splat(float x)
+{
+    HarmV r;
+#pragma unroll
+    for (int i = 0; i < OG_HPAIRS; ++i) r.p[i] = og_f2{x, x};
+    return r;
+}
+__device__ __forceinline__ HarmV harm_make(const float (&t)[OG_HPL])
+{
+    HarmV r;
+#pragma unroll
+    for (int i = 0; i < OG_HPAIRS; ++i) r.p[i] = og_f2{t[2 * i], t[2 * i + 1]};
+    return r;
+}
 template <int LPV>
 __device__ __forceinline__ HarmV ldl_h(const OgBlockArgs& a, const VoiceCtx& c, int k)
 {
-    const float4 q = *reinterpret_cast<const float4*>(a.lane_state + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL);
-    return HarmV{og_f2{q.x, q.y}, og_f2{q.z, q.w}};
+    const float* src = reinterpret_cast<const float*>(a.lane_state) + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL;
+    HarmV r;
+#if OG_HPL >= 4
+#pragma unroll
+    for (int i = 0; i < OG_HPL / 4; ++i) { // 16-byte accesses: the lanes of a wave read consecutive bytes
+        const float4 q = reinterpret_cast<const float4*>(src)[i];
+        r.p[2 * i] = og_f2{q.x, q.y};
+        r.p[2 * i + 1] = og_f2{q.z, q.w};
+    }
+#else
+    const float2 q = *reinterpret_cast<const float2*>(src);
+    r.p[0] = og_f2{q.x, q.y};
+#endif
+    return r;
 }
 template <int LPV>
 __device__ __forceinline__ void stl_h(const OgBlockArgs& a, const VoiceCtx& c, int k, const HarmV& x)
 {
-    *reinterpret_cast<float4*>(a.lane_state + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL) =
-        make_float4(x.a.x, x.a.y, x.b.x, x.b.y);
+    float* dst = reinterpret_cast<float*>(a.lane_state) + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL;
+#if OG_HPL >= 4
+#pragma unroll
+    for (int i = 0; i < OG_HPL / 4; ++i)
+        reinterpret_cast<float4*>(dst)[i] = make_float4(x.p[2 * i].x, x.p[2 * i].y, x.p[2 * i + 1].x, x.p[2 * i + 1].y);
+#else
+    *reinterpret_cast<float2*>(dst) = make_float2(x.p[0].x, x.p[0].y);
+#endif
 }
 
 // All LDS traffic of the mix bus stays inside one wave (DS operations of a wave execute in order),

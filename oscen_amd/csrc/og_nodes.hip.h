@@ -880,16 +880,16 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
 OG_DEV HarmV ep_amp_tick(EpAmp& a)
 {
     const bool fresh = a.step == 0u;
-    const og_f2 ta = f2_mul(a.cur.a, a.mult.a), tb = f2_mul(a.cur.b, a.mult.b);
-    a.tgt.a.x = fresh ? ta.x : a.tgt.a.x;
-    a.tgt.a.y = fresh ? ta.y : a.tgt.a.y;
-    a.tgt.b.x = fresh ? tb.x : a.tgt.b.x;
-    a.tgt.b.y = fresh ? tb.y : a.tgt.b.y;
     const bool ramping = a.step < EP_INTERP_STEPS;
     const float t = ramping ? (float)(a.step + 1u) / (float)EP_INTERP_STEPS : 1.0f;
     const float u = 1.0f - t;
-    a.cur.a = f2_add(f2_mul(a.cur.a, u), f2_mul(a.tgt.a, t));
-    a.cur.b = f2_add(f2_mul(a.cur.b, u), f2_mul(a.tgt.b, t));
+#pragma unroll
+    for (int i = 0; i < OG_HPAIRS; ++i) {
+        const og_f2 tn = f2_mul(a.cur.p[i], a.mult.p[i]);
+        a.tgt.p[i].x = fresh ? tn.x : a.tgt.p[i].x;
+        a.tgt.p[i].y = fresh ? tn.y : a.tgt.p[i].y;
+        a.cur.p[i] = f2_add(f2_mul(a.cur.p[i], u), f2_mul(a.tgt.p[i], t));
+    }
     a.step = ramping ? a.step + 1u : 0u;
     return a.cur;
 }
@@ -912,7 +912,15 @@ OG_DEV void ep_bank_gate(EpBank& b, float v) // on_gate :115-122
 // bit-exact libm restatement (the rotation is applied every sample, an ulp here is a drift there).  Out of line on
 // purpose: this is a few hundred instructions that run only when a note changes the frequency; inlined into the voice
 // kernel they cost the hot loop its registers (the kernel spilled).  out = mre[OG_HPL] then mim[OG_HPL].
-__device__ __attribute__((noinline)) void ep_bank_tables(float frequency, float sr, uint32_t h0, float* __restrict__ out)
+// Results go through LDS (one column per lane), not through a stack array: an array whose address escapes into an
+// out-of-line function lives in scratch memory, and a kernel that touches scratch at all pays the scratch set-up at
+// every wave launch.
+#ifdef OG_EP_TABLES_INLINE // experiment switch (profiles/r03_epiano_lanes.md)
+__device__ __forceinline__ void ep_bank_tables(
+#else
+__device__ __attribute__((noinline)) void ep_bank_tables(
+#endif
+    float frequency, float sr, uint32_t h0, float* __restrict__ out, uint32_t stride)
 {
     const float nyquist = sr * 0.5f;
 #pragma unroll 1
@@ -924,8 +932,8 @@ __device__ __attribute__((noinline)) void ep_bank_tables(float frequency, float 
             c = og_cosf_exact(angle);
             s = og_sinf_exact(angle);
         }
-        out[j] = c;
-        out[OG_HPL + j] = s;
+        out[(uint32_t)j * stride] = c;
+        out[(uint32_t)(OG_HPL + j) * stride] = s;
     }
 }
 
@@ -936,10 +944,14 @@ OG_DEV void ep_bank_update(EpBank& b, uint32_t h0, float frequency, float sr)
 {
     if (frequency > 0.0f && !(fabsf(b.last_frequency - frequency) < 0.01f)) {
         b.last_frequency = frequency;
-        float tab[2 * OG_HPL];
-        ep_bank_tables(frequency, sr, h0, tab);
-        b.mre = HarmV{og_f2{tab[0], tab[1]}, og_f2{tab[2], tab[3]}};
-        b.mim = HarmV{og_f2{tab[4], tab[5]}, og_f2{tab[6], tab[7]}};
+        __shared__ float ep_tab[2 * OG_HPL][OG_WAVE]; // (one-wave workgroups: column = lane)
+        float* tab = &ep_tab[0][threadIdx.x % OG_WAVE];
+        ep_bank_tables(frequency, sr, h0, tab, OG_WAVE);
+#pragma unroll
+        for (int i = 0; i < OG_HPAIRS; ++i) {
+            b.mre.p[i] = og_f2{tab[(2 * i) * OG_WAVE], tab[(2 * i + 1) * OG_WAVE]};
+            b.mim.p[i] = og_f2{tab[(OG_HPL + 2 * i) * OG_WAVE], tab[(OG_HPL + 2 * i + 1) * OG_WAVE]};
+        }
         b.re = harm_splat(1.0f);
         b.im = harm_splat(0.0f);
         b.mul_dirty = true;
@@ -953,19 +965,22 @@ OG_DEV void ep_bank_update(EpBank& b, uint32_t h0, float frequency, float sr)
 template <bool VOICE_SUM>
 OG_DEV float ep_bank_tick(EpBank& b, const HarmV& amp)
 {
-    // Complex::mul :66-72 on two harmonics per instruction
-    const og_f2 re_a = f2_sub(f2_mul(b.re.a, b.mre.a), f2_mul(b.im.a, b.mim.a)), im_a = f2_add(f2_mul(b.re.a, b.mim.a), f2_mul(b.im.a, b.mre.a));
-    const og_f2 re_b = f2_sub(f2_mul(b.re.b, b.mre.b), f2_mul(b.im.b, b.mim.b)), im_b = f2_add(f2_mul(b.re.b, b.mim.b), f2_mul(b.im.b, b.mre.b));
-    b.re.a = re_a;
-    b.im.a = im_a;
-    b.re.b = re_b;
-    b.im.b = im_b;
-    const og_f2 p = f2_add(f2_mul(im_a, amp.a), f2_mul(im_b, amp.b)); // (h0 + h2, h1 + h3)
-    float s = p.x + p.y;
+    // Complex::mul :66-72 on two harmonics per instruction; the lane folds its pairs (h0 + h2 + .., h1 + h3 + ..), then
+    // the two halves
+    og_f2 acc = og_f2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < OG_HPAIRS; ++i) {
+        const og_f2 re = f2_sub(f2_mul(b.re.p[i], b.mre.p[i]), f2_mul(b.im.p[i], b.mim.p[i]));
+        const og_f2 im = f2_add(f2_mul(b.re.p[i], b.mim.p[i]), f2_mul(b.im.p[i], b.mre.p[i]));
+        b.re.p[i] = re;
+        b.im.p[i] = im;
+        const og_f2 w = f2_mul(im, amp.p[i]);
+        acc = (i == 0) ? w : f2_add(acc, w);
+    }
+    float s = acc.x + acc.y;
     if (VOICE_SUM) {
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
+#pragma unroll
+        for (int m = 1; m < EP_LPV; m <<= 1) s += __shfl_xor(s, m);
     }
     return s * 3.0f;
 }
