@@ -2470,9 +2470,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         fail("the post-mix node must be wired `<voice output> -> node.input` and `node.output -> <graph output>`");
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live) out.lpv = std::max(out.lpv, cg.nodes[i].type->lpv);
-    // harmonics per lane of an array-valued voice (OG_HPL): 4 = eight lanes per 32-harmonic voice.  OGC_HPL=2|8 builds the
-    // 16 x 2 / 4 x 8 forms for comparison (profiles/r03_epiano_lanes.md); the state layout [voice][32] does not change.
-    int hpl = 4;
+    // harmonics per lane of an array-valued voice (OG_HPL).  Measured, electric piano, 262 144 voices (interleaved A/B,
+    // profiles/r03_epiano_lanes.md): 16 lanes x 2 harmonics 0.95e11, 8 x 4 (round 2) 1.15e11, 4 x 8 1.26e11 at two
+    // waves per SIMD and 1.28e11 at three -- the per-voice bookkeeping (ramp step, interpolation weights, event and
+    // bus plumbing: ~15 of the 38 instructions a lane issues per frame at 8 x 4) is paid once per lane, so fewer lanes
+    // per voice amortise it over more harmonics; 156 VGPRs still leave three waves per SIMD.  OGC_HPL=2|4|8 overrides;
+    // the state layout [voice][32] does not depend on it.
+    int hpl = 8;
     if (const char* eh = getenv("OGC_HPL")) {
         const int h = atoi(eh);
         if (h == 2 || h == 4 || h == 8) hpl = h;
@@ -3273,7 +3277,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << ".\n"
         << "// Node order: ";
     for (auto& nn : out.node_order) src << nn << " ";
-    if (out.lpv > 1 && out.lane_width != 4) src << "\n#define OG_HPL " << out.lane_width << " // harmonics per lane (OGC_HPL)";
+    if (out.lpv > 1) src << "\n#define OG_HPL " << out.lane_width << " // harmonics per lane (OGC_HPL)";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
         << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.ramp_stride + f] : og::slot_f(A, (slot)))\n"
@@ -3284,7 +3288,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
     // register budget of the ordinary kernel: 4 waves per SIMD = 128 VGPRs.  The 4-lanes-per-voice e-piano form
-    // (OGC_HPL=8) keeps twice the harmonics per lane and needs the 256-VGPR budget (2 waves per SIMD)
+    // (OG_HPL = 8) keeps eight harmonics of nine arrays per lane: it is given the two-waves-per-SIMD budget and takes
+    // 156 VGPRs of it without a spill -- which still makes three waves per SIMD resident.  (Forcing the three-wave budget,
+    // 168 VGPRs, measured 1.7 % faster but the allocator then spills 80 registers around the chunk loop: not taken.)
     int waves_eu = (out.lpv > 1 && out.lane_width == 8) ? 2 : 4;
     if (const char* ew = getenv("OGC_WAVES_EU")) waves_eu = std::max(1, std::min(8, atoi(ew)));
     for (auto& v : variants)

@@ -296,7 +296,7 @@ __device__ __forceinline__ void st_u(const OgBlockArgs& a, const VoiceCtx& c, in
 // on packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations per issue, each rounded exactly
 // like its scalar form).
 #ifndef OG_HPL
-#define OG_HPL 4 // harmonics per lane (2, 4 or 8: 16, 8 or 4 lanes per 32-harmonic voice); a generated source may pre-define it
+#define OG_HPL 8 // harmonics per lane (2, 4 or 8: 16, 8 or 4 lanes per 32-harmonic voice); a generated source pre-defines it
 #endif
 #define OG_HPAIRS (OG_HPL / 2)
 typedef float og_f2 __attribute__((ext_vector_type(2)));

@@ -31,7 +31,7 @@ for k in out["kernel_stats"]:
         out["kernel_hash"] = m.group(1)
         out["kernel_name"] = k["name"]
         break
-LPV = {"epiano_voice": 8}.get(GRAPH, 1)
+LPV = {"epiano_voice": 4}.get(GRAPH, 1)  # lanes per voice (round 3: 4 lanes x 8 harmonics)
 waves = (V * LPV + 63) // 64
 # A launch renders the blocks queued since the previous one (bench.py --bus-batch, default 32).  The timed region of
 # bench.py starts with a fresh queue, so the first ceil(warmup / batch) launches of the voice kernel are warm-up and the
