@@ -260,8 +260,46 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device)
         out.append(rec)
         del midi
         eng.close()
+    # the multi-GPU real-time entry (og_midi_process_block over og_cluster_process_block): what can be measured on one
+    # GPU is its HOST side -- one thread per shard, cross-stream events, the per-device accumulation, the pinned
+    # hand-over -- with both shards on this device (no RCCL leg: a communicator needs distinct devices)
+    cluster_rec = None
+    try:
+        V = 131072
+        cl = oscen_amd.Cluster(graph, V, [device, device], sample_rate=48000.0)
+        cl.set_voice_values("frequency", oscen_amd.note_plans(V)["frequency"])
+        midi = oscen_amd.Midi(cl)
+        midi.set_queue_capacity(max(32, midi_per_block))
+        rng = np.random.default_rng(0x05CE2026)
+        notes = rng.integers(36, 97, size=(64, midi_per_block)).astype(np.uint8)
+        frames = np.sort(rng.integers(0, block, size=(64, midi_per_block)), axis=1).astype(np.uint32)
+        packed = [midi.pack_messages(notes[i - (i % 2)], frames[i], on=(i % 2 == 0)) for i in range(64)]
+        nb = max(200, n_blocks // 4)
+        lat = np.empty(nb, dtype=np.float64)
+        for i in range(50 + nb):
+            t0 = time.perf_counter()
+            if midi_per_block:
+                midi.send_packed(packed[i % 64])
+            bus = midi.process_block(block)
+            if i >= 50:
+                lat[i - 50] = time.perf_counter() - t0
+        lat_ms = lat * 1e3
+        cluster_rec = {
+            "entry": "og_midi_create_cluster + og_midi_process_block (og_cluster_process_block), 2 shards on ONE device: host-side "
+                     "cost of the cluster entry only, no RCCL leg",
+            "voices": V, "shards": 2, "blocks": nb, "midi_messages_per_block": midi_per_block,
+            "latency_ms": {"p50": float(np.percentile(lat_ms, 50)), "p99": float(np.percentile(lat_ms, 99)), "max": float(lat_ms.max()),
+                           "mean": float(lat_ms.mean())},
+            "deadline_ms": deadline_ms, "deadline_misses": int(np.count_nonzero(lat_ms > deadline_ms)),
+            "bus_peak": float(np.abs(bus).max()),
+        }
+        del midi
+        cl.close()
+    except Exception as e:  # (never fail the bench line over the side record)
+        cluster_rec = {"error": str(e)[:200]}
     ok = [r for r in out if r["deadline_misses"] == 0 and r["bus_peak"] > 0.0]
     return {
+        "cluster_entry_host_side": cluster_rec,
         "entry": "og_midi_send_batch + og_midi_process_block (blocking: bus in host memory when the call returns), "
                  "one launch per block, default batching",
         "block": block,

@@ -20,4 +20,9 @@ for pmc in "${PASSES[@]}"; do
   timeout 300 rocprofv3 --pmc $pmc -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
 done
 echo "$CMD" > $OUT/command.txt
-find $OUT -name "*.csv" | head -50 > $OUT/files.txt
+# summarise here (the databases are too large to travel back) and keep only the logs
+if [ -n "${PROF_SUMMARY_ARGS:-}" ]; then
+  PROF_OUT=$ROOT/gpurun_out/profiles_out python $ROOT/scripts/prof_summary.py $TAG $PROF_SUMMARY_ARGS > $OUT/summary.log 2>&1
+  tail -3 $OUT/summary.log
+  rm -rf $OUT/stats $OUT/pmc_*/
+fi

@@ -39,11 +39,11 @@ for p in $PARTS; do
       timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log ;;
     prof)
       # (the command the driver's BENCH line is taken with: its blocks-per-launch must match for the PMC numbers to apply)
-      bash scripts/gpu_profile.sh ${TAG}_fm65536 --steps 20 --warmup 5
-      bash scripts/gpu_profile.sh ${TAG}_fm65536_default
-      bash scripts/gpu_profile.sh ${TAG}_fm262144 --voices-per-gpu 262144
-      bash scripts/gpu_profile.sh ${TAG}_epiano --graph epiano_voice --voices-per-gpu 262144 --steps 94
-      bash scripts/gpu_profile.sh ${TAG}_sat4x --graph sat4x_voice --voices-per-gpu 131072 --steps 94
+      PROF_SUMMARY_ARGS="65536 256 fm_voice" bash scripts/gpu_profile.sh ${TAG}_fm65536 --steps 20 --warmup 5
+      PROF_SUMMARY_ARGS="65536 256 fm_voice" bash scripts/gpu_profile.sh ${TAG}_fm65536_default
+      PROF_SUMMARY_ARGS="262144 256 fm_voice" bash scripts/gpu_profile.sh ${TAG}_fm262144 --voices-per-gpu 262144
+      PROF_SUMMARY_ARGS="262144 256 epiano_voice" bash scripts/gpu_profile.sh ${TAG}_epiano --graph epiano_voice --voices-per-gpu 262144 --steps 94
+      PROF_SUMMARY_ARGS="131072 256 sat4x_voice" bash scripts/gpu_profile.sh ${TAG}_sat4x --graph sat4x_voice --voices-per-gpu 131072 --steps 94
       ;;
   esac
 done
