@@ -266,6 +266,101 @@ struct og_cluster {
         }
     }
 
+    // steps (2)-(4) of a batch whose shard launches have been issued into buffer b: per-device accumulation, ONE reduce over
+    // xGMI, post-mix stage on the root, hand-over to the pinned staging buffer (host_ready[b] fires when it is there)
+    void reduce_and_hand_over(int b, size_t nf)
+    {
+        const size_t n_sh = shard.size();
+        const size_t vc = vch;
+        // (2) per device: add the buffers of the other shards on that device into the first one's
+        for (size_t d = 0; d < devs.size(); ++d) {
+            HIPCK(hipSetDevice(devs[d]));
+            float* acc = nullptr;
+            for (size_t s = 0; s < n_sh; ++s) {
+                if (dev_of_shard[s] != (int)d) continue;
+                HIPCK(hipStreamWaitEvent(dev_stream[d], sh_done[b][s], 0));
+                if (!acc) {
+                    acc = sh_buf[b][s];
+                } else {
+                    hipLaunchKernelGGL(og_bus_accumulate, dim3((uint32_t)((nf * vc + 255) / 256)), dim3(256), 0, dev_stream[d], acc,
+                                       sh_buf[b][s], nf * vc);
+                }
+            }
+            dev_acc[b][d] = acc;
+        }
+        // (3) ONE reduce of the whole batch over xGMI (root = devs[0])
+        if (use_rccl) {
+            Rccl& R = rccl();
+            R.ck(R.GroupStart(), "ncclGroupStart");
+            for (size_t d = 0; d < devs.size(); ++d)
+                R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf * vc, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
+            R.ck(R.GroupEnd(), "ncclGroupEnd");
+            n_reduces += 1;
+        }
+        // (4) root: post-mix stage, then hand the batch to the host through a pinned staging buffer
+        HIPCK(hipSetDevice(devs[0]));
+        const float* mono = dev_acc[b][0];
+        if (tremolo) {
+            og_engine* e0 = shard[0];
+            ogc::UEnv env = e0->env();
+            const float rate = e0->cg->tremolo_rate(env), depth = e0->cg->tremolo_depth(env);
+            for (size_t g = 0; g < nf; g += OG_MAX_BLOCK) {
+                const uint32_t frames = (uint32_t)std::min<size_t>(OG_MAX_BLOCK, nf - g);
+                hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, dev_stream[0], mono + g, frames, rate, depth, e0->sr,
+                                   d_phase, d_out + 2 * g);
+            }
+            HIPCK(hipMemcpyAsync(h_pin[b], d_out, nf * 2 * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
+        } else {
+            HIPCK(hipMemcpyAsync(h_pin[b], mono, nf * vc * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0])); // (Frame<2> voices: interleaved L R)
+        }
+        HIPCK(hipEventRecord(host_ready[b], dev_stream[0]));
+        // buffer b may be rewritten once every reader on its device is done
+        for (size_t d = 0; d < devs.size(); ++d) {
+            HIPCK(hipSetDevice(devs[d]));
+            HIPCK(hipEventRecord(dev_free[b][d], dev_stream[d]));
+        }
+    }
+
+    // ONE block, for the real-time entry (og_cluster_process_block): the CALLING thread issues every shard's two launches
+    // itself (a block is one voice-kernel launch and one bus reduce per shard: ~10 us of host time each) instead of
+    // waking a thread per shard, and waits for the hand-over by polling the event -- a condition-variable wake-up or a
+    // blocking event wait costs a scheduler round trip, which on a loaded host is where a 5.3 ms audio deadline is
+    // lost (measured on a shared box: 7 ms outliers through the threaded path).  The shard buffers alternate between
+    // calls; the events that guard them are the same as in render().
+    int rt_buf = 0;
+    void process_one_block(uint32_t frames, float* out)
+    {
+        ensure_buffers(frames);
+        const int b = rt_buf;
+        rt_buf ^= 1;
+        const size_t vc = vch;
+        for (size_t s = 0; s < shard.size(); ++s) {
+            og_engine* e = shard[s];
+            HIPCK(hipSetDevice(e->device));
+            HIPCK(hipStreamWaitEvent(e->stream, dev_free[b][dev_of_shard[s]], 0));
+            e->process_async(frames, sh_buf[b][s]);
+            e->flush_bus();
+            HIPCK(hipEventRecord(sh_done[b][s], e->stream));
+        }
+        (void)vc;
+        reduce_and_hand_over(b, frames);
+        HIPCK(hipSetDevice(devs[0]));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(host_ready[b]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIPCK(q);
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+                HIPCK(hipEventSynchronize(host_ready[b])); // (something far slower than a block is in front of it)
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        memcpy(out, h_pin[b], (size_t)frames * channels * sizeof(float));
+    }
+
     // Render `total_frames` in blocks of `block`; the summed (and post-mixed) bus ends up in out (host).
     void render(uint64_t total_frames, uint32_t block, float* out)
     {
@@ -297,53 +392,7 @@ struct og_cluster {
                 });
             }
             wait_all();
-            // (2) per device: add the buffers of the other shards on that device into the first one's
-            for (size_t d = 0; d < devs.size(); ++d) {
-                HIPCK(hipSetDevice(devs[d]));
-                float* acc = nullptr;
-                for (size_t s = 0; s < n_sh; ++s) {
-                    if (dev_of_shard[s] != (int)d) continue;
-                    HIPCK(hipStreamWaitEvent(dev_stream[d], sh_done[b][s], 0));
-                    if (!acc) {
-                        acc = sh_buf[b][s];
-                    } else {
-                        hipLaunchKernelGGL(og_bus_accumulate, dim3((uint32_t)((nf * vc + 255) / 256)), dim3(256), 0, dev_stream[d], acc,
-                                           sh_buf[b][s], nf * vc);
-                    }
-                }
-                dev_acc[b][d] = acc;
-            }
-            // (3) ONE reduce of the whole batch over xGMI (root = devs[0])
-            if (use_rccl) {
-                Rccl& R = rccl();
-                R.ck(R.GroupStart(), "ncclGroupStart");
-                for (size_t d = 0; d < devs.size(); ++d)
-                    R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf * vc, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
-                R.ck(R.GroupEnd(), "ncclGroupEnd");
-                n_reduces += 1;
-            }
-            // (4) root: post-mix stage, then hand the batch to the host through a pinned staging buffer
-            HIPCK(hipSetDevice(devs[0]));
-            const float* mono = dev_acc[b][0];
-            if (tremolo) {
-                og_engine* e0 = shard[0];
-                ogc::UEnv env = e0->env();
-                const float rate = e0->cg->tremolo_rate(env), depth = e0->cg->tremolo_depth(env);
-                for (size_t g = 0; g < nf; g += OG_MAX_BLOCK) {
-                    const uint32_t frames = (uint32_t)std::min<size_t>(OG_MAX_BLOCK, nf - g);
-                    hipLaunchKernelGGL(og_bus_tremolo, dim3(1), dim3(512), 0, dev_stream[0], mono + g, frames, rate, depth, e0->sr,
-                                       d_phase, d_out + 2 * g);
-                }
-                HIPCK(hipMemcpyAsync(h_pin[b], d_out, nf * 2 * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0]));
-            } else {
-                HIPCK(hipMemcpyAsync(h_pin[b], mono, nf * vc * sizeof(float), hipMemcpyDeviceToHost, dev_stream[0])); // (Frame<2> voices: interleaved L R)
-            }
-            HIPCK(hipEventRecord(host_ready[b], dev_stream[0]));
-            // buffer b may be rewritten once every reader on its device is done
-            for (size_t d = 0; d < devs.size(); ++d) {
-                HIPCK(hipSetDevice(devs[d]));
-                HIPCK(hipEventRecord(dev_free[b][d], dev_stream[d]));
-            }
+            reduce_and_hand_over(b, nf);
             // drain the PREVIOUS batch while this one runs
             if (have_prev) {
                 HIPCK(hipEventSynchronize(host_ready[b ^ 1]));
@@ -563,7 +612,7 @@ int og_cluster_process_block(og_cluster* c, uint32_t frames, float* out_bus)
     }
     if (!out_bus) return set_err(OG_E_INVALID, "null argument");
     return guard([&] {
-        c->render(frames, frames, out_bus);
+        c->process_one_block(frames, out_bus);
         return OG_OK;
     });
 }
