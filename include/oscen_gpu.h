@@ -276,7 +276,7 @@ uint32_t og_state_words_per_voice(const og_engine* e);
 /* words a steady-state block writes back (read-mostly tables -- e-piano decay/release/rotation multipliers -- are
  * only stored in blocks whose events rewrote them) */
 uint32_t og_state_words_written_per_voice(const og_engine* e);
-uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 8 for graphs with per-harmonic arrays (4 harmonics per lane) */
+uint32_t og_lanes_per_voice(const og_engine* e); /* 1, or 4 for graphs with per-harmonic arrays (8 harmonics per lane) */
 int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched kernel: 0 = one wave per 64 voices,
                                                  2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
