@@ -466,3 +466,180 @@ class EPianoVoice:
             s = f32(s + prod[i])
         self.output = f32(s * f32(3))
         return self.output
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 3: the multirate path (BASELINE config 5) -- PolyBlepOscillator, HardClip, the 23-tap half-band sinc FIR
+# resamplers and the SatGraph body -- transliterated from the RUST sources:
+#   PolyBlepOscillator   oscen-lib/src/oscillators/mod.rs:88-233  (poly_blep :139-153, poly_blamp :155-169, process :176-232)
+#   Halfband2xUpStage / Halfband2xDownStage / SincUpFir / SincDownFir   oscen-lib/src/resample/sinc_fir.rs:33-266
+#   taps                 oscen-lib/src/resample/coeffs.rs:17-27
+#   HardClip, SatGraph   examples/oversampled-saturator/src/main.rs:32-80; multirate frame body
+#                        oscen-graph-compiler/src/codegen/emit_frame.rs:114-176 (inner nodes see sr * N, emit_struct.rs:575-587)
+# ---------------------------------------------------------------------------------------------------------------
+F32_EPSILON = f32(1.1920929e-07)
+TAU = f32(6.2831855)  # std::f32::consts::TAU
+
+
+def rem_euclid1(x):  # f32::rem_euclid(1.0): r = x % 1.0 (C fmod); if r < 0 { r + 1.0 }
+    r = f32(np.fmod(f32(x), f32(1.0)))
+    return f32(r + f32(1.0)) if r < f32(0.0) else r
+
+
+class PolyBlep:
+    SINE, SAW, SQUARE, TRIANGLE = range(4)
+
+    def __init__(self, frequency, amplitude, waveform, sample_rate):
+        self.phase = f32(0.0)
+        self.phase_mod = f32(0.0)
+        self.frequency = f32(frequency)
+        self.frequency_mod = f32(0.0)
+        self.amplitude = f32(amplitude)
+        self.pulse_width = f32(0.5)
+        self.output = f32(0.0)
+        self.waveform = waveform
+        self.sample_rate = f32(sample_rate)
+
+    @staticmethod
+    def poly_blep(t, dt):
+        if dt <= F32_EPSILON:
+            return f32(0.0)
+        if t < dt:
+            x = f32(t / dt)
+            return f32(f32(f32(x + x) - f32(x * x)) - f32(1.0))
+        if t > f32(f32(1.0) - dt):
+            x = f32(f32(t - f32(1.0)) / dt)
+            return f32(f32(f32(f32(x * x) + x) + x) + f32(1.0))
+        return f32(0.0)
+
+    @staticmethod
+    def poly_blamp(t, dt):
+        if dt <= F32_EPSILON:
+            return f32(0.0)
+        if t < dt:
+            x = f32(f32(t / dt) - f32(1.0))
+            return f32(f32(-f32(f32(x * x) * x)) / f32(3.0))
+        if t > f32(f32(1.0) - dt):
+            x = f32(f32(f32(t - f32(1.0)) / dt) + f32(1.0))
+            return f32(f32(f32(x * x) * x) / f32(3.0))
+        return f32(0.0)
+
+    def process(self):
+        frequency = max(f32(self.frequency * f32(f32(1.0) + self.frequency_mod)), f32(0.0))
+        amplitude = self.amplitude
+        pulse_width = clamp(self.pulse_width, 0.0001, 0.9999)
+        phase = rem_euclid1(f32(self.phase + self.phase_mod))
+        freq_per_sample = f32(frequency / max(self.sample_rate, F32_EPSILON))
+        dt = min(freq_per_sample, f32(1.0))
+        if pulse_width <= f32(0.0):
+            pulse_width = f32(0.0001)
+        if frequency >= f32(self.sample_rate * f32(0.25)):
+            value = sinf(f32(phase * TAU))
+        elif self.waveform == self.SINE:
+            value = sinf(f32(phase * TAU))
+        elif self.waveform == self.SAW:
+            y = f32(f32(f32(2.0) * phase) - f32(1.0))
+            value = f32(y - self.poly_blep(phase, dt))
+        elif self.waveform == self.SQUARE:
+            y = f32(1.0) if phase < pulse_width else f32(-1.0)
+            y = f32(y + self.poly_blep(phase, dt))
+            t = rem_euclid1(f32(f32(phase + f32(1.0)) - pulse_width))
+            value = f32(y - self.poly_blep(t, dt))
+        else:
+            y = f32(f32(4.0) * phase)
+            if y >= f32(3.0):
+                y = f32(y - f32(4.0))
+            elif y > f32(1.0):
+                y = f32(f32(2.0) - y)
+            t1 = rem_euclid1(f32(phase + f32(0.25)))
+            t2 = rem_euclid1(f32(phase + f32(0.75)))
+            value = f32(y + f32(f32(f32(4.0) * dt) * f32(self.poly_blamp(t1, dt) - self.poly_blamp(t2, dt))))
+        value = f32(value * amplitude)
+        self.output = value
+        self.phase = rem_euclid1(f32(self.phase + freq_per_sample))
+        return value
+
+
+HALFBAND_23_HALF = [f32(-3.8558514e-5), f32(1.2218465e-3), f32(-7.2854808e-3), f32(2.6409210e-2), f32(-7.8128843e-2),
+                    f32(3.0782697e-1)]
+HALFBAND_23_CENTER = f32(0.4999897)
+
+
+class HalfbandUp:  # Halfband2xUpStage  sinc_fir.rs:33-82
+    def __init__(self):
+        self.history = [f32(0.0)] * 12
+        self.head = 0
+
+    def step(self, x):
+        cap = 12
+        self.head = (self.head + 1) % cap
+        self.history[self.head] = f32(x)
+        at = lambda d: self.history[(self.head + cap - d) % cap]
+        out1 = f32(at(5) * f32(f32(2.0) * HALFBAND_23_CENTER))
+        acc = f32(0.0)
+        for k, tap in enumerate(HALFBAND_23_HALF):
+            acc = f32(acc + f32(f32(at(k) + at(11 - k)) * tap))
+        return f32(acc * f32(2.0)), out1
+
+
+class HalfbandDown:  # Halfband2xDownStage  sinc_fir.rs:96-144
+    def __init__(self):
+        self.history = [f32(0.0)] * 24
+        self.head = 0
+
+    def step(self, x0, x1):
+        cap = 24
+        self.head = (self.head + 1) % cap
+        self.history[self.head] = f32(x0)
+        self.head = (self.head + 1) % cap
+        self.history[self.head] = f32(x1)
+        at = lambda d: self.history[(self.head + cap - 1 - d) % cap]
+        acc = f32(at(11) * HALFBAND_23_CENTER)
+        for k, tap in enumerate(HALFBAND_23_HALF):
+            acc = f32(acc + f32(f32(at(2 * k) + at(22 - 2 * k)) * tap))
+        return acc
+
+
+class SincUp:  # SincUpFir<N>::upsample  sinc_fir.rs:166-184
+    def __init__(self, n):
+        self.n = n
+        self.stages = [HalfbandUp() for _ in range(n.bit_length() - 1)]
+
+    def upsample(self, x):
+        buf = [f32(x)]
+        for st in self.stages:
+            nxt = []
+            for v in buf:
+                a, b = st.step(v)
+                nxt += [a, b]
+            buf = nxt
+        return buf
+
+
+class SincDown:  # SincDownFir<N>::downsample  sinc_fir.rs:232-248
+    def __init__(self, n):
+        self.n = n
+        self.stages = [HalfbandDown() for _ in range(n.bit_length() - 1)]
+
+    def downsample(self, xs):
+        buf = [f32(v) for v in xs]
+        for st in self.stages:
+            buf = [st.step(buf[2 * i], buf[2 * i + 1]) for i in range(len(buf) // 2)]
+        return buf[0]
+
+
+class SatVoice:
+    """SatGraph_<N>x (examples/oversampled-saturator/src/main.rs:64-80): osc = PolyBlepOscillator::saw(f, 0.6) * N,
+    clip = HardClip::new() * N, osc.output -> clip.input, [sinc] clip.output -> audio_out; N = 1: no resampler"""
+
+    def __init__(self, sr, n, frequency):
+        self.n = n
+        self.osc = PolyBlep(frequency, 0.6, PolyBlep.SAW, f32(f32(sr) * f32(n)))
+        self.down = SincDown(n) if n > 1 else None
+
+    def frame(self):
+        xs = []
+        for _ in range(self.n):
+            driven = f32(self.osc.process() * f32(1.5))
+            xs.append(clamp(driven, -0.7, 0.7))
+        return self.down.downsample(xs) if self.down else xs[0]

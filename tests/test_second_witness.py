@@ -69,3 +69,51 @@ def test_electric_piano_voice_bit_identical_between_the_two_restatements():
         b = np.array([v.frame(g.get(f)) for f in range(frames)], dtype=np.float32)
         assert np.array_equal(a, b)
         assert np.abs(a).max() > 1e-3
+
+
+def test_saturator_voice_and_sinc_resamplers_bit_identical_between_the_two_restatements():
+    """BASELINE config 5 (PolyBLEP saw * 4 -> HardClip * 4 -> [sinc] down) and the sinc FIR kernels on their own: the C
+    oracle against the second transliteration from the Rust sources (resample/sinc_fir.rs, oscillators/mod.rs), bit for
+    bit -- the sinc FIR had no second witness before round 3."""
+    import ctypes as C
+
+    lib = ol.load()
+    # (a) the whole voice, 4x and 1x, three frequencies incl. one above sr/4 of the outer rate
+    for kind, n in ((ol.BANK_SAT4X, 4), (ol.BANK_SAT1X, 1)):
+        for freq in (110.0, 2000.0, 3999.0):
+            bank = ol.Bank(kind, 1, SR)
+            bank.set_voice_frequency(0, freq)
+            got = []
+            for _ in range(4):
+                _, taps = bank.process_block(256, taps=[0])
+                got.append(taps[0])
+            got = np.concatenate(got)
+            v = sw.SatVoice(SR, n, freq)
+            want = np.array([v.frame() for _ in range(1024)], dtype=np.float32)
+            assert np.array_equal(got, want), (kind, freq, float(np.abs(got - want).max()))
+            assert np.abs(want).max() > 0.3
+    # (b) up and down kernels fed noise, N = 2, 4, 8
+    rng = np.random.default_rng(8)
+    for n in (2, 4, 8):
+        up_c, dn_c = ol.SincUp(), ol.SincDown()
+        lib.oo_sinc_up_new(C.byref(up_c), n)
+        lib.oo_sinc_down_new(C.byref(dn_c), n)
+        up_w, dn_w = sw.SincUp(n), sw.SincDown(n)
+        buf = np.zeros(n, dtype=np.float32)
+        for x in rng.uniform(-1.0, 1.0, 300).astype(np.float32):
+            lib.oo_sinc_up_process(C.byref(up_c), float(x), ol.fptr(buf))
+            want = np.array(up_w.upsample(x), dtype=np.float32)
+            assert np.array_equal(buf, want), (n, buf, want)
+            y_c = np.float32(lib.oo_sinc_down_process(C.byref(dn_c), ol.fptr(buf)))
+            assert y_c == dn_w.downsample(want), n
+    # (c) every PolyBLEP waveform against the oracle's node
+    for wave_c, wave_w in ((ol.PB_SINE, sw.PolyBlep.SINE), (ol.PB_SAW, sw.PolyBlep.SAW), (ol.PB_SQUARE, sw.PolyBlep.SQUARE),
+                           (ol.PB_TRIANGLE, sw.PolyBlep.TRIANGLE)):
+        for freq in (55.0, 880.0, 13000.0):
+            o = ol.PolyBlep()
+            lib.oo_polyblep_new(C.byref(o), freq, 0.8, wave_c)
+            o.sample_rate = SR
+            w = sw.PolyBlep(freq, 0.8, wave_w, SR)
+            for _ in range(2000):
+                lib.oo_polyblep_process(C.byref(o))
+                assert np.float32(o.output) == w.process(), (wave_c, freq)
