@@ -62,9 +62,13 @@ def pmc_profile(voices, block, graph, kernel_hash, blocks_per_launch=None):
     if match:
         d = match[1]
         valu = d.get("pmc_voice_kernel", {}).get("SQ_INSTS_VALU", {}).get("avg_per_dispatch")
+        # the shader clock the kernel actually ran at under the profiler: GRBM_GUI_ACTIVE counts busy cycles of all 8
+        # XCDs per launch; / 8 / the launch duration of the same run
+        grbm = d.get("pmc_voice_kernel", {}).get("GRBM_GUI_ACTIVE", {}).get("avg_per_dispatch")
+        sclk = grbm / 8.0 / (d["timed_avg_us"] * 1e-6) / 1e9 if (grbm and d.get("timed_avg_us")) else None
         return {"bytes": d["hbm_traffic"]["total_bytes_corrected"], "valu": valu, "blocks_per_launch": d.get("blocks_per_launch", 1.0),
-                "source": os.path.relpath(match[0], ROOT), "stale": None}
-    return {"bytes": None, "valu": None, "blocks_per_launch": None, "source": None,
+                "source": os.path.relpath(match[0], ROOT), "stale": None, "sclk_ghz": sclk}
+    return {"bytes": None, "valu": None, "blocks_per_launch": None, "source": None, "sclk_ghz": None,
             "stale": os.path.relpath(stale, ROOT) if stale else None}
 
 
@@ -394,6 +398,11 @@ def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed):
             "frac": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 2.0),
             "frac_of_measured_ceiling": pmc_valu / (kern_ms * 1e-3) / 1e9 / (1024 * 2.4 / 3.05),
             "valu_wave_inst_per_64_voices_per_frame": pmc_valu / (V / 64.0 * block * blocks_per_launch),
+            # cycles one SIMD spends per VALU wave-instruction of this launch, at the clock the profile saw (the part
+            # runs at ~2.1 GHz under this load, not at the 2.4 GHz the peaks above are quoted for): 2.0 would be the
+            # nominal issue rate, 3.05 the FMA-stream ceiling
+            "sclk_ghz_profiled": prof.get("sclk_ghz"),
+            "cycles_per_valu_inst_per_simd": (kern_ms * 1e-3 * prof["sclk_ghz"] * 1e9) / (pmc_valu / 1024.0) if prof.get("sclk_ghz") else None,
             "source": pmc_src,
         },
     }
