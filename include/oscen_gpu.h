@@ -266,8 +266,14 @@ int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames);
 uint32_t og_channels(const og_engine* e);
 /* 1: every voice contributes an f32 sample per frame; 2: the graph's stream output is fed a Frame<2> (e.g. a per-voice
  * pan): both channels are summed over the voices, the bus is interleaved L R and og_read_voice_taps delivers
- * [tap][frame][2].  (og_channels is also 2 for a mono voice sum with a stereo post-mix node.) */
+ * [tap][frame][2]; up to 4 with several stream outputs (below).  (og_channels is also 2 for a mono voice sum with a
+ * stereo post-mix node.) */
 uint32_t og_voice_channels(const og_engine* e);
+/* A voice graph with SEVERAL stream outputs (`output out_a: stream; output out_b: stream; output out: stream;`,
+ * oscen-lib/tests/multirate_graph.rs:444-458 -- the reference exposes `graph.out_a`, `graph.out_b`, `graph.out`) has one
+ * bus channel per output (a Frame<2> output: two), in declaration order, at most 4: out_bus[frames][og_channels()], taps
+ * [tap][frame][og_voice_channels()].  og_output_channel tells where an output sits in a frame. */
+int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, uint32_t* width);
 uint32_t og_num_voices(const og_engine* e);
 uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
 uint64_t og_frames_processed(const og_engine* e);

@@ -819,7 +819,7 @@ struct og_engine {
         HIPCK(hipMalloc(&d_partials, (size_t)n_wg * max_frames * 4 * vc));
         HIPCK(hipMemset(d_partials, 0, (size_t)n_wg * max_frames * 4 * vc));
         HIPCK(hipMalloc(&d_partials2, ((size_t)n_wg / OG_RED_GROUP + 2 + 64) * max_frames * 4));
-        HIPCK(hipMalloc(&d_stage_bus, max_frames * 2 * 4));
+        HIPCK(hipMalloc(&d_stage_bus, max_frames * OG_MAX_BUS_CHANNELS * 4));
         if (cg->bus_tremolo) HIPCK(hipMalloc(&d_mono, max_frames * 4));
         const size_t rows = (size_t)(cg->n_ramps + cg->n_streams);
         for (int i = 0; i < RAMP_RING && rows; ++i) {
@@ -1429,7 +1429,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
         e->alloc_bus_buffers(1);
-        HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * 2 * 4));
+        HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * OG_MAX_BUS_CHANNELS * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_tap_slot, 0xFF, (size_t)n_voices * 4));
         if (!cg.event_outputs.empty() || cg.has_node_event_outputs) {
@@ -1675,7 +1675,7 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus(); // earlier async blocks keep their own destinations
-        if (!e->h_bus_pinned) HIPCK(hipHostMalloc((void**)&e->h_bus_pinned, (size_t)OG_MAX_BLOCK * 2 * 4, hipHostMallocDefault));
+        if (!e->h_bus_pinned) HIPCK(hipHostMalloc((void**)&e->h_bus_pinned, (size_t)OG_MAX_BLOCK * OG_MAX_BUS_CHANNELS * 4, hipHostMallocDefault));
         // ask for the stream marker behind this block's launch BEFORE the block is queued: with one block per launch
         // (the default) process_async launches it itself, and a marker requested afterwards would never be written
         // (the wait then ran into its 20 ms timeout on every call -- ADVICE r2)
@@ -1843,6 +1843,17 @@ int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames)
 
 uint32_t og_channels(const og_engine* e) { return e ? e->cg->channels : 0; }
 uint32_t og_voice_channels(const og_engine* e) { return e ? e->cg->voice_channels : 0; }
+int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, uint32_t* width)
+{
+    if (!e || !name) return set_err(OG_E_INVALID, "null argument");
+    for (const auto& oc : e->cg->output_channels)
+        if (oc.name == name) {
+            if (offset) *offset = (uint32_t)oc.offset;
+            if (width) *width = (uint32_t)oc.width;
+            return OG_OK;
+        }
+    return set_err(OG_E_INVALID, std::string("no stream output named '") + name + "' on the bus");
+}
 uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }

@@ -2572,6 +2572,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         };
         for (auto& kv : out_edges)
             for (auto& src : kv.second) stereo_out = stereo_out || width_of(src.src) == 2;
+        // (several stream outputs = several bus channels: summed by the ordinary kernel only, like a Frame<2> output)
+        {
+            int n_stream_outs = 0;
+            for (size_t oi = 0; oi < g.outputs.size(); ++oi)
+                if (g.outputs[oi].kind == Kind::Stream && out_edges.count((int)oi) && (int)oi != bus_src_output) ++n_stream_outs;
+            if (n_stream_outs > 1 && !out.bus_tremolo) stereo_out = true;
+        }
         bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback && !cg.dynamic_events &&
                     !any_delay && !stereo_out;
         // estimated per-tick VALU cost of every node, in emission order
@@ -2733,6 +2740,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             cg.frame_log << "        if (__any((int)(" << q << ".n != 0u))) og::ev_out_log(A, c, " << out.event_outputs.size() << "u, f, " << q << ");\n";
             out.event_outputs.push_back(g.outputs[oi].name);
         }
+        std::vector<int> formed(g.outputs.size(), 0); // channels of every stream output that has sources
         for (size_t oi : oorder) {
             if (g.outputs[oi].kind == Kind::Event) continue;
             auto it = out_edges.find((int)oi);
@@ -2741,7 +2749,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 continue;
             }
             if ((int)oi == bus_final_output) fail("graph output fed by the post-mix node cannot have other sources");
-            if (!consumed[oi] && ++n_stream > 1) fail("only one stream output per voice graph is supported in this version");
+            ++n_stream;
             std::string acc, acc_r;
             bool stereo = false;
             for (size_t k = 0; k < it->second.size(); ++k) {
@@ -2754,8 +2762,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (k > 0 && v.is_frame() != stereo) fail("graph output '" + g.outputs[oi].name + "' mixes f32 and Frame<2> sources");
                 stereo = v.is_frame();
                 if (stereo) { // a Frame<2> voice: both channels summed over the voices, bus interleaved (BlockRender<Frame<2>>)
-                    if (out.lpv != 1 || out.bus_tremolo || cg.N > 1)
-                        fail("a Frame<2> graph output is not supported in array-valued, multirate or post-mix graphs yet");
+                    if (out.lpv != 1 || out.bus_tremolo)
+                        fail("a Frame<2> graph output is not supported in array-valued or post-mix graphs yet");
                     acc = (k == 0) ? v.ch[0].e : "(" + acc + " + " + v.ch[0].e + ")";
                     acc_r = (k == 0) ? v.ch[1].e : "(" + acc_r + " + " + v.ch[1].e + ")";
                     continue;
@@ -2768,33 +2776,53 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (declared && (declared == 2) != stereo)
                 fail("graph output '" + g.outputs[oi].name + "' is declared " + (declared == 2 ? "Frame<2>" : "f32") + " but fed " +
                      (stereo ? "a Frame<2>" : "an f32 stream"));
-            if (consumed[oi]) { // read by another output: a named value of this frame, not the bus
-                const std::string var = "go" + std::to_string(oi);
-                Val ov;
-                ov.rate = Rate::Vary;
-                if (stereo) {
-                    cg.os() << "        const float " << var << "_l = " << acc << ", " << var << "_r = " << acc_r << ";\n";
-                    Val l, r;
-                    l.rate = r.rate = Rate::Vary;
-                    l.e = var + "_l";
-                    r.e = var + "_r";
-                    ov.ch = {l, r};
-                } else {
-                    cg.os() << "        const float " << var << " = " << acc << ";\n";
-                    ov.e = var;
-                }
-                cg.output_vals[g.outputs[oi].name] = ov;
-                continue;
-            }
+            // every stream output is a named value of this frame: other outputs may read it (`out_a + out_b -> out`),
+            // and ALL of them go onto the mix bus, one channel (Frame<2>: two) each, in declaration order
+            const std::string var = "go" + std::to_string(oi);
+            Val ov;
+            ov.rate = Rate::Vary;
             if (stereo) {
-                cg.os() << "        const og::Out2 g_out = {" << acc << ", " << acc_r << "};\n";
-                out.voice_channels = 2;
-                out.channels = 2;
+                cg.os() << "        const float " << var << "_l = " << acc << ", " << var << "_r = " << acc_r << ";\n";
+                Val l, r;
+                l.rate = r.rate = Rate::Vary;
+                l.e = var + "_l";
+                r.e = var + "_r";
+                ov.ch = {l, r};
             } else {
-                cg.os() << "        const float g_out = " << acc << ";\n";
+                cg.os() << "        const float " << var << " = " << acc << ";\n";
+                ov.e = var;
             }
+            cg.output_vals[g.outputs[oi].name] = ov;
+            formed[oi] = stereo ? 2 : 1;
+        }
+        // the bus: the formed stream outputs in DECLARATION order
+        std::vector<std::string> chans;
+        for (size_t oi = 0; oi < g.outputs.size(); ++oi) {
+            if (!formed[oi]) continue;
+            const std::string var = "go" + std::to_string(oi);
+            out.output_channels.push_back({g.outputs[oi].name, (int)chans.size(), formed[oi]});
+            if (formed[oi] == 2) {
+                chans.push_back(var + "_l");
+                chans.push_back(var + "_r");
+            } else {
+                chans.push_back(var);
+            }
+        }
+        if (chans.size() > 1 && (out.lpv != 1 || out.bus_tremolo))
+            fail("several bus channels (stream outputs / Frame<2>) are not supported in array-valued or post-mix graphs yet");
+        if (chans.size() > 4) fail("the mix bus carries at most 4 channels (stream outputs, Frame<2> counting two)");
+        if (chans.size() == 1) {
+            cg.os() << "        const float g_out = " << chans[0] << ";\n";
+            bus_expr = "g_out";
+        } else if (chans.size() > 1) {
+            cg.os() << "        const og::OutN<" << chans.size() << "> g_out = {{";
+            for (size_t k = 0; k < chans.size(); ++k) cg.os() << (k ? ", " : "") << chans[k];
+            cg.os() << "}};\n";
+            out.voice_channels = (uint32_t)chans.size();
+            out.channels = (uint32_t)chans.size();
             bus_expr = "g_out";
         }
+        (void)n_stream;
     }
     out.can_split = cg.split;
     out.max_pipeline = !cg.groups4.empty() ? 4 : (!cg.groups2.empty() ? 2 : 1);
@@ -2912,7 +2940,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::ostringstream body;
     body << "template <bool RAMPS, bool TAPS>\n"
          << "__device__ __forceinline__ void voice_block(const OgBlockArgs& A)\n{\n"
-         << "    __shared__ og::" << (stereo_out ? "BusLds2" : "BusLds") << " bus;\n"
+         << "    __shared__ og::" << (out.voice_channels > 1 ? "BusLdsN<" + std::to_string(out.voice_channels) + ">" : std::string("BusLds")) << " bus;\n"
          << (out.rings.empty() ? std::string()
                                : "    __shared__ float ring_lds[" + std::to_string(out.rings.size()) +
                                      "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
@@ -2943,7 +2971,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (const auto& r : cg.sec[k].env_rs) m = m.empty() ? r : "(" + m + " + " + r + ")";
         return m;
     };
-    body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> " << (stereo_out ? "og::Out2" : "float") << " {\n"
+    body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> " << (out.voice_channels > 1 ? "og::OutN<" + std::to_string(out.voice_channels) + ">" : std::string("float")) << " {\n"
          << group_tick({all_stages}, 0);
     if (cg.frame_end.str().empty()) {
         body << "        return " << bus_expr << ";\n    };\n";

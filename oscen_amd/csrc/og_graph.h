@@ -151,7 +151,12 @@ struct CompiledGraph {
     std::vector<std::string> event_outputs; // the graph's event outputs that a node feeds, in declaration order (og_read_output_events)
     bool has_node_event_outputs = false;    // some live node has an #[output(event)] field (drops are counted on the device)
     uint32_t channels = 1;
-    uint32_t voice_channels = 1; // 2: the voice graph's stream output is fed a Frame<2> (summed per channel, bus interleaved)
+    uint32_t voice_channels = 1; // channels of the voice sum: one per stream output of the voice graph, a Frame<2> output two
+    struct OutChan {
+        std::string name;
+        int offset, width;
+    };
+    std::vector<OutChan> output_channels; // where every stream output sits in a frame of the bus / of a tap
     uint32_t latency_samples = 0;
     std::vector<std::string> node_order; // topological order actually emitted (introspection/tests)
     int find_input(const std::string& n) const;

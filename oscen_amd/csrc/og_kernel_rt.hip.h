@@ -439,35 +439,42 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
 
 __device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLds&) {} // (rows are written as they are formed)
 
-// ---- a Frame<2> voice output (the graph's stream output is fed a stereo frame): two tiles, two planes of partial
-// rows, taps [tap][frame][2] -- same calls, picked by overload
-struct Out2 {
-    float l, r;
+// ---- several bus channels: a Frame<2> voice output (a per-voice pan) and / or several stream outputs of the voice
+// graph (`output out_a: stream; output out_b: stream; ...`: every one of them is summed over the voices like the
+// reference sums `voices.<out>`).  N tiles, N planes of partial rows, taps [tap][frame][N] -- same calls, picked by
+// overload.
+#define OG_MAX_BUS_CHANNELS 4
+template <int N>
+struct OutN {
+    float v[N];
 };
-struct BusLds2 {
-    BusLds ch[2];
+template <int N>
+struct BusLdsN {
+    BusLds ch[N];
 };
-template <bool TAPS, bool ALL_LANES = false>
-__device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds2& lds, uint32_t f, uint32_t j, Out2 out)
+using Out2 = OutN<2>;
+using BusLds2 = BusLdsN<2>;
+template <bool TAPS, bool ALL_LANES = false, int N = 2>
+__device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLdsN<N>& lds, uint32_t f, uint32_t j, OutN<N> out)
 {
     const bool on = c.valid && (ALL_LANES || c.lead);
-    const float yl = on ? out.l : 0.0f, yr = on ? out.r : 0.0f;
-    lds.ch[0].tile[j][c.lane] = yl;
-    lds.ch[1].tile[j][c.lane] = yr;
-    if (TAPS) {
-        if (c.tap >= 0 && c.lead) {
-            a.taps[((size_t)c.tap * a.frames + f) * 2] = yl;
-            a.taps[((size_t)c.tap * a.frames + f) * 2 + 1] = yr;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float y = on ? out.v[k] : 0.0f;
+        lds.ch[k].tile[j][c.lane] = y;
+        if (TAPS) {
+            if (c.tap >= 0 && c.lead) a.taps[((size_t)c.tap * a.frames + f) * N + k] = y;
         }
     }
 }
-__device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLds2& lds, uint32_t base, uint32_t n)
+template <int N>
+__device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLdsN<N>& lds, uint32_t base, uint32_t n)
 {
     wave_sync();
     const uint32_t j = c.lane & (OG_BUS_CHUNK - 1);
     const uint32_t q = c.lane / OG_BUS_CHUNK;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < N; ++k) {
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < OG_WAVE / 4; ++i) s += lds.ch[k].tile[j][q * (OG_WAVE / 4) + i];
@@ -478,7 +485,8 @@ __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const Voi
     }
     wave_sync();
 }
-__device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLds2&) {}
+template <int N>
+__device__ __forceinline__ void bus_flush(const OgBlockArgs&, const VoiceCtx&, BusLdsN<N>&) {}
 
 } // namespace og
 

@@ -66,7 +66,18 @@ def test_graph_outputs_as_connection_sources_with_two_policies():
     freqs = np.array([55.0, 220.0, 441.0, 1234.5, 3000.0, 7000.0], dtype=f32)
     eng = oscen_amd.Engine(g, n, sample_rate=SR)
     eng.set_voice_values("frequency", freqs)
-    got = render_taps(eng, n, frames, blocks)
+    # three stream outputs = three bus channels in declaration order (the reference exposes graph.out_a / out_b / out)
+    assert eng.channels == 3 and eng.lib.og_voice_channels(eng.h) == 3
+    assert [eng.output_channel(nm) for nm in ("out_a", "out_b", "out")] == [(0, 1), (1, 1), (2, 1)]
+    eng.set_voice_taps(list(range(n)))
+    got3, bus = [], []
+    for _ in range(blocks):
+        bus.append(eng.process_block(frames))
+        got3.append(eng.read_voice_taps(frames))
+    got3, bus = np.concatenate(got3, axis=1), np.concatenate(bus, axis=0)
+    assert got3.shape == (n, frames * blocks, 3) and bus.shape == (frames * blocks, 3)
+    got = got3[:, :, 2]
+    ref_a, ref_b = np.zeros_like(got), np.zeros_like(got)
     worst = 0.0
     for v in range(n):
         a = polyblep(lib, freqs[v], 0.5, ol.PB_SAW, SR * 2)
@@ -83,9 +94,14 @@ def test_graph_outputs_as_connection_sources_with_two_policies():
             out_a = f32(lib.oo_sinc_down_process(C.byref(dn), ol.fptr(xa)))
             out_b = f32(lib.oo_linear_down_process(2, ol.fptr(xb)))
             ref[i] = out_a + out_b
-        worst = max(worst, rel_err(got[v], ref))
+            ref_a[v, i], ref_b[v, i] = out_a, out_b
+        worst = max(worst, rel_err(got[v], ref), rel_err(got3[v, :, 0], ref_a[v]), rel_err(got3[v, :, 1], ref_b[v]))
         assert np.abs(ref).max() > 0.2
     assert worst <= 1e-5, worst
+    # the bus: every channel is the sum over the voices
+    for c, r in ((0, ref_a), (1, ref_b)):
+        want = r.astype(np.float64).sum(axis=0)
+        assert np.max(np.abs(bus[:, c] - want)) <= 2e-6 * np.abs(r).sum(axis=0).max() + 1e-6
     assert eng.latency_samples == 5  # the sinc edge: 11 * (2 - 1) / 2 (emit_struct.rs:534-570); linear adds (2 - 1) / 2 / 2 = 0
 
 

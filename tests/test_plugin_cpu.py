@@ -261,12 +261,12 @@ def test_frame_ports_lower_to_channel_values():
     st.connect("osc.output", "w.input")
     st.connect("w.output", "out")
     src = st.kernel_source()
-    assert "og::BusLds2 bus;" in src and "-> og::Out2 {" in src and "og_k2_" not in src
+    assert "og::BusLdsN<2> bus;" in src and "-> og::OutN<2> {" in src and "og_k2_" not in src
     assert st.jit_check() > 0
     # the DSL's typed output (`output out: stream: Frame<2>;`, examples/electric-piano/src/main.rs:51) is kept and checked
     typed = st.to_dsl().replace("output out: stream;", "output out: stream: Frame<2>;")
     g2 = oscen_amd.Graph(dsl=typed)
-    assert "output out: stream: Frame<2>;" in g2.to_dsl() and "og::BusLds2 bus;" in g2.kernel_source()
+    assert "output out: stream: Frame<2>;" in g2.to_dsl() and "og::BusLdsN<2> bus;" in g2.kernel_source()
     with pytest.raises(oscen_amd.OscenError, match="declared Frame<2> but fed an f32 stream"):
         oscen_amd.Graph(dsl=typed.replace("w.output -> out", "osc.output -> out")).kernel_source()
     with pytest.raises(oscen_amd.OscenError, match="declared f32 but fed a Frame<2>"):
