@@ -200,3 +200,21 @@ def test_stereo_voice_outputs_through_the_cluster(monkeypatch):
         assert np.max(np.abs(pb - want)) <= 1e-4 * scale
     finally:
         oscen_amd.unregister_node("ClPan::new")
+
+
+def test_eight_shard_cluster_on_one_device_matches_the_single_engine(monkeypatch):
+    """the shape of BASELINE config 4 (eight shards, one reduce per batch) at a small size with all shards on the one
+    device there is: global voice ranges, per-shard note streams, the per-device accumulation of eight buffers, the RCCL
+    leg with a one-rank communicator; render (threaded, batched) and the per-block real-time entry (thread-free)"""
+    monkeypatch.setenv("OSCEN_GPU_FORCE_RCCL", "1")
+    n, total, block = 8 * 640 + 37, 1280, 256   # (a ragged total: the shards differ in size)
+    want = single("fm_voice", n, total, block)
+    got, cl = cluster("fm_voice", n, total, block, shards=8)
+    assert cl.num_shards == 8 and cl.num_devices == 1 and cl.rccl_reduces == 1
+    sizes = [cl.shard(s).n_voices for s in range(8)]
+    assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.max(np.abs(got - want)) <= 1e-4 * scale and np.abs(want).max() > 1e-2
+    per_block, cl2 = cluster("fm_voice", n, total, block, shards=8, per_block=True)
+    assert np.array_equal(per_block, got)           # the two entries agree bit for bit
+    assert cl2.rccl_reduces == total // block       # one reduce per block through the real-time entry

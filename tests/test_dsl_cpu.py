@@ -1,4 +1,5 @@
 """Text front end for `graph! { ... }` bodies (oscen-graph-compiler/src/parse.rs grammar). CPU only."""
+import re
 import pytest
 
 import oscen_amd
@@ -142,3 +143,84 @@ def test_dsl_feedback_through_delay():
     assert "mix.output -> [d] -> fbk.input;" in back and "mix.output -> [3] -> out;" in back
     g2 = oscen_amd.Graph(dsl=back, per_voice=["frequency"])
     assert g2.kernel_source() == src
+
+
+def test_poly_wrapper_lowering_with_a_registered_voice_type_and_its_diagnostics():
+    """MidiParser -> VoiceAllocator<N> -> [MidiVoiceHandler; N] -> [Voice; N] -> sum (examples/fm-synth/src/lib.rs:68-131)
+    with a voice graph of one's own: registered as a graph type, the wrapper text lowers to a voice-bank kernel whose
+    inputs are the handler-fed per-voice inputs followed by the wrapper's (ramped) parameters; malformed wrappers are
+    diagnosed."""
+    voice = oscen_amd.Graph(dsl="""
+        name: MyVoice;
+        input freq: value = 220.0;
+        input trig: event;
+        input tone: value = 1500.0;
+        output audio: stream;
+        nodes {
+            osc = PolyBlepOscillator::saw(220.0, 0.4);
+            env = AdsrEnvelope::new(0.01, 0.1, 0.6, 0.2);
+            lp = TptFilter::new(1500.0, 0.8);
+        }
+        connections {
+            freq -> osc.frequency; trig -> env.gate; tone -> lp.cutoff;
+            osc.output * env.output -> lp.input; lp.output -> audio;
+        }
+    """)
+    wrapper = """
+        name: MyPoly;
+        input midi_in: event;
+        input brightness: value = 1800.0 [200.0..8000.0, ramp: 441];
+        output mix: stream;
+        nodes {
+            parser = MidiParser::new();
+            alloc = VoiceAllocator::<6>::new();
+            handlers = [MidiVoiceHandler::new(); 6];
+            voices = [MyVoice::new(); 6];
+        }
+        connections {
+            midi_in -> parser.midi_in;
+            parser.note_on -> alloc.note_on;  parser.note_off -> alloc.note_off;
+            alloc.voices -> handlers.note_on;  alloc.voices -> handlers.note_off;
+            handlers.frequency -> voices.freq;  handlers.gate -> voices.trig;
+            brightness -> voices.tone;
+            voices.audio -> mix;
+        }
+    """
+    with pytest.raises(oscen_amd.OscenError, match="not a graph type"):
+        oscen_amd.Graph(dsl=wrapper).kernel_source()
+    oscen_amd.register_graph_type("MyVoice", voice)
+    try:
+        g = oscen_amd.Graph(dsl=wrapper)
+        assert g.poly_info() == {"declared_voices": 6, "frequency_input": "freq", "gate_input": "trig"}
+        src = g.kernel_source()
+        # per-voice frequency input 0, gate event, then the wrapper's ramped parameter (ramp row 0); the voice's own node names
+        assert "vin_0" in src and "og::adsr_gate(" in src and "RV(0, " in src
+        order = re.search(r"// Node order: (.*)", src).group(1).split()
+        assert order == ["osc", "env", "lp"], order
+        assert g.jit_check() > 0
+        # the same bank written by hand
+        flat = oscen_amd.Graph("flat")
+        flat.input_value("freq", 220.0, per_voice=True)
+        flat.input_event("trig")
+        flat.input_value("brightness", 1800.0, ramp=441)
+        flat.output_stream("mix")
+        flat.node("osc", "PolyBlepOscillator::saw", 220.0, 0.4)
+        flat.node("env", "AdsrEnvelope::new", 0.01, 0.1, 0.6, 0.2)
+        flat.node("lp", "TptFilter::new", 1500.0, 0.8)
+        for a, b in (("freq", "osc.frequency"), ("trig", "env.gate"), ("brightness", "lp.cutoff"),
+                     ("osc.output * env.output", "lp.input"), ("lp.output", "mix")):
+            flat.connect(a, b)
+        strip = lambda t: re.sub(r"from graph '[^']*'|\"(MyPoly|flat)\"", "", t)
+        assert strip(flat.kernel_source()) == strip(src)
+        # diagnostics
+        bad = wrapper.replace("handlers.gate -> voices.trig;", "")
+        with pytest.raises(oscen_amd.OscenError, match="gate"):
+            oscen_amd.Graph(dsl=bad).kernel_source()
+        bad = wrapper.replace("handlers = [MidiVoiceHandler::new(); 6];", "handlers = [MidiVoiceHandler::new(); 4];")
+        with pytest.raises(oscen_amd.OscenError, match="4 voice handlers for 6 voices"):
+            oscen_amd.Graph(dsl=bad).kernel_source()
+        bad = wrapper.replace("voices.audio -> mix;", "voices.audio -> mix; midi_in -> voices.trig;")
+        with pytest.raises(oscen_amd.OscenError, match="may only feed the MidiParser"):
+            oscen_amd.Graph(dsl=bad).kernel_source()
+    finally:
+        oscen_amd.unregister_graph_type("MyVoice")
