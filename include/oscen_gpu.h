@@ -320,7 +320,8 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
  * superseded segments is reused, so steady live playing never needs the O(V) timeline rebuild) */
 uint64_t og_event_ring_wraps(const og_engine* e);
 /* the blocking entry (og_process_block / og_midi_process_block): calls that waited on the completion word, and how
- * many of those waits ran into the 20 ms fallback (a stream synchronise) -- 0 unless a block is slower than that */
+ * many of those waits ended because the stream was found finished (hipStreamQuery, asked every 128 us from 256 us on)
+ * before the completion word was seen -- 0 in the ordinary case */
 int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_timeouts);
 /* average device time of the voice kernel over the launches since the last
  * call (HIP events on the engine's stream); returns <0 if timing is off */

@@ -34,35 +34,132 @@ struct og_midi {
     std::vector<Voice> voices;
     uint32_t current_age = 0;
     // The reference scans all voices per note (24 of them).  With N = the bank size the same decisions come from
-    // three indexes (binary heaps with lazy deletion: ~tens of ns per note, no allocation in steady state):
+    // three indexes of FIXED size (one slot per voice each; nothing is allocated, rebuilt or compacted while playing,
+    // so a message costs O(log N) at worst whatever came before it -- the earlier lazy-deletion heaps grew with every
+    // note and paid for it with multi-millisecond reallocations at large N):
     //  * voices become active in index order and never turn inactive again (release keeps `active`,
     //    voice_allocator.rs:101-108), so "first inactive voice" is a counter;
-    //  * stealing = min over (released ? 0 : 1, age): ages are unique, so one age-ordered heap per release state;
-    //  * find_voice_for_note = lowest index among the held voices playing that note: a min-heap of indices per note.
-    // An entry is stale when the voice has since changed state (its age / note / release flag no longer match).
+    //  * stealing = min over (released ? 0 : 1, age).  Ages are handed out in increasing order at allocation, so the
+    //    HELD voices in age order are a FIFO: a doubly linked list through the voices (append on allocation, unlink on
+    //    release, the head is the oldest).  The RELEASED voices enter in any age order and leave only by being
+    //    allocated, oldest first: a binary min-heap by age in which every entry is live;
+    //  * find_voice_for_note = lowest index among the held voices playing that note: a min-heap of voice indices per
+    //    note with the position of every voice kept beside it (a held voice is in exactly one of them), so that a voice
+    //    leaves its note's heap the moment it is released or stolen.
     uint32_t n_fresh = 0; // voices [0, n_fresh) are active
+    static constexpr uint32_t NIL = 0xFFFFFFFFu;
+    std::vector<uint32_t> held_prev, held_next; // age-ordered list of the held voices
+    uint32_t held_head = NIL, held_tail = NIL;
+    void held_append(uint32_t i)
+    {
+        held_prev[i] = held_tail;
+        held_next[i] = NIL;
+        if (held_tail != NIL) held_next[held_tail] = i;
+        else held_head = i;
+        held_tail = i;
+    }
+    void held_unlink(uint32_t i)
+    {
+        const uint32_t p = held_prev[i], q = held_next[i];
+        if (p != NIL) held_next[p] = q;
+        else held_head = q;
+        if (q != NIL) held_prev[q] = p;
+        else held_tail = p;
+    }
     struct AgeEntry {
         uint32_t age, voice;
-        bool operator>(const AgeEntry& o) const { return age > o.age; }
     };
-    template <class T>
-    struct MinHeap {
-        std::vector<T> v;
-        void push(const T& x)
-        {
-            v.push_back(x);
-            std::push_heap(v.begin(), v.end(), std::greater<T>());
+    std::vector<AgeEntry> released; // min-heap by age, at most one entry per voice (reserved for N at creation)
+    void released_push(AgeEntry e)
+    {
+        size_t k = released.size();
+        released.push_back(e);
+        while (k > 0) {
+            const size_t up = (k - 1) / 2;
+            if (released[up].age <= e.age) break;
+            released[k] = released[up];
+            k = up;
         }
-        void pop()
-        {
-            std::pop_heap(v.begin(), v.end(), std::greater<T>());
-            v.pop_back();
+        released[k] = e;
+    }
+    uint32_t released_pop()
+    {
+        const uint32_t voice = released.front().voice;
+        const AgeEntry e = released.back();
+        released.pop_back();
+        const size_t m = released.size();
+        if (m) {
+            size_t k = 0;
+            for (;;) {
+                size_t c = 2 * k + 1;
+                if (c >= m) break;
+                if (c + 1 < m && released[c + 1].age < released[c].age) c += 1;
+                if (released[c].age >= e.age) break;
+                released[k] = released[c];
+                k = c;
+            }
+            released[k] = e;
         }
-        const T& top() const { return v.front(); }
-        bool empty() const { return v.empty(); }
-    };
-    MinHeap<AgeEntry> released_by_age, held_by_age;
-    MinHeap<uint32_t> held_by_note[256];
+        return voice;
+    }
+    std::vector<uint32_t> by_note[256]; // min-heaps of voice indices
+    std::vector<uint32_t> note_pos;     // where voice i sits in by_note[its note]
+    void note_place(std::vector<uint32_t>& h, size_t k, uint32_t i)
+    {
+        h[k] = i;
+        note_pos[i] = (uint32_t)k;
+    }
+    void note_up(std::vector<uint32_t>& h, size_t k, uint32_t i)
+    {
+        while (k > 0) {
+            const size_t up = (k - 1) / 2;
+            if (h[up] <= i) break;
+            note_place(h, k, h[up]);
+            k = up;
+        }
+        note_place(h, k, i);
+    }
+    void note_down(std::vector<uint32_t>& h, size_t k, uint32_t i)
+    {
+        const size_t m = h.size();
+        for (;;) {
+            size_t c = 2 * k + 1;
+            if (c >= m) break;
+            if (c + 1 < m && h[c + 1] < h[c]) c += 1;
+            if (h[c] >= i) break;
+            note_place(h, k, h[c]);
+            k = c;
+        }
+        note_place(h, k, i);
+    }
+    void note_insert(uint8_t note, uint32_t i)
+    {
+        auto& h = by_note[note];
+        h.push_back(i);
+        note_up(h, h.size() - 1, i);
+    }
+    void note_erase(uint8_t note, uint32_t i)
+    {
+        auto& h = by_note[note];
+        const size_t k = note_pos[i];
+        const uint32_t last = h.back();
+        h.pop_back();
+        if (k == h.size()) return;
+        if (k > 0 && h[(k - 1) / 2] > last) note_up(h, k, last);
+        else note_down(h, k, last);
+    }
+    void size_indexes()
+    {
+        voices.resize(n);
+        held_prev.assign(n, NIL);
+        held_next.assign(n, NIL);
+        note_pos.assign(n, 0);
+        released.reserve(n);
+        // a note's heap holds what is held on that note; reserve the even share of the 128 notes a few times over (a
+        // bank that piles more than that on one note grows that heap, once)
+        const size_t share = std::min<size_t>(n, std::max<size_t>(1024, (size_t)n / 16));
+        for (auto& h : by_note) h.reserve(share);
+    }
     // `midi_in` is an ArrayVec<EventInstance, 32> (graph/types.rs:18) in front of MAX_VOICES = 24 voices; the capacity
     // is lifted with N in the same proportion (32 per 24 voices); og_midi_set_queue_capacity overrides it
     uint32_t queue_cap = 32;
@@ -82,69 +179,40 @@ struct og_midi {
     };
     std::deque<Out> log;
 
-    bool held_ok(const AgeEntry& e) const { return voices[e.voice].active && !voices[e.voice].released && voices[e.voice].age == e.age; }
-    bool released_ok(const AgeEntry& e) const { return voices[e.voice].active && voices[e.voice].released && voices[e.voice].age == e.age; }
     // allocate_voice  voice_allocator.rs:57-89
     uint32_t allocate(uint8_t note)
     {
         uint32_t i;
         if (n_fresh < n) {
             i = n_fresh++;
+        } else if (!released.empty()) {
+            i = released_pop(); // released voices first, the oldest of them
         } else {
-            while (!released_by_age.empty() && !released_ok(released_by_age.top())) released_by_age.pop();
-            if (!released_by_age.empty()) {
-                i = released_by_age.top().voice; // released voices first, the oldest of them
-                released_by_age.pop();
-            } else {
-                while (!held_ok(held_by_age.top())) held_by_age.pop(); // all held: the oldest (never empty here)
-                i = held_by_age.top().voice;
-                held_by_age.pop();
-            }
+            i = held_head; // all held: the oldest (never empty here)
+            held_unlink(i);
+            note_erase((uint8_t)voices[i].note, i);
         }
         Voice& v = voices[i];
         v.active = true;
         v.released = false;
         v.note = note;
         v.age = current_age++;
-        held_by_age.push(AgeEntry{v.age, i});
-        held_by_note[note].push(i);
-        // stale entries never outnumber the live ones by much: rebuild a heap that has grown past 4 N
-        if (held_by_age.v.size() > 4u * (size_t)n + 64u) rebuild();
+        held_append(i);
+        note_insert(note, i);
         return i;
-    }
-    void rebuild()
-    {
-        held_by_age.v.clear();
-        released_by_age.v.clear();
-        for (auto& h : held_by_note) h.v.clear();
-        for (uint32_t i = 0; i < n_fresh; ++i) {
-            const Voice& v = voices[i];
-            if (v.released) {
-                released_by_age.v.push_back(AgeEntry{v.age, i});
-            } else {
-                held_by_age.v.push_back(AgeEntry{v.age, i});
-                if (v.note >= 0) held_by_note[v.note & 255].v.push_back(i);
-            }
-        }
-        std::make_heap(held_by_age.v.begin(), held_by_age.v.end(), std::greater<AgeEntry>());
-        std::make_heap(released_by_age.v.begin(), released_by_age.v.end(), std::greater<AgeEntry>());
-        for (auto& h : held_by_note) std::make_heap(h.v.begin(), h.v.end(), std::greater<uint32_t>());
     }
     int find(uint8_t note) // find_voice_for_note :92-98
     {
-        auto& h = held_by_note[note];
-        while (!h.empty()) {
-            const Voice& v = voices[h.top()];
-            if (v.active && !v.released && v.note == (int)note) return (int)h.top();
-            h.pop();
-        }
-        return -1;
+        const auto& h = by_note[note];
+        return h.empty() ? -1 : (int)h.front();
     }
-    void release(uint32_t i) // release_voice :101-108
+    void release(uint32_t i) // release_voice :101-108 (only ever called on a held voice: find() returns nothing else)
     {
+        held_unlink(i);
+        note_erase((uint8_t)voices[i].note, i);
         voices[i].released = true;
         voices[i].note = -1;
-        released_by_age.push(AgeEntry{voices[i].age, i});
+        released_push(AgeEntry{voices[i].age, i});
     }
     static float note_to_freq(uint8_t note) // midi.rs:69-72
     {
@@ -249,7 +317,7 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
         delete m;
         return OG_E_INVALID;
     }
-    m->voices.resize(m->n);
+    m->size_indexes();
     m->queue_cap = 32u * ((m->n + 23u) / 24u);
     *out = m;
     return OG_OK;
@@ -270,7 +338,7 @@ int og_midi_create_cluster(og_cluster* c, const char* frequency_input, const cha
         delete m;
         return OG_E_INVALID;
     }
-    m->voices.resize(m->n);
+    m->size_indexes();
     m->queue_cap = 32u * ((m->n + 23u) / 24u);
     *out = m;
     return OG_OK;

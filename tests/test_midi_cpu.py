@@ -109,3 +109,61 @@ def test_midi_in_queue_capacity_and_late_messages():
     big.flush()
     st = big.voice_state(0)
     assert st["active"] and st["age"] == 100000  # voice 0 was the oldest held voice when the 100001st note arrived
+
+
+class ScanAllocator:
+    """voice_allocator.rs:57-108 as written: a scan over all voices per decision (what og_midi's indexes must reproduce)"""
+
+    def __init__(self, n):
+        self.v = [dict(active=False, released=False, note=None, age=0) for _ in range(n)]
+        self.age = 0
+
+    def allocate(self, note):
+        for i, s in enumerate(self.v):                                    # :59-68 first inactive voice
+            if not s["active"]:
+                break
+        else:                                                             # :72-80 (released first, then oldest)
+            i = min(range(len(self.v)), key=lambda k: (0 if self.v[k]["released"] else 1, self.v[k]["age"]))
+        self.v[i] = dict(active=True, released=False, note=note, age=self.age)
+        self.age += 1
+        return i
+
+    def note_off(self, note):                                             # :92-108
+        for i, s in enumerate(self.v):
+            if s["active"] and not s["released"] and s["note"] == note:
+                s["released"], s["note"] = True, None
+                return i
+        return None
+
+
+def test_allocator_indexes_equal_the_reference_scan_under_heavy_stealing():
+    """og_midi answers allocate / find / release from fixed-size indexes (held FIFO, released heap, per-note heaps
+    with positions) instead of the reference's scans: every decision and the whole voice table must still equal the
+    scan's, through thousands of steals, repeated notes on several voices and note-offs for notes nobody holds"""
+    rng = np.random.default_rng(20260927)
+    for n, n_notes, p_off, steps in ((1, 3, 0.3, 300), (5, 4, 0.45, 3000), (24, 12, 0.5, 6000), (67, 128, 0.35, 8000), (300, 6, 0.55, 12000)):
+        m = oscen_amd.Midi(n_voices=n)
+        m.set_queue_capacity(1 << 20)
+        ref = ScanAllocator(n)
+        want = []
+        for step in range(steps):
+            note = int(rng.integers(30, 30 + n_notes))
+            if rng.random() < p_off:
+                m.note_off(note)
+                i = ref.note_off(note)
+                if i is not None:
+                    want.append((i, False))
+            else:
+                m.note_on(note, velocity=100)
+                want.append((ref.allocate(note), True))
+            if step % 97 == 96 or step == steps - 1:
+                m.flush()
+                got = [(voice, hz is not None) for voice, _fo, hz, _gate in m.pop_outputs()]
+                assert got == want, (n, step)
+                want = []
+                for k in range(n):
+                    s = m.voice_state(k)
+                    r = ref.v[k]
+                    assert (s["active"], s["released"], s["note"]) == (r["active"], r["released"], r["note"]), (n, step, k)
+                    if r["active"]:
+                        assert s["age"] == r["age"]
