@@ -555,7 +555,7 @@ def main():
     ap.add_argument("--rt-blocks", type=int, default=2000, help="blocks per bank size of the real-time record")
     ap.add_argument("--rt-paced-blocks", type=int, default=1500,
                     help="blocks of the paced run (one call per 5.33 ms block period) on the largest bank of the real-time record")
-    ap.add_argument("--rt-voices", default="65536,131072,1048576,4194304",
+    ap.add_argument("--rt-voices", default="65536,131072,1048576,4194304,8388608",
                     help="bank sizes of the real-time record (comma separated)")
     ap.add_argument("--rt-midi", type=int, default=1000, help="live MIDI messages per block in the real-time record")
     ap.add_argument("--cluster", action="store_true",

@@ -121,6 +121,27 @@ typedef struct {
 #define OG_NODE_EVENTS_PER_FRAME 2
 int og_register_node(const og_node_type* t);
 int og_unregister_node(const char* type_ctor);
+
+/* ---- named functions on a connection (ast.rs:126-128 `Call`; oscen-lib/tests/connection_expr_functions.rs:14-27,
+ * connection_expr_function_paths.rs:15-26) -------------------------------------------------------------------------
+ * `half(a.output) -> out`, `dsp::decode_ms(s.output) -> out`, `merge2(a.output, b.output) -> out`: the reference
+ * passes the call through to a pure Rust function in scope.  Here that function is registered once, its body as
+ * DEVICE SOURCE like a node's process(): every f32 parameter is a `const float <name>`, every Frame<N> parameter a
+ * `const og::Frame<N> <name>` (`.v[i]`, `+`, `-`, `* float`), the body returns a `float` or an `og::Frame<N>`.
+ * A call matches a registration by the path as written, by its last segment (what `use dsp::decode_ms;` gives), or a
+ * registration under a longer path ending in it.  Calls whose path ends in `Frame` (`Frame::<2>(a, b)`,
+ * `oscen::frame::Frame(a, b)`) are the frame constructor and need no registration; `x.tanh()`, `x.clamp(lo, hi)` and the
+ * other f32 methods are built in.  The result of a function is a per-frame value whatever its arguments are. */
+typedef struct {
+    const char* name;               /* "half" or "dsp::decode_ms" */
+    uint32_t n_args;                /* 1..8 */
+    const char* const* arg_names;
+    const uint32_t* arg_channels;   /* per argument: 0 or 1 = f32, N (2..4) = Frame<N>; NULL = all f32 */
+    uint32_t result_channels;       /* 0 or 1 = f32, N = Frame<N> */
+    const char* source;             /* the function body, e.g. "return x * 0.5f;" */
+} og_function_type;
+int og_register_function(const og_function_type* f);
+int og_unregister_function(const char* name);
 /* A graph description usable as a node of other graphs (`inner = InnerGraph;`, nested graphs:
  * examples/src/bin/nested_static_graph_test.rs): expanded inline, its inputs/outputs become the node's ports. */
 int og_register_graph_type(const char* type_name, const og_graph_desc* g);

@@ -1210,6 +1210,30 @@ int og_unregister_node(const char* type_ctor)
     return ogc::unregister_user_node(type_ctor) ? OG_OK : set_err(OG_E_INVALID, std::string("no user node type '") + type_ctor + "'");
 }
 
+int og_register_function(const og_function_type* f)
+{
+    if (!f || !f->name || !f->source || !f->n_args || !f->arg_names) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        ogc::UserFunction u;
+        u.name = f->name;
+        for (uint32_t k = 0; k < f->n_args; ++k) {
+            if (!f->arg_names[k]) throw std::runtime_error("null argument name");
+            u.arg_names.push_back(f->arg_names[k]);
+            u.arg_channels.push_back(f->arg_channels && f->arg_channels[k] > 1 ? (int)f->arg_channels[k] : 1);
+        }
+        u.result_channels = f->result_channels > 1 ? (int)f->result_channels : 1;
+        u.source = f->source;
+        ogc::register_user_function(u);
+        return OG_OK;
+    });
+}
+
+int og_unregister_function(const char* name)
+{
+    if (!name) return set_err(OG_E_INVALID, "null argument");
+    return ogc::unregister_user_function(name) ? OG_OK : set_err(OG_E_INVALID, std::string("no function '") + name + "'");
+}
+
 int og_register_graph_type(const char* type_name, const og_graph_desc* g)
 {
     if (!type_name || !g) return set_err(OG_E_INVALID, "null argument");

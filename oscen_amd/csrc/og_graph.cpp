@@ -86,11 +86,15 @@ Val vconst(float c)
 
 // ---- expression parsing ------------------------------------------------------
 struct Expr {
-    enum T { Num, Ref, Bin, Neg } t = Num;
+    // Call: `half(a.output)`, `dsp::decode_ms(s.output)`, `Frame::<2>(a.output, b.output)` (ast.rs:126-128);
+    // Method: `x.tanh()`, `x.clamp(0.0, 1.0)` (ast.rs:120-121); Chan: `s.output[1]` (one channel of a Frame<N>)
+    enum T { Num, Ref, Bin, Neg, Call, Method, Chan } t = Num;
     float num = 0;
-    std::string node, port; // Ref: port empty => bare identifier
+    std::string node, port; // Ref: port empty => bare identifier.  Call: node = the path as written; Method: node = its name
     char op = 0;
     std::shared_ptr<Expr> a, b;
+    std::vector<std::shared_ptr<Expr>> args; // Call / Method
+    long index = 0;                          // Chan
 };
 using ExprP = std::shared_ptr<Expr>;
 
@@ -125,7 +129,7 @@ struct Parser {
         if (eat('(')) {
             ExprP e = sum();
             if (!eat(')')) fail("missing ')' in '" + s + "'");
-            return e;
+            return postfix(e);
         }
         if (eat('-')) {
             auto e = std::make_shared<Expr>();
@@ -152,18 +156,111 @@ struct Parser {
         }
         std::string id = ident();
         if (id.empty()) fail("bad expression '" + s + "'");
+        // a path `segment (:: segment)*` names a function (parse.rs:1046-1084); `::<N>` is the dropped width of a Frame
+        // constructor and is rejected on any other path
+        std::string path = id, last = id;
+        size_t n_seg = 1;
+        for (;;) {
+            ws();
+            if (!(i + 1 < s.size() && s[i] == ':' && s[i + 1] == ':')) break;
+            i += 2;
+            ws();
+            if (i < s.size() && s[i] == '<') {
+                if (last != "Frame") fail("turbofish arguments are only supported on the `Frame` constructor ('" + s + "')");
+                while (i < s.size() && s[i] != '>') ++i;
+                if (i >= s.size()) fail("missing '>' in '" + s + "'");
+                ++i;
+                ws();
+                if (!(i < s.size() && s[i] == '(')) fail("expected `(` after `Frame::<N>` in '" + s + "'");
+                break;
+            }
+            last = ident();
+            if (last.empty()) fail("bad path in '" + s + "'");
+            path += "::" + last;
+            n_seg += 1;
+        }
+        ws();
+        if (i < s.size() && s[i] == '(') {
+            // `name(` directly after a bare identifier or a path: a call -- but not the legacy `osc.output()` accessor,
+            // which is handled after the port below
+            ++i;
+            auto c = std::make_shared<Expr>();
+            c->t = Expr::Call;
+            c->node = path;
+            c->port = last;
+            c->args = call_args();
+            return postfix(c);
+        }
+        if (n_seg > 1)
+            fail("a path is only valid as a function name in a connection; endpoints use `node.field` ('" + s + "')");
         auto e = std::make_shared<Expr>();
         e->t = Expr::Ref;
         e->node = id;
         ws();
-        if (i < s.size() && s[i] == '.') {
+        if (i + 1 < s.size() && s[i] == '.' && (isalpha((unsigned char)s[i + 1]) || s[i + 1] == '_')) {
+            const size_t save = i;
             ++i;
-            e->port = ident();
-            if (eat('(')) { // legacy `osc.output()` accessor syntax
-                if (!eat(')')) fail("bad accessor in '" + s + "'");
+            const std::string port = ident();
+            ws();
+            if (i < s.size() && s[i] == '(' && !(i + 1 < s.size() && s[i + 1] == ')' && !is_method(port))) {
+                i = save; // `input.tanh()`: a method on a bare identifier (graph input)
+            } else {
+                e->port = port;
+                if (eat('(')) { // legacy `osc.output()` accessor syntax
+                    if (!eat(')')) fail("bad accessor in '" + s + "'");
+                }
             }
         }
-        return e;
+        return postfix(e);
+    }
+    static bool is_method(const std::string& name);
+    std::vector<ExprP> call_args() // after '(' : `expr (, expr)*` up to the matching ')'
+    {
+        std::vector<ExprP> args;
+        ws();
+        if (eat(')')) return args;
+        for (;;) {
+            args.push_back(sum());
+            if (eat(',')) {
+                ws();
+                if (eat(')')) break; // trailing comma
+                continue;
+            }
+            if (!eat(')')) fail("missing ')' in '" + s + "'");
+            break;
+        }
+        return args;
+    }
+    // `[k]` (a channel of a Frame<N>) and `.method(args)` after a primary (parse.rs:1098-1123)
+    ExprP postfix(ExprP e)
+    {
+        for (;;) {
+            ws();
+            if (i < s.size() && s[i] == '[') {
+                ++i;
+                ws();
+                std::string num;
+                while (i < s.size() && isdigit((unsigned char)s[i])) num.push_back(s[i++]);
+                if (num.empty() || !eat(']')) fail("expected `[index]` in '" + s + "'");
+                auto c = std::make_shared<Expr>();
+                c->t = Expr::Chan;
+                c->a = e;
+                c->index = strtol(num.c_str(), nullptr, 10);
+                e = c;
+            } else if (i + 1 < s.size() && s[i] == '.' && (isalpha((unsigned char)s[i + 1]) || s[i + 1] == '_')) {
+                ++i;
+                const std::string name = ident();
+                if (!eat('(')) fail("'" + name + "' in '" + s + "': a field can only follow a node name; a method call needs `(`");
+                auto m = std::make_shared<Expr>();
+                m->t = Expr::Method;
+                m->node = name;
+                m->a = e;
+                m->args = call_args();
+                e = m;
+            } else {
+                return e;
+            }
+        }
     }
     ExprP product()
     {
@@ -214,6 +311,81 @@ void collect_refs(const ExprP& e, std::vector<const Expr*>& out)
     if (e->t == Expr::Ref) out.push_back(e.get());
     collect_refs(e->a, out);
     collect_refs(e->b, out);
+    for (const ExprP& x : e->args) collect_refs(x, out);
+}
+
+std::string sanitize(const std::string& s);
+bool is_ident(const std::string& s);
+
+// ---- f32 methods usable on a connection (`x.tanh()`, `x.clamp(0.0, 1.0)`: ast.rs:120-121; the reference passes
+// the call through to Rust's f32, whose transcendental methods bind to the platform libm) ------------------------
+struct MethodInfo {
+    int n_args;
+    const char* dev; // device expression: $0 = receiver, $1.. = arguments
+    float (*host)(float, float, float);
+};
+const std::map<std::string, MethodInfo>& method_table()
+{
+    static const std::map<std::string, MethodInfo> T = {
+        {"abs", {0, "__builtin_fabsf($0)", [](float x, float, float) { return fabsf(x); }}},
+        {"sqrt", {0, "__fsqrt_rn($0)", [](float x, float, float) { return sqrtf(x); }}},
+        {"cbrt", {0, "cbrtf($0)", [](float x, float, float) { return cbrtf(x); }}},
+        {"recip", {0, "(1.0f / $0)", [](float x, float, float) { return 1.0f / x; }}},
+        {"tanh", {0, "tanhf($0)", [](float x, float, float) { return tanhf(x); }}},
+        {"sinh", {0, "sinhf($0)", [](float x, float, float) { return sinhf(x); }}},
+        {"cosh", {0, "coshf($0)", [](float x, float, float) { return coshf(x); }}},
+        {"sin", {0, "og_sinf_exact($0)", [](float x, float, float) { return sinf(x); }}},
+        {"cos", {0, "og_cosf_exact($0)", [](float x, float, float) { return cosf(x); }}},
+        {"tan", {0, "tanf($0)", [](float x, float, float) { return tanf(x); }}},
+        {"asin", {0, "asinf($0)", [](float x, float, float) { return asinf(x); }}},
+        {"acos", {0, "acosf($0)", [](float x, float, float) { return acosf(x); }}},
+        {"atan", {0, "atanf($0)", [](float x, float, float) { return atanf(x); }}},
+        {"atan2", {1, "atan2f($0, $1)", [](float x, float y, float) { return atan2f(x, y); }}},
+        {"hypot", {1, "hypotf($0, $1)", [](float x, float y, float) { return hypotf(x, y); }}},
+        {"exp", {0, "expf($0)", [](float x, float, float) { return expf(x); }}},
+        {"exp2", {0, "exp2f($0)", [](float x, float, float) { return exp2f(x); }}},
+        {"exp_m1", {0, "expm1f($0)", [](float x, float, float) { return expm1f(x); }}},
+        {"ln", {0, "logf($0)", [](float x, float, float) { return logf(x); }}},
+        {"ln_1p", {0, "log1pf($0)", [](float x, float, float) { return log1pf(x); }}},
+        {"log2", {0, "log2f($0)", [](float x, float, float) { return log2f(x); }}},
+        {"log10", {0, "log10f($0)", [](float x, float, float) { return log10f(x); }}},
+        {"powf", {1, "powf($0, $1)", [](float x, float y, float) { return powf(x, y); }}},
+        {"powi", {1, "powf($0, $1)", [](float x, float y, float) { return powf(x, y); }}},
+        {"floor", {0, "floorf($0)", [](float x, float, float) { return floorf(x); }}},
+        {"ceil", {0, "ceilf($0)", [](float x, float, float) { return ceilf(x); }}},
+        {"round", {0, "roundf($0)", [](float x, float, float) { return roundf(x); }}},
+        {"trunc", {0, "truncf($0)", [](float x, float, float) { return truncf(x); }}},
+        {"fract", {0, "($0 - truncf($0))", [](float x, float, float) { return x - truncf(x); }}},
+        {"signum", {0, "(($0) != ($0) ? ($0) : __builtin_copysignf(1.0f, ($0)))", [](float x, float, float) { return x != x ? x : (std::signbit(x) ? -1.0f : 1.0f); }}},
+        {"min", {1, "fminf($0, $1)", [](float x, float y, float) { return fminf(x, y); }}},
+        {"max", {1, "fmaxf($0, $1)", [](float x, float y, float) { return fmaxf(x, y); }}},
+        {"clamp", {2, "fminf(fmaxf($0, $1), $2)", [](float x, float lo, float hi) { return x != x ? x : (x < lo ? lo : (x > hi ? hi : x)); }}},
+        {"mul_add", {2, "__builtin_fmaf($0, $1, $2)", [](float x, float a, float b) { return fmaf(x, a, b); }}},
+        {"to_radians", {0, "($0 * 0x1.1df46ap-6f)", [](float x, float, float) { return x * 0x1.1df46ap-6f; }}},
+        {"to_degrees", {0, "($0 * 0x1.ca5dc2p+5f)", [](float x, float, float) { return x * 0x1.ca5dc2p+5f; }}},
+    };
+    return T;
+}
+bool Parser::is_method(const std::string& name) { return method_table().count(name) > 0; }
+
+// ---- named functions applied on a connection (og_register_function): the pure in-scope Rust functions of
+// `decode_ms(s.output) -> out`, `dsp::half(a.output) -> out` (oscen-lib/tests/connection_expr_functions.rs) ----------
+std::map<std::string, UserFunction>& function_registry()
+{
+    static std::map<std::string, UserFunction> R;
+    return R;
+}
+const UserFunction* lookup_function(const std::string& path, const std::string& last)
+{
+    auto& R = function_registry();
+    auto it = R.find(path); // as written (`dsp::decode_ms`), then by its last segment (what `use dsp::decode_ms` would give)
+    if (it == R.end()) it = R.find(last);
+    if (it == R.end())
+        for (auto& kv : R) { // a registration under a longer path matches a call through a shorter one
+            const std::string& k = kv.first;
+            if (k.size() > last.size() + 2 && k.compare(k.size() - last.size() - 2, std::string::npos, "::" + last) == 0) return &kv.second;
+        }
+    return it == R.end() ? nullptr : &it->second;
 }
 
 // ---- node type registry ------------------------------------------------------
@@ -620,12 +792,145 @@ struct Codegen {
             for (int c = 0; c < width; ++c) r.ch.push_back(node_output(nit->second, e->node, e->port + "#" + std::to_string(c)));
             return r;
         }
+        case Expr::Chan: { // `s.output[1]`: one channel of a Frame<N> source
+            Val a = eval(e->a);
+            if (!a.is_frame()) fail("`[" + std::to_string(e->index) + "]` needs a Frame<N> source (an element of a node array is `name[i].port`)");
+            if (e->index < 0 || (size_t)e->index >= a.ch.size())
+                fail("channel " + std::to_string(e->index) + " of a Frame<" + std::to_string(a.ch.size()) + ">");
+            return a.ch[(size_t)e->index];
+        }
+        case Expr::Method: return method(e);
+        case Expr::Call: return call(e);
         default: {
             Val a = eval(e->a), b = eval(e->b);
             if (a.is_frame() || b.is_frame()) return frame_arith(a, b, e->op, std::string("frame ") + e->op + " ...");
             return arith(a, b, e->op);
         }
         }
+    }
+
+    // joins what a derived value inherits from the values it is computed from
+    static void inherit(Val& r, const Val& a)
+    {
+        r.rate = join(r.rate, a.rate);
+        r.stream = r.stream || a.stream;
+        r.inner = r.inner || a.inner;
+        r.voice_inputs.insert(a.voice_inputs.begin(), a.voice_inputs.end());
+    }
+    void check_same_domain(const std::vector<Val>& vs, const std::string& what)
+    {
+        bool in = false, outr = false;
+        for (const Val& v : vs) {
+            if (v.rate != Rate::Vary) continue;
+            (v.inner ? in : outr) = true;
+        }
+        if (in && outr) fail("'" + what + "' mixes outer-rate and oversampled node outputs; connect them through a cross-rate edge");
+    }
+    Val method(const ExprP& e)
+    {
+        auto mit = method_table().find(e->node);
+        if (mit == method_table().end()) fail("unknown f32 method '." + e->node + "()' on a connection");
+        const MethodInfo& mi = mit->second;
+        if ((int)e->args.size() != mi.n_args)
+            fail("'." + e->node + "()' takes " + std::to_string(mi.n_args) + " argument(s), " + std::to_string(e->args.size()) + " given");
+        std::vector<Val> vs{eval(e->a)};
+        for (const ExprP& x : e->args) vs.push_back(eval(x));
+        for (const Val& v : vs)
+            if (v.is_frame()) fail("'." + e->node + "()' is an f32 method: a Frame<N> has no such method (take a channel: `x[0]`)");
+        check_same_domain(vs, "." + e->node + "()");
+        Val r;
+        std::string d = mi.dev;
+        for (size_t k = vs.size(); k-- > 0;) { // ($2 before $1 before $0: none is a prefix of a later one)
+            const std::string key = "$" + std::to_string(k);
+            for (size_t p = d.find(key); p != std::string::npos; p = d.find(key, p + vs[k].e.size())) d.replace(p, key.size(), vs[k].e);
+        }
+        r.e = d;
+        bool hosts = true;
+        for (const Val& v : vs) {
+            inherit(r, v);
+            hosts = hosts && (bool)v.host;
+        }
+        if (r.rate <= Rate::UBlock) {
+            if (hosts) {
+                HostFn h0 = vs[0].host, h1 = vs.size() > 1 ? vs[1].host : HostFn(), h2 = vs.size() > 2 ? vs[2].host : HostFn();
+                auto fn = mi.host;
+                r.host = [fn, h0, h1, h2](const UEnv& env) { return fn(h0(env), h1 ? h1(env) : 0.0f, h2 ? h2(env) : 0.0f); };
+            } else {
+                r.rate = Rate::Vary;
+            }
+        }
+        return r;
+    }
+    Val call(const ExprP& e)
+    {
+        std::vector<Val> vs;
+        for (const ExprP& x : e->args) vs.push_back(eval(x));
+        if (e->port == "Frame") { // any call path ending in `Frame` is the frame constructor (parse.rs:1051-1075)
+            if (vs.size() < 2 || vs.size() > 4) fail("Frame(..) takes 2 to 4 channels ('" + e->node + "')");
+            Val r;
+            r.rate = Rate::Vary;
+            for (const Val& v : vs) {
+                if (v.is_frame()) fail("Frame(..) takes f32 channels ('" + e->node + "')");
+                r.ch.push_back(v);
+            }
+            check_same_domain(vs, e->node + "(..)");
+            return r;
+        }
+        const UserFunction* f = lookup_function(e->node, e->port);
+        if (!f)
+            fail("unknown function '" + e->node + "' in a connection: the reference resolves it to a Rust function in scope; here it has to be "
+                 "registered (og_register_function)");
+        if (vs.size() != f->arg_names.size())
+            fail("function '" + e->node + "' takes " + std::to_string(f->arg_names.size()) + " argument(s), " + std::to_string(vs.size()) + " given");
+        std::vector<Val> flat;
+        std::string args;
+        for (size_t k = 0; k < vs.size(); ++k) {
+            const int w = f->arg_channels[k];
+            if ((vs[k].is_frame() ? (int)vs[k].ch.size() : 1) != w)
+                fail("function '" + e->node + "': argument '" + f->arg_names[k] + "' is " + (w > 1 ? "a Frame<" + std::to_string(w) + ">" : "an f32") +
+                     ", the source is " + (vs[k].is_frame() ? "a Frame<" + std::to_string(vs[k].ch.size()) + ">" : "an f32"));
+            if (k) args += ", ";
+            if (w > 1) {
+                std::string init;
+                for (const Val& c : vs[k].ch) {
+                    init += (init.empty() ? "" : ", ") + c.e;
+                    flat.push_back(c);
+                }
+                args += "og::Frame<" + std::to_string(w) + ">{{" + init + "}}";
+            } else {
+                args += vs[k].e;
+                flat.push_back(vs[k]);
+            }
+        }
+        check_same_domain(flat, e->node + "(..)");
+        const std::string fn = "og_fn_" + sanitize(f->name);
+        if (!user_fns.count("~fn:" + f->name)) {
+            std::ostringstream d;
+            auto ty = [](int w) { return w > 1 ? "og::Frame<" + std::to_string(w) + ">" : std::string("float"); };
+            d << "// function " << f->name << " (og_register_function)\n__device__ __forceinline__ " << ty(f->result_channels) << " " << fn << "(";
+            for (size_t k = 0; k < f->arg_names.size(); ++k)
+                d << (k ? ", " : "") << "const " << ty(f->arg_channels[k]) << " " << f->arg_names[k];
+            d << ")\n{\n" << f->source << "\n}\n";
+            user_fns["~fn:" + f->name] = d.str();
+        }
+        // no host-side evaluation of device source: the result is a per-frame value whatever its arguments are
+        Val base;
+        base.rate = Rate::Vary;
+        for (const Val& v : flat) inherit(base, v);
+        base.rate = Rate::Vary;
+        const std::string c = fn + "(" + args + ")";
+        if (f->result_channels <= 1) {
+            base.e = c;
+            return base;
+        }
+        Val r;
+        r.rate = Rate::Vary;
+        for (int k = 0; k < f->result_channels; ++k) { // (the inlined pure call is evaluated once: common subexpression)
+            Val ch = base;
+            ch.e = c + ".v[" + std::to_string(k) + "]";
+            r.ch.push_back(ch);
+        }
+        return r;
     }
 };
 
@@ -1533,9 +1838,19 @@ std::vector<Tok> scan(const std::string& s)
         const char c = s[i];
         if (isalpha((unsigned char)c) || c == '_') {
             Tok t{Tok::Ident, ""};
+            const size_t start = i;
             while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_')) t.text.push_back(s[i++]);
             size_t j = i;
             while (j < s.size() && isspace((unsigned char)s[j])) ++j;
+            // not a reference: a method name (`.tanh(`), a function name (`half(`) or a segment of its path (`dsp::`)
+            size_t b = start;
+            while (b > 0 && isspace((unsigned char)s[b - 1])) --b;
+            const bool after_dot = b > 0 && s[b - 1] == '.', after_path = b > 1 && s[b - 1] == ':' && s[b - 2] == ':';
+            const bool before_call = j < s.size() && s[j] == '(', before_path = j + 1 < s.size() && s[j] == ':' && s[j + 1] == ':';
+            if (after_dot || before_call || before_path || after_path) {
+                for (char ch : t.text) other(ch);
+                continue;
+            }
             if (j < s.size() && s[j] == '[') {
                 size_t k = j + 1;
                 std::string num;
@@ -2143,6 +2458,30 @@ GraphDesc lower_poly_wrapper(const GraphDesc& g, PolyInfo* info)
 }
 
 GraphDesc expand(const GraphDesc& g) { return expand_passthrough(expand_nested(expand_arrays(lower_poly_wrapper(g)), 0)); }
+
+void register_user_function(const UserFunction& f)
+{
+    if (f.name.empty()) fail("function without a name");
+    size_t b = 0;
+    for (;;) { // every path segment an identifier
+        const size_t c = f.name.find("::", b);
+        if (!is_ident(f.name.substr(b, c == std::string::npos ? std::string::npos : c - b))) fail("function name '" + f.name + "' is not a path of identifiers");
+        if (c == std::string::npos) break;
+        b = c + 2;
+    }
+    const std::string last = f.name.substr(b);
+    if (last == "Frame") fail("'Frame' is the frame constructor");
+    if (f.arg_names.size() != f.arg_channels.size() || f.arg_names.empty() || f.arg_names.size() > 8)
+        fail("function '" + f.name + "': 1 to 8 arguments, one width each");
+    for (size_t k = 0; k < f.arg_names.size(); ++k) {
+        if (!is_ident(f.arg_names[k])) fail("function '" + f.name + "': bad argument name '" + f.arg_names[k] + "'");
+        if (f.arg_channels[k] < 1 || f.arg_channels[k] > 4) fail("function '" + f.name + "': an argument is an f32 (1) or a Frame<2..4>");
+    }
+    if (f.result_channels < 1 || f.result_channels > 4) fail("function '" + f.name + "': the result is an f32 (1) or a Frame<2..4>");
+    if (f.source.empty()) fail("function '" + f.name + "' has no body");
+    function_registry()[f.name] = f;
+}
+bool unregister_user_function(const std::string& name) { return function_registry().erase(name) > 0; }
 
 void register_user_node(const UserNodeType& t)
 {

@@ -200,6 +200,18 @@ struct UserNodeType {
 void register_user_node(const UserNodeType& t); // throws on malformed descriptions or a clash with a built-in type
 bool unregister_user_node(const std::string& type);
 
+// named pure functions applied on a connection (`half(a.output) -> out`, `dsp::decode_ms(s.output) -> out`;
+// ast.rs:126-128, oscen-lib/tests/connection_expr_functions.rs): device source, like a user node's process()
+struct UserFunction {
+    std::string name;                   // "half", or a path "dsp::decode_ms"
+    std::vector<std::string> arg_names; // parameter names inside `source`
+    std::vector<int> arg_channels;      // 1 = f32, N = Frame<N> (og::Frame<N>)
+    int result_channels = 1;
+    std::string source;                 // the function body: `return x * 0.5f;`
+};
+void register_user_function(const UserFunction& f); // throws on a malformed description
+bool unregister_user_function(const std::string& name);
+
 // graph types usable as nodes of other graphs (nested graphs: `sub = SubGraph::new()`), expanded inline
 void register_graph_type(const std::string& name, const GraphDesc& g);
 bool unregister_graph_type(const std::string& name);

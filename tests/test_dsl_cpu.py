@@ -224,3 +224,57 @@ def test_poly_wrapper_lowering_with_a_registered_voice_type_and_its_diagnostics(
             oscen_amd.Graph(dsl=bad).kernel_source()
     finally:
         oscen_amd.unregister_graph_type("MyVoice")
+
+
+def test_calls_on_a_connection_parse_and_report_like_the_reference():
+    """ast.rs:113-129 / parse.rs:1027-1123: `path(args)` calls, `.method(args)`, `[k]` channel index; the diagnostics of
+    oscen-macros/tests/ui/{turbofish_non_frame,unknown_node_in_call_arg}.rs"""
+    oscen_amd.register_node("DxConst::new", inputs=[], outputs=["output"], n_ctor_args=1, state=[("val", "f32", 0.0, 0)],
+                            process="    output = val;\n")
+    oscen_amd.register_node("DxStereo::new", inputs=[], outputs=[("output", 2)], process="    output.v[0] = 0.5f;\n    output.v[1] = 0.25f;\n")
+    oscen_amd.register_function("dsp::halve", ["x"], "return x * 0.5f;")
+    oscen_amd.register_function("swap", [("v", 2)], "og::Frame<2> o; o.v[0] = v.v[1]; o.v[1] = v.v[0]; return o;", result_channels=2)
+
+    def lower(conn, out="stream"):
+        g = oscen_amd.Graph(dsl=f"name: Dx; output out: {out}; nodes {{ a = DxConst::new(0.8); s = DxStereo::new(); osc = DxConst::new(0.1); }} "
+                                f"connections {{ {conn} }}")
+        return g.kernel_source()
+
+    try:
+        src = lower("halve(a.output) -> out;")                     # last path segment, like `use dsp::halve;`
+        assert "og_fn_dsp__halve(" in src and "return x * 0.5f;" in src
+        assert "og_fn_dsp__halve(" in lower("dsp::halve(a.output).abs() + 1.0 -> out;")
+        assert "og_fn_swap(" in lower("swap(s.output) -> out;", "stream: Frame<2>")
+        assert "og_fn_swap(" in lower("swap(swap(s.output))[0] -> out;")
+        assert "tanhf(" in lower("a.output.tanh() -> out;")
+        for conn, out, msg in [
+            ("dsp::split::<4>(osc.output) -> out;", "stream", "turbofish arguments are only supported on the `Frame` constructor"),
+            ("double(ocs.output) -> out;", "stream", "unknown node 'ocs'"),
+            ("double(osc.output) -> out;", "stream", "unknown function 'double'"),
+            ("halve(s.output) -> out;", "stream", "argument 'x' is an f32, the source is a Frame<2>"),
+            ("swap(a.output) -> out;", "stream: Frame<2>", "argument 'v' is a Frame<2>, the source is an f32"),
+            ("halve(a.output, a.output) -> out;", "stream", "takes 1 argument(s), 2 given"),
+            ("a.output.frobnicate() -> out;", "stream", "unknown f32 method '.frobnicate()'"),
+            ("a.output.clamp(0.0) -> out;", "stream", "'.clamp()' takes 2 argument(s), 1 given"),
+            ("s.output.tanh() -> out;", "stream", "is an f32 method"),
+            ("a.output[0] -> out;", "stream", "needs a Frame<N> source"),
+            ("s.output[2] -> out;", "stream", "channel 2 of a Frame<2>"),
+            ("dsp::a.output -> out;", "stream", "a path is only valid as a function name"),
+            ("Frame(a.output) -> out;", "stream: Frame<2>", "Frame(..) takes 2 to 4 channels"),
+            ("Frame(s.output, a.output) -> out;", "stream: Frame<2>", "Frame(..) takes f32 channels"),
+        ]:
+            with pytest.raises(oscen_amd.OscenError) as ei:
+                lower(conn, out)
+            assert msg in str(ei.value), (conn, str(ei.value))
+        for bad in ("", "1x", "a::", "Frame", "x::Frame"):
+            with pytest.raises(oscen_amd.OscenError):
+                oscen_amd.register_function(bad, ["x"], "return x;")
+        with pytest.raises(oscen_amd.OscenError):
+            oscen_amd.register_function("f", [("x", 9)], "return x;")
+    finally:
+        oscen_amd.unregister_node("DxConst::new")
+        oscen_amd.unregister_node("DxStereo::new")
+        oscen_amd.unregister_function("dsp::halve")
+        oscen_amd.unregister_function("swap")
+    with pytest.raises(oscen_amd.OscenError):
+        oscen_amd.unregister_function("swap")
