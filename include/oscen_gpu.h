@@ -43,6 +43,8 @@ extern "C" {
 
 /* input flags */
 #define OG_IN_PER_VOICE 1u /* value fed per voice (MidiVoiceHandler.frequency, oscen-lib/src/midi.rs:49) */
+#define OG_IN_CHANNELS(n) ((uint32_t)(n) << 8) /* stream inputs: `input stream dry: Frame<n>;` (n = 2..4;
+                                                * oscen-lib/tests/stereo_render.rs:46-47) */
 
 typedef struct og_graph_desc og_graph_desc; /* a `graph! { ... }` body, builder form */
 typedef struct og_engine og_engine;         /* N voices of one voice graph + the mix bus */
@@ -269,11 +271,13 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
 
 /* Stream inputs of the graph (`pub <stream_in>_block: [f32; 512]`, codegen/mod.rs:1196): the caller fills the block
  * before process_block; every voice of the bank reads the same samples.  The buffer keeps its contents between blocks,
- * like the generated field. */
+ * like the generated field.  A Frame<N> input (`[Frame<N>; 512]`) takes n FRAMES of N interleaved samples. */
 int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint32_t n);
 uint32_t og_num_stream_inputs(const og_engine* e); /* BlockRender::NUM_STREAM_INPUTS */
+uint32_t og_stream_input_channels(const og_engine* e, uint32_t input); /* 1 = f32, N = Frame<N>; 0: not a stream input */
 /* BlockRender::render(inputs, tail)  oscen-lib/src/graph/offline.rs:46-90: one buffer per stream input (declaration
- * order), total = max input length + tail frames, shorter inputs padded with silence, chunks of 512 frames.
+ * order; lengths in FRAMES, a Frame<N> input holds N interleaved samples per frame -- `render_mono(&[Frame<2>], tail)`,
+ * oscen-lib/tests/stereo_render.rs:96-99), total = max input length + tail frames, shorter inputs padded with silence, chunks of 512 frames.
  * out_bus[total * channels] (host); *frames_rendered = total (call with out_bus == NULL and total known = 0 is a no-op). */
 int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs,
                      uint64_t tail, float* out_bus, uint64_t* frames_rendered);

@@ -196,7 +196,16 @@ void parse_input(Lexer& lx, GraphDesc& g)
     GInput in;
     in.name = name;
     in.kind = kind_of(kind, lx.line);
-    if (lx.eat(':')) (void)lx.until("=;"); // type annotation
+    if (lx.eat(':')) { // type annotation; `input stream dry: Frame<2>;` makes a stream input N channels wide
+        std::string ty = lx.until("=;");
+        ty.erase(std::remove_if(ty.begin(), ty.end(), [](char ch) { return isspace((unsigned char)ch); }), ty.end());
+        if (in.kind == Kind::Stream) {
+            if (ty == "Stereo") in.channels = 2;
+            else if (ty == "Quad") in.channels = 4;
+            else if (ty.rfind("Frame<", 0) == 0) in.channels = atoi(ty.c_str() + 6);
+            if (in.channels < 1 || in.channels > 4) dfail("input '" + name + "': a stream input is an f32 or a Frame<2..4>", lx.line);
+        }
+    }
     if (lx.eat('=')) {
         in.def = lx.number();
         if (lx.peek() == '[') {
@@ -480,6 +489,7 @@ std::string to_dsl(const GraphDesc& g)
     o << "name: " << g.name << ";\n\n";
     for (const auto& in : g.inputs) {
         o << "input " << in.name << ": " << kn[(int)in.kind];
+        if (in.kind == Kind::Stream && in.channels > 1) o << ": Frame<" << in.channels << ">";
         if (in.kind == Kind::Value) {
             o << " = " << num(in.def);
             if (in.ramp_frames) o << " [ramp: " << in.ramp_frames << "]";

@@ -886,7 +886,8 @@ struct og_engine {
             for (size_t i = 0; i < cg->inputs.size(); ++i) {
                 if (cg->inputs[i].ramp_row >= 0) values[i] = ramps[i].current;
                 const int srow = cg->inputs[i].stream_row;
-                if (srow >= 0) memcpy(tab + (size_t)srow * stride + q_frames, stream_blocks[i].data(), (size_t)frames * 4);
+                for (int k = 0; srow >= 0 && k < std::max(1, cg->inputs[i].decl.channels); ++k) // (planar: one row per channel)
+                    memcpy(tab + (size_t)(srow + k) * stride + q_frames, stream_blocks[i].data() + (size_t)k * OG_MAX_BLOCK, (size_t)frames * 4);
             }
         }
         QueuedBlock qb;
@@ -1128,6 +1129,9 @@ int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float def, 
     in.def = def;
     in.ramp_frames = ramp_frames;
     in.per_voice = (flags & OG_IN_PER_VOICE) != 0;
+    const uint32_t ch = (flags >> 8) & 0xFu; // OG_IN_CHANNELS(n): a Frame<n> stream input
+    if (ch > 4 || (ch > 1 && kind != OG_KIND_STREAM)) return set_err(OG_E_INVALID, "OG_IN_CHANNELS: a stream input is an f32 or a Frame<2..4>");
+    in.channels = ch > 1 ? (int)ch : 1;
     g->g.inputs.push_back(in);
     return (int)g->g.inputs.size() - 1;
 }
@@ -1478,7 +1482,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         }
         e->stream_blocks.resize(cg.inputs.size());
         for (size_t i = 0; i < cg.inputs.size(); ++i)
-            if (cg.inputs[i].stream_row >= 0) e->stream_blocks[i].assign(OG_MAX_BLOCK, 0.0f);
+            if (cg.inputs[i].stream_row >= 0) e->stream_blocks[i].assign((size_t)OG_MAX_BLOCK * std::max(1, cg.inputs[i].decl.channels), 0.0f);
         e->upload_initial_state(); // Graph::new(): 44.1 kHz until init()
         *out = e.release();
         return OG_OK;
@@ -1780,19 +1784,28 @@ int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint
     if (!e || (n && !samples)) return set_err(OG_E_INVALID, "null argument");
     if (input >= e->cg->inputs.size() || e->cg->inputs[input].stream_row < 0) return set_err(OG_E_INVALID, "not a stream input");
     if (n > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "a stream block holds at most 512 samples");
-    memcpy(e->stream_blocks[input].data(), samples, (size_t)n * 4);
+    const uint32_t w = (uint32_t)std::max(1, e->cg->inputs[input].decl.channels); // Frame<N>: `samples` holds n frames of N, interleaved
+    float* blk = e->stream_blocks[input].data();
+    for (uint32_t k = 0; k < w; ++k)
+        for (uint32_t j = 0; j < n; ++j) blk[(size_t)k * OG_MAX_BLOCK + j] = samples[(size_t)j * w + k];
     return OG_OK;
 }
 
-uint32_t og_num_stream_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->n_streams : 0; }
+uint32_t og_num_stream_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->n_stream_inputs : 0; }
+
+uint32_t og_stream_input_channels(const og_engine* e, uint32_t input)
+{
+    if (!e || input >= e->cg->inputs.size() || e->cg->inputs[input].stream_row < 0) return 0;
+    return (uint32_t)std::max(1, e->cg->inputs[input].decl.channels);
+}
 
 int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs, uint64_t tail,
                      float* out_bus, uint64_t* frames_rendered)
 {
     if (!e || (n_inputs && (!inputs || !input_lens))) return set_err(OG_E_INVALID, "null argument");
     if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
-    if (n_inputs != (uint32_t)e->cg->n_streams) // render(): assert_eq!(inputs.len(), NUM_STREAM_INPUTS)
-        return set_err(OG_E_INVALID, "render: expected " + std::to_string(e->cg->n_streams) + " input streams, got " + std::to_string(n_inputs));
+    if (n_inputs != (uint32_t)e->cg->n_stream_inputs) // render(): assert_eq!(inputs.len(), NUM_STREAM_INPUTS)
+        return set_err(OG_E_INVALID, "render: expected " + std::to_string(e->cg->n_stream_inputs) + " input streams, got " + std::to_string(n_inputs));
     uint64_t in_len = 0;
     for (uint32_t i = 0; i < n_inputs; ++i) in_len = std::max(in_len, input_lens[i]);
     const uint64_t total = in_len + tail;
@@ -1821,7 +1834,10 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
                 const uint32_t n = (uint32_t)std::min<uint64_t>(OG_MAX_BLOCK, total - pos);
                 for (uint32_t k = 0; k < n_inputs; ++k) {
                     float* blk = e->stream_blocks[sidx[k]].data();
-                    for (uint32_t j = 0; j < n; ++j) blk[j] = (pos + j < input_lens[k]) ? inputs[k][pos + j] : 0.0f; // silence past the end
+                    const uint32_t w = (uint32_t)std::max(1, e->cg->inputs[sidx[k]].decl.channels); // (lengths count FRAMES)
+                    for (uint32_t c = 0; c < w; ++c)
+                        for (uint32_t j = 0; j < n; ++j) // silence past the end
+                            blk[(size_t)c * OG_MAX_BLOCK + j] = (pos + j < input_lens[k]) ? inputs[k][(pos + j) * w + c] : 0.0f;
                 }
                 e->process_async(n, d_all + pos * ch);
             }

@@ -542,9 +542,16 @@ struct Codegen {
         const InputInfo& in = out.inputs[idx];
         Val v;
         if (in.decl.kind == Kind::Stream) { // `<stream_in>_block[f]`: the same sample for every voice of the bank
-            v.e = "ST(" + std::to_string(in.stream_row) + ")";
-            v.rate = Rate::UFrame;
-            v.stream = true;
+            auto row = [&](int r) {
+                Val c;
+                c.e = "ST(" + std::to_string(r) + ")";
+                c.rate = Rate::UFrame;
+                c.stream = true;
+                return c;
+            };
+            if (in.decl.channels <= 1) return row(in.stream_row);
+            v.rate = Rate::Vary; // (a frame: its channels carry the rates)
+            for (int k = 0; k < in.decl.channels; ++k) v.ch.push_back(row(in.stream_row + k));
             return v;
         }
         if (in.decl.kind != Kind::Value) fail("input '" + in.decl.name + "' is not a value input");
@@ -1986,6 +1993,17 @@ GraphDesc expand_arrays(const GraphDesc& g)
             }
             if (n_idents != 1 || !plain)
                 fail("array source inside a compound expression needs an array destination ('" + e.src + " -> " + e.dst + "')");
+            if (!e.policy.empty()) {
+                // across a rate boundary the elements are summed at the SOURCE rate, in index order, and the sum goes
+                // through one resampler (`[sinc] emitters.output -> out` with `emitters = [..; 4] * 2`:
+                // codegen/emit_edge.rs:208-236 `__sum`, captured per inner tick, emit_frame.rs:428-458)
+                GEdge x = e;
+                x.src.clear();
+                for (uint32_t i = 0; i < src_n; ++i) x.src += (i ? " + " : "") + with_index(src, i, false);
+                x.dst = unscan(dst);
+                o.edges.push_back(x);
+                continue;
+            }
             for (uint32_t i = 0; i < src_n; ++i) { // several sources into one input = their sum in edge (= index) order
                 GEdge x = e;
                 x.src = with_index(src, i, false);
@@ -2487,7 +2505,8 @@ void register_user_node(const UserNodeType& t)
 {
     if (t.type.empty()) fail("node type needs a name");
     if (registry().count(t.type)) fail("'" + t.type + "' is a built-in node type");
-    if (t.outputs.empty() && t.ev_outputs.empty()) fail("node type '" + t.type + "' needs at least one output");
+    // (no outputs at all = a sink, `StereoSink { #[input(stream)] input, last }` of the reference's fixtures: its effect
+    // is the state it keeps; ir/passes/dead_nodes.rs keeps such nodes when the graph declares no outputs)
     std::set<std::string> names;
     auto uniq = [&](const std::string& n) {
         if (!is_ident(n)) fail("node type '" + t.type + "': '" + n + "' is not an identifier");
@@ -2588,7 +2607,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (in.ramp_frames) info.ramp_row = out.n_ramps++;
             }
         } else { // stream input: one per-frame row of the block table, broadcast to every voice
-            info.stream_row = -2 - out.n_streams++; // final row = n_ramps + k, fixed below once n_ramps is known
+            info.stream_row = -2 - out.n_streams; // final row = n_ramps + k, fixed below once n_ramps is known
+            out.n_streams += std::max(1, in.channels);
+            out.n_stream_inputs += 1;
         }
         out.inputs.push_back(info);
     }

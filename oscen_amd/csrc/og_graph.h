@@ -48,6 +48,7 @@ struct GInput {
     float def = 0.0f;
     uint32_t ramp_frames = 0; // [ramp: N] (value inputs only)
     bool per_voice = false;   // value input fed per voice (MidiVoiceHandler.frequency)
+    int channels = 1;         // stream inputs: `input stream dry: Frame<2>;` (oscen-lib/tests/stereo_render.rs:46-47) = N rows
 };
 struct GOutput {
     std::string name;
@@ -146,7 +147,9 @@ struct CompiledGraph {
     std::vector<UniformProg> uprogs;
     int n_slots = 0;
     int n_ramps = 0;
-    int n_streams = 0; // graph-level stream inputs (`<stream_in>_block`): rows n_ramps.. of the per-frame table
+    int n_streams = 0; // rows n_ramps.. of the per-frame table taken by graph-level stream inputs (`<stream_in>_block`;
+                       // a Frame<N> input takes N consecutive rows, one per channel)
+    int n_stream_inputs = 0; // the stream inputs themselves (BlockRender::NUM_STREAM_INPUTS)
     int n_event_inputs = 0;
     std::vector<std::string> event_outputs; // the graph's event outputs that a node feeds, in declaration order (og_read_output_events)
     bool has_node_event_outputs = false;    // some live node has an #[output(event)] field (drops are counted on the device)
