@@ -241,3 +241,119 @@ def test_frame_literal_constructor_argument():
         assert np.allclose(bus[:, 0], n * f32(0.3), rtol=1e-6) and np.allclose(bus[:, 1], n * f32(-0.7), rtol=1e-6)
     finally:
         oscen_amd.unregister_node("R3ConstSrc::new")
+
+
+def test_oversampled_array_fans_into_an_outer_output_through_one_resampler():
+    """`emitters = [..; 3] * 2; [sinc] emitters.output -> out` (oscen-lib/tests/multirate_array_fanout.rs:106-115): the
+    elements are summed at the inner rate in index order and the sum goes through ONE downsampler
+    (codegen/emit_edge.rs:208-236, emit_frame.rs:428-458)"""
+    lib = ol.load()
+    g = oscen_amd.Graph(dsl="""
+        name: FanInOs;
+        input frequency: value = 220.0;
+        output out: stream;
+        nodes { oscs = [PolyBlepOscillator::saw(220.0, 0.3); 3] * 2; }
+        connections {
+            frequency -> oscs[0].frequency;
+            frequency * 1.5 -> oscs[1].frequency;
+            frequency * 2.01 -> oscs[2].frequency;
+            [sinc] oscs.output -> out;
+        }
+    """, per_voice=["frequency"])
+    n, frames, blocks = 5, 160, 3
+    freqs = np.array([55.0, 220.0, 441.0, 1234.5, 3000.0], dtype=f32)
+    eng = oscen_amd.Engine(g, n, sample_rate=SR)
+    eng.set_voice_values("frequency", freqs)
+    assert eng.latency_samples == 5
+    got = render_taps(eng, n, frames, blocks)
+    worst = 0.0
+    for v in range(n):
+        oscs = [polyblep(lib, f32(freqs[v]) * f32(k), 0.3, ol.PB_SAW, SR * 2) if k != 1.0 else polyblep(lib, freqs[v], 0.3, ol.PB_SAW, SR * 2)
+                for k in (1.0, 1.5, 2.01)]
+        dn = ol.SincDown()
+        lib.oo_sinc_down_new(C.byref(dn), 2)
+        ref = np.zeros(frames * blocks, dtype=f32)
+        buf = np.zeros(2, dtype=f32)
+        for i in range(len(ref)):
+            for j in range(2):
+                s = f32(0.0)
+                for o in oscs:
+                    lib.oo_polyblep_process(C.byref(o))
+                    s = f32(s + f32(o.output))
+                buf[j] = s
+            ref[i] = lib.oo_sinc_down_process(C.byref(dn), ol.fptr(buf))
+        assert np.abs(ref).max() > 0.2
+        worst = max(worst, rel_err(got[v], ref))
+    assert worst <= 1e-5, worst
+
+
+def test_frame_stream_input_offline_render_equals_the_block_path():
+    """`input stream dry: Frame<2>; output stream wet: Frame<2>; dry -> g.inp; g.out -> wet` rendered with
+    BlockRender::render over a Frame<2> buffer (oscen-lib/tests/stereo_render.rs:43-112): frame for frame the input
+    times the gain per channel, and the same as feeding `dry_block` block by block"""
+    oscen_amd.register_node(
+        "R3StereoGain::new", inputs=[("inp", "stream", 0.0, -1, 2)], outputs=[("out", 2)], n_ctor_args=1,
+        state=[("gain", "f32", 1.0, 0)], process="    out = inp * gain;\n")
+    try:
+        g = oscen_amd.Graph(dsl="""
+            name: StereoGainGraph;
+            input stream dry: Frame<2>;
+            output stream wet: Frame<2>;
+            nodes { g = R3StereoGain::new(0.5); }
+            connections { dry -> g.inp; g.out -> wet; }
+        """)
+        assert "input dry: stream: Frame<2>;" in g.to_dsl()
+        rng = np.random.default_rng(12)
+        x = rng.uniform(-1.0, 1.0, size=(2000, 2)).astype(f32)  # distinct per-channel input
+        n = 3
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        assert eng.lib.og_num_stream_inputs(eng.h) == 1 and eng.lib.og_stream_input_channels(eng.h, eng.index("dry")) == 2
+        got = eng.render_inputs([x], tail=40)
+        assert got.shape == (2040, 2)
+        want = np.concatenate([x * f32(0.5) * f32(n), np.zeros((40, 2), dtype=f32)])
+        assert np.allclose(got, want, rtol=0, atol=1e-6)
+        eng2 = oscen_amd.Engine(g, n, sample_rate=SR)
+        parts = []
+        for pos in range(0, 2000, 250):
+            eng2.set_stream_block("dry", x[pos:pos + 250])
+            parts.append(eng2.process_block(250))
+        assert np.array_equal(np.concatenate(parts), got[:2000])
+        with pytest.raises(ValueError):
+            eng2.set_stream_block("dry", x[:10, 0])
+    finally:
+        oscen_amd.unregister_node("R3StereoGain::new")
+
+
+def test_frame_stream_input_across_a_rate_boundary():
+    """a Frame<2> stream input feeding an oversampled node: one resampler per channel, like any Frame<2> edge"""
+    lib = ol.load()
+    oscen_amd.register_node(
+        "R3StereoClip2::new", inputs=[("inp", "stream", 0.0, -1, 2)], outputs=[("out", 2)],
+        process="    out.v[0] = og::clampf(inp.v[0] * 3.0f, -0.4f, 0.4f);\n    out.v[1] = og::clampf(inp.v[1] * 3.0f, -0.4f, 0.4f);\n")
+    try:
+        g = oscen_amd.Graph(dsl="""
+            name: StereoOs;
+            input stream dry: Frame<2>;
+            output stream wet: Frame<2>;
+            nodes { c = R3StereoClip2::new() * 2; }
+            connections { [linear] dry -> c.inp; [sinc] c.out -> wet; }
+        """)
+        rng = np.random.default_rng(3)
+        x = (rng.uniform(-1.0, 1.0, size=(700, 2)) * np.array([0.3, 0.2])).astype(f32)
+        eng = oscen_amd.Engine(g, 1, sample_rate=SR)
+        got = eng.render_inputs([x])
+        ref = np.zeros_like(got)
+        for c in range(2):
+            up, dn = ol.LinearUp(), ol.SincDown()
+            lib.oo_linear_up_new(C.byref(up), 2)
+            lib.oo_sinc_down_new(C.byref(dn), 2)
+            buf, cl = np.zeros(2, dtype=f32), np.zeros(2, dtype=f32)
+            for i in range(len(x)):
+                lib.oo_linear_up_process(C.byref(up), float(x[i, c]), ol.fptr(buf))
+                for j in range(2):
+                    cl[j] = min(max(f32(buf[j] * f32(3.0)), f32(-0.4)), f32(0.4))
+                ref[i, c] = lib.oo_sinc_down_process(C.byref(dn), ol.fptr(cl))
+        assert np.abs(ref).max() > 0.1
+        assert rel_err(got, ref) <= 1e-5, rel_err(got, ref)
+    finally:
+        oscen_amd.unregister_node("R3StereoClip2::new")
