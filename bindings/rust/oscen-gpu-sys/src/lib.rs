@@ -128,3 +128,18 @@ extern "C" {
     pub fn og_blocking_stats(e: *const og_engine, calls: *mut u64, marker_timeouts: *mut u64) -> c_int;
     pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
 }
+
+// ---- round 3 (late): named functions on a connection, Frame<N> stream inputs ----
+#[repr(C)] pub struct og_function_type {
+    pub name: *const c_char, pub n_args: u32, pub arg_names: *const *const c_char, pub arg_channels: *const u32,
+    pub result_channels: u32, pub source: *const c_char,
+}
+extern "C" {
+    pub fn og_register_function(f: *const og_function_type) -> c_int;
+    pub fn og_unregister_function(name: *const c_char) -> c_int;
+    pub fn og_stream_input_channels(e: *const og_engine, input: u32) -> u32;
+}
+extern "C" {
+    pub fn og_state_field_index(e: *const og_engine, path: *const c_char) -> c_int;
+    pub fn og_read_state_field(e: *mut og_engine, path: *const c_char, first_voice: u32, n: u32, out: *mut c_void) -> c_int;
+}

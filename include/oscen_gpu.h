@@ -282,6 +282,16 @@ uint32_t og_stream_input_channels(const og_engine* e, uint32_t input); /* 1 = f3
 int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs,
                      uint64_t tail, float* out_bus, uint64_t* frames_rendered);
 
+/* `graph.<node>.<field>`: the fields of the generated struct's nodes are public in the reference and its fixtures read
+ * them after process() (`graph.sinks[i].last`, oscen-lib/tests/connection_expr_functions.rs:300-330;
+ * `graph.inner.dummy.val`, examples/src/bin/nested_static_graph_test.rs:71).  A node's persistent fields (the `state`
+ * of a registered node type, the built-in nodes' filter / envelope / phase words) are planes of the state image:
+ * path = "node.field", "array[i].field" or "nested.node.field"; out[n] receives the field of voices first_voice.. as
+ * 4-byte words (f32 fields as floats, u32 fields as integers).  Flushes queued blocks first.  The index call returns
+ * the plane number or -1. */
+int og_state_field_index(const og_engine* e, const char* path);
+int og_read_state_field(og_engine* e, const char* path, uint32_t first_voice, uint32_t n, void* out);
+
 /* Introspection of `graph.voices[i].<out>` (tests poke node fields in the
  * reference): record the per-voice output of the listed voices during the
  * following blocks.  og_read_voice_taps copies the last block: out[n*frames]. */

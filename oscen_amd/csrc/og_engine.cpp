@@ -1853,6 +1853,46 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
     });
 }
 
+// `graph.<node>.<field>`: the generated struct's node fields are public in the reference and its tests read them
+// (`graph.sinks[i].last`, `graph.inner.dummy.val`).  Here a node's persistent fields are planes of the state image.
+static int find_state_word(const og_engine* e, const char* path)
+{
+    // the reference's spelling -> the names of the flattened graph: `sinks[1].last` -> `sinks__1.last`,
+    // `inner.dummy.val` -> `inner_dummy.val` (the last dot separates node and field)
+    std::string p;
+    for (const char* c = path; *c; ++c) {
+        if (*c == '[') p += "__";
+        else if (*c != ']' && !isspace((unsigned char)*c)) p.push_back(*c);
+    }
+    const size_t last = p.rfind('.');
+    for (size_t k = 0; k < p.size(); ++k)
+        if (p[k] == '.' && k != last) p[k] = '_';
+    for (size_t w = 0; w < e->cg->state.size(); ++w)
+        if (e->cg->state[w].name == p) return (int)w;
+    return -1;
+}
+
+int og_state_field_index(const og_engine* e, const char* path)
+{
+    if (!e || !path) return -1;
+    return find_state_word(e, path);
+}
+
+int og_read_state_field(og_engine* e, const char* path, uint32_t first_voice, uint32_t n, void* out)
+{
+    if (!e || !path || (n && !out)) return set_err(OG_E_INVALID, "null argument");
+    const int w = find_state_word(e, path);
+    if (w < 0) return set_err(OG_E_INVALID, std::string("no state field '") + path + "'");
+    if ((uint64_t)first_voice + n > e->V) return set_err(OG_E_INVALID, "voice range out of bounds");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        e->flush_bus();
+        if (n) HIPCK(hipMemcpyAsync(out, e->d_state + (size_t)w * e->V + first_voice, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return OG_OK;
+    });
+}
+
 int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
 {
     if (!e || (n && !voices)) return set_err(OG_E_INVALID, "null argument");

@@ -1870,12 +1870,20 @@ std::vector<Tok> scan(const std::string& s)
             }
             if (j < s.size() && s[j] == '.' && j + 1 < s.size() && (isalpha((unsigned char)s[j + 1]) || s[j + 1] == '_')) {
                 size_t k = j + 1;
-                while (k < s.size() && (isalnum((unsigned char)s[k]) || s[k] == '_')) t.port.push_back(s[k++]);
-                i = k;
-                if (i + 1 < s.size() && s[i] == '(' && s[i + 1] == ')') {
-                    t.call = true;
-                    i += 2;
-                }
+                std::string port;
+                while (k < s.size() && (isalnum((unsigned char)s[k]) || s[k] == '_')) port.push_back(s[k++]);
+                size_t q = k;
+                while (q < s.size() && isspace((unsigned char)s[q])) ++q;
+                const bool paren = q < s.size() && s[q] == '(';
+                const bool accessor = paren && q + 1 < s.size() && s[q + 1] == ')' && !Parser::is_method(port); // legacy `osc.output()`
+                if (!paren || accessor) {
+                    t.port = port;
+                    i = k;
+                    if (accessor) {
+                        t.call = true;
+                        i = q + 2;
+                    }
+                } // else `input.abs()`: a method on a bare identifier -- the `.abs(` stays text
             }
             out.push_back(t);
         } else if (isdigit((unsigned char)c) || (c == '.' && i + 1 < s.size() && isdigit((unsigned char)s[i + 1]))) {

@@ -191,3 +191,35 @@ def test_method_on_a_block_uniform_value_is_evaluated_on_the_host():
         outs.append(eng.read_voice_taps(frames))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[3]) and np.array_equal(outs[4], outs[5])
     assert np.abs(outs[0]).max() > 0.05 and not np.array_equal(outs[0], outs[2])
+
+
+def test_output_less_fixture_graphs_read_through_node_fields(registered):
+    """the reference's sink fixtures declare no graph output and are read through the nodes' public fields
+    (`graph.sinks[i].last`, connection_expr_functions.rs:232-330; ir/passes/dead_nodes.rs:17-19 keeps every node of such a
+    graph): og_read_state_field plays that part"""
+    oscen_amd.register_node("CxLatch::new", inputs=[("input", "stream", 0.0, -1)], outputs=[], state=[("last", "f32", 0.0, -1)],
+                            process="    last = input;\n")
+    oscen_amd.register_node("CxLatch2::new", inputs=[("input", "stream", 0.0, -1, 2)], outputs=[],
+                            state=[("last_l", "f32", 0.0, -1), ("last_r", "f32", 0.0, -1)], process="    last_l = input.v[0];\n    last_r = input.v[1];\n")
+    try:
+        n = 70
+        x = np.linspace(-1.0, 1.0, n).astype(f32)
+        g = oscen_amd.Graph(dsl="""name: CxNoOut; input x: value = 0.0;
+            nodes { s = CxStereoConst::new(0.6, 0.1); sinks = [CxLatch2::new(); 3]; mono = [CxLatch::new(); 2]; one = CxLatch::new(); }
+            connections { decode_ms(s.output) -> sinks.input; half(x) -> mono.input; x.abs() * 3.0 -> one.input; }""", per_voice=["x"])
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        eng.set_voice_values("x", x)
+        bus = eng.process_block(32)
+        assert not bus.any()  # no graph output: a silent bus
+        for i in range(3):
+            assert np.allclose(eng.read_state_field("sinks[%d].last_l" % i), 0.5, atol=1e-6)
+            assert np.allclose(eng.read_state_field("sinks[%d].last_r" % i), 0.7, atol=1e-6)
+        for i in range(2):
+            assert np.array_equal(eng.read_state_field("mono[%d].last" % i), x * f32(0.5))
+        assert np.array_equal(eng.read_state_field("one.last", first=10, n=20), (np.abs(x) * f32(3.0))[10:30])
+        assert eng.lib.og_state_field_index(eng.h, b"one.last") >= 0 and eng.lib.og_state_field_index(eng.h, b"one.nothing") == -1
+        with pytest.raises(oscen_amd.OscenError):
+            eng.read_state_field("nobody.last")
+    finally:
+        oscen_amd.unregister_node("CxLatch::new")
+        oscen_amd.unregister_node("CxLatch2::new")
