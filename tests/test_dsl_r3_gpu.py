@@ -357,3 +357,95 @@ def test_frame_stream_input_across_a_rate_boundary():
         assert rel_err(got, ref) <= 1e-5, rel_err(got, ref)
     finally:
         oscen_amd.unregister_node("R3StereoClip2::new")
+
+
+def test_value_event_and_stream_fan_out_into_oversampled_arrays():
+    """oscen-lib/tests/multirate_array_fanout.rs restated with plug-in nodes: a value broadcast into an oversampled array
+    (:43-77), a parallel `[latch]` edge array -> oversampled array with independent per-element values (:166-207), a
+    gate event broadcast into an oversampled array (:245-277), and the voice-shaped array at 2x with one endpoint of every
+    kind, summed through `[sinc]` into the outer output (:323-392)"""
+    lib = ol.load()
+    oscen_amd.register_node("R3ValueLatch::new", inputs=[("input", "value", 0.0, -1)], outputs=["output"],
+                            state=[("seen", "f32", 0.0, -1), ("ticks", "u32", 0, -1)],
+                            process="    output = input;\n    seen = input;\n    ticks += 1u;\n")
+    oscen_amd.register_node("R3ValueHolder::new", inputs=[("val", "value", 0.0, 0)], outputs=["output"], n_ctor_args=1,
+                            process="    output = val;\n")
+    oscen_amd.register_node("R3GateCount::new", inputs=[("gate", "event", 0.0, -1)], outputs=["output"],
+                            state=[("gates", "f32", 0.0, -1), ("last", "f32", -1.0, -1)],
+                            handlers={"gate": "    gates += 1.0f;\n    last = value;\n"}, process="    output = gates;\n")
+    oscen_amd.register_node("R3MockVoice::new", inputs=[("freq", "value", 0.0, -1), ("gate", "event", 0.0, -1), ("mod_in", "stream", 0.0, -1)],
+                            outputs=["audio_out"], state=[("gate_seen", "f32", 0.0, -1)],
+                            handlers={"gate": "    gate_seen = 1.0f;\n"},
+                            process="    audio_out = gate_seen != 0.0f ? freq * 0.001f + mod_in : 0.0f;\n")
+    try:
+        n = 6
+        # value broadcast + parallel [latch] edges into 2x arrays
+        g = oscen_amd.Graph(dsl="""name: R3Fan; input src: value = 0.0;
+            nodes { latches = [R3ValueLatch::new(); 4] * 2; h0 = R3ValueHolder::new(0.1); h1 = R3ValueHolder::new(0.3);
+                    h2 = R3ValueHolder::new(0.5); h3 = R3ValueHolder::new(0.7); par = [R3ValueLatch::new(); 4] * 2; }
+            connections { src -> latches.input; [latch] h0.output -> par[0].input; [latch] h1.output -> par[1].input;
+                          [latch] h2.output -> par[2].input; [latch] h3.output -> par[3].input; }""", per_voice=["src"])
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        src = np.linspace(0.2, 0.7, n).astype(f32)
+        eng.set_voice_values("src", src)
+        eng.process_block(8)
+        for i, want in enumerate((0.1, 0.3, 0.5, 0.7)):
+            assert np.array_equal(eng.read_state_field("latches[%d].seen" % i), src)
+            assert np.allclose(eng.read_state_field("par[%d].seen" % i), want, atol=1e-7)          # independent per element
+            assert np.array_equal(eng.read_state_field("par[%d].ticks" % i, dtype=np.uint32), np.full(n, 16, dtype=np.uint32))  # 2 ticks per outer frame
+        # a gate event broadcast into an oversampled array: every element's handler runs once per event
+        g2 = oscen_amd.Graph(dsl="""name: R3EvFan; input gate: event; output out: stream;
+            nodes { caps = [R3GateCount::new(); 4] * 2; }
+            connections { gate -> caps.gate; [linear] caps.output -> out; }""")
+        eng2 = oscen_amd.Engine(g2, n, sample_rate=SR)
+        eng2.push_voice_event("gate", 2, 1, 0.5)
+        eng2.push_voice_event("gate", 2, 9, 0.75)
+        eng2.push_voice_event("gate", 4, 63, 1.0)
+        eng2.set_voice_taps(list(range(n)))
+        eng2.process_block(64)
+        taps = eng2.read_voice_taps(64)
+        for i in range(4):
+            assert np.array_equal(eng2.read_state_field("caps[%d].gates" % i), np.array([0, 0, 2, 0, 1, 0], dtype=f32))
+            assert np.array_equal(eng2.read_state_field("caps[%d].last" % i), np.array([-1, -1, 0.75, -1, 1.0, -1], dtype=f32))
+        # the sum of the four counters leaves through ONE linear downsampler: frames 1..8 of voice 2 see 4, from 9 on 8
+        # (oracle: oo_linear_down_process averages the two inner ticks of an outer frame, which are equal here)
+        assert np.array_equal(taps[2], np.array([0.0] + [4.0] * 8 + [8.0] * 55, dtype=f32))
+        assert np.array_equal(taps[4, :63], np.zeros(63, dtype=f32)) and taps[4, 63] == 4.0
+        # the voice shape at 2x: value + event + stream in, stream out through [sinc]
+        g3 = oscen_amd.Graph(dsl="""name: VoiceShapeArrayAt2x; input frequency: value = 440.0; input mod_signal: stream; input gate: event;
+            output audio_out: stream;
+            nodes { voices = [R3MockVoice::new(); 8] * 2; }
+            connections { frequency -> voices.freq; mod_signal -> voices.mod_in; gate -> voices.gate; [sinc] voices.audio_out -> audio_out; }""",
+                             per_voice=["frequency"])
+        eng3 = oscen_amd.Engine(g3, n, sample_rate=SR)
+        freqs = np.array([110.0, 220.0, 330.0, 440.0, 550.0, 660.0], dtype=f32)
+        eng3.set_voice_values("frequency", freqs)
+        eng3.set_stream_block("mod_signal", np.full(256, 0.1, dtype=f32))
+        for v in range(n):
+            eng3.push_voice_event("gate", v, 3 * v, 1.0)
+        eng3.set_voice_taps(list(range(n)))
+        eng3.process_block(256)
+        got = eng3.read_voice_taps(256)
+        for v in range(n):
+            dn = ol.SincDown()
+            lib.oo_sinc_down_new(C.byref(dn), 2)
+            # mod_signal crosses outer -> inner by the DEFAULT stream policy = sinc (codegen/helpers.rs:48-59); audio_out
+            # comes back through the explicit sinc
+            lu = ol.SincUp()
+            lib.oo_sinc_up_new(C.byref(lu), 2)
+            ref = np.zeros(256, dtype=f32)
+            buf, acc = np.zeros(2, dtype=f32), np.zeros(2, dtype=f32)
+            for i in range(256):
+                lib.oo_sinc_up_process(C.byref(lu), 0.1, ol.fptr(buf))
+                for j in range(2):
+                    one = f32(f32(freqs[v] * f32(0.001)) + buf[j]) if i >= 3 * v else f32(0.0)
+                    s = f32(0.0)
+                    for _ in range(8):
+                        s = f32(s + one)
+                    acc[j] = s
+                ref[i] = lib.oo_sinc_down_process(C.byref(dn), ol.fptr(acc))
+            assert rel_err(got[v], ref) <= 1e-5, (v, rel_err(got[v], ref))
+        assert np.abs(got).max() > 1.0
+    finally:
+        for t in ("R3ValueLatch::new", "R3ValueHolder::new", "R3GateCount::new", "R3MockVoice::new"):
+            oscen_amd.unregister_node(t)
