@@ -143,3 +143,54 @@ extern "C" {
     pub fn og_state_field_index(e: *const og_engine, path: *const c_char) -> c_int;
     pub fn og_read_state_field(e: *mut og_engine, path: *const c_char, first_voice: u32, n: u32, out: *mut c_void) -> c_int;
 }
+extern "C" {
+    pub fn og_cluster_read_output_events(c: *mut og_cluster, buf: *mut og_out_event, cap: u32, n: *mut u32, n_overflowed: *mut u64) -> c_int;
+    pub fn og_cluster_events_dropped(c: *mut og_cluster) -> u64;
+}
+
+// ---- the rest of include/oscen_gpu.h: event outputs of the graph, taps, introspection, statistics ----
+#[repr(C)] #[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct og_out_event { pub voice: u32, pub output: u32, pub frame: u64, pub value: c_float, pub reserved: u32 }
+extern "C" {
+    pub fn og_version() -> *const c_char;
+    pub fn og_num_inputs(e: *const og_engine) -> u32;
+    pub fn og_get_value(e: *const og_engine, input: u32, out: *mut c_float) -> c_int;
+    pub fn og_flush(e: *mut og_engine) -> c_int;
+    pub fn og_set_bus_batching(e: *mut og_engine, blocks: u32) -> c_int;
+    pub fn og_frames_processed(e: *const og_engine) -> u64;
+    pub fn og_num_event_outputs(e: *const og_engine) -> u32;
+    pub fn og_event_output_index(e: *const og_engine, name: *const c_char) -> c_int;
+    pub fn og_read_output_events(e: *mut og_engine, buf: *mut og_out_event, cap: u32, n: *mut u32, n_overflowed: *mut u64) -> c_int;
+    pub fn og_output_channel(e: *const og_engine, name: *const c_char, offset: *mut u32, width: *mut u32) -> c_int;
+    pub fn og_events_dropped(e: *const og_engine) -> u64;
+    pub fn og_event_stats(e: *const og_engine, full_rebuilds: *mut u64, incremental_updates: *mut u64, resident_events: *mut u64) -> c_int;
+    pub fn og_set_voice_taps(e: *mut og_engine, voices: *const u32, n: u32) -> c_int;
+    pub fn og_read_voice_taps(e: *mut og_engine, out: *mut c_float, n: u32, frames: u32) -> c_int;
+    pub fn og_enable_kernel_timing(e: *mut og_engine, on: c_int) -> c_int;
+    pub fn og_kernel_time_ms(e: *mut og_engine, n_launches: *mut u32) -> f64;
+    pub fn og_kernel_blocks_timed(e: *const og_engine) -> u64;
+    pub fn og_kernel_is_jit(e: *const og_engine) -> c_int;
+    pub fn og_kernel_name(e: *const og_engine) -> *const c_char;
+    pub fn og_uses_split_kernel(e: *const og_engine) -> c_int;
+    pub fn og_lanes_per_voice(e: *const og_engine) -> u32;
+    pub fn og_voices_per_wave(e: *const og_engine) -> u32;
+    pub fn og_partial_rows(e: *const og_engine) -> u32;
+    pub fn og_bus_reduce_passes(e: *const og_engine) -> u32;
+    pub fn og_state_words_per_voice(e: *const og_engine) -> u32;
+    pub fn og_state_words_written_per_voice(e: *const og_engine) -> u32;
+    pub fn og_graph_kernel_source(g: *const og_graph_desc, buf: *mut c_char, cap: usize) -> i64;
+    pub fn og_graph_jit_check(g: *const og_graph_desc, arch: *const c_char) -> i64;
+    pub fn og_midi_dropped(m: *const og_midi) -> u64;
+    pub fn og_midi_pop_output(m: *mut og_midi, voice: *mut u32, frame: *mut u32, frequency: *mut c_float,
+                              has_frequency: *mut c_int, gate: *mut c_float) -> c_int;
+    pub fn og_midi_voice_state(m: *const og_midi, voice: u32, active: *mut c_int, released: *mut c_int, note: *mut c_int,
+                               age: *mut u32) -> c_int;
+    pub fn og_cluster_num_devices(c: *const og_cluster) -> u32;
+    pub fn og_cluster_num_shards(c: *const og_cluster) -> u32;
+    pub fn og_cluster_num_voices(c: *const og_cluster) -> u64;
+    pub fn og_cluster_rccl_reduces(c: *const og_cluster) -> u64;
+    pub fn og_cluster_shard(c: *mut og_cluster, s: u32, first_voice: *mut u64) -> *mut og_engine;
+    pub fn og_cluster_set_value_immediate(c: *mut og_cluster, input: u32, v: c_float) -> c_int;
+    pub fn og_cluster_schedule_voice_events(c: *mut og_cluster, input: u32, n: u64, voices: *const u64,
+                                            abs_frames: *const u64, values: *const c_float) -> c_int;
+}

@@ -407,6 +407,9 @@ uint32_t og_cluster_num_devices(const og_cluster* c); /* distinct GPUs = ranks o
 uint64_t og_cluster_num_voices(const og_cluster* c);
 uint32_t og_cluster_channels(const og_cluster* c);
 uint64_t og_cluster_rccl_reduces(const og_cluster* c); /* ncclReduce batches issued so far (0 on a one-device cluster) */
+/* event outputs of the graph (og_read_output_events) over all shards: merged into (frame, GLOBAL voice, push order) */
+int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n, uint64_t* n_overflowed);
+uint64_t og_cluster_events_dropped(og_cluster* c); /* og_events_dropped summed over the shards */
 /* the engine of shard s (owned by the cluster) and its first global voice: taps, state snapshots, statistics */
 og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice);
 

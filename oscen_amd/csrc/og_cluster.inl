@@ -521,6 +521,48 @@ og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice)
     return c->shard[s];
 }
 
+// Event outputs of the graph over a cluster: every shard keeps its own log (a voice lives in one shard); the logs are
+// merged into (frame, GLOBAL voice, push order) -- what one engine of that size would hand over.
+int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n_out, uint64_t* n_overflowed)
+{
+    if (!c || (cap && !buf) || !n_out) return set_err(OG_E_INVALID, "null argument");
+    *n_out = 0;
+    if (n_overflowed) *n_overflowed = 0;
+    if (c->total > 0xFFFFFFFFull) return set_err(OG_E_UNSUPPORTED, "event outputs carry 32-bit voice ids");
+    std::vector<og_out_event> all;
+    uint64_t over = 0;
+    for (size_t s = 0; s < c->shard.size(); ++s) {
+        og_engine* e = c->shard[s];
+        if (!e->d_out_ev) continue;
+        std::vector<og_out_event> part(e->out_ev_cap);
+        uint32_t n = 0;
+        uint64_t o = 0;
+        const int rc = og_read_output_events(e, part.data(), (uint32_t)part.size(), &n, &o);
+        if (rc != OG_OK) return rc;
+        over += o;
+        for (uint32_t i = 0; i < n; ++i) {
+            part[i].voice += (uint32_t)c->lo[s];
+            all.push_back(part[i]);
+        }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const og_out_event& a, const og_out_event& b) {
+        if (a.frame != b.frame) return a.frame < b.frame;
+        return a.voice < b.voice; // (a voice's events of one frame stay in push order: each shard's list is sorted)
+    });
+    const size_t give = std::min<size_t>(all.size(), cap);
+    for (size_t i = 0; i < give; ++i) buf[i] = all[i];
+    *n_out = (uint32_t)give;
+    if (n_overflowed) *n_overflowed = over + (all.size() - give);
+    return OG_OK;
+}
+
+uint64_t og_cluster_events_dropped(og_cluster* c)
+{
+    uint64_t d = 0;
+    for (size_t s = 0; c && s < c->shard.size(); ++s) d += og_events_dropped(c->shard[s]);
+    return d;
+}
+
 int og_cluster_input_index(const og_cluster* c, const char* name) { return c ? og_input_index(c->shard[0], name) : set_err(OG_E_INVALID, "null cluster"); }
 
 #define OG_CLUSTER_BROADCAST(call)                   \

@@ -161,9 +161,9 @@ def test_multirate_lowering(lib):
         g.kernel_source()
 
 
-def test_rust_sys_crate_declares_only_header_symbols_with_matching_arity():
+def test_rust_sys_crate_binds_the_whole_header_with_matching_arity():
     """bindings/rust/oscen-gpu-sys (shipped as source: no rustc here) must bind what include/oscen_gpu.h
-    declares -- same names, same number of parameters."""
+    declares -- every function, same names, same number of parameters -- and every struct passed by pointer."""
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -182,6 +182,9 @@ def test_rust_sys_crate_declares_only_header_symbols_with_matching_arity():
     for name, n in bound.items():
         assert name in decl, name + " is not declared in include/oscen_gpu.h"
         assert decl[name] == n, (name, decl[name], n)
+    assert sorted(set(decl) - set(bound)) == []  # nothing of the C ABI is left unbound
+    for ty in set(re.findall(r"\}\s*(og_\w+)\s*;", hdr)):  # `typedef struct { .. } og_x;`
+        assert re.search(r"pub struct %s\b" % ty, rs), ty + " has no #[repr(C)] twin"
 
 
 def test_kernel_structure_chunk_variants_and_pipelines():

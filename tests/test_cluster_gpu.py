@@ -218,3 +218,53 @@ def test_eight_shard_cluster_on_one_device_matches_the_single_engine(monkeypatch
     per_block, cl2 = cluster("fm_voice", n, total, block, shards=8, per_block=True)
     assert np.array_equal(per_block, got)           # the two entries agree bit for bit
     assert cl2.rccl_reduces == total // block       # one reduce per block through the real-time entry
+
+
+def test_graph_event_outputs_over_a_cluster_equal_the_single_engine():
+    """og_cluster_read_output_events: every shard logs the events of its own voices; merged they are the single engine's
+    list -- (frame, GLOBAL voice, push order) -- and the dropped pushes add up (og_cluster_events_dropped)"""
+    oscen_amd.register_node(
+        "ClBurst::new", inputs=[("period", "value", 100.0, 0), ("pushes", "value", 1.0, 1)], outputs=["level"], n_ctor_args=2,
+        state=[("count", "u32", 0, -1), ("fired", "f32", 0.0, -1)], event_outputs=["tick"],
+        process="""
+    count += 1u;
+    if ((float)count >= period) {
+        count = 0u;
+        fired += 1.0f;
+        for (int k = 0; k < (int)pushes; ++k) tick.push(fired * 10.0f + (float)k);
+    }
+    level = fired;
+""")
+    try:
+        g = oscen_amd.Graph("cl_bursts")
+        g.input_value("period", 100.0, per_voice=True)
+        g.input_value("pushes", 1.0, per_voice=True)
+        g.output_stream("out")
+        g.output_event("ticks")
+        g.node("b", "ClBurst::new", 100.0, 1.0)
+        g.connect("period", "b.period")
+        g.connect("pushes", "b.pushes")
+        g.connect("b.level", "out")
+        g.connect("b.tick", "ticks")
+        n = 333
+        periods = (37 + (np.arange(n) * 7) % 90).astype(np.float32)
+        pushes = (1 + np.arange(n) % 3).astype(np.float32)  # a third push on one frame is dropped and counted
+        one = oscen_amd.Engine(g, n, sample_rate=SR)
+        cl = oscen_amd.Cluster(g, n, [0, 0, 0], sample_rate=SR)
+        for x in (one, cl):
+            x.set_voice_values("period", periods)
+            x.set_voice_values("pushes", pushes)
+        for frames in (256, 100, 412):
+            a = one.process_block(frames)
+            b = cl.process_block(frames)
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-5)
+        ev1, over1 = one.read_output_events()
+        ev2, over2 = cl.read_output_events()
+        assert over1 == 0 and over2 == 0 and len(ev1) > 1000
+        assert np.array_equal(ev1, ev2)
+        assert ev2["voice"].max() > 300  # global voice ids
+        assert one.events_dropped == cl.events_dropped > 0
+        ev3, _ = cl.read_output_events()
+        assert len(ev3) == 0
+    finally:
+        oscen_amd.unregister_node("ClBurst::new")
