@@ -220,6 +220,34 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device,
 
     deadline_ms = block / 48000.0 * 1e3
     out = []
+    # The loops below time Python calls.  A generation-2 collection of this process's heap (torch is imported: ~10^6
+    # tracked objects) takes 20-35 ms and lands on whichever block allocates the 700th object since the last one: seen
+    # as one 24-34 ms "block" in every few thousand, at any bank size.  That is the harness, not the entry (a C or Rust
+    # host has no collector; scripts/dbg_rt_hiccup.py, which does not import torch, shows none in 40 000 blocks), so the
+    # collector is parked while the latencies are taken.
+    import gc
+
+    gc.collect()
+    t0 = time.perf_counter()
+    gc.collect()  # (a second full collection of the now clean heap: what one generation-2 pass costs this process)
+    gc_ms = (time.perf_counter() - t0) * 1e3
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        rec = _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out)
+        rec["harness"] = {"python_gc": "disabled while latencies are taken", "full_collection_ms": gc_ms,
+                          "tracked_objects": len(gc.get_objects())}
+        return rec
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out):
+    import numpy as np
+
+    import oscen_amd
+
     for V in voices_list:
         eng = oscen_amd.Engine(graph, V, device=device, sample_rate=48000.0)
         plans = oscen_amd.note_plans(V)
