@@ -88,6 +88,7 @@ extern "C" {
     pub process_src: *const c_char, pub event_handler_src: *const *const c_char, pub cost_hint: u32,
     pub event_outputs: *const *const c_char, pub n_event_outputs: u32,
     pub output_channels: *const u32,
+    pub event_queue_capacity: u32,
 }
 extern "C" {
     pub fn og_graph_add_node_array(g: *mut og_graph_desc, name: *const c_char, type_ctor: *const c_char,

@@ -110,8 +110,8 @@ typedef struct {
     uint32_t cost_hint;                    /* estimated VALU instructions per tick; 0 = estimate from the source */
     /* `#[output(event)]` fields (oscen-macros/src/lib.rs:127-133).  process() and the handlers see each as an
      * object with `push(float scalar)` (= EventOutput::try_push of a scalar payload at the current frame; at most
-     * OG_NODE_EVENTS_PER_FRAME = 2 per frame and output, further pushes are dropped like try_push on a full queue --
-     * the reference's queue holds 32 -- and counted in og_events_dropped).  `a.trig -> b.gate` runs b's on_gate for every event a pushed on that frame,
+     * event_queue_capacity -- default OG_NODE_EVENTS_PER_FRAME = 2, at most 32 like the reference's queue -- per frame
+     * and output, further pushes are dropped like try_push on a full queue and counted in og_events_dropped).  `a.trig -> b.gate` runs b's on_gate for every event a pushed on that frame,
      * before b.process(); the outputs are cleared once per frame (clear_event_outputs, lib.rs:237-256). */
     const char* const* event_outputs;
     uint32_t n_event_outputs;
@@ -119,8 +119,14 @@ typedef struct {
                                             * `og::Frame<N>&` in the source.  Frame edges: copy, element-wise fan-in sum,
                                             * `frame + frame`, `frame - frame`, `frame * f32`, `-frame` in compound sources;
                                             * the built-in frame node is TptFilter::<Frame<N>>::new (N = 2, 4). */
+    uint32_t event_queue_capacity;         /* pushes per FRAME each event output of this type holds: 0 = the default
+                                            * OG_NODE_EVENTS_PER_FRAME = 2, up to 32 = the reference's
+                                            * ArrayVec<EventInstance, 32> (graph/types.rs:18).  The queue lives in
+                                            * registers: a graph's kernel is built for the largest capacity among its
+                                            * node types (that many VGPRs per event output). */
 } og_node_type;
 #define OG_NODE_EVENTS_PER_FRAME 2
+#define OG_NODE_EVENTS_MAX 32
 int og_register_node(const og_node_type* t);
 int og_unregister_node(const char* type_ctor);
 

@@ -1203,6 +1203,8 @@ int og_register_node(const og_node_type* t)
         }
         u.process_src = t->process_src;
         u.weight = (int)t->cost_hint;
+        if (t->event_queue_capacity > 32) throw std::runtime_error("event_queue_capacity: at most 32 (the reference's ArrayVec<EventInstance, 32>)");
+        u.event_capacity = (int)t->event_queue_capacity;
         ogc::register_user_node(u);
         return OG_OK;
     });

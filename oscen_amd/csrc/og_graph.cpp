@@ -484,6 +484,7 @@ struct Codegen {
     std::ostringstream& os() { return dom == 0 ? S().s_pre : (dom == 1 ? S().s_inner : S().s_post); }
     std::ostringstream common_decl, common_load; // per-voice value inputs: visible to both stages
     std::map<std::string, std::string> user_fns; // device functions of the user node types this graph uses
+    int ev_capacity = 2; // OG_NODE_EVENTS_PER_FRAME of this graph: the largest event_queue_capacity among its node types
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
     bool any_derive = false;
@@ -1136,9 +1137,10 @@ void NodeCtx::on_event(const std::string& port, const std::function<std::string(
     const std::string q = "n" + std::to_string(src.id) + "_" + nv->second.second;
     cg.os() << "        if (__any((int)(" << q << ".n != 0u))) { // events '" << src.decl->name << "." << nv->second.second
             << "' pushed on this frame\n"
-            << "            #pragma unroll\n"
+            << "            OG_EV_LOOP_PRAGMA\n" // (unrolled up to a capacity of 4, a rolled loop above: the handler is inlined per copy)
             << "            for (uint32_t evk = 0; evk < OG_NODE_EVENTS_PER_FRAME; ++evk)\n"
-            << "                if (evk < " << q << ".n) {\n"
+            << "                if (OG_NODE_EVENTS_PER_FRAME > 4 && !__any((int)(evk < " << q << ".n))) break;\n"
+            << "                else if (evk < " << q << ".n) {\n"
             << "                const float evv = " << q << ".get(evk);\n"
             << gen("evv") << "                }\n"
             << "        }\n";
@@ -1716,6 +1718,7 @@ void emit_user(NodeCtx& x)
     }
     // event outputs: one register queue each, visible to the handlers (kernel event loop) and to the tick
     std::vector<std::string> evo;
+    if (!u.ev_outputs.empty() && u.event_capacity > x.cg.ev_capacity) x.cg.ev_capacity = std::min(32, u.event_capacity);
     for (const std::string& o : u.ev_outputs) {
         evo.push_back(x.p + o);
         x.cg.S().decl << "    og::EvOut " << x.p << o << ";\n";
@@ -3659,7 +3662,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::string user_src;
     for (const auto& kv : cg.user_fns) user_src += kv.second;
     const std::string body_s = user_src + body.str();
-    out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv) + "|rt" + OG_RT_DIGEST);
+    out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv) + (cg.ev_capacity != 2 ? "|evq" + std::to_string(cg.ev_capacity) : std::string()) +
+                     "|rt" + OG_RT_DIGEST);
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
 
@@ -3674,7 +3678,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << "// Node order: ";
     for (auto& nn : out.node_order) src << nn << " ";
     if (out.lpv > 1) src << "\n#define OG_HPL " << out.lane_width << " // harmonics per lane (OGC_HPL)";
+    if (cg.ev_capacity != 2) src << "\n#define OG_NODE_EVENTS_PER_FRAME " << cg.ev_capacity << " // event_queue_capacity of a node type of this graph";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"
+        << "#if OG_NODE_EVENTS_PER_FRAME <= 4\n#define OG_EV_LOOP_PRAGMA _Pragma(\"unroll\")\n#else\n#define OG_EV_LOOP_PRAGMA _Pragma(\"unroll 1\")\n#endif\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
         << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.ramp_stride + f] : og::slot_f(A, (slot)))\n"
         << "#define ST(row) A.ramp_table[(size_t)(row) * A.ramp_stride + f]\n\n"

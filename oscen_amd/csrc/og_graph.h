@@ -199,6 +199,7 @@ struct UserNodeType {
     std::string process_src;
     std::map<std::string, std::string> handlers; // event input -> body of on_<input>()
     int weight = 0; // estimated VALU cost per tick (0 = estimate from the source)
+    int event_capacity = 0; // pushes per frame an event output of this type holds (0 = 2; the reference: 32)
 };
 void register_user_node(const UserNodeType& t); // throws on malformed descriptions or a clash with a built-in type
 bool unregister_user_node(const std::string& type);

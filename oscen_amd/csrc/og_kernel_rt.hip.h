@@ -160,20 +160,31 @@ struct Frame {
 };
 
 // An event output of a node (`#[output(event)]`, EventOutput): the scalar events the node pushed on the current
-// frame.  Lives in registers (no dynamic indexing), cleared at the end of every frame.
+// frame.  Lives in registers -- every access is a compile-time index or a select chain, never a dynamic one -- and is
+// cleared at the end of every frame.  Capacity: 2 unless a node type of the graph asks for more (og_node_type::
+// event_queue_capacity, up to the 32 of the reference's ArrayVec<EventInstance, 32>, graph/types.rs:18): the generator
+// then defines OG_NODE_EVENTS_PER_FRAME in front of this header.
+#ifndef OG_NODE_EVENTS_PER_FRAME
 #define OG_NODE_EVENTS_PER_FRAME 2
+#endif
 struct EvOut {
     uint32_t n = 0u;
     uint32_t lost = 0u; // pushes past the capacity on this frame (reported through OgBlockArgs::ev_lost, og_events_dropped)
-    float v0 = 0.0f, v1 = 0.0f;
+    float v[OG_NODE_EVENTS_PER_FRAME] = {};
     __device__ __forceinline__ void push(float x) // try_push: dropped when the frame's queue is full
     {
-        v1 = (n == 1u) ? x : v1;
-        v0 = (n == 0u) ? x : v0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++k) v[k] = (n == k) ? x : v[k];
         lost += (n >= (uint32_t)OG_NODE_EVENTS_PER_FRAME) ? 1u : 0u;
         n = min(n + 1u, (uint32_t)OG_NODE_EVENTS_PER_FRAME);
     }
-    __device__ __forceinline__ float get(uint32_t k) const { return k == 0u ? v0 : v1; }
+    __device__ __forceinline__ float get(uint32_t k) const
+    {
+        float r = v[0];
+#pragma unroll
+        for (uint32_t j = 1; j < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++j) r = (k == j) ? v[j] : r;
+        return r;
+    }
     __device__ __forceinline__ void clear() { n = 0u; lost = 0u; }
 };
 
@@ -257,12 +268,20 @@ __device__ __forceinline__ void ev_report_lost(const OgBlockArgs& a, const Voice
 __device__ __forceinline__ void ev_out_log(const OgBlockArgs& a, const VoiceCtx& c, uint32_t output, uint32_t f, const EvOut& q)
 {
     if (!(c.valid && c.lead) || !a.out_ev_count) return;
+#if OG_NODE_EVENTS_PER_FRAME <= 4
 #pragma unroll
     for (uint32_t k = 0; k < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++k)
         if (k < q.n) {
+#else
+    for (uint32_t k = 0; k < q.n; ++k) {
+        {
+#endif
             const uint32_t idx = atomicAdd(a.out_ev_count, 1u);
             if (idx < a.out_ev_cap) a.out_ev[idx] = OgOutEvent{c.v, output, a.frame0 + (uint64_t)f, q.get(k), idx};
         }
+#if OG_NODE_EVENTS_PER_FRAME > 4
+    }
+#endif
 }
 
 // pop the current event and arm the next one

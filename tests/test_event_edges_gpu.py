@@ -251,3 +251,80 @@ def test_graph_event_outputs_reach_the_host_in_frame_voice_push_order():
         assert len(ev) == 64 and over > 0
     finally:
         oscen_amd.unregister_node("Burst::new")
+
+
+@pytest.mark.parametrize("capacity", [5, 32])
+def test_event_queue_capacity_up_to_the_reference_32(capacity):
+    """`event_queue_capacity` of a node type (the reference's EventOutput is an ArrayVec<EventInstance, 32>,
+    graph/types.rs:18): a node that pushes k events on one frame keeps min(k, capacity) of them, in push order, both for
+    the graph's event output (host log) and for a node-to-node event edge (the consumer's handler runs once per event);
+    only what exceeds the capacity is dropped, and counted"""
+    oscen_amd.register_node(
+        "QBurst::new", inputs=[("period", "value", 100.0, 0), ("pushes", "value", 1.0, 1)], outputs=["level"], n_ctor_args=2,
+        state=[("count", "u32", 0, -1), ("fired", "f32", 0.0, -1)], event_outputs=["tick"], event_capacity=capacity,
+        process="""
+    count += 1u;
+    if ((float)count >= period) {
+        count = 0u;
+        fired += 1.0f;
+        for (int k = 0; k < (int)pushes; ++k) tick.push(fired * 100.0f + (float)k);
+    }
+    level = fired;
+""")
+    oscen_amd.register_node(
+        "QSum::new", inputs=[("trig", "event", 0.0, -1)], outputs=["total"], state=[("acc", "f32", 0.0, -1), ("calls", "f32", 0.0, -1)],
+        handlers={"trig": "    acc += value;\n    calls += 1.0f;\n"}, process="    total = acc;\n")
+    try:
+        g = oscen_amd.Graph("qbursts")
+        g.input_value("period", 100.0, per_voice=True)
+        g.input_value("pushes", 1.0, per_voice=True)
+        g.output_stream("out")
+        g.output_event("ticks")
+        g.node("b", "QBurst::new", 100.0, 1.0)
+        g.node("s", "QSum::new")
+        g.connect("period", "b.period")
+        g.connect("pushes", "b.pushes")
+        g.connect("b.tick", "s.trig")
+        g.connect("b.tick", "ticks")
+        g.connect("s.total", "out")
+        n = 130
+        periods = (23 + (np.arange(n) * 5) % 60).astype(np.float32)
+        pushes = (np.arange(n) % (capacity + 3)).astype(np.float32)  # 0 .. capacity + 2 pushes per firing
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        eng.set_voice_values("period", periods)
+        eng.set_voice_values("pushes", pushes)
+        eng.set_voice_taps(list(range(n)))
+        frames = 300
+        eng.process_block(frames)
+        taps = eng.read_voice_taps(frames)
+        ev, over = eng.read_output_events()
+        assert over == 0
+        want, lost = [], 0
+        acc = np.zeros(n, dtype=np.float32)
+        calls = np.zeros(n)
+        for v in range(n):
+            count, fired = 0, 0.0
+            for f in range(frames):
+                count += 1
+                if np.float32(count) >= periods[v]:
+                    count = 0
+                    fired += 1.0
+                    for k in range(int(pushes[v])):
+                        if k < capacity:
+                            x = np.float32(np.float32(fired * 100.0) + np.float32(k))
+                            want.append((f, v, x))
+                            acc[v] = np.float32(acc[v] + x)
+                            calls[v] += 1
+                        else:
+                            lost += 1
+        want.sort(key=lambda t: (t[0], t[1]))
+        assert len(ev) == len(want) and len(want) > 300
+        assert np.array_equal(ev["frame"], np.array([w[0] for w in want], dtype=np.uint64))
+        assert np.array_equal(ev["voice"], np.array([w[1] for w in want], dtype=np.uint32))
+        assert np.array_equal(ev["value"], np.array([w[2] for w in want], dtype=np.float32))
+        assert np.array_equal(taps[:, -1], acc)                                   # the consumer saw every kept event, in order
+        assert np.array_equal(eng.read_state_field("s.calls"), calls.astype(np.float32))
+        assert eng.events_dropped == lost and lost > 0
+    finally:
+        oscen_amd.unregister_node("QBurst::new")
+        oscen_amd.unregister_node("QSum::new")
