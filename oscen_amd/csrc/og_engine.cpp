@@ -167,6 +167,90 @@ struct HipError : std::runtime_error {
             throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                         \
     } while (0)
 
+// Host memory this library does not own (a caller's array, a std::vector) never goes to hipMemcpyAsync directly.  For
+// a transfer above a size threshold the runtime pins the pages where they lie (a userptr mapping) and keeps the
+// pinning cached; whenever the kernel later migrates, compacts or unmaps those pages the driver evicts and restores
+// EVERY queue of the process.  Measured through the blocking entry at 4 M / 8 M voices (bench.py's real-time record:
+// the 32 MB frequency array of og_set_voice_values and the event-timeline vectors of the first rebuild were such
+// mappings): one ~23 ms stall of the stream -- several missed audio deadlines -- every few thousand blocks.  So every
+// transfer larger than a staging copy goes through two pinned bounce buffers of this engine's own.
+struct Bounce {
+    static constexpr size_t CHUNK = (size_t)4 << 20, DIRECT = 16384; // (below DIRECT the runtime stages the bytes itself)
+    void* h[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int k = 0;
+    void ensure()
+    {
+        if (h[0]) return;
+        for (int i = 0; i < 2; ++i) {
+            HIPCK(hipHostMalloc(&h[i], CHUNK, hipHostMallocDefault));
+            HIPCK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+    // host -> device, asynchronous like hipMemcpyAsync from pinned memory: `src` may be reused when the call returns
+    void h2d(void* dst, const void* src, size_t n, hipStream_t s)
+    {
+        if (n <= DIRECT) {
+            if (n) HIPCK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
+            return;
+        }
+        ensure();
+        for (size_t off = 0; off < n; off += CHUNK) {
+            const size_t len = std::min(CHUNK, n - off);
+            if (busy[k]) HIPCK(hipEventSynchronize(ev[k]));
+            memcpy(h[k], (const char*)src + off, len);
+            HIPCK(hipMemcpyAsync((char*)dst + off, h[k], len, hipMemcpyHostToDevice, s));
+            HIPCK(hipEventRecord(ev[k], s));
+            busy[k] = true;
+            k ^= 1;
+        }
+    }
+    // device -> host; the bytes are in `dst` when the call returns (the stream is drained up to the copy)
+    void d2h(void* dst, const void* src, size_t n, hipStream_t s)
+    {
+        if (n <= DIRECT) {
+            if (n) HIPCK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            return;
+        }
+        ensure();
+        size_t pend_off[2] = {0, 0}, pend_len[2] = {0, 0};
+        auto land = [&](int i) {
+            if (!pend_len[i]) return;
+            HIPCK(hipEventSynchronize(ev[i]));
+            memcpy((char*)dst + pend_off[i], h[i], pend_len[i]);
+            pend_len[i] = 0;
+            busy[i] = false;
+        };
+        for (int i = 0; i < 2; ++i)
+            if (busy[i]) { // (an upload still reading the buffer)
+                HIPCK(hipEventSynchronize(ev[i]));
+                busy[i] = false;
+            }
+        for (size_t off = 0; off < n; off += CHUNK) {
+            const size_t len = std::min(CHUNK, n - off);
+            land(k);
+            HIPCK(hipMemcpyAsync(h[k], (const char*)src + off, len, hipMemcpyDeviceToHost, s));
+            HIPCK(hipEventRecord(ev[k], s));
+            pend_off[k] = off;
+            pend_len[k] = len;
+            k ^= 1;
+        }
+        land(k);
+        land(k ^ 1);
+    }
+    void release()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            h[i] = nullptr;
+            ev[i] = nullptr;
+        }
+    }
+};
+
 struct Ramp { // ValueRampState  oscen-lib/src/graph/types.rs:300-373
     float current = 0, target = 0, increment = 0;
     uint32_t frames_remaining = 0;
@@ -272,6 +356,7 @@ struct og_engine {
     uint32_t lanes = OG_WAVE;
     uint32_t split = 0; // pipeline depth of the launched kernel variant: 0 (ordinary), 2 or 4 waves per 64 voices
     uint32_t* d_state = nullptr;
+    Bounce bounce; // pinned staging for transfers from / to memory that is not ours
     uint32_t* d_lane_state = nullptr;
     float* d_ring[OG_MAX_RINGS] = {nullptr, nullptr, nullptr, nullptr}; // delay lines [capacity][V]
     uint32_t ring_cap[OG_MAX_RINGS] = {0, 0, 0, 0};
@@ -433,6 +518,7 @@ struct og_engine {
         // a borrowed stream (og_set_stream) may already be gone: wait for the device instead of touching it
         if (own_stream && stream) (void)hipStreamSynchronize(stream);
         else (void)hipDeviceSynchronize();
+        bounce.release();
         (void)hipFree(d_state);
         (void)hipFree(d_lane_state);
         for (int k = 0; k < OG_MAX_RINGS; ++k) (void)hipFree(d_ring[k]);
@@ -476,14 +562,14 @@ struct og_engine {
             const uint32_t bits = cg->state[w].init(e);
             std::fill(img.begin() + w * V, img.begin() + (w + 1) * V, bits);
         }
-        HIPCK(hipMemcpyAsync(d_state, img.data(), img.size() * 4, hipMemcpyHostToDevice, stream));
+        bounce.h2d(d_state, img.data(), img.size() * 4, stream);
         std::vector<uint32_t> limg;
         if (!cg->lane_state.empty()) {
             const size_t per = (size_t)V * cg->lpv * cg->lane_width;
             limg.resize(cg->lane_state.size() * per);
             for (size_t k = 0; k < cg->lane_state.size(); ++k)
                 std::fill(limg.begin() + k * per, limg.begin() + (k + 1) * per, cg->lane_state[k].init(e));
-            HIPCK(hipMemcpyAsync(d_lane_state, limg.data(), limg.size() * 4, hipMemcpyHostToDevice, stream));
+            bounce.h2d(d_lane_state, limg.data(), limg.size() * 4, stream);
         }
         if (d_bus_phase) HIPCK(hipMemsetAsync(d_bus_phase, 0, 4, stream));
         // prepare(): every Delay gets a fresh zeroed ring sized from the sample rate (delay/mod.rs:59-69)
@@ -612,9 +698,9 @@ struct og_engine {
             ev_cap = std::max<size_t>(n + n / 2, 1024) + headroom;
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
         }
-        if (n) HIPCK(hipMemcpyAsync(d_events, evs.data(), n * sizeof(OgEvent), hipMemcpyHostToDevice, stream));
-        HIPCK(hipMemcpyAsync(d_ev_cursor, cursor.data(), (size_t)V * 4, hipMemcpyHostToDevice, stream));
-        HIPCK(hipMemcpyAsync(d_ev_end, end.data(), (size_t)V * 4, hipMemcpyHostToDevice, stream));
+        if (n) bounce.h2d(d_events, evs.data(), n * sizeof(OgEvent), stream);
+        bounce.h2d(d_ev_cursor, cursor.data(), (size_t)V * 4, stream);
+        bounce.h2d(d_ev_end, end.data(), (size_t)V * 4, stream);
         HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
         h_events.swap(evs);
         h_events.resize(ev_cap); // mirror of the whole ring
@@ -1592,7 +1678,7 @@ int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t c
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
         const size_t w = (size_t)e->cg->inputs[input].state_word;
-        HIPCK(hipMemcpyAsync(e->d_state + w * e->V + first, v, (size_t)count * 4, hipMemcpyHostToDevice, e->stream));
+        e->bounce.h2d(e->d_state + w * e->V + first, v, (size_t)count * 4, e->stream);
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -1707,7 +1793,7 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
         return guard([&] {
             e->flush_bus();
             if (out_bus && frames)
-                HIPCK(hipMemcpyAsync(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, hipMemcpyDeviceToHost, e->stream));
+                e->bounce.d2h(out_bus, e->d_bus, (size_t)frames * e->cg->channels * 4, e->stream);
             HIPCK(hipStreamSynchronize(e->stream));
             return OG_OK;
         });
@@ -1770,7 +1856,7 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
                 e->process_async(frames, d_all + f0 * ch);
             }
             e->flush_bus();
-            HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total_frames * ch * 4, hipMemcpyDeviceToHost, e->stream));
+            e->bounce.d2h(out_bus, d_all, (size_t)total_frames * ch * 4, e->stream);
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {
             (void)hipFree(d_all);
@@ -1844,7 +1930,7 @@ int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* i
                 e->process_async(n, d_all + pos * ch);
             }
             e->flush_bus();
-            HIPCK(hipMemcpyAsync(out_bus, d_all, (size_t)total * ch * 4, hipMemcpyDeviceToHost, e->stream));
+            e->bounce.d2h(out_bus, d_all, (size_t)total * ch * 4, e->stream);
             HIPCK(hipStreamSynchronize(e->stream));
         } catch (...) {
             (void)hipFree(d_all);
@@ -1889,7 +1975,7 @@ int og_read_state_field(og_engine* e, const char* path, uint32_t first_voice, ui
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        if (n) HIPCK(hipMemcpyAsync(out, e->d_state + (size_t)w * e->V + first_voice, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+        if (n) e->bounce.d2h(out, e->d_state + (size_t)w * e->V + first_voice, (size_t)n * 4, e->stream);
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -1907,7 +1993,8 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
             if (voices[i] >= e->V) throw std::runtime_error("tap voice out of range");
             slot[voices[i]] = (int32_t)i;
         }
-        HIPCK(hipMemcpy(e->d_tap_slot, slot.data(), (size_t)e->V * 4, hipMemcpyHostToDevice));
+        e->bounce.h2d(e->d_tap_slot, slot.data(), (size_t)e->V * 4, e->stream);
+        HIPCK(hipStreamSynchronize(e->stream));
         if (e->d_taps) HIPCK(hipFree(e->d_taps));
         e->d_taps = nullptr;
         if (n) {
@@ -1927,7 +2014,7 @@ int og_read_voice_taps(og_engine* e, float* out, uint32_t n, uint32_t frames)
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        HIPCK(hipMemcpyAsync(out, e->d_taps, (size_t)n * frames * 4 * e->cg->voice_channels, hipMemcpyDeviceToHost, e->stream));
+        e->bounce.d2h(out, e->d_taps, (size_t)n * frames * 4 * e->cg->voice_channels, e->stream);
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -2009,7 +2096,7 @@ int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_
         HIPCK(hipStreamSynchronize(e->stream));
         const uint32_t have = std::min(count, e->out_ev_cap);
         std::vector<OgOutEvent> ev(have);
-        if (have) HIPCK(hipMemcpyAsync(ev.data(), e->d_out_ev, (size_t)have * sizeof(OgOutEvent), hipMemcpyDeviceToHost, e->stream));
+        if (have) e->bounce.d2h(ev.data(), e->d_out_ev, (size_t)have * sizeof(OgOutEvent), e->stream);
         HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, sizeof(uint32_t), e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         e->out_ev_overflow += count - have;
@@ -2164,13 +2251,13 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
         collect_unconsumed(e, evs);
         if (cap < dsp_bytes(e) + control_bytes(e, evs.size())) throw std::runtime_error("buffer too small");
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
-        HIPCK(hipMemcpyAsync(dst, e->d_state, a, hipMemcpyDeviceToHost, e->stream));
-        if (b) HIPCK(hipMemcpyAsync((char*)dst + a, e->d_lane_state, b, hipMemcpyDeviceToHost, e->stream));
+        e->bounce.d2h(dst, e->d_state, a, e->stream);
+        if (b) e->bounce.d2h((char*)dst + a, e->d_lane_state, b, e->stream);
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync((char*)dst + a + b, e->d_bus_phase, 4, hipMemcpyDeviceToHost, e->stream));
         size_t off = a + b + (e->d_bus_phase ? 4 : 0);
         for (size_t k = 0; k < e->cg->rings.size(); ++k) {
             const size_t n = (size_t)e->ring_cap[k] * e->V * 4;
-            if (n) HIPCK(hipMemcpyAsync((char*)dst + off, e->d_ring[k], n, hipMemcpyDeviceToHost, e->stream));
+            if (n) e->bounce.d2h((char*)dst + off, e->d_ring[k], n, e->stream);
             off += n;
         }
         HIPCK(hipStreamSynchronize(e->stream));
@@ -2222,13 +2309,13 @@ int og_load_state(og_engine* e, const void* src, size_t len)
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
         const size_t a = e->cg->state.size() * (size_t)e->V * 4, b = e->cg->lane_state.size() * (size_t)e->V * e->cg->lpv * e->cg->lane_width * 4;
-        HIPCK(hipMemcpyAsync(e->d_state, src, a, hipMemcpyHostToDevice, e->stream));
-        if (b) HIPCK(hipMemcpyAsync(e->d_lane_state, (const char*)src + a, b, hipMemcpyHostToDevice, e->stream));
+        e->bounce.h2d(e->d_state, src, a, e->stream);
+        if (b) e->bounce.h2d(e->d_lane_state, (const char*)src + a, b, e->stream);
         if (e->d_bus_phase) HIPCK(hipMemcpyAsync(e->d_bus_phase, (const char*)src + a + b, 4, hipMemcpyHostToDevice, e->stream));
         size_t off = a + b + (e->d_bus_phase ? 4 : 0);
         for (size_t k = 0; k < e->cg->rings.size(); ++k) {
             const size_t n = (size_t)e->ring_cap[k] * e->V * 4;
-            if (n) HIPCK(hipMemcpyAsync(e->d_ring[k], (const char*)src + off, n, hipMemcpyHostToDevice, e->stream));
+            if (n) e->bounce.h2d(e->d_ring[k], (const char*)src + off, n, e->stream);
             off += n;
         }
         e->reset_timeline();
