@@ -16,6 +16,14 @@ Sources followed:
   TptFilter<f32>   oscen-lib/src/filters/tpt/mod.rs:47-123
   FMVoice          examples/fm-synth/src/fm_voice.rs:6-156 (schedule: any topological order, the graph is feed-forward)
   AmplitudeSource / OscillatorBank / ElectricPianoVoiceNode  examples/electric-piano/src/electric_piano_voice.rs:50-402
+  PolyBlepOscillator, Halfband2x{Up,Down}Stage, Sinc{Up,Down}Fir, the saturator voice   (round 3)
+  Oscillator       oscen-lib/src/oscillators/mod.rs:7-77
+  IirLowpass       oscen-lib/src/filters/iir_lowpass/mod.rs:15-163
+  RingBuffer / Delay  oscen-lib/src/ring_buffer/mod.rs, oscen-lib/src/delay/mod.rs:5-83
+  LP18Filter       examples/nih-twin-peaks/src/lp18_filter.rs:7-104
+  Tremolo          examples/electric-piano/src/tremolo.rs:8-67
+  IirHalfband{Up,Down}, Linear{Up,Down}  oscen-lib/src/resample/{halfband_iir.rs,linear.rs}   (round 3, late)
+With these every node the C oracle restates has a second, independent restatement that agrees with it bit for bit.
 """
 import ctypes
 import ctypes.util
@@ -643,3 +651,305 @@ class SatVoice:
             driven = f32(self.osc.process() * f32(1.5))
             xs.append(clamp(driven, -0.7, 0.7))
         return self.down.downsample(xs) if self.down else xs[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3 (late): the nodes that still had one restatement only.  Written from the Rust sources named on each class.
+# ---------------------------------------------------------------------------------------------------------------------
+for _n in ("tanhf",):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float]
+_libm.fmodf.restype = ctypes.c_float
+_libm.fmodf.argtypes = [ctypes.c_float, ctypes.c_float]
+_libm.fmaf.restype = ctypes.c_float
+_libm.fmaf.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float]
+
+PI = f32(np.pi)  # std::f32::consts::PI
+
+
+def tanhf(x):
+    return f32(_libm.tanhf(float(x)))
+
+
+def fmodf(x, y):  # Rust's `%` on f32
+    return f32(_libm.fmodf(float(x), float(y)))
+
+
+def fract(x):  # f32::fract = x - x.trunc()
+    x = f32(x)
+    return f32(x - f32(np.trunc(x)))
+
+
+class Oscillator:  # oscen-lib/src/oscillators/mod.rs:7-77
+    SINE, SQUARE, SAW = range(3)
+
+    def __init__(self, frequency, amplitude, waveform, sr):
+        self.phase = f32(0.0)
+        self.frequency = f32(frequency)
+        self.frequency_mod = f32(0.0)
+        self.amplitude = f32(amplitude)
+        self.waveform = waveform
+        self.sr = f32(sr)
+        self.output = f32(0.0)
+
+    def _wave(self, p):
+        if self.waveform == self.SINE:  # |p| (p * 2.0 * PI).sin()
+            return sinf(f32(f32(p * f32(2.0)) * PI))
+        if self.waveform == self.SQUARE:
+            return f32(1.0) if p < f32(0.5) else f32(-1.0)
+        transition_width = f32(0.1)
+        raw_saw = f32(f32(f32(2.0) * p) - f32(1.0))
+        edge = f32(f32(1.0) - f32(transition_width / f32(2.0)))
+        if p > edge:
+            t = f32(f32(p - edge) / f32(transition_width / f32(2.0)))
+            return f32(f32(-1.0) + f32(f32(f32(1.0) - f32(t * t)) * f32(raw_saw + f32(1.0))))
+        return raw_saw
+
+    def process(self):
+        frequency = f32(self.frequency * f32(f32(1.0) + self.frequency_mod))
+        modulated_phase = fmodf(self.phase, 1.0)
+        self.output = f32(self._wave(modulated_phase) * self.amplitude)
+        self.phase = f32(self.phase + f32(frequency / self.sr))
+        self.phase = fmodf(self.phase, 1.0)
+        return self.output
+
+
+class IirLowpass:  # oscen-lib/src/filters/iir_lowpass/mod.rs:15-163
+    DENORMAL = f32(1e-15)
+
+    def __init__(self, cutoff, q, sr):
+        self.cutoff, self.q, self.sr = f32(cutoff), f32(q), f32(sr)
+        self.b0, self.b1, self.b2, self.a1, self.a2 = f32(1.0), f32(0.0), f32(0.0), f32(0.0), f32(0.0)
+        self.v1 = self.v2 = f32(0.0)
+        self.frame_counter, self.frames_per_update = 0, 32
+        self.update_coefficients()  # prepare()
+
+    def update_coefficients(self):
+        nyquist = f32(f32(self.sr * f32(0.5)) - f32(np.finfo(np.float32).eps))
+        freq = clamp(self.cutoff, 20.0, nyquist)
+        q = self.q if self.q > f32(0.01) else f32(0.01)  # .max(0.01)
+        n = f32(f32(1.0) / tanf(f32(f32(PI * freq) / self.sr)))
+        n_squared = f32(n * n)
+        c1 = f32(f32(1.0) / f32(f32(f32(1.0) + f32(f32(f32(1.0) / q) * n)) + n_squared))
+        self.b0 = c1
+        self.b1 = f32(c1 * f32(2.0))
+        self.b2 = c1
+        self.a1 = f32(f32(c1 * f32(2.0)) * f32(f32(1.0) - n_squared))
+        self.a2 = f32(c1 * f32(f32(f32(1.0) - f32(f32(f32(1.0) / q) * n)) + n_squared))
+
+    def process(self, x):
+        if self.frame_counter == 0:
+            self.update_coefficients()
+        self.frame_counter = (self.frame_counter + 1) % self.frames_per_update
+        x = f32(x)
+        if abs(x) < self.DENORMAL:
+            x = f32(0.0)
+        out = f32(f32(self.b0 * x) + self.v1)
+        self.v1 = f32(f32(f32(self.b1 * x) - f32(self.a1 * out)) + self.v2)
+        self.v2 = f32(f32(self.b2 * x) - f32(self.a2 * out))
+        if abs(self.v1) < self.DENORMAL:
+            self.v1 = f32(0.0)
+        if abs(self.v2) < self.DENORMAL:
+            self.v2 = f32(0.0)
+        return out
+
+
+class RingBuffer:  # oscen-lib/src/ring_buffer/mod.rs (PowerOfTwo mode, the default)
+    def __init__(self, size):
+        cap = 1
+        while cap < max(size, 1):
+            cap *= 2
+        self.buf = np.zeros(cap, dtype=np.float32)
+        self.capacity, self.mask, self.write_pos = cap, cap - 1, 0
+
+    def push(self, v):
+        self.buf[self.write_pos] = f32(v)
+        self.write_pos = (self.write_pos + 1) & self.mask
+
+    def read_pos(self, offset):
+        n = f32(self.capacity)
+        rp = f32(f32(f32(self.write_pos) - f32(offset)) - f32(1.0))
+        return fmodf(f32(fmodf(rp, n) + n), n)
+
+    def get_cubic(self, offset):
+        rp = self.read_pos(offset)
+        i = int(rp)
+        f = fract(rp)
+        v0, v1 = self.buf[(i - 1) & self.mask], self.buf[i]
+        v2, v3 = self.buf[(i + 1) & self.mask], self.buf[(i + 2) & self.mask]
+        c0 = v1
+        c1 = f32(f32(0.5) * f32(v2 - v0))
+        c2 = f32(f32(f32(v0 - f32(f32(2.5) * v1)) + f32(f32(2.0) * v2)) - f32(f32(0.5) * v3))
+        c3 = f32(f32(f32(0.5) * f32(v3 - v0)) + f32(f32(1.5) * f32(v1 - v2)))
+        return f32(c0 + f32(f * f32(c1 + f32(f * f32(c2 + f32(f * c3))))))
+
+    def get_linear(self, offset):
+        rp = self.read_pos(offset)
+        i = int(rp)
+        f = fract(rp)
+        a, b = self.buf[i], self.buf[(i + 1) & self.mask]
+        return f32(_libm.fmaf(float(a), float(f32(f32(1.0) - f)), float(f32(b * f))))  # a.mul_add(1.0 - f, b * f)
+
+    def get(self, offset):
+        off = f32(offset)
+        if not off > f32(0.0):  # offset.max(0.0)
+            off = f32(0.0)
+        fr = fract(off)
+        if fr < f32(1e-6) or f32(f32(1.0) - fr) < f32(1e-6):
+            r = float(off)  # f32::round: half away from zero
+            samples = int(np.floor(r + 0.5)) if r >= 0 else int(np.ceil(r - 0.5))
+            idx = ((self.write_pos + self.capacity) - (samples % self.capacity) - 1) % self.capacity
+            return f32(self.buf[idx])
+        return self.get_cubic(off) if self.capacity >= 4 else self.get_linear(off)
+
+
+class Delay:  # oscen-lib/src/delay/mod.rs:5-83
+    def __init__(self, delay_samples, feedback, sr):
+        self.delay_samples, self.feedback = f32(delay_samples), f32(feedback)
+        size = min(int(f32(f32(2.0) * f32(sr))), 88200)  # prepare(): (target_seconds * sr) as usize, capped
+        self.buffer = RingBuffer(size)
+        self.frame_counter, self.frames_per_update = 0, 32
+
+    def process(self, x):
+        if self.frame_counter == 0:
+            max_delay = f32(f32(self.buffer.capacity) - f32(1.0))
+            self.delay_samples = clamp(self.delay_samples, 0.0, max_delay)
+            self.feedback = clamp(self.feedback, 0.0, 0.99)
+        self.frame_counter = (self.frame_counter + 1) % self.frames_per_update
+        delayed = self.buffer.get(self.delay_samples)
+        self.buffer.push(f32(f32(x) + f32(delayed * self.feedback)))
+        return delayed
+
+
+class Lp18:  # examples/nih-twin-peaks/src/lp18_filter.rs:7-104
+    def __init__(self, cutoff, resonance, sr):
+        self.cutoff, self.fmod, self.sr = f32(cutoff), f32(0.0), f32(sr)
+        self.resonance = clamp(resonance, 0.0, 0.99)
+        self.z = [f32(0.0)] * 3
+        self.last_cutoff, self.last_fmod, self.last_resonance = f32(cutoff), f32(0.0), f32(resonance)
+        self.update_cutoff()  # prepare()
+        self.h = f32(f32(2.0) * self.resonance)
+
+    def update_cutoff(self):
+        fc = clamp(f32(f32(self.cutoff + self.fmod) / self.sr), 0.001, 0.33)
+        self.g = tanf(f32(PI * fc))
+
+    def process(self, x):
+        if self.cutoff != self.last_cutoff or self.fmod != self.last_fmod:
+            self.last_cutoff, self.last_fmod = self.cutoff, self.fmod
+            self.update_cutoff()
+        if self.resonance != self.last_resonance:
+            self.last_resonance = self.resonance
+            self.resonance = clamp(self.resonance, 0.0, 0.99)
+            self.h = f32(f32(2.0) * self.resonance)
+        g, z = self.g, self.z
+        hp = f32(f32(f32(f32(f32(x) - f32(self.h * z[0])) - z[1]) - z[2]) / f32(f32(1.0) + g))
+        bp1 = f32(f32(g * hp) + z[0])
+        z[0] = tanhf(bp1)
+        bp2 = f32(f32(g * bp1) + z[1])
+        z[1] = bp2
+        lp = f32(f32(g * bp2) + z[2])
+        z[2] = lp
+        return lp
+
+
+class Tremolo:  # examples/electric-piano/src/tremolo.rs:8-67
+    def __init__(self, sr):
+        self.rate, self.depth, self.phase, self.sr = f32(5.0), f32(0.5), f32(0.0), f32(sr)
+
+    def process(self, x):
+        x = f32(x)
+        lfo = sinf(f32(f32(self.phase * f32(2.0)) * PI))
+        scaled_depth = f32(self.depth / f32(3.0))
+        pan = f32(f32(0.5) + f32(lfo * scaled_depth))
+        out = (f32(x * pan), f32(x * f32(f32(1.0) - pan)))
+        self.phase = fract(f32(self.phase + f32(self.rate / self.sr)))
+        return out
+
+
+class _Allpass1:  # resample/halfband_iir.rs Allpass1::step
+    TH = f32(1e-15)
+
+    def __init__(self, a):
+        self.a, self.x_prev, self.y_prev = f32(a), f32(0.0), f32(0.0)
+
+    def step(self, x):
+        x = f32(x)
+        y = f32(f32(f32(x - self.y_prev) * self.a) + self.x_prev)
+        self.x_prev = f32(0.0) if abs(x) < self.TH else x
+        self.y_prev = f32(0.0) if abs(y) < self.TH else y
+        return y
+
+
+class _IirHalfband2x:  # IirHalfband2x::{step_up, step_down}
+    A = (0.135_574_1, 0.697_584_9)  # resample/coeffs.rs BRANCH_A_BETAS / BRANCH_B_BETAS
+    B = (0.425_380_4, 0.905_560_1)
+
+    def __init__(self):
+        self.a = [_Allpass1(c) for c in self.A]
+        self.b = [_Allpass1(c) for c in self.B]
+        self.prev_odd_in = f32(0.0)
+
+    def step_up(self, x):
+        a = b = f32(x)
+        for s in self.a:
+            a = s.step(a)
+        for s in self.b:
+            b = s.step(b)
+        return a, b
+
+    def step_down(self, x0, x1):
+        a, b = f32(x0), self.prev_odd_in
+        for s in self.a:
+            a = s.step(a)
+        for s in self.b:
+            b = s.step(b)
+        self.prev_odd_in = f32(x1)
+        return f32(f32(a + b) * f32(0.5))
+
+
+class IirUp:  # IirHalfbandUp<N>::upsample
+    def __init__(self, n):
+        self.n = n
+        self.stages = [_IirHalfband2x() for _ in range(n.bit_length() - 1)]
+
+    def upsample(self, x):
+        buf = [f32(x)]
+        for st in self.stages:
+            nxt = []
+            for v in buf:
+                nxt.extend(st.step_up(v))
+            buf = nxt
+        return buf
+
+
+class IirDown:  # IirHalfbandDown<N>::downsample
+    def __init__(self, n):
+        self.n = n
+        self.stages = [_IirHalfband2x() for _ in range(n.bit_length() - 1)]
+
+    def downsample(self, xs):
+        buf = [f32(v) for v in xs]
+        for st in self.stages:
+            buf = [st.step_down(buf[2 * i], buf[2 * i + 1]) for i in range(len(buf) // 2)]
+        return buf[0]
+
+
+class LinearUp:  # resample/linear.rs:8-35
+    def __init__(self, n):
+        self.n, self.prev = n, f32(0.0)
+
+    def upsample(self, x):
+        x = f32(x)
+        n_inv = f32(f32(1.0) / f32(self.n))
+        delta = f32(x - self.prev)
+        out = [f32(self.prev + f32(delta * f32(f32(i) * n_inv))) for i in range(self.n)]
+        self.prev = x
+        return out
+
+
+def linear_down(xs):  # resample/linear.rs:48-66
+    acc = f32(0.0)
+    for x in xs:
+        acc = f32(acc + f32(x))
+    return f32(acc * f32(f32(1.0) / f32(len(xs))))

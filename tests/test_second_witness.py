@@ -117,3 +117,116 @@ def test_saturator_voice_and_sinc_resamplers_bit_identical_between_the_two_resta
             for _ in range(2000):
                 lib.oo_polyblep_process(C.byref(o))
                 assert np.float32(o.output) == w.process(), (wave_c, freq)
+
+
+def test_remaining_nodes_bit_identical_between_the_two_restatements():
+    """Oscillator (sine / square / saw), IirLowpass, RingBuffer + Delay (exact, cubic and feedback reads), LP18Filter,
+    Tremolo, the IIR half-band and linear resamplers: the C oracle against the second transliteration written from the
+    Rust sources (tests/second_witness.py, round 3 late) -- bit for bit on noise and on swept parameters.  With this every
+    node the oracle restates has two independent restatements."""
+    import ctypes as C
+
+    lib = ol.load()
+    rng = np.random.default_rng(77)
+    # Oscillator: every waveform, a frequency modulation stream, amplitudes
+    for wave in (0, 1, 2):
+        for freq in (110.0, 997.3, 7040.0):
+            o = ol.Oscillator()
+            lib.oo_oscillator_new(C.byref(o), freq, 0.7, wave)
+            o.sample_rate = SR
+            w = sw.Oscillator(freq, 0.7, wave, SR)
+            for fm in rng.uniform(-0.2, 0.2, 1500).astype(np.float32):
+                o.frequency_mod = float(fm)
+                w.frequency_mod = np.float32(fm)
+                lib.oo_oscillator_process(C.byref(o))
+                assert np.float32(o.output) == w.process(), (wave, freq)
+    # IirLowpass: cutoff / q changed while running (picked up every 32 frames), denormal-sized input
+    for cutoff, q in ((1000.0, 0.707), (60.0, 4.0), (19000.0, 0.3)):
+        f = ol.IirLowpass()
+        lib.oo_iir_lowpass_new(C.byref(f), cutoff, q)
+        f.sample_rate = SR
+        lib.oo_iir_lowpass_prepare(C.byref(f))
+        w = sw.IirLowpass(cutoff, q, SR)
+        xs = rng.uniform(-1.0, 1.0, 3000).astype(np.float32)
+        xs[100:110] = np.float32(1e-20)
+        for i, x in enumerate(xs):
+            if i == 1000:
+                f.cutoff = 3333.0
+                w.cutoff = np.float32(3333.0)
+            if i == 2000:
+                f.q = 0.001
+                w.q = np.float32(0.001)
+            f.input = float(x)
+            lib.oo_iir_lowpass_process(C.byref(f))
+            assert np.float32(f.output) == w.process(x), (cutoff, i)
+    # Delay: integer, fractional (cubic), beyond-capacity and changing delays, feedback
+    for sr in (48000.0, 8000.0):
+        for delay_samples, feedback in ((0.0, 0.0), (17.0, 0.5), (33.37, 0.8), (1e9, 1.5), (2.9999995, 0.2)):
+            d = ol.Delay()
+            lib.oo_delay_new(C.byref(d), delay_samples, feedback)
+            d.sample_rate = sr
+            lib.oo_delay_prepare(C.byref(d))
+            w = sw.Delay(delay_samples, feedback, sr)
+            assert d.buffer.capacity == w.buffer.capacity
+            for i, x in enumerate(rng.uniform(-1.0, 1.0, 1200).astype(np.float32)):
+                if i == 600:
+                    d.delay_samples = 100.25
+                    w.delay_samples = np.float32(100.25)
+                d.input = float(x)
+                lib.oo_delay_process(C.byref(d))
+                assert np.float32(d.output) == w.process(x), (sr, delay_samples, i)
+            lib.oo_delay_free(C.byref(d))
+    # LP18Filter: cutoff / fmod / resonance changes, loud input (the tanh stage)
+    for cutoff, res in ((800.0, 0.3), (5000.0, 0.95), (30.0, 2.0)):
+        f = ol.Lp18()
+        lib.oo_lp18_new(C.byref(f), cutoff, res)
+        f.sample_rate = SR
+        lib.oo_lp18_prepare(C.byref(f))
+        w = sw.Lp18(cutoff, res, SR)
+        for i, x in enumerate((rng.uniform(-1.0, 1.0, 2000) * 3.0).astype(np.float32)):
+            if i == 500:
+                f.fmod = 250.0
+                w.fmod = np.float32(250.0)
+            if i == 1000:
+                f.resonance = 1.7
+                w.resonance = np.float32(1.7)
+            if i == 1500:
+                f.cutoff = 12000.0
+                w.cutoff = np.float32(12000.0)
+            f.input = float(x)
+            lib.oo_lp18_process(C.byref(f))
+            assert np.float32(f.output) == w.process(x), (cutoff, i)
+    # Tremolo: rate / depth, both channels
+    t = ol.Tremolo()
+    lib.oo_tremolo_new(C.byref(t))
+    t.sample_rate = SR
+    w = sw.Tremolo(SR)
+    for i, x in enumerate(rng.uniform(-1.0, 1.0, 3000).astype(np.float32)):
+        if i == 1000:
+            t.rate, t.depth = 7.3, 0.9
+            w.rate, w.depth = np.float32(7.3), np.float32(0.9)
+        t.input = float(x)
+        lib.oo_tremolo_process(C.byref(t))
+        l, r = w.process(x)
+        assert (np.float32(t.output[0]), np.float32(t.output[1])) == (l, r), i
+    # IIR half-band and linear resamplers, N = 2, 4, 8
+    for n in (2, 4, 8):
+        up_c, dn_c = ol.IirResampler(), ol.IirResampler()
+        lib.oo_iir_resampler_new(C.byref(up_c), n)
+        lib.oo_iir_resampler_new(C.byref(dn_c), n)
+        up_w, dn_w = sw.IirUp(n), sw.IirDown(n)
+        lu_c = ol.LinearUp()
+        lib.oo_linear_up_new(C.byref(lu_c), n)
+        lu_w = sw.LinearUp(n)
+        buf = np.zeros(n, dtype=np.float32)
+        xs = rng.uniform(-1.0, 1.0, 400).astype(np.float32)
+        xs[50:60] = np.float32(1e-20)
+        for x in xs:
+            lib.oo_iir_up_process(C.byref(up_c), float(x), ol.fptr(buf))
+            want = np.array(up_w.upsample(x), dtype=np.float32)
+            assert np.array_equal(buf, want), n
+            assert np.float32(lib.oo_iir_down_process(C.byref(dn_c), ol.fptr(buf))) == dn_w.downsample(want), n
+            lib.oo_linear_up_process(C.byref(lu_c), float(x), ol.fptr(buf))
+            want = np.array(lu_w.upsample(x), dtype=np.float32)
+            assert np.array_equal(buf, want), n
+            assert np.float32(lib.oo_linear_down_process(n, ol.fptr(buf))) == sw.linear_down(want), n
