@@ -359,7 +359,7 @@ const std::map<std::string, MethodInfo>& method_table()
         {"signum", {0, "(($0) != ($0) ? ($0) : __builtin_copysignf(1.0f, ($0)))", [](float x, float, float) { return x != x ? x : (std::signbit(x) ? -1.0f : 1.0f); }}},
         {"min", {1, "fminf($0, $1)", [](float x, float y, float) { return fminf(x, y); }}},
         {"max", {1, "fmaxf($0, $1)", [](float x, float y, float) { return fmaxf(x, y); }}},
-        {"clamp", {2, "fminf(fmaxf($0, $1), $2)", [](float x, float lo, float hi) { return x != x ? x : (x < lo ? lo : (x > hi ? hi : x)); }}},
+        {"clamp", {2, "(($0) != ($0) ? ($0) : fminf(fmaxf($0, $1), $2))", [](float x, float lo, float hi) { return x != x ? x : (x < lo ? lo : (x > hi ? hi : x)); }}},
         {"mul_add", {2, "__builtin_fmaf($0, $1, $2)", [](float x, float a, float b) { return fmaf(x, a, b); }}},
         {"to_radians", {0, "($0 * 0x1.1df46ap-6f)", [](float x, float, float) { return x * 0x1.1df46ap-6f; }}},
         {"to_degrees", {0, "($0 * 0x1.ca5dc2p+5f)", [](float x, float, float) { return x * 0x1.ca5dc2p+5f; }}},
@@ -2939,10 +2939,22 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     if (e->port == ti->outputs[o]) return ti->out_channels[o];
                 return 1;
             }
+            if (e->t == Expr::Ref) { // a Frame<N> stream input of the graph
+                auto iit = cg.input_by_name.find(e->node);
+                return iit == cg.input_by_name.end() ? 1 : std::max(1, out.inputs[iit->second].decl.channels);
+            }
+            if (e->t == Expr::Chan || e->t == Expr::Method) return 1;
+            if (e->t == Expr::Call) {
+                if (e->port == "Frame") return (int)e->args.size();
+                const UserFunction* f = lookup_function(e->node, e->port);
+                return f ? f->result_channels : 1;
+            }
             return std::max(width_of(e->a), width_of(e->b));
         };
         for (auto& kv : out_edges)
-            for (auto& src : kv.second) stereo_out = stereo_out || width_of(src.src) == 2;
+            for (auto& src : kv.second) stereo_out = stereo_out || width_of(src.src) >= 2;
+        for (size_t oi = 0; oi < g.outputs.size(); ++oi) // (a declared `output out: stream: Frame<2>`)
+            stereo_out = stereo_out || (g.outputs[oi].kind == Kind::Stream && g.outputs[oi].channels >= 2);
         // (several stream outputs = several bus channels: summed by the ordinary kernel only, like a Frame<2> output)
         {
             int n_stream_outs = 0;

@@ -278,3 +278,38 @@ def test_calls_on_a_connection_parse_and_report_like_the_reference():
         oscen_amd.unregister_function("swap")
     with pytest.raises(oscen_amd.OscenError):
         oscen_amd.unregister_function("swap")
+
+
+def test_calls_on_a_connection_compile_in_every_kernel_shape():
+    """named functions, methods and frame constructors inside the shapes the generator treats differently -- across a
+    rate boundary, in array broadcasts, inside a nested graph, feeding a Frame<2> output of a graph whose nodes would
+    otherwise get the pipelined kernels (a frame-valued output is summed by the ordinary kernel only) -- each compiled
+    for gfx950 (og_graph_jit_check)"""
+    oscen_amd.register_function("half", ["x"], "return x * 0.5f;")
+    oscen_amd.register_function("ms", [("v", 2)], "og::Frame<2> o; o.v[0] = v.v[0] - v.v[1]; o.v[1] = v.v[0] + v.v[1]; return o;",
+                                result_channels=2)
+    inner = oscen_amd.Graph(dsl="name: DxInnerFn; input x: stream; output y: stream; nodes { c = HardClip::new(); } "
+                                "connections { half(x) * 3.0 -> c.input; half(c.output).abs() -> y; }")
+    oscen_amd.register_graph_type("DxInnerFn", inner)
+    try:
+        cases = [
+            ("a = PolyBlepOscillator::saw(220.0, 0.5) * 2;", "[sinc] half(a.output) -> out;", "stream"),
+            ("a = PolyBlepOscillator::saw(220.0, 0.5); c = HardClip::new() * 4;", "[linear] half(a.output).tanh() -> c.input; [sinc] c.output -> out;", "stream"),
+            ("oscs = [PolyBlepOscillator::saw(220.0, 0.5); 3];", "half(oscs[1].output) + oscs[2].output.abs() -> out;", "stream"),
+            ("oscs = [PolyBlepOscillator::saw(220.0, 0.5); 2]; g = [Gain::new(0.5); 2];", "half(oscs.output) -> g.input; g.output -> out;", "stream"),
+            ("a = PolyBlepOscillator::saw(220.0, 0.5); n = DxInnerFn::new();", "a.output -> n.x; n.y -> out;", "stream"),
+            ("a = PolyBlepOscillator::saw(220.0, 0.5); b = PolyBlepOscillator::sine(330.0, 0.5);", "ms(Frame(a.output, b.output)) * 0.5 -> out;", "stream: Frame<2>"),
+            ("a = PolyBlepOscillator::saw(220.0, 0.5); f = TptFilter::new(1000.0, 0.7);",
+             "a.output -> f.input; cutoff.clamp(100.0, 4000.0) + half(a.output) * 100.0 -> f.cutoff; f.output -> out;", "stream"),
+        ]
+        for nodes, conns, ty in cases:
+            g = oscen_amd.Graph(dsl=f"name: DxT; input cutoff: value = 800.0; output out: {ty}; nodes {{ {nodes} }} connections {{ {conns} }}")
+            src = g.kernel_source()
+            assert "og_fn_half(" in src or "og_fn_ms(" in src
+            if ty != "stream":
+                assert "voice_block_p2" not in src  # no pipelined kernels for a frame-valued output
+            assert g.jit_check() > 1000, conns
+    finally:
+        oscen_amd.unregister_graph_type("DxInnerFn")
+        oscen_amd.unregister_function("half")
+        oscen_amd.unregister_function("ms")
