@@ -78,7 +78,8 @@ int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type
  * `fn on_<event_input>(&mut self, &EventInstance)` handlers.  Here the two bodies are DEVICE SOURCE (C++): inside
  * them every stream/value input is a `const float <name>`, every private field a `float& <name>` (or `uint32_t&`),
  * every output a `float& <name>` to assign, plus `const float sample_rate`; an event handler also sees
- * `const float value` (the scalar payload) but only the VALUE inputs (streams do not exist yet when an event
+ * `const float value` (the scalar payload) -- and, if its source names it, `const uint32_t frame_offset`
+ * (EventInstance::frame_offset: the offset inside the process_block call, times N for a `* N` node) -- but only the VALUE inputs (streams do not exist yet when an event
  * fires).  og_math.h / og_nodes.hip.h helpers (og_sinf, og::clampf, ...) are in scope.  The bodies are compiled into
  * the fused voice kernel by hiprtc when an engine is created for a graph that uses the type.  Process-wide registry. */
 typedef struct {

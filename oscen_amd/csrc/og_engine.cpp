@@ -1029,6 +1029,14 @@ struct og_engine {
         // changes one; ramped inputs are read from the table whenever a ramp moved inside the queue)
         {
             ogc::UEnv e = env();
+            uint32_t starts[OG_MAX_LAUNCH_BLOCKS + 1];
+            uint32_t acc = 0, nb = 0;
+            for (const QueuedBlock& qb : queue) {
+                if (nb < OG_MAX_LAUNCH_BLOCKS) starts[nb++] = acc;
+                acc += qb.frames;
+            }
+            e.block_starts = starts;
+            e.n_blocks = nb;
             for (const auto& up : cg->uprogs) A.slots[up.dst] = up.fn(e);
         }
         const bool ramps_on = q_ramps && q_ramp_slot >= 0;

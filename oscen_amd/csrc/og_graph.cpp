@@ -484,6 +484,7 @@ struct Codegen {
     std::ostringstream& os() { return dom == 0 ? S().s_pre : (dom == 1 ? S().s_inner : S().s_post); }
     std::ostringstream common_decl, common_load; // per-voice value inputs: visible to both stages
     std::map<std::string, std::string> user_fns; // device functions of the user node types this graph uses
+    int blk_slot0 = -1;  // first of the 32 slots holding the block starts of a launch (allocated when a handler reads frame_offset)
     int ev_capacity = 2; // OG_NODE_EVENTS_PER_FRAME of this graph: the largest event_queue_capacity among its node types
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
@@ -1668,6 +1669,28 @@ void emit_user(NodeCtx& x)
             st.push_back(x.state_f(f.name, [init](const UEnv&) { return init; }));
         }
     }
+    // EventInstance::frame_offset (graph/types.rs): a handler whose source names `frame_offset` receives the offset of the
+    // event inside the process_block call it belongs to, rescaled by N for a node of the oversampled region
+    // (compute_event_rescale, ir/lower.rs:846-852; oscen-lib/tests/multirate_graph.rs EventOffsetRescale)
+    bool uses_offset = false;
+    for (const auto& h : u.handlers) {
+        const std::string& hs = h.second;
+        for (size_t pos = hs.find("frame_offset"); pos != std::string::npos; pos = hs.find("frame_offset", pos + 1)) {
+            const bool lb = pos == 0 || !(isalnum((unsigned char)hs[pos - 1]) || hs[pos - 1] == '_');
+            const bool rb = pos + 12 >= hs.size() || !(isalnum((unsigned char)hs[pos + 12]) || hs[pos + 12] == '_');
+            uses_offset = uses_offset || (lb && rb);
+        }
+    }
+    if (uses_offset && x.cg.blk_slot0 < 0) {
+        for (int k = 0; k < 32; ++k) {
+            const int sl = x.cg.new_slot([k](const UEnv& e) { return (uint32_t)k < e.n_blocks && e.block_starts ? e.block_starts[k] : 0xFFFFFFFFu; });
+            if (k == 0) x.cg.blk_slot0 = sl;
+        }
+        x.cg.common_decl << "    auto blk_off = [&](const uint32_t ff) __attribute__((always_inline)) -> uint32_t { // offset inside its block\n"
+                         << "        uint32_t s0 = 0u;\n"
+                         << "        for (uint32_t k = 1u; k < 32u; ++k) { const uint32_t st = SU(" << x.cg.blk_slot0 << "u + k); s0 = (st <= ff) ? st : s0; }\n"
+                         << "        return ff - s0;\n    };\n";
+    }
     // the device functions of this type, once per graph
     if (!x.cg.user_fns.count(u.type)) {
         std::ostringstream d;
@@ -1681,6 +1704,7 @@ void emit_user(NodeCtx& x)
             if (handler) {
                 sep();
                 q << "const float value";
+                if (uses_offset) q << ", const uint32_t frame_offset";
             }
             for (const UserPort& p : u.inputs) {
                 if (p.kind == Kind::Event) continue;
@@ -1743,7 +1767,9 @@ void emit_user(NodeCtx& x)
         for (const std::string& v : evo) args << ", " << v;
         args << ", " << x.sf(s_sr) << ");\n";
         const std::string tail = args.str(), name = fn + "_on_" + h.first;
-        x.on_event(h.first, [&](const std::string& val) { return "                " + name + "(" + val + tail; });
+        const std::string off = !uses_offset ? std::string()
+                                             : (x.n.domain == 1 ? ", blk_off(f) * " + std::to_string(x.cg.N) + "u" : std::string(", blk_off(f)"));
+        x.on_event(h.first, [&](const std::string& val) { return "                " + name + "(" + val + off + tail; });
     }
     for (const auto& kv : x.n.ev_edges)
         if (!u.handlers.count(kv.first))

@@ -39,6 +39,10 @@ enum class Rate {
 struct UEnv { // host-side evaluation environment for block-uniform expressions
     float sample_rate;
     const float* input_values; // by graph-input index (ramped inputs: `.current`)
+    // the blocks one launch renders: first frame of block k inside the launch (block 0 starts at 0), for handlers that
+    // read EventInstance::frame_offset (the offset inside the process_block call)
+    const uint32_t* block_starts = nullptr;
+    uint32_t n_blocks = 0;
 };
 using HostFn = std::function<float(const UEnv&)>;
 

@@ -449,3 +449,39 @@ def test_value_event_and_stream_fan_out_into_oversampled_arrays():
     finally:
         for t in ("R3ValueLatch::new", "R3ValueHolder::new", "R3GateCount::new", "R3MockVoice::new"):
             oscen_amd.unregister_node(t)
+
+
+def test_event_handlers_see_the_frame_offset_of_the_event():
+    """`fn on_gate(&mut self, ev: &EventInstance) { self.captured_offset = ev.frame_offset as f32; }`: the offset inside the
+    process_block call, times N for a node of the oversampled region (oscen-lib/tests/multirate_graph.rs EventOffsetRescale,
+    multirate_array_fanout.rs:245-277: outer offset 1 at `* 2` -> 2) -- also when several blocks share one launch"""
+    oscen_amd.register_node("R3OffCap::new", inputs=[("gate", "event", 0.0, -1)], outputs=["captured_offset"],
+                            state=[("cap", "f32", -1.0, -1), ("hits", "f32", 0.0, -1)],
+                            handlers={"gate": "    cap = (float)frame_offset;\n    hits += 1.0f;\n"}, process="    captured_offset = cap;\n")
+    try:
+        n = 5
+        for rate, scale in (("", 1), (" * 2", 2), (" * 4", 4)):
+            g = oscen_amd.Graph(dsl=f"""name: R3Off; input gate: event; output out: stream;
+                nodes {{ caps = [R3OffCap::new(); 3]{rate}; }}
+                connections {{ gate -> caps.gate; {'[latch] ' if rate else ''}caps.captured_offset -> out; }}""")
+            eng = oscen_amd.Engine(g, n, sample_rate=SR)
+            eng.push_voice_event("gate", 1, 1, 1.0)      # the reference's case: frame_offset 1
+            eng.push_voice_event("gate", 3, 63, 1.0)
+            eng.process_block(64)
+            for i in range(3):
+                assert np.array_equal(eng.read_state_field("caps[%d].cap" % i), np.array([-1, 1 * scale, -1, 63 * scale, -1], dtype=f32))
+            # several blocks in one launch: the offset stays relative to the event's own block
+            eng.set_bus_batching(0)
+            blocks = (256, 100, 37, 256, 200)
+            start = eng.frames_processed
+            at = {0: (4, 199), 2: (2, 36), 4: (3, 0)}  # voice -> (block index, offset)
+            for v, (b, off) in at.items():
+                eng.schedule_voice_event("gate", v, start + sum(blocks[:b]) + off, 1.0)
+            for b in blocks:
+                eng.process_block_async(b)
+            eng.flush()
+            want = np.array([199 * scale, 1 * scale, 36 * scale, 63 * scale, 0 * scale], dtype=f32)
+            assert np.array_equal(eng.read_state_field("caps[2].cap"), want), (rate, eng.read_state_field("caps[2].cap"))
+            assert np.array_equal(eng.read_state_field("caps[0].hits"), np.array([1, 1, 1, 1, 1], dtype=f32))
+    finally:
+        oscen_amd.unregister_node("R3OffCap::new")
