@@ -162,6 +162,43 @@ impl<const IN: usize> GpuGraph<IN> {
     }
 }
 
+/// A pure function applied on a connection (`half(a.output) -> out`, `dsp::decode_ms(s.output) -> out`): what the
+/// reference resolves to a Rust function in scope is registered here once, its body as device source.
+/// `args`: (parameter name, channels) with channels 1 = f32, N = Frame<N> (`og::Frame<N>`, `.v[i]`).
+pub fn register_function(name: &str, args: &[(&str, u32)], result_channels: u32, body: &str) -> Result<(), GpuError> {
+    let c_name = CString::new(name).unwrap();
+    let c_body = CString::new(body).unwrap();
+    let names: Vec<CString> = args.iter().map(|a| CString::new(a.0).unwrap()).collect();
+    let name_ptrs: Vec<*const std::os::raw::c_char> = names.iter().map(|n| n.as_ptr()).collect();
+    let widths: Vec<u32> = args.iter().map(|a| a.1).collect();
+    let f = sys::og_function_type {
+        name: c_name.as_ptr(), n_args: args.len() as u32, arg_names: name_ptrs.as_ptr(), arg_channels: widths.as_ptr(),
+        result_channels, source: c_body.as_ptr(),
+    };
+    ck(unsafe { sys::og_register_function(&f) }).map(|_| ())
+}
+
+impl<const IN: usize> GpuGraph<IN> {
+    /// `graph.<node>.<field>` of every voice in `first_voice .. first_voice + n` (the generated struct's node fields are
+    /// public in the reference; here a node's persistent fields are planes of the state image): "node.field",
+    /// "array[i].field", "nested.node.field"
+    pub fn read_state_field(&mut self, path: &str, first_voice: u32, n: u32) -> Result<Vec<f32>, GpuError> {
+        let c_path = CString::new(path).unwrap();
+        let mut out = vec![0.0f32; n as usize];
+        ck(unsafe { sys::og_read_state_field(self.e, c_path.as_ptr(), first_voice, n, out.as_mut_ptr().cast()) })?;
+        Ok(out)
+    }
+    /// the events the voices pushed into the graph's event outputs since the last call, ordered by (frame, voice, push
+    /// order) -- what iterating `graph.<event_output>` gives after process_block -- and how many the log could not hold
+    pub fn read_output_events(&mut self, cap: usize) -> Result<(Vec<sys::og_out_event>, u64), GpuError> {
+        let mut buf = vec![sys::og_out_event::default(); cap];
+        let (mut n, mut over) = (0u32, 0u64);
+        ck(unsafe { sys::og_read_output_events(self.e, buf.as_mut_ptr(), cap as u32, &mut n, &mut over) })?;
+        buf.truncate(n as usize);
+        Ok((buf, over))
+    }
+}
+
 /// A struct with the generated graph's own method names for a fixed input list:
 ///   gpu_graph! { FMGraphGpu, dsl = include_str!("fm_voice.graph"), per_voice = [frequency],
 ///                values = [op3_ratio, op3_level, filter_cutoff], events = [gate] }
