@@ -2139,6 +2139,8 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
         }
         // rewrite an inner expression: nodes get the prefix, inputs become the outer sources (or the default)
         std::string carried_policy; // policy of the outer edge into the input the expression being rewritten reads
+        std::set<std::string> pass_made; // unit-gain "input field" nodes created for compound reads of policy-fed inputs
+        std::vector<GEdge> pass_edges;
         auto rewrite = [&](const std::string& expr, bool& is_event, std::string& event_src) {
             std::vector<Tok> t = scan(expr);
             carried_policy.clear();
@@ -2161,9 +2163,31 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
                             else
                                 for (char ch : q.text) plain = plain && isspace((unsigned char)ch);
                         }
-                        if (idents != 1 || !plain)
-                            fail("nested graph input '" + n.name + "." + gi.name + "' is fed through [" + pit->second +
-                                 "] but read inside a compound expression ('" + expr + "')");
+                        if (idents != 1 || !plain) {
+                            // read inside a compound expression (`half(x) * 3.0 -> c.input`): the reference resamples the
+                            // outer source into the inner graph's input FIELD and the expression reads the field.  The
+                            // field here is a unit-gain node of the nested graph's rate (x * 1.0 is x, bit for bit) fed
+                            // through the policy; the expression reads its output.
+                            const std::string pass = pre + "in__" + gi.name;
+                            if (!pass_made.count(pass)) {
+                                auto src0 = sb.in_src.find(gi.name);
+                                if (src0 == sb.in_src.end()) fail("internal: policy without a source for '" + gi.name + "'");
+                                GNode pn;
+                                pn.name = pass;
+                                pn.type = "Gain::new";
+                                pn.args = {1.0f};
+                                pn.rate_factor = n.rate_factor;
+                                o.nodes.push_back(pn);
+                                GEdge pe;
+                                for (size_t i = 0; i < src0->second.size(); ++i) pe.src += (i ? " + (" : "(") + src0->second[i] + ")";
+                                pe.dst = pass + ".input";
+                                pe.policy = pit->second;
+                                pass_edges.push_back(pe);
+                                pass_made.insert(pass);
+                            }
+                            k = Tok{Tok::Other, "(" + pass + ".output)"};
+                            continue;
+                        }
                         carried_policy = pit->second;
                     }
                 }
@@ -2222,6 +2246,7 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
             x.dst = unscan(dst);
             o.edges.push_back(x);
         }
+        for (const GEdge& pe : pass_edges) outer.push_back(pe); // (their sources are outer expressions: rewritten below)
     }
     // outer edges: `sub.out` stands for the inner expression
     for (GEdge e : outer) {

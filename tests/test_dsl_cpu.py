@@ -313,3 +313,26 @@ def test_calls_on_a_connection_compile_in_every_kernel_shape():
         oscen_amd.unregister_graph_type("DxInnerFn")
         oscen_amd.unregister_function("half")
         oscen_amd.unregister_function("ms")
+
+
+def test_policy_fed_nested_input_read_inside_a_compound_expression():
+    """`[linear] a.output -> n.x` into an oversampled nested graph whose body reads `x` inside compound expressions
+    (`half(x) * 3.0 -> c.input`): the outer source is resampled ONCE into the inner input field -- a unit-gain node of the
+    nested rate -- and the expressions read the field: the same kernel as the hand-flattened graph"""
+    oscen_amd.register_function("half", ["x"], "return x * 0.5f;")
+    inner = oscen_amd.Graph(dsl="name: DxPInner; input x: stream; output y: stream; nodes { c = HardClip::new(); } "
+                                "connections { half(x) * 3.0 -> c.input; half(c.output).abs() + x * 0.1 -> y; }")
+    oscen_amd.register_graph_type("DxPInner", inner)
+    try:
+        nested = oscen_amd.Graph(dsl="""name: DxPO; input frequency: value = 220.0; output out: stream;
+            nodes { a = PolyBlepOscillator::saw(220.0, 0.5); n = DxPInner::new() * 2; }
+            connections { frequency -> a.frequency; [linear] a.output -> n.x; [sinc] n.y -> out; }""", per_voice=["frequency"])
+        flat = oscen_amd.Graph(dsl="""name: DxPO; input frequency: value = 220.0; output out: stream;
+            nodes { a = PolyBlepOscillator::saw(220.0, 0.5); n_c = HardClip::new() * 2; n_in__x = Gain::new(1.0) * 2; }
+            connections { frequency -> a.frequency; [linear] a.output -> n_in__x.input; half(n_in__x.output) * 3.0 -> n_c.input;
+                          [sinc] half(n_c.output).abs() + n_in__x.output * 0.1 -> out; }""", per_voice=["frequency"])
+        assert nested.kernel_source() == flat.kernel_source()
+        assert nested.jit_check() > 1000
+    finally:
+        oscen_amd.unregister_graph_type("DxPInner")
+        oscen_amd.unregister_function("half")
