@@ -3184,50 +3184,59 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
             if ((int)oi == bus_final_output) fail("graph output fed by the post-mix node cannot have other sources");
             ++n_stream;
-            std::string acc, acc_r;
-            bool stereo = false;
+            // a Frame<N> voice (N = 2..4): every channel summed over the voices, bus interleaved (BlockRender<Frame<N>>)
+            std::vector<std::string> acc; // one accumulated expression per channel
+            int width = 0;                // 1 = f32, N = Frame<N>
             for (size_t k = 0; k < it->second.size(); ++k) {
                 if (it->second.size() > 1 && !it->second[k].policy.empty())
                     fail("fan-in summing supports only same-rate sources (graph output)");
                 Val v = cg.cross(cg.eval(it->second[k].src), it->second[k].policy, false, false);
-                if (v.is_frame() && v.ch.size() != 2)
-                    fail("graph output '" + g.outputs[oi].name + "' is fed a Frame<" + std::to_string(v.ch.size()) +
-                         ">: the mix bus carries f32 or Frame<2> voices");
-                if (k > 0 && v.is_frame() != stereo) fail("graph output '" + g.outputs[oi].name + "' mixes f32 and Frame<2> sources");
-                stereo = v.is_frame();
-                if (stereo) { // a Frame<2> voice: both channels summed over the voices, bus interleaved (BlockRender<Frame<2>>)
+                const int w = v.is_frame() ? (int)v.ch.size() : 1;
+                if (w > 4) fail("graph output '" + g.outputs[oi].name + "' is fed a Frame<" + std::to_string(w) + ">: the mix bus carries f32 or Frame<2..4> voices");
+                if (k > 0 && w != width)
+                    fail("graph output '" + g.outputs[oi].name + "' mixes " + (width > 1 ? "Frame<" + std::to_string(width) + ">" : std::string("f32")) +
+                         " and " + (w > 1 ? "Frame<" + std::to_string(w) + ">" : std::string("f32")) + " sources");
+                width = w;
+                if (w > 1) {
                     if (out.lpv != 1 || out.bus_tremolo)
-                        fail("a Frame<2> graph output is not supported in array-valued or post-mix graphs yet");
-                    acc = (k == 0) ? v.ch[0].e : "(" + acc + " + " + v.ch[0].e + ")";
-                    acc_r = (k == 0) ? v.ch[1].e : "(" + acc_r + " + " + v.ch[1].e + ")";
+                        fail("a Frame<N> graph output is not supported in array-valued or post-mix graphs yet");
+                    if (k == 0) acc.assign((size_t)w, std::string());
+                    for (int c = 0; c < w; ++c) acc[(size_t)c] = (k == 0) ? v.ch[(size_t)c].e : "(" + acc[(size_t)c] + " + " + v.ch[(size_t)c].e + ")";
                     continue;
                 }
                 if (it->second.size() > 1 && v.inner) fail("fan-in summing supports only same-rate sources (graph output)");
-                acc = (k == 0) ? v.e : "(" + acc + " + " + v.e + ")";
+                if (k == 0) acc.assign(1, std::string());
+                acc[0] = (k == 0) ? v.e : "(" + acc[0] + " + " + v.e + ")";
             }
             const int declared = g.outputs[oi].channels; // `output out: stream: Frame<2>;` (0: not declared)
-            if (declared > 2) fail("graph output '" + g.outputs[oi].name + "': the mix bus carries f32 or Frame<2> voices");
-            if (declared && (declared == 2) != stereo)
-                fail("graph output '" + g.outputs[oi].name + "' is declared " + (declared == 2 ? "Frame<2>" : "f32") + " but fed " +
-                     (stereo ? "a Frame<2>" : "an f32 stream"));
+            if (declared > 4) fail("graph output '" + g.outputs[oi].name + "': the mix bus carries f32 or Frame<2..4> voices");
+            if (declared && declared != width)
+                fail("graph output '" + g.outputs[oi].name + "' is declared " + (declared > 1 ? "Frame<" + std::to_string(declared) + ">" : std::string("f32")) +
+                     " but fed " + (width > 1 ? "a Frame<" + std::to_string(width) + ">" : std::string("an f32 stream")));
             // every stream output is a named value of this frame: other outputs may read it (`out_a + out_b -> out`),
-            // and ALL of them go onto the mix bus, one channel (Frame<2>: two) each, in declaration order
+            // and ALL of them go onto the mix bus, one channel (Frame<N>: N) each, in declaration order
             const std::string var = "go" + std::to_string(oi);
+            auto chan_name = [&](int c) { // (Frame<2> keeps its _l / _r names: the text of existing kernels does not move)
+                return width == 2 ? var + (c == 0 ? "_l" : "_r") : var + "_c" + std::to_string(c);
+            };
             Val ov;
             ov.rate = Rate::Vary;
-            if (stereo) {
-                cg.os() << "        const float " << var << "_l = " << acc << ", " << var << "_r = " << acc_r << ";\n";
-                Val l, r;
-                l.rate = r.rate = Rate::Vary;
-                l.e = var + "_l";
-                r.e = var + "_r";
-                ov.ch = {l, r};
+            if (width > 1) {
+                cg.os() << "        const float ";
+                for (int c = 0; c < width; ++c) {
+                    cg.os() << (c ? ", " : "") << chan_name(c) << " = " << acc[(size_t)c];
+                    Val cv;
+                    cv.rate = Rate::Vary;
+                    cv.e = chan_name(c);
+                    ov.ch.push_back(cv);
+                }
+                cg.os() << ";\n";
             } else {
-                cg.os() << "        const float " << var << " = " << acc << ";\n";
+                cg.os() << "        const float " << var << " = " << acc[0] << ";\n";
                 ov.e = var;
             }
             cg.output_vals[g.outputs[oi].name] = ov;
-            formed[oi] = stereo ? 2 : 1;
+            formed[oi] = width;
         }
         // the bus: the formed stream outputs in DECLARATION order
         std::vector<std::string> chans;
@@ -3238,13 +3247,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (formed[oi] == 2) {
                 chans.push_back(var + "_l");
                 chans.push_back(var + "_r");
+            } else if (formed[oi] > 2) {
+                for (int c = 0; c < formed[oi]; ++c) chans.push_back(var + "_c" + std::to_string(c));
             } else {
                 chans.push_back(var);
             }
         }
         if (chans.size() > 1 && (out.lpv != 1 || out.bus_tremolo))
             fail("several bus channels (stream outputs / Frame<2>) are not supported in array-valued or post-mix graphs yet");
-        if (chans.size() > 4) fail("the mix bus carries at most 4 channels (stream outputs, Frame<2> counting two)");
+        if (chans.size() > 4) fail("the mix bus carries at most 4 channels (stream outputs, a Frame<N> counting N)");
         if (chans.size() == 1) {
             cg.os() << "        const float g_out = " << chans[0] << ";\n";
             bus_expr = "g_out";

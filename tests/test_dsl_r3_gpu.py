@@ -485,3 +485,36 @@ def test_event_handlers_see_the_frame_offset_of_the_event():
             assert np.array_equal(eng.read_state_field("caps[0].hits"), np.array([1, 1, 1, 1, 1], dtype=f32))
     finally:
         oscen_amd.unregister_node("R3OffCap::new")
+
+
+def test_frame3_and_frame4_graph_outputs():
+    """`output out: stream: Frame<4>` (oscen-lib/src/frame.rs: Quad): every channel of a Frame<N> voice output is summed over
+    the voices onto its own bus channel, N = 3 and 4 like N = 2"""
+    lib = ol.load()
+    for width in (3, 4):
+        nodes = " ".join("o%d = PolyBlepOscillator::saw(%.1f, 0.3);" % (i, 110.0 * (i + 1)) for i in range(width))
+        conns = " ".join("frequency * %d.0 -> o%d.frequency;" % (i + 1, i) for i in range(width))
+        chans = ", ".join("o%d.output" % i for i in range(width))
+        g = oscen_amd.Graph(dsl=f"""name: R3F{width}; input frequency: value = 110.0; output out: stream: Frame<{width}>;
+            nodes {{ {nodes} }} connections {{ {conns} Frame({chans}) * 0.5 -> out; }}""", per_voice=["frequency"])
+        n, frames = 67, 200
+        freqs = (50.0 + 3.0 * np.arange(n)).astype(f32)
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        eng.set_voice_values("frequency", freqs)
+        assert eng.channels == width and eng.output_channel("out") == (0, width)
+        eng.set_voice_taps([0, 33, 66])
+        bus = eng.process_block(frames)
+        taps = eng.read_voice_taps(frames)
+        assert bus.shape == (frames, width) and taps.shape == (3, frames, width)
+        want_bus = np.zeros((frames, width), dtype=np.float64)
+        for v in range(n):
+            for c in range(width):
+                o = polyblep(lib, f32(freqs[v]) * f32(c + 1), 0.3, ol.PB_SAW, SR)
+                col = np.zeros(frames, dtype=f32)
+                for i in range(frames):
+                    lib.oo_polyblep_process(C.byref(o))
+                    col[i] = f32(f32(o.output) * f32(0.5))
+                want_bus[:, c] += col
+                if v in (0, 33, 66):
+                    assert rel_err(taps[(0, 33, 66).index(v), :, c], col) <= 1e-5
+        assert np.max(np.abs(bus - want_bus)) <= 2e-6 * n

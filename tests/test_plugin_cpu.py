@@ -252,7 +252,7 @@ def test_frame_ports_lower_to_channel_values():
     bad(lambda h: (h.connect("w.output", "m.input"), h.connect("m.output", "out")), "takes an f32 stream")
     bad(lambda h: (h.connect("osc.output", "f.input"), h.connect("f.output", "n.input"), h.connect("n.output", "out")),
         "its source is an f32 stream")
-    bad(lambda h: (h.connect("w.output", "out"), h.connect("osc.output", "out")), "mixes f32 and Frame<2> sources")
+    bad(lambda h: (h.connect("w.output", "out"), h.connect("osc.output", "out")), "mixes Frame<2> and f32 sources")
     # a Frame<2> straight to the graph output: a stereo mix bus (two tiles, the ordinary kernel only)
     st = oscen_amd.Graph("st")
     st.output_stream("out")
