@@ -474,7 +474,7 @@ struct Codegen {
                                              // `steady` tick for a whole chunk of CHUNK frames (e.g. og::ep_amp_tick)
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
-        std::ostringstream s_pre, s_up, s_inner, s_cap, s_down, s_post;
+        std::ostringstream s_pre, s_up, s_inner, s_log, s_cap, s_down, s_post; // (s_log: graph event outputs of inner nodes, logged before s_cap clears them)
         std::map<int, std::ostringstream> ev_handlers; // per graph event input
     };
     Sect sec[16];
@@ -3169,9 +3169,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             auto eo = ev_out_edges.find((int)oi);
             if (eo == ev_out_edges.end()) continue; // declared, never fed: nothing ever arrives
             const NodeInst& src = cg.nodes[eo->second.first];
-            if (src.domain == 1) fail("event output '" + g.outputs[oi].name + "' is fed from an oversampled node (cross-rate event drains are not built)");
             const std::string q = "n" + std::to_string(src.id) + "_" + eo->second.second;
-            cg.frame_log << "        if (__any((int)(" << q << ".n != 0u))) og::ev_out_log(A, c, " << out.event_outputs.size() << "u, f, " << q << ");\n";
+            // an oversampled node's queue is cleared after every INNER tick: its events are logged there, all N ticks of
+            // outer frame f under frame f (the inner -> outer rescale of a cross-rate event edge, ir/lower.rs:846-852)
+            std::ostringstream& log = src.domain == 1 ? cg.sec[cg.stage_of.size() > (size_t)src.id ? cg.stage_of[src.id] : 0].s_log : cg.frame_log;
+            log << (src.domain == 1 ? "    " : "") << "        if (__any((int)(" << q << ".n != 0u))) og::ev_out_log(A, c, " << out.event_outputs.size() << "u, f, " << q << ");\n";
             out.event_outputs.push_back(g.outputs[oi].name);
         }
         std::vector<int> formed(g.outputs.size(), 0); // channels of every stream output that has sources
@@ -3281,7 +3283,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         t << S.s_pre.str() << S.s_up.str();
         if (cg.N > 1)
             t << "#pragma unroll\n        for (int j = 0; j < " << cg.N << "; ++j) { // oversampled inner loop\n"
-              << S.s_inner.str() << S.s_cap.str() << "        }\n";
+              << S.s_inner.str() << S.s_log.str() << S.s_cap.str() << "        }\n";
         t << S.s_down.str() << S.s_post.str();
         return t.str();
     };

@@ -328,3 +328,43 @@ def test_event_queue_capacity_up_to_the_reference_32(capacity):
     finally:
         oscen_amd.unregister_node("QBurst::new")
         oscen_amd.unregister_node("QSum::new")
+
+
+def test_event_output_of_an_oversampled_node():
+    """a `* 2` / `* 4` node pushing into a graph event output: its queue is cleared after every inner tick, so its events
+    are logged there -- every inner tick of outer frame f under frame f, in tick order (the inner -> outer rescale of a
+    cross-rate event edge, ir/lower.rs:846-852)"""
+    oscen_amd.register_node(
+        "OsBurst::new", inputs=[("period", "value", 10.0, 0)], outputs=["level"], n_ctor_args=1,
+        state=[("count", "u32", 0, -1), ("fired", "f32", 0.0, -1)], event_outputs=["tick"],
+        process="    count += 1u;\n    if ((float)count >= period) { count = 0u; fired += 1.0f; tick.push(fired); }\n    level = fired;\n")
+    try:
+        for factor in (2, 4):
+            g = oscen_amd.Graph(dsl=f"""name: OsEv; input period: value = 10.0; output out: stream; output ticks: event;
+                nodes {{ b = OsBurst::new(10.0) * {factor}; }}
+                connections {{ period -> b.period; [latch] b.level -> out; b.tick -> ticks; }}""", per_voice=["period"])
+            n, frames = 40, 300
+            periods = (1 + (np.arange(n) * 3) % 17).astype(np.float32)  # period 1: an event on EVERY inner tick
+            eng = oscen_amd.Engine(g, n, sample_rate=SR)
+            eng.set_voice_values("period", periods)
+            eng.process_block(frames)
+            ev, over = eng.read_output_events()
+            assert over == 0
+            want = []
+            for v in range(n):
+                count, fired = 0, 0.0
+                for f in range(frames):
+                    for _ in range(factor):
+                        count += 1
+                        if np.float32(count) >= periods[v]:
+                            count = 0
+                            fired += 1.0
+                            want.append((f, v, np.float32(fired)))
+            want.sort(key=lambda t: (t[0], t[1]))
+            assert len(ev) == len(want) > 2000
+            assert np.array_equal(ev["frame"], np.array([w[0] for w in want], dtype=np.uint64))
+            assert np.array_equal(ev["voice"], np.array([w[1] for w in want], dtype=np.uint32))
+            assert np.array_equal(ev["value"], np.array([w[2] for w in want], dtype=np.float32))
+            assert eng.events_dropped == 0
+    finally:
+        oscen_amd.unregister_node("OsBurst::new")
