@@ -155,10 +155,10 @@ struct og_midi {
         held_next.assign(n, NIL);
         note_pos.assign(n, 0);
         released.reserve(n);
-        // a note's heap holds what is held on that note; reserve the even share of the 128 notes a few times over (a
-        // bank that piles more than that on one note grows that heap, once)
-        const size_t share = std::min<size_t>(n, std::max<size_t>(1024, (size_t)n / 16));
-        for (auto& h : by_note) h.reserve(share);
+        // a note's heap holds what is held on that note; reserve four times the even share of the 128 MIDI notes (address
+        // space only until touched; a bank that piles more than that on one note grows that heap, once)
+        const size_t share = std::min<size_t>(n, std::max<size_t>(1024, (size_t)n / 32));
+        for (size_t k = 0; k < 128; ++k) by_note[k].reserve(share);
     }
     // `midi_in` is an ArrayVec<EventInstance, 32> (graph/types.rs:18) in front of MAX_VOICES = 24 voices; the capacity
     // is lifted with N in the same proportion (32 per 24 voices); og_midi_set_queue_capacity overrides it
