@@ -2736,7 +2736,113 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         return (it != cg.node_by_name.end() && g.nodes[it->second].bus) ? it->second : -1;
     };
     int bus_src_output = -1, bus_final_output = -1;
-    for (const GEdge& e : g.edges) {
+    // ---- endpoint kinds, as far as the reference's macro knows them (ir/lower.rs:233-338 infer_endpoint_types): typed
+    // graph inputs / outputs and stream-only policies seed kinds, connection statements propagate them both ways to a
+    // fixpoint; node-to-node endpoints nobody typed stay unknown.  Their one consequence (codegen/emit_node.rs:35-58
+    // classify_stream_fanin): SEVERAL edges into a destination known to be a VALUE are assigned one after the other --
+    // the last one wins -- while a stream or unknown destination gets their sum.
+    std::set<size_t> overwritten; // indices of g.edges a later edge into the same value destination replaces
+    {
+        enum K { Unknown = 0, Stream, Value, Event };
+        auto strip = [](std::string t) {
+            t.erase(std::remove_if(t.begin(), t.end(), [](char ch) { return isspace((unsigned char)ch); }), t.end());
+            return t;
+        };
+        std::map<std::string, K> known; // "node.port"
+        auto decl_kind = [](Kind k) { return k == Kind::Stream ? Stream : (k == Kind::Value ? Value : Event); };
+        std::function<K(const ExprP&)> kind_of = [&](const ExprP& e) -> K {
+            if (!e) return Unknown;
+            switch (e->t) {
+            case Expr::Num: return Value;
+            case Expr::Ref: {
+                if (e->port.empty()) {
+                    auto ii = cg.input_by_name.find(e->node);
+                    if (ii != cg.input_by_name.end()) return decl_kind(g.inputs[ii->second].kind);
+                    auto oi = cg.output_by_name.find(e->node);
+                    return oi != cg.output_by_name.end() ? decl_kind(g.outputs[oi->second].kind) : Unknown;
+                }
+                auto it = known.find(e->node + "." + e->port);
+                return it == known.end() ? Unknown : it->second;
+            }
+            case Expr::Chan:
+            case Expr::Neg: return kind_of(e->a);
+            case Expr::Bin: {
+                const K l = kind_of(e->a), r = kind_of(e->b);
+                if (l == Unknown || r == Unknown || l == Event || r == Event) return Unknown;
+                return (l == Stream || r == Stream) ? Stream : Value;
+            }
+            default: return Unknown; // calls and methods: no type inference for arbitrary functions
+            }
+        };
+        struct Stmt {
+            size_t idx;
+            ExprP src;
+            std::string dst, src_endpoint; // dst: "node.port" or an output name; src_endpoint: set when the source is a plain node endpoint
+            bool dst_is_node;
+        };
+        std::vector<Stmt> stmts;
+        for (size_t idx = 0; idx < g.edges.size(); ++idx) {
+            const GEdge& e = g.edges[idx];
+            if (bus_node_of(e.dst) >= 0 || bus_node_of(e.src) >= 0) continue;
+            Stmt st;
+            st.idx = idx;
+            try {
+                st.src = Parser(e.src).parse();
+            } catch (const std::exception&) {
+                continue; // (reported by the pass below)
+            }
+            st.dst = strip(e.dst);
+            st.dst_is_node = st.dst.find('.') != std::string::npos;
+            if (st.src->t == Expr::Ref && !st.src->port.empty()) st.src_endpoint = st.src->node + "." + st.src->port;
+            if (e.policy == "linear" || e.policy == "sinc" || e.policy == "sinc_iir") { // stream-only kernels: both ends are streams
+                if (st.dst_is_node) known.emplace(st.dst, Stream);
+                if (!st.src_endpoint.empty()) known.emplace(st.src_endpoint, Stream);
+            }
+            stmts.push_back(st);
+        }
+        for (size_t round = 0; round <= stmts.size(); ++round) {
+            bool changed = false;
+            for (const Stmt& st : stmts) {
+                const K sk = kind_of(st.src);
+                if (sk != Unknown && st.dst_is_node && !known.count(st.dst)) {
+                    known[st.dst] = sk;
+                    changed = true;
+                }
+                K dk = Unknown;
+                if (st.dst_is_node) {
+                    auto it = known.find(st.dst);
+                    dk = it == known.end() ? Unknown : it->second;
+                } else {
+                    auto oi = cg.output_by_name.find(st.dst);
+                    if (oi != cg.output_by_name.end()) dk = decl_kind(g.outputs[oi->second].kind);
+                }
+                if (dk != Unknown && !st.src_endpoint.empty() && !known.count(st.src_endpoint)) {
+                    known[st.src_endpoint] = dk;
+                    changed = true;
+                }
+            }
+            if (!changed) break;
+        }
+        std::map<std::string, std::vector<size_t>> by_dst;
+        for (const Stmt& st : stmts)
+            if (!g.edges[st.idx].feedback) by_dst[st.dst].push_back(st.idx);
+        for (const auto& kv : by_dst) {
+            if (kv.second.size() < 2) continue;
+            K dk = Unknown;
+            if (kv.first.find('.') != std::string::npos) {
+                auto it = known.find(kv.first);
+                dk = it == known.end() ? Unknown : it->second;
+            } else {
+                auto oi = cg.output_by_name.find(kv.first);
+                if (oi != cg.output_by_name.end()) dk = decl_kind(g.outputs[oi->second].kind);
+            }
+            if (dk == Value)
+                for (size_t k = 0; k + 1 < kv.second.size(); ++k) overwritten.insert(kv.second[k]);
+        }
+    }
+    for (size_t edge_index = 0; edge_index < g.edges.size(); ++edge_index) {
+        const GEdge& e = g.edges[edge_index];
+        if (overwritten.count(edge_index)) continue; // (a later edge into this value destination replaces it)
         // ---- post-mix (bus) stage: `voices.output -> tremolo.input; v -> tremolo.depth; tremolo.output -> out`
         const int bdst = bus_node_of(e.dst), bsrc = bus_node_of(e.src);
         if (bdst >= 0 || bsrc >= 0) {

@@ -336,3 +336,51 @@ def test_policy_fed_nested_input_read_inside_a_compound_expression():
     finally:
         oscen_amd.unregister_graph_type("DxPInner")
         oscen_amd.unregister_function("half")
+
+
+def test_several_edges_into_a_value_destination_follow_the_reference_kind_propagation():
+    """ir/lower.rs:233-338 + codegen/emit_node.rs:35-58: typed graph endpoints and stream-only policies seed endpoint kinds,
+    connection statements propagate them both ways; several edges into a destination KNOWN to be a value are assigned one
+    after the other (the last wins), several edges into a stream or an untyped destination are summed"""
+    head = "name: DxK; input cutoff: value = 900.0; input frequency: value = 220.0; output out: stream; "
+    nodes = "nodes { osc = PolyBlepOscillator::saw(220.0, 0.5); lfo = PolyBlepOscillator::sine(3.0, 200.0); f = TptFilter::new(1000.0, 0.7); } "
+
+    def src(conns):
+        g = oscen_amd.Graph(dsl=head + nodes + "connections { frequency -> osc.frequency; osc.output -> f.input; f.output -> out; " + conns + " }",
+                            per_voice=["frequency"])
+        return g.kernel_source()
+
+    only_lfo = src("lfo.output -> f.cutoff;")
+    only_cut = src("cutoff -> f.cutoff;")
+    summed = src("cutoff + lfo.output -> f.cutoff;")
+    assert len({only_lfo, only_cut, summed}) == 3
+    # `cutoff` is a typed value input: f.cutoff is a value endpoint, the later edge replaces the earlier one
+    assert src("cutoff -> f.cutoff; lfo.output -> f.cutoff;") == only_lfo
+    assert src("lfo.output -> f.cutoff; cutoff -> f.cutoff;") == only_cut
+    # a literal-scaled value input is still a value (Binary(Value, Value)); a call has no inferred kind, so nothing types
+    # the destination and the edges are summed
+    assert src("cutoff * 0.5 -> f.cutoff; lfo.output -> f.cutoff;") == only_lfo
+    # untyped node-to-node endpoints: the sum, in edge order
+    two = src("lfo.output -> f.cutoff; osc.output -> f.cutoff;")
+    assert "(n1_output + " in two or "+ n0_output" in two or " + " in two
+    assert two != only_lfo
+    # `osc.output -> out` types osc.output as a STREAM (out is a typed stream output), which types f.cutoff when osc feeds
+    # it first: a stream destination sums even when a value input joins later
+    def src2(conns):  # ... with osc.output also wired to a typed stream output
+        g = oscen_amd.Graph(dsl="name: DxK; input cutoff: value = 900.0; input frequency: value = 220.0; output out: stream; output raw: stream; "
+                                + nodes + "connections { frequency -> osc.frequency; osc.output -> f.input; f.output -> out; osc.output -> raw; "
+                                + conns + " }", per_voice=["frequency"])
+        return g.kernel_source()
+
+    assert src("osc.output -> f.cutoff; cutoff -> f.cutoff;") == only_cut          # osc.output untyped here: the value input wins
+    s1 = src2("osc.output -> f.cutoff; cutoff -> f.cutoff;")
+    assert s1 not in (src2("cutoff -> f.cutoff;"), src2("osc.output -> f.cutoff;"))  # typed stream: the sum
+    # a stream-only policy seeds the kind as well (both ends of a [linear] / [sinc] / [sinc_iir] edge are streams): c.output
+    # is a stream, so g.gain is a stream destination and `amount` joins the sum instead of replacing it
+    def src3(gain_conns):
+        g = oscen_amd.Graph(dsl="""name: DxK2; input amount: value = 0.5; output out: stream; output aux: stream;
+            nodes { a = PolyBlepOscillator::saw(220.0, 0.5) * 2; c = HardClip::new() * 2; g = Gain::new(1.0) * 2; }
+            connections { a.output -> c.input; [sinc] c.output -> aux; a.output -> g.input; [sinc] g.output -> out; """ + gain_conns + " }")
+        return g.kernel_source()
+
+    assert src3("c.output -> g.gain; amount -> g.gain;") == src3("c.output + amount -> g.gain;")
