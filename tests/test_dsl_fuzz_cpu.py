@@ -126,3 +126,56 @@ def test_random_bodies_lower_and_compile_or_are_rejected_with_a_diagnostic():
         oscen_amd.unregister_node("FzStereo::new")
         oscen_amd.unregister_function("fz::half")
         oscen_amd.unregister_function("swap2")
+
+
+def test_mutated_bodies_and_garbage_expressions_end_in_a_diagnostic():
+    """robustness of the front end: graph! bodies with random insertions / deletions / duplications / truncations and
+    connection sources made of random tokens either lower or raise OscenError -- no crash, no hang (a `graph!` body with a
+    mistake in it must come back as a message)"""
+    import random
+
+    rnd = random.Random(7)
+    seeds = [oscen_amd.Graph(builtin=b).to_dsl() for b in ("fm_voice", "sub_voice", "sat4x_voice", "echo_voice")]
+    seeds.append("""name: Wrap; input midi_in: event; input cutoff: value = 900.0 [ramp: 64]; output out: stream: Frame<2>;
+        nodes { p = MidiParser::new(); va = VoiceAllocator::<4>::new(); h = [MidiVoiceHandler::new(); 4]; voices = [FMVoice::new(); 4]; }
+        connections { midi_in -> p.midi_in; p.note_on -> va.note_on; p.note_off -> va.note_off; va.voices -> h.note_on; va.voices -> h.note_off;
+                      h.frequency -> voices.frequency; h.gate -> voices.gate; cutoff -> voices.filter_cutoff; voices.audio_out -> out; }""")
+    tokens = ["->", ";", "{", "}", "(", ")", "[", "]", "*", "+", "-", "/", ".", ",", "::", "<", ">", "=", "Frame", "0.5", "1e9", "nodes",
+              "connections", "input", "output", "stream", "value", "event", "sinc", "x", "a.output", "[a; 3]", "* 2", "::<2>", '"', "'", "\\", "\n"]
+    lowered = rejected = 0
+    for _ in range(400):
+        b = rnd.choice(seeds)
+        for _ in range(rnd.randint(1, 4)):
+            r, pos = rnd.random(), rnd.randint(0, len(b))
+            if r < 0.4:
+                b = b[:pos] + rnd.choice(tokens) + b[pos:]
+            elif r < 0.7:
+                b = b[:pos] + b[min(len(b), pos + rnd.randint(1, 12)):]
+            elif r < 0.85:
+                e = min(len(b), pos + rnd.randint(1, 30))
+                b = b[:pos] + b[pos:e] * 2 + b[e:]
+            else:
+                b = b[:pos]
+        try:
+            oscen_amd.Graph(dsl=b).kernel_source()
+            lowered += 1
+        except oscen_amd.OscenError:
+            rejected += 1
+    atoms = ["a.output", "b.output", "cutoff", "0.5", "2", "(", ")", "+", "-", "*", "/", ".", ",", "[0]", "[9]", "Frame", "Frame::<2>", "::", "half",
+             ".tanh()", ".clamp(0.0, 1.0)", ".max(", ".abs", "out0", " ", "nobody.output", "a.nothing", "a", "[", "]", "<", ">"]
+    for _ in range(600):
+        expr = "".join(rnd.choice(atoms) + rnd.choice(["", " "]) for _ in range(rnd.randint(1, 9)))
+        g = oscen_amd.Graph("ef")
+        g.input_value("cutoff", 900.0)
+        g.output_stream("out0")
+        g.output_stream("out1")
+        g.node("a", "PolyBlepOscillator::saw", 220.0, 0.5)
+        g.node("b", "PolyBlepOscillator::sine", 330.0, 0.5)
+        try:
+            g.connect("b.output", "out0")
+            g.connect(expr, "out1")
+            g.kernel_source()
+            lowered += 1
+        except oscen_amd.OscenError:
+            rejected += 1
+    assert lowered > 10 and rejected > 500, (lowered, rejected)
