@@ -208,7 +208,8 @@ def host_facts():
     return facts
 
 
-def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks=0):
+def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks=0, loaded_voices=(), loaded_blocks=0,
+                    loaded_paced=0):
     """The real-time entry, measured as a host would call it: one blocking og_midi_process_block per 256-frame block
     (the reference's audio callback: drain the MIDI queue, process_block, copy the bus out --
     examples/fm-synth/src/main.rs:148-215, 512-frame callback :273-277), one kernel launch per block, nothing
@@ -234,7 +235,8 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device,
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
-        rec = _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out)
+        rec = _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out,
+                               loaded_voices, loaded_blocks, loaded_paced)
         rec["harness"] = {"python_gc": "disabled while latencies are taken", "full_collection_ms": gc_ms,
                           "tracked_objects": len(gc.get_objects())}
         return rec
@@ -243,74 +245,161 @@ def realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device,
             gc.enable()
 
 
-def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out):
+def _mem_budget_bytes():
+    """Host memory this process may use for a resident score: a quarter of what the box / cgroup leaves."""
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+                break
+    except Exception:
+        pass
+    try:
+        m = open("/sys/fs/cgroup/memory.max").read().strip()
+        if m != "max":
+            lim = int(m)
+            try:
+                lim -= int(open("/sys/fs/cgroup/memory.current").read().strip())
+            except Exception:
+                pass
+            avail = lim if avail is None else min(avail, lim)
+    except Exception:
+        pass
+    return (avail if avail is not None else 64 << 30) // 4
+
+
+def _rt_bank(graph, V, block, n_blocks, paced_blocks, midi_per_block, device, deadline_ms, loaded, max_events):
+    """One bank of the real-time record.  loaded = the synthetic score of SURVEY 8(d) (every voice plays its cyclic 1 s
+    note plan: 3 gate events per voice per second) is resident in HBM for the whole run, ON TOP of the live MIDI."""
     import numpy as np
 
     import oscen_amd
 
-    for V in voices_list:
-        eng = oscen_amd.Engine(graph, V, device=device, sample_rate=48000.0)
-        plans = oscen_amd.note_plans(V)
+    warm = 50
+    note = None
+    if loaded:
+        # events the run needs: 3 per voice per 48 000 frames; a host-memory bound (~100 B per event while the timeline
+        # is built) shortens the run instead of risking the box
+        per_block = 3.0 * V * block / 48000.0
+        fit = int(max_events / per_block) - warm
+        if fit < n_blocks + paced_blocks:
+            scale = fit / float(n_blocks + paced_blocks)
+            n_blocks, paced_blocks = max(200, int(n_blocks * scale)), (max(100, int(paced_blocks * scale)) if paced_blocks else 0)
+            note = "run shortened to %d + %d blocks: the resident score is bounded to %.0f M events by host memory" % (n_blocks, paced_blocks, max_events / 1e6)
+    eng = oscen_amd.Engine(graph, V, device=device, sample_rate=48000.0)
+    plans = oscen_amd.note_plans(V)
+    n_resident = 0
+    t_score = time.perf_counter()
+    if loaded:
+        total_frames = (warm + n_blocks + paced_blocks + 2) * block
+        ev_v, ev_f0, ev_x = plans["events"]
+        reps = -(-total_frames // 48000)
+        plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
+        # a live message re-writes its voice's remaining score as a fresh segment behind the score (og_reserve_events):
+        # midi_per_block voices per block, half the run's events per voice on average, twice over for margin
+        per_voice = 3.0 * total_frames / 48000.0
+        eng.reserve_events(int(midi_per_block * (warm + n_blocks + paced_blocks) * per_voice) + (1 << 20))
+        n_resident = oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+        plans["events"] = None
+    else:
         eng.set_voice_values("frequency", plans["frequency"])
-        midi = oscen_amd.Midi(eng)
-        midi.set_queue_capacity(max(32, midi_per_block))
-        rng = np.random.default_rng(0x05CE2026)
-        n_pat = 64  # message patterns built once: the loop pays for the engine's live path, not for numpy
-        notes = rng.integers(36, 97, size=(n_pat, midi_per_block)).astype(np.uint8)
-        frames = np.sort(rng.integers(0, block, size=(n_pat, midi_per_block)), axis=1).astype(np.uint32)
-        packed = [midi.pack_messages(notes[i - (i % 2)], frames[i], on=(i % 2 == 0)) for i in range(n_pat)]
-        warm = 50
-        lat = np.empty(n_blocks, dtype=np.float64)
-        peak = 0.0
-        for i in range(warm + n_blocks):
+    midi = oscen_amd.Midi(eng)
+    midi.set_queue_capacity(max(32, midi_per_block))
+    rng = np.random.default_rng(0x05CE2026)
+    n_pat = 64  # message patterns built once: the loop pays for the engine's live path, not for numpy
+    notes = rng.integers(36, 97, size=(n_pat, midi_per_block)).astype(np.uint8)
+    frames = np.sort(rng.integers(0, block, size=(n_pat, midi_per_block)), axis=1).astype(np.uint32)
+    packed = [midi.pack_messages(notes[i - (i % 2)], frames[i], on=(i % 2 == 0)) for i in range(n_pat)]
+    lat = np.empty(n_blocks, dtype=np.float64)
+    peak = 0.0
+    first_ms = None
+    for i in range(warm + n_blocks):
+        t0 = time.perf_counter()
+        if midi_per_block:
+            midi.send_packed(packed[i % n_pat])
+        bus = midi.process_block(block)
+        t1 = time.perf_counter()
+        if i == 0:
+            first_ms = (t1 - t0) * 1e3  # (a resident score goes to the device with the first block: warm-up, not timed)
+            t_score = t1 - t_score
+        if i >= warm:
+            lat[i - warm] = t1 - t0
+            peak = max(peak, float(np.abs(bus).max()))
+    calls, timeouts = eng.blocking_stats
+    lat_ms = lat * 1e3
+    worst = np.argsort(lat_ms)[-5:][::-1]
+    rec = {
+        "voices": V,
+        "blocks": n_blocks,
+        "midi_messages_per_block": midi_per_block,
+        "resident_score_events": n_resident,
+        "latency_ms": {"p50": float(np.percentile(lat_ms, 50)), "p99": float(np.percentile(lat_ms, 99)),
+                       "p999": float(np.percentile(lat_ms, 99.9)), "max": float(lat_ms.max()), "mean": float(lat_ms.mean())},
+        "deadline_ms": deadline_ms,
+        "deadline_misses": int(np.count_nonzero(lat_ms > deadline_ms)),
+        "value_blocking": V * block / float(lat.mean()),
+        "marker_timeouts": timeouts,
+        "worst_blocks": [[int(i), float(lat_ms[i])] for i in worst],
+        "event_stats": eng.event_stats,
+        "bus_peak": peak,
+        "kernel_variant": eng.kernel_variant,
+        "first_block_ms": first_ms,
+        "setup_s": t_score,
+    }
+    if note:
+        rec["note"] = note
+    if paced_blocks:
+        # the same entry called when a sound card would call it: once per block PERIOD (the loop above calls back
+        # to back, i.e. holds the GPU at full load; here it idles between blocks and the clocks follow)
+        plat = np.empty(paced_blocks, dtype=np.float64)
+        t_next = time.perf_counter()
+        for i in range(paced_blocks):
+            t_next += deadline_ms * 1e-3
+            while time.perf_counter() < t_next:
+                pass
             t0 = time.perf_counter()
             if midi_per_block:
                 midi.send_packed(packed[i % n_pat])
-            bus = midi.process_block(block)
-            t1 = time.perf_counter()
-            if i >= warm:
-                lat[i - warm] = t1 - t0
-                peak = max(peak, float(np.abs(bus).max()))
-        calls, timeouts = eng.blocking_stats
-        lat_ms = lat * 1e3
-        worst = np.argsort(lat_ms)[-5:][::-1]
-        rec = {
-            "voices": V,
-            "blocks": n_blocks,
-            "midi_messages_per_block": midi_per_block,
-            "latency_ms": {"p50": float(np.percentile(lat_ms, 50)), "p99": float(np.percentile(lat_ms, 99)),
-                           "p999": float(np.percentile(lat_ms, 99.9)), "max": float(lat_ms.max()), "mean": float(lat_ms.mean())},
-            "deadline_ms": deadline_ms,
-            "deadline_misses": int(np.count_nonzero(lat_ms > deadline_ms)),
-            "value_blocking": V * block / float(lat.mean()),
-            "marker_timeouts": timeouts,
-            "worst_blocks": [[int(i), float(lat_ms[i])] for i in worst],
-            "event_stats": eng.event_stats,
-            "bus_peak": peak,
-            "kernel_variant": eng.kernel_variant,
-        }
-        if paced_blocks and V == max(voices_list):
-            # the same entry called when a sound card would call it: once per block PERIOD (the loop above calls back
-            # to back, i.e. holds the GPU at full load; here it idles between blocks and the clocks follow)
-            plat = np.empty(paced_blocks, dtype=np.float64)
-            t_next = time.perf_counter()
-            for i in range(paced_blocks):
-                t_next += deadline_ms * 1e-3
-                while time.perf_counter() < t_next:
-                    pass
-                t0 = time.perf_counter()
-                if midi_per_block:
-                    midi.send_packed(packed[i % n_pat])
-                midi.process_block(block)
-                plat[i] = time.perf_counter() - t0
-            plat *= 1e3
-            rec["paced"] = {"blocks": paced_blocks, "period_ms": deadline_ms,
-                            "latency_ms": {"p50": float(np.percentile(plat, 50)), "p99": float(np.percentile(plat, 99)),
-                                           "p999": float(np.percentile(plat, 99.9)), "max": float(plat.max()), "mean": float(plat.mean())},
-                            "deadline_misses": int(np.count_nonzero(plat > deadline_ms))}
-        out.append(rec)
-        del midi
-        eng.close()
+            midi.process_block(block)
+            plat[i] = time.perf_counter() - t0
+        plat *= 1e3
+        rec["paced"] = {"blocks": paced_blocks, "period_ms": deadline_ms,
+                        "latency_ms": {"p50": float(np.percentile(plat, 50)), "p99": float(np.percentile(plat, 99)),
+                                       "p999": float(np.percentile(plat, 99.9)), "max": float(plat.max()), "mean": float(plat.mean())},
+                        "deadline_misses": int(np.count_nonzero(plat > deadline_ms))}
+    del midi
+    eng.close()
+    return rec
+
+
+def _rt_ok(r):
+    return r["deadline_misses"] == 0 and r.get("paced", {}).get("deadline_misses", 0) == 0 and r["bus_peak"] > 0.0
+
+
+def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device, paced_blocks, deadline_ms, out,
+                     loaded_voices=(), loaded_blocks=0, loaded_paced=0):
+    import numpy as np
+
+    import oscen_amd
+
+    for V in voices_list:  # the idle bank: live MIDI only (at most a few 10^4 of the voices sound)
+        out.append(_rt_bank(graph, V, block, n_blocks, paced_blocks if V == max(voices_list) else 0, midi_per_block, device,
+                            deadline_ms, False, 0))
+    # the LOADED bank: every voice plays the synthetic score the throughput lines use, plus the live messages
+    loaded = []
+    max_events = min(150e6, _mem_budget_bytes() / 100.0)
+    for V in loaded_voices:
+        loaded.append(_rt_bank(graph, V, block, loaded_blocks, 0, midi_per_block, device, deadline_ms, True, max_events))
+    paced_rec = None
+    ok_loaded = [r for r in loaded if _rt_ok(r)]
+    if ok_loaded and loaded_paced:  # the largest bank that met every deadline back to back, now called once per block period
+        Vp = max(r["voices"] for r in ok_loaded)
+        pr = _rt_bank(graph, Vp, block, 200, loaded_paced, midi_per_block, device, deadline_ms, True, max_events)
+        paced_rec = {"voices": Vp, "note": pr.get("note"), "resident_score_events": pr["resident_score_events"], **pr["paced"]}
+        for r in loaded:
+            if r["voices"] == Vp:
+                r["paced"] = pr["paced"]
     # the multi-GPU real-time entry (og_midi_process_block over og_cluster_process_block): what can be measured on one
     # GPU is its HOST side -- one thread per shard, cross-stream events, the per-device accumulation, the pinned
     # hand-over -- with both shards on this device (no RCCL leg: a communicator needs distinct devices)
@@ -348,19 +437,27 @@ def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device
         cl.close()
     except Exception as e:  # (never fail the bench line over the side record)
         cluster_rec = {"error": str(e)[:200]}
-    ok = [r for r in out if r["deadline_misses"] == 0 and r.get("paced", {}).get("deadline_misses", 0) == 0 and r["bus_peak"] > 0.0]
+    ok = [r for r in out if _rt_ok(r)]
+    ok_loaded = [r for r in loaded if _rt_ok(r)]
+    best = max(ok_loaded, key=lambda r: r["voices"]) if ok_loaded else None
     return {
         "cluster_entry_host_side": cluster_rec,
         "entry": "og_midi_send_batch + og_midi_process_block (blocking: bus in host memory when the call returns), "
                  "one launch per block, default batching",
         "block": block,
+        # every voice playing the resident synthetic score (3 gate events per voice per second) + the live messages
+        "loaded": {"runs": loaded, "paced": paced_rec,
+                   "score": "oscen_amd.note_plans: the 1 s plan of every voice, cyclic, resident in HBM (schedule_note_plans)"},
+        # live MIDI only: at most a few 10^4 voices sound, the rest take the cheapest chunk variant
+        "idle_bank": {"runs": out,
+                      "realtime_voices_at_48k": max([r["voices"] for r in ok]) if ok else 0},
         "runs": out,
-        # the largest bank measured here whose EVERY block met the deadline (not an extrapolation)
-        "realtime_voices_at_48k": max([r["voices"] for r in ok]) if ok else 0,
-        # p99-latency-scaled estimate from the largest such bank (how many voices would still fit the deadline if the
-        # block time scaled linearly): an upper bound, not a measurement
-        "realtime_voices_at_48k_extrapolated": (max(ok, key=lambda r: r["voices"])["voices"] * deadline_ms /
-                                                max(ok, key=lambda r: r["voices"])["latency_ms"]["p99"]) if ok else 0,
+        # the largest LOADED bank measured here whose EVERY block met the deadline (not an extrapolation)
+        "realtime_voices_at_48k": best["voices"] if best else 0,
+        "realtime_voices_at_48k_is": "loaded bank (resident score on every voice + live MIDI), back to back and paced",
+        # p99-latency-scaled estimate from that bank (how many voices would still fit the deadline if the block time
+        # scaled linearly): an upper bound, not a measurement
+        "realtime_voices_at_48k_extrapolated": (best["voices"] * deadline_ms / best["latency_ms"]["p99"]) if best else 0,
     }
 
 
@@ -586,6 +683,11 @@ def main():
     ap.add_argument("--rt-voices", default="65536,131072,1048576,4194304,8388608",
                     help="bank sizes of the real-time record (comma separated)")
     ap.add_argument("--rt-midi", type=int, default=1000, help="live MIDI messages per block in the real-time record")
+    ap.add_argument("--rt-loaded-voices", default="1048576,4194304,6291456,8388608",
+                    help="bank sizes of the LOADED real-time record: the synthetic score resident on every voice + the live "
+                         "messages (empty: skip)")
+    ap.add_argument("--rt-loaded-blocks", type=int, default=2000, help="back-to-back blocks per loaded bank")
+    ap.add_argument("--rt-loaded-paced-blocks", type=int, default=1500, help="paced blocks on the largest loaded bank that met every deadline")
     ap.add_argument("--cluster", action="store_true",
                     help="multi-GPU through the C-ABI cluster (og_cluster_*, one process) instead of one rank per GPU; "
                          "with --gpus 1 the plain engine path runs (identical to the default)")
@@ -615,7 +717,9 @@ def main():
         # the bench process torch is loaded: its heap makes a collector pass cost 20-40 ms, and the pageable transfers
         # torch made for the timed regions leave pinned host mappings behind whose later release stalls the GPU queues.)
         rt_voices = [int(x) for x in args.rt_voices.split(",") if x.strip()]
-        rec = realtime_record(args.graph, args.block, rt_voices, args.rt_blocks, args.rt_midi, 0, args.rt_paced_blocks)
+        ld_voices = [int(x) for x in args.rt_loaded_voices.split(",") if x.strip()]
+        rec = realtime_record(args.graph, args.block, rt_voices, args.rt_blocks, args.rt_midi, 0, args.rt_paced_blocks,
+                              ld_voices, args.rt_loaded_blocks, args.rt_loaded_paced_blocks)
         sys.stdout.flush()
         print("REALTIME_RECORD " + json.dumps(rec))
         return 0
@@ -845,9 +949,10 @@ def main():
             env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "").split(",")[local_rank] if env.get("HIP_VISIBLE_DEVICES") else str(local_rank)
             cmd = [sys.executable, os.path.abspath(__file__), "--realtime-child", "--graph", args.graph, "--block", str(block),
                    "--rt-voices", args.rt_voices, "--rt-blocks", str(args.rt_blocks), "--rt-midi", str(args.rt_midi),
-                   "--rt-paced-blocks", str(args.rt_paced_blocks)]
+                   "--rt-paced-blocks", str(args.rt_paced_blocks), "--rt-loaded-voices", args.rt_loaded_voices,
+                   "--rt-loaded-blocks", str(args.rt_loaded_blocks), "--rt-loaded-paced-blocks", str(args.rt_loaded_paced_blocks)]
             try:
-                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
                 rec = [ln for ln in out.stdout.splitlines() if ln.startswith("REALTIME_RECORD ")]
                 if out.returncode != 0 or not rec:
                     raise RuntimeError("child exited with %d: %s" % (out.returncode, out.stderr[-400:]))
@@ -855,7 +960,9 @@ def main():
                 line["realtime"]["process"] = "a child process of bench.py (numpy + the engine; torch is not loaded there)"
             except Exception as e:  # (fall back to measuring in this process rather than losing the record)
                 rt_voices = [int(x) for x in args.rt_voices.split(",") if x.strip()]
-                line["realtime"] = realtime_record(args.graph, block, rt_voices, args.rt_blocks, args.rt_midi, local_rank, args.rt_paced_blocks)
+                ld_voices = [int(x) for x in args.rt_loaded_voices.split(",") if x.strip()]
+                line["realtime"] = realtime_record(args.graph, block, rt_voices, args.rt_blocks, args.rt_midi, local_rank, args.rt_paced_blocks,
+                                                   ld_voices, args.rt_loaded_blocks, args.rt_loaded_paced_blocks)
                 line["realtime"]["process"] = "bench.py itself (the child process failed: %s)" % str(e)[:200]
             line["realtime_voices_at_48k"] = line["realtime"]["realtime_voices_at_48k"]
         else:

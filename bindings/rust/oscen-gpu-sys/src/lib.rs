@@ -128,6 +128,8 @@ extern "C" {
                                   out: *mut *mut og_midi) -> c_int;
     pub fn og_blocking_stats(e: *const og_engine, calls: *mut u64, marker_timeouts: *mut u64) -> c_int;
     pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
+    pub fn og_reserve_events(e: *mut og_engine, n_events: u64) -> c_int;
+    pub fn og_sync_event_counters(e: *mut og_engine) -> c_int;
 }
 
 // ---- round 3 (late): named functions on a connection, Frame<N> stream inputs ----

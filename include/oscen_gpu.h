@@ -32,6 +32,7 @@ extern "C" {
 #define OG_E_DEVICE (-3)      /* HIP error or no device                 */
 #define OG_E_STATE (-4)       /* call order (e.g. process before init)  */
 #define OG_E_OVERFLOW (-5)    /* event queue capacity (event dropped)   */
+#define OG_E_NOMEM (-6)       /* host allocation failed                 */
 
 #define OG_MAX_BLOCK_SIZE 512u /* MAX_BLOCK_SIZE, oscen-lib/src/graph/types.rs:12 */
 #define OG_MAX_EVENTS_PER_BLOCK 32u /* per voice per endpoint per block, types.rs:18 */
@@ -329,15 +330,21 @@ int og_uses_split_kernel(const og_engine* e); /* pipeline depth of the launched 
                                                  2 or 4 = that many waves per 64 voices (small banks) */
 uint32_t og_voices_per_wave(const og_engine* e); /* 64, or 32/16 when that puts two waves on every SIMD */
 /* events that were never delivered: try_push overflows and late block-local events (host side) + pushes the in-voice
- * event queues of user nodes could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output; counted on the device) */
+ * event queues of user nodes could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output; counted on the device).
+ * A pure getter (safe to poll from a monitoring thread): the device-side count is what og_sync_event_counters(),
+ * og_synchronize() or og_read_output_events() -- called by the rendering thread -- last folded in. */
 uint64_t og_events_dropped(const og_engine* e);
+/* launches the queued blocks, synchronises the stream and folds the device-side "pushes lost" counter into
+ * og_events_dropped(); a no-op for graphs without in-voice event queues.  Errors are reported, not swallowed. */
+int og_sync_event_counters(og_engine* e);
 
 /* ---- event OUTPUTS of the graph (`output x: event;` fed by a node's #[output(event)] field: EventOutput,
  * oscen-lib/src/graph/types.rs:137-241; in the reference the caller iterates `graph.x` after process_block).
  * With N voices the events of all voices go to one device log; og_read_output_events moves what has arrived since the
  * last call to the host, ordered by (frame, voice, push order).  `frame` is absolute (frames since og_init):
  * frame_offset within the last block = frame - (og_frames_processed() - frames of that block).  The log holds
- * max(65 536, 4 x voices) events between two reads; what does not fit is counted in *n_overflowed. */
+ * max(65 536, 4 x voices) events between two reads; what does not fit THE LOG is counted in *n_overflowed.  Events that
+ * were drained from the log but did not fit `buf` stay queued on the host and come first in the next call. */
 typedef struct {
     uint32_t voice;
     uint32_t output; /* og_event_output_index */
@@ -361,6 +368,13 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 /* times the live path's append pointer wrapped around the device event buffer (a ring: the space of consumed /
  * superseded segments is reused, so steady live playing never needs the O(V) timeline rebuild) */
 uint64_t og_event_ring_wraps(const og_engine* e);
+/* room, in events, the device timeline keeps BEHIND a bulk score for live pushes (default: half the score + 2 M).
+ * A live push re-writes the touched voice's remaining events as a fresh segment at the tail; a voice that still has a
+ * long resident score ahead of it costs that many events per push, and once the tail meets the (still live) score the
+ * timeline is rebuilt -- O(score), a missed audio deadline.  A host that plays live on top of a long resident score
+ * sizes the room once, before the score goes to the device.  No counterpart in the reference (its queues are the
+ * fixed 32-deep ArrayVecs of graph/types.rs:18; the score there is the caller's own loop). */
+int og_reserve_events(og_engine* e, uint64_t n_events);
 /* the blocking entry (og_process_block / og_midi_process_block): calls that waited on the completion word, and how
  * many of those waits ended because the stream was found finished (hipStreamQuery, asked every 128 us from 256 us on)
  * before the completion word was seen -- 0 in the ordinary case */

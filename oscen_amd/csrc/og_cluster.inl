@@ -140,6 +140,7 @@ constexpr uint32_t CL_BATCH_BLOCKS = 256; // blocks per reduce
 
 struct og_cluster {
     std::vector<og_engine*> shard;
+    std::vector<og_out_event> out_ev_carry, out_ev_scratch; // og_cluster_read_output_events: queue (global voice ids) / per-shard scratch
     std::vector<uint64_t> lo; // first global voice of every shard; lo[n] = total
     std::vector<int> devs;    // distinct devices, devs[0] = root
     std::vector<int> dev_of_shard;
@@ -525,41 +526,53 @@ og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice)
 // merged into (frame, GLOBAL voice, push order) -- what one engine of that size would hand over.
 int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n_out, uint64_t* n_overflowed)
 {
+    return ogabi::guard([&]() -> int {
     if (!c || (cap && !buf) || !n_out) return set_err(OG_E_INVALID, "null argument");
     *n_out = 0;
     if (n_overflowed) *n_overflowed = 0;
     if (c->total > 0xFFFFFFFFull) return set_err(OG_E_UNSUPPORTED, "event outputs carry 32-bit voice ids");
-    std::vector<og_out_event> all;
+    // drain every shard's queue through one persistent scratch buffer into the cluster's own queue (global voice ids);
+    // what the caller's buffer cannot take stays queued for the next call
+    std::vector<og_out_event>& all = c->out_ev_carry;
+    const size_t old = all.size();
     uint64_t over = 0;
+    if (c->out_ev_scratch.empty()) c->out_ev_scratch.resize(65536);
     for (size_t s = 0; s < c->shard.size(); ++s) {
         og_engine* e = c->shard[s];
         if (!e->d_out_ev) continue;
-        std::vector<og_out_event> part(e->out_ev_cap);
         uint32_t n = 0;
-        uint64_t o = 0;
-        const int rc = og_read_output_events(e, part.data(), (uint32_t)part.size(), &n, &o);
-        if (rc != OG_OK) return rc;
-        over += o;
-        for (uint32_t i = 0; i < n; ++i) {
-            part[i].voice += (uint32_t)c->lo[s];
-            all.push_back(part[i]);
-        }
+        do {
+            uint64_t o = 0;
+            const int rc = og_read_output_events(e, c->out_ev_scratch.data(), (uint32_t)c->out_ev_scratch.size(), &n, &o);
+            if (rc != OG_OK) return rc;
+            over += o;
+            for (uint32_t i = 0; i < n; ++i) {
+                og_out_event x = c->out_ev_scratch[i];
+                x.voice += (uint32_t)c->lo[s];
+                all.push_back(x);
+            }
+        } while (n == c->out_ev_scratch.size());
     }
-    std::stable_sort(all.begin(), all.end(), [](const og_out_event& a, const og_out_event& b) {
+    std::stable_sort(all.begin() + (ptrdiff_t)old, all.end(), [](const og_out_event& a, const og_out_event& b) {
         if (a.frame != b.frame) return a.frame < b.frame;
         return a.voice < b.voice; // (a voice's events of one frame stay in push order: each shard's list is sorted)
     });
     const size_t give = std::min<size_t>(all.size(), cap);
     for (size_t i = 0; i < give; ++i) buf[i] = all[i];
+    all.erase(all.begin(), all.begin() + (ptrdiff_t)give);
     *n_out = (uint32_t)give;
-    if (n_overflowed) *n_overflowed = over + (all.size() - give);
+    if (n_overflowed) *n_overflowed = over; // (only what a shard's device log could not hold)
     return OG_OK;
+    });
 }
 
 uint64_t og_cluster_events_dropped(og_cluster* c)
 {
     uint64_t d = 0;
-    for (size_t s = 0; c && s < c->shard.size(); ++s) d += og_events_dropped(c->shard[s]);
+    for (size_t s = 0; c && s < c->shard.size(); ++s) {
+        (void)og_sync_event_counters(c->shard[s]); // (the caller is the rendering thread: og_cluster* is not const here)
+        d += og_events_dropped(c->shard[s]);
+    }
     return d;
 }
 
@@ -579,6 +592,7 @@ int og_cluster_set_value_immediate(og_cluster* c, uint32_t input, float v) { OG_
 
 int og_cluster_set_voice_values(og_cluster* c, uint32_t input, uint64_t first_voice, uint64_t count, const float* v)
 {
+    return ogabi::guard([&]() -> int {
     if (!c || !v) return set_err(OG_E_INVALID, "null argument");
     if (first_voice + count > c->total) return set_err(OG_E_INVALID, "voice range out of bounds");
     for (size_t s = 0; s < c->shard.size(); ++s) {
@@ -588,6 +602,7 @@ int og_cluster_set_voice_values(og_cluster* c, uint32_t input, uint64_t first_vo
         if (rc != OG_OK) return rc;
     }
     return OG_OK;
+    });
 }
 
 int og_cluster_push_voice_event(og_cluster* c, uint32_t input, uint64_t voice, uint32_t frame_offset, float scalar)
@@ -609,6 +624,7 @@ int og_cluster_push_voice_value(og_cluster* c, uint32_t input, uint64_t voice, u
 int og_cluster_schedule_voice_events(og_cluster* c, uint32_t input, uint64_t n, const uint64_t* voices, const uint64_t* abs_frames,
                                      const float* values)
 {
+    return ogabi::guard([&]() -> int {
     if (!c || (n && (!voices || !abs_frames || !values))) return set_err(OG_E_INVALID, "null argument");
     std::vector<std::vector<uint32_t>> lv(c->shard.size());
     std::vector<std::vector<uint64_t>> lf(c->shard.size());
@@ -626,6 +642,7 @@ int og_cluster_schedule_voice_events(og_cluster* c, uint32_t input, uint64_t n, 
         if (rc != OG_OK) return rc;
     }
     return OG_OK;
+    });
 }
 
 int og_cluster_render(og_cluster* c, uint64_t total_frames, uint32_t block, float* out_bus)

@@ -27,6 +27,7 @@
 namespace ogc {
 namespace {
 
+[[noreturn]] void dfail_unsupported(const std::string& m, size_t line) { throw ogabi::Unsupported("oscen graph dsl: line " + std::to_string(line) + ": " + m); }
 [[noreturn]] void dfail(const std::string& m, size_t line) { throw std::runtime_error("oscen graph dsl: line " + std::to_string(line) + ": " + m); }
 
 struct Lexer {
@@ -348,7 +349,7 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
     if (lx.eat('*')) {
         n.rate_factor = (uint32_t)lx.number();
     } else if (lx.peek() == '/') {
-        dfail("node undersampling (`/ N`) is not supported (neither is it by the reference v1)", lx.line);
+        dfail_unsupported("node undersampling (`/ N`) is not supported (neither is it by the reference v1)", lx.line);
     }
     lx.expect(';');
     g.nodes.push_back(n);
@@ -458,7 +459,7 @@ GraphDesc parse_dsl(const std::string& text, const std::vector<std::string>& per
                 parse_connection(lx, g);
             }
         } else if (lx.peek_ident("external")) {
-            dfail("`external` asset handles are not supported", lx.line);
+            dfail_unsupported("`external` asset handles are not supported", lx.line);
         } else {
             dfail("unexpected token '" + std::string(1, lx.peek()) + "'", lx.line);
         }

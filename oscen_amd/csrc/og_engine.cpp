@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/oscen_gpu.h"
+#include "og_abi.h"
 #include "og_graph.h"
 #include "og_jit.h"
 #include "og_math.h"
@@ -149,17 +150,25 @@ OgLaunchFn og_find_kernel(uint64_t hash)
 }
 
 namespace {
-
 thread_local std::string g_err;
-int set_err(int code, const std::string& m)
+}
+namespace ogabi {
+int set_error(int code, const std::string& m)
 {
-    g_err = m;
+    try {
+        g_err = m;
+    } catch (...) { // (out of memory while recording the message: keep the code)
+        g_err.clear();
+    }
     return code;
 }
+} // namespace ogabi
 
-struct HipError : std::runtime_error {
-    using std::runtime_error::runtime_error;
-};
+namespace {
+
+int set_err(int code, const std::string& m) { return ogabi::set_error(code, m); }
+
+using HipError = ogabi::DeviceError;
 #define HIPCK(expr)                                                                                    \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -364,6 +373,8 @@ struct og_engine {
     float* d_bus_phase = nullptr; // Tremolo.phase
     OgEvent* d_events = nullptr;
     size_t ev_cap = 0;
+    size_t ev_headroom_env = 0; // OSCEN_GPU_EV_HEADROOM at og_create (0 = unset)
+    size_t ev_reserve = 0; // og_reserve_events: room kept behind a bulk score for live segments
     uint32_t* d_ev_end = nullptr;
     uint32_t* d_ev_cursor = nullptr;
     float* d_partials = nullptr;
@@ -397,6 +408,7 @@ struct og_engine {
     uint32_t out_ev_cap = 0;
     uint64_t out_ev_overflow = 0;       // events that did not fit the log (reported by og_read_output_events)
     uint64_t ev_lost_total = 0;         // in-voice pushes lost, read back so far
+    std::vector<OgOutEvent> out_ev_carry; // og_read_output_events: drained from the device log, not yet handed out
     float* d_taps = nullptr;
     int32_t* d_tap_slot = nullptr;
     uint32_t n_taps = 0;
@@ -454,6 +466,7 @@ struct og_engine {
         return ev_tail + n < head ? ev_tail : SIZE_MAX; // wrapped: the tail runs up to the head
     }
     bool ev_rebuild = false;             // next block must rebuild the whole timeline
+    void sync_lost_counter(); // device "lost pushes" counter -> ev_lost_total (synchronises the stream)
     OgEvent* h_stage_ev[EV_RING] = {};   // pinned
     uint32_t* h_stage_upd[EV_RING] = {}; // pinned, n x {voice, cursor, end}
     uint32_t* d_stage_upd[EV_RING] = {};
@@ -462,6 +475,7 @@ struct og_engine {
     bool batch_staged = false;                 // the batch being assembled reads a host staging buffer
     volatile uint64_t* h_progress = nullptr;  // pinned: number of the last batch the stream has finished (og_stream_mark)
     float* h_bus_pinned = nullptr; // pinned + device-visible: destination of a blocking block's bus (og_process_block)
+    bool blocking_memcpy = false; // OSCEN_GPU_BLOCKING_MEMCPY (A/B knob), read once at og_create
     uint64_t blocking_waits = 0, blocking_timeouts = 0; // og_process_block calls / calls whose marker wait timed out
     bool wait_progress(uint64_t seq) // false: the stream was found finished before the marker was seen
     {
@@ -690,12 +704,12 @@ struct og_engine {
         }
         const size_t n = evs.size();
         if (n > 0xFFFFFFF0ull) throw std::runtime_error("event timeline too long");
-        if (n + std::min<size_t>(EV_STAGE_EVENTS, 64) > ev_cap || !d_events) {
+        if (n + std::max<size_t>(std::min<size_t>(EV_STAGE_EVENTS, 64), ev_reserve) > ev_cap || !d_events) {
             if (d_events) HIPCK(hipFree(d_events));
             d_events = nullptr;
             size_t headroom = 64 * EV_STAGE_EVENTS; // room for appended segments (32 MB) before the next compaction
-            if (const char* hv = getenv("OSCEN_GPU_EV_HEADROOM")) headroom = std::max<size_t>(64, (size_t)atoll(hv)); // (tests: force compactions)
-            ev_cap = std::max<size_t>(n + n / 2, 1024) + headroom;
+            if (ev_headroom_env) headroom = ev_headroom_env; // OSCEN_GPU_EV_HEADROOM (tests: force compactions), read at og_create
+            ev_cap = std::max<size_t>(n + std::max<size_t>(n / 2, ev_reserve), 1024) + headroom;
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
         }
         if (n) bounce.h2d(d_events, evs.data(), n * sizeof(OgEvent), stream);
@@ -1121,20 +1135,7 @@ struct og_engine {
 
 namespace {
 
-template <class F>
-int guard(F&& f)
-{
-    try {
-        return f();
-    } catch (const HipError& e) {
-        return set_err(OG_E_DEVICE, e.what());
-    } catch (const std::exception& e) {
-        const std::string m = e.what();
-        const bool unsup = m.find("not supported") != std::string::npos || m.find("unsupported") != std::string::npos ||
-                           m.find("in this version") != std::string::npos;
-        return set_err(unsup ? OG_E_UNSUPPORTED : OG_E_INVALID, m);
-    }
-}
+using ogabi::guard; // Error (carries its OG_E_* code) / bad_alloc / std::exception -> code + og_last_error(); og_abi.h
 
 int check_value_input(const og_engine* e, uint32_t input, bool per_voice)
 {
@@ -1190,11 +1191,13 @@ const char* og_version(void) { return "oscen_amd 0.1 (gfx950)"; }
 
 int og_graph_new(const char* name, og_graph_desc** out)
 {
+    return ogabi::guard([&]() -> int {
     if (!name || !out) return set_err(OG_E_INVALID, "null argument");
     auto* g = new og_graph_desc;
     g->g.name = name;
     *out = g;
     return OG_OK;
+    });
 }
 
 int og_graph_builtin(const char* name, og_graph_desc** out)
@@ -1215,6 +1218,7 @@ int og_graph_builtin(const char* name, og_graph_desc** out)
 
 int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float def, uint32_t ramp_frames, uint32_t flags)
 {
+    return ogabi::guard([&]() -> int {
     if (!g || !name) return set_err(OG_E_INVALID, "null argument");
     if (kind < 0 || kind > 2) return set_err(OG_E_INVALID, "bad endpoint kind");
     ogc::GInput in;
@@ -1228,19 +1232,23 @@ int og_graph_add_input(og_graph_desc* g, const char* name, int kind, float def, 
     in.channels = ch > 1 ? (int)ch : 1;
     g->g.inputs.push_back(in);
     return (int)g->g.inputs.size() - 1;
+    });
 }
 
 int og_graph_add_output(og_graph_desc* g, const char* name, int kind)
 {
+    return ogabi::guard([&]() -> int {
     if (!g || !name) return set_err(OG_E_INVALID, "null argument");
     if (kind < 0 || kind > 2) return set_err(OG_E_INVALID, "bad endpoint kind");
     g->g.outputs.push_back({name, (ogc::Kind)kind});
     return (int)g->g.outputs.size() - 1;
+    });
 }
 
 int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args,
                       uint32_t rate_factor)
 {
+    return ogabi::guard([&]() -> int {
     if (!g || !name || !type_ctor || (n_args && !args)) return set_err(OG_E_INVALID, "null argument");
     ogc::GNode n;
     n.name = name;
@@ -1249,6 +1257,7 @@ int og_graph_add_node(og_graph_desc* g, const char* name, const char* type_ctor,
     n.rate_factor = rate_factor ? rate_factor : 1;
     g->g.nodes.push_back(n);
     return (int)g->g.nodes.size() - 1;
+    });
 }
 
 int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args,
@@ -1306,8 +1315,10 @@ int og_register_node(const og_node_type* t)
 
 int og_unregister_node(const char* type_ctor)
 {
+    return ogabi::guard([&]() -> int {
     if (!type_ctor) return set_err(OG_E_INVALID, "null argument");
     return ogc::unregister_user_node(type_ctor) ? OG_OK : set_err(OG_E_INVALID, std::string("no user node type '") + type_ctor + "'");
+    });
 }
 
 int og_register_function(const og_function_type* f)
@@ -1330,8 +1341,10 @@ int og_register_function(const og_function_type* f)
 
 int og_unregister_function(const char* name)
 {
+    return ogabi::guard([&]() -> int {
     if (!name) return set_err(OG_E_INVALID, "null argument");
     return ogc::unregister_user_function(name) ? OG_OK : set_err(OG_E_INVALID, std::string("no function '") + name + "'");
+    });
 }
 
 int og_register_graph_type(const char* type_name, const og_graph_desc* g)
@@ -1345,8 +1358,10 @@ int og_register_graph_type(const char* type_name, const og_graph_desc* g)
 
 int og_unregister_graph_type(const char* type_name)
 {
+    return ogabi::guard([&]() -> int {
     if (!type_name) return set_err(OG_E_INVALID, "null argument");
     return ogc::unregister_graph_type(type_name) ? OG_OK : set_err(OG_E_INVALID, std::string("no graph type '") + type_name + "'");
+    });
 }
 
 int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_ctor, const float* args, uint32_t n_args)
@@ -1358,13 +1373,16 @@ int og_graph_add_bus_node(og_graph_desc* g, const char* name, const char* type_c
 
 int og_graph_connect(og_graph_desc* g, const char* src, const char* dst, const char* policy)
 {
+    return ogabi::guard([&]() -> int {
     if (!g || !src || !dst) return set_err(OG_E_INVALID, "null argument");
     g->g.edges.push_back({src, dst, policy ? policy : ""});
     return OG_OK;
+    });
 }
 
 int og_graph_connect_via(og_graph_desc* g, const char* src, const char* via, const char* dst)
 {
+    return ogabi::guard([&]() -> int {
     if (!g || !src || !via || !dst) return set_err(OG_E_INVALID, "null argument");
     std::string v = via;
     bool numeric = !v.empty();
@@ -1385,6 +1403,7 @@ int og_graph_connect_via(og_graph_desc* g, const char* src, const char* via, con
     g->g.edges.push_back(in_leg);
     g->g.edges.push_back(out_leg);
     return OG_OK;
+    });
 }
 
 int og_graph_parse(const char* dsl_text, const char* per_voice_inputs, og_graph_desc** out)
@@ -1437,6 +1456,7 @@ int og_graph_poly_info(const og_graph_desc* g, uint32_t* declared_voices, char* 
 
 int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap)
 {
+    return ogabi::guard_value<int64_t>((int64_t)OG_E_NOMEM, [&]() -> int64_t {
     if (!g) return set_err(OG_E_INVALID, "null graph");
     const std::string t = ogc::to_dsl(g->g);
     if (buf && cap) {
@@ -1445,6 +1465,7 @@ int64_t og_graph_to_dsl(const og_graph_desc* g, char* buf, size_t cap)
         buf[n] = 0;
     }
     return (int64_t)t.size();
+    });
 }
 
 void og_graph_free(og_graph_desc* g) { delete g; }
@@ -1502,6 +1523,8 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // Measured on MI355X (65 536 fm voices): 64 lanes 0.129 ms, 32 lanes 0.185 ms, 16 lanes
             // 0.325 ms per block -- a wave-instruction costs the same issue time however many of its
             // lanes are active, so narrowing only multiplies instructions.  Kept as an experiment knob.
+            e->blocking_memcpy = getenv("OSCEN_GPU_BLOCKING_MEMCPY") != nullptr; // (environment knobs are read HERE, once)
+            if (const char* hv = getenv("OSCEN_GPU_EV_HEADROOM")) e->ev_headroom_env = std::max<size_t>(64, (size_t)atoll(hv));
             uint32_t lanes = OG_WAVE;
             if (const char* ev = getenv("OSCEN_GPU_LANES")) {
                 const int l = atoi(ev);
@@ -1600,6 +1623,7 @@ int og_init(og_engine* e, float sample_rate)
         e->reset_timeline();
         if (e->d_out_ev_count) HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, 2 * sizeof(uint32_t), e->stream));
         e->out_ev_overflow = 0;
+        e->out_ev_carry.clear();
         e->ev_lost_total = 0;
         e->frame_now = 0;
         e->inited = true;
@@ -1609,9 +1633,11 @@ int og_init(og_engine* e, float sample_rate)
 
 int og_input_index(const og_engine* e, const char* name)
 {
+    return ogabi::guard([&]() -> int {
     if (!e || !name) return set_err(OG_E_INVALID, "null argument");
     int i = e->cg->find_input(name);
     return i >= 0 ? i : set_err(OG_E_INVALID, std::string("no input named '") + name + "'");
+    });
 }
 uint32_t og_num_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->inputs.size() : 0; }
 
@@ -1719,6 +1745,7 @@ int og_schedule_voice_value(og_engine* e, uint32_t input, uint32_t voice, uint64
 int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uint32_t* voices, const uint64_t* abs_frames,
                              const float* values)
 {
+    return ogabi::guard([&]() -> int {
     if (!e || (n && (!voices || !abs_frames || !values))) return set_err(OG_E_INVALID, "null argument");
     if (input >= e->cg->inputs.size()) return set_err(OG_E_INVALID, "input index out of range");
     const auto& in = e->cg->inputs[input];
@@ -1732,6 +1759,7 @@ int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uin
     for (uint32_t i = 0; i < n; ++i)
         e->pending.push_back(HostEvent{voices[i], std::max(abs_frames[i], e->frame_now), target, values[i], e->seq++, false});
     return OG_OK;
+    });
 }
 
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
@@ -1759,6 +1787,7 @@ int og_synchronize(og_engine* e)
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
         HIPCK(hipStreamSynchronize(e->stream));
+        e->sync_lost_counter(); // (graphs with in-voice event queues only)
         return OG_OK;
     });
 }
@@ -1795,7 +1824,7 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus)
     if (!e) return set_err(OG_E_INVALID, "null engine");
     if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
     if (frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 0..512");
-    if (frames == 0 || !out_bus || e->n_taps > 0 || getenv("OSCEN_GPU_BLOCKING_MEMCPY")) { // (taps are read with a stream sync anyway)
+    if (frames == 0 || !out_bus || e->n_taps > 0 || e->blocking_memcpy) { // (taps are read with a stream sync anyway)
         int rc = og_process_block_async(e, frames, nullptr);
         if (rc) return rc;
         return guard([&] {
@@ -1877,6 +1906,7 @@ int og_render(og_engine* e, uint64_t total_frames, uint32_t block, float* out_bu
 
 int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint32_t n)
 {
+    return ogabi::guard([&]() -> int {
     if (!e || (n && !samples)) return set_err(OG_E_INVALID, "null argument");
     if (input >= e->cg->inputs.size() || e->cg->inputs[input].stream_row < 0) return set_err(OG_E_INVALID, "not a stream input");
     if (n > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "a stream block holds at most 512 samples");
@@ -1885,14 +1915,17 @@ int og_set_stream_block(og_engine* e, uint32_t input, const float* samples, uint
     for (uint32_t k = 0; k < w; ++k)
         for (uint32_t j = 0; j < n; ++j) blk[(size_t)k * OG_MAX_BLOCK + j] = samples[(size_t)j * w + k];
     return OG_OK;
+    });
 }
 
 uint32_t og_num_stream_inputs(const og_engine* e) { return e ? (uint32_t)e->cg->n_stream_inputs : 0; }
 
 uint32_t og_stream_input_channels(const og_engine* e, uint32_t input)
 {
+    return ogabi::guard_value<uint32_t>((uint32_t)0, [&]() -> uint32_t {
     if (!e || input >= e->cg->inputs.size() || e->cg->inputs[input].stream_row < 0) return 0;
     return (uint32_t)std::max(1, e->cg->inputs[input].decl.channels);
+    });
 }
 
 int og_render_inputs(og_engine* e, const float* const* inputs, const uint64_t* input_lens, uint32_t n_inputs, uint64_t tail,
@@ -2032,6 +2065,7 @@ uint32_t og_channels(const og_engine* e) { return e ? e->cg->channels : 0; }
 uint32_t og_voice_channels(const og_engine* e) { return e ? e->cg->voice_channels : 0; }
 int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, uint32_t* width)
 {
+    return ogabi::guard([&]() -> int {
     if (!e || !name) return set_err(OG_E_INVALID, "null argument");
     for (const auto& oc : e->cg->output_channels)
         if (oc.name == name) {
@@ -2040,6 +2074,7 @@ int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, ui
             return OG_OK;
         }
     return set_err(OG_E_INVALID, std::string("no stream output named '") + name + "' on the bus");
+    });
 }
 uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
@@ -2059,37 +2094,49 @@ uint32_t og_state_words_written_per_voice(const og_engine* e)
 uint32_t og_lanes_per_voice(const og_engine* e) { return e ? (uint32_t)e->cg->lpv : 0; }
 int og_uses_split_kernel(const og_engine* e) { return e ? (int)e->split : 0; }
 uint32_t og_voices_per_wave(const og_engine* e) { return e ? e->lanes / (uint32_t)e->cg->lpv : 0; }
-uint64_t og_events_dropped(const og_engine* ce)
+// Side-effect free (a monitoring thread may poll it while the audio thread renders): host-side drops plus what
+// og_sync_event_counters() last folded in from the device.
+uint64_t og_events_dropped(const og_engine* e) { return e ? e->dropped + e->ev_lost_total : 0; }
+
+// in-voice event queues (#[output(event)] fields of user nodes) hold OG_NODE_EVENTS_PER_FRAME events per frame and
+// output; what they could not hold is counted on the device.  This launches the queued blocks, reads that counter back
+// (one small copy + a stream synchronise; graphs with such nodes only) and folds it into og_events_dropped().  Called
+// by the thread that renders; og_synchronize() and og_read_output_events() do it as part of their own synchronise.
+int og_sync_event_counters(og_engine* e)
 {
-    if (!ce) return 0;
-    og_engine* e = const_cast<og_engine*>(ce);
-    // in-voice event queues (#[output(event)] fields of user nodes) hold OG_NODE_EVENTS_PER_FRAME events per frame and
-    // output; what they could not hold is counted on the device and read back here (one small copy, graphs with such
-    // nodes only)
-    if (e->d_out_ev_count && e->cg->has_node_event_outputs && e->inited) {
-        try {
-            HIPCK(hipSetDevice(e->device));
-            e->flush_bus();
-            uint32_t lost = 0;
-            HIPCK(hipMemcpyAsync(&lost, e->d_out_ev_count + 1, sizeof lost, hipMemcpyDeviceToHost, e->stream));
-            HIPCK(hipMemsetAsync(e->d_out_ev_count + 1, 0, sizeof(uint32_t), e->stream));
-            HIPCK(hipStreamSynchronize(e->stream));
-            e->ev_lost_total += lost;
-        } catch (const std::exception&) {
-        }
-    }
-    return e->dropped + e->ev_lost_total;
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    return guard([&] {
+        e->sync_lost_counter();
+        return OG_OK;
+    });
 }
 
 uint32_t og_num_event_outputs(const og_engine* e) { return e ? (uint32_t)e->cg->event_outputs.size() : 0; }
 int og_event_output_index(const og_engine* e, const char* name)
 {
+    return ogabi::guard([&]() -> int {
     if (!e || !name) return set_err(OG_E_INVALID, "null argument");
     for (size_t i = 0; i < e->cg->event_outputs.size(); ++i)
         if (e->cg->event_outputs[i] == name) return (int)i;
     return set_err(OG_E_INVALID, std::string("no event output named '") + name + "'");
+    });
 }
 
+void og_engine::sync_lost_counter()
+{
+    if (!(d_out_ev_count && cg->has_node_event_outputs && inited)) return;
+    HIPCK(hipSetDevice(device));
+    flush_bus();
+    uint32_t lost = 0;
+    HIPCK(hipMemcpyAsync(&lost, d_out_ev_count + 1, sizeof lost, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemsetAsync(d_out_ev_count + 1, 0, sizeof(uint32_t), stream));
+    HIPCK(hipStreamSynchronize(stream));
+    ev_lost_total += lost;
+}
+
+// Drains the device log into a host-side queue and hands out the oldest `cap` events; what does not fit the caller's
+// buffer STAYS queued for the next call (round 3 threw it away).  `n_overflowed` counts only what the device log itself
+// could not hold.
 int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_t* n_out, uint64_t* n_overflowed)
 {
     if (!e || (cap && !buf) || !n_out) return set_err(OG_E_INVALID, "null argument");
@@ -2099,27 +2146,34 @@ int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        uint32_t count = 0;
-        HIPCK(hipMemcpyAsync(&count, e->d_out_ev_count, sizeof count, hipMemcpyDeviceToHost, e->stream));
+        uint32_t counters[2] = {0u, 0u}; // {events logged, in-voice pushes lost}
+        HIPCK(hipMemcpyAsync(counters, e->d_out_ev_count, sizeof counters, hipMemcpyDeviceToHost, e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
+        const uint32_t count = counters[0];
         const uint32_t have = std::min(count, e->out_ev_cap);
-        std::vector<OgOutEvent> ev(have);
-        if (have) e->bounce.d2h(ev.data(), e->d_out_ev, (size_t)have * sizeof(OgOutEvent), e->stream);
-        HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, sizeof(uint32_t), e->stream));
+        const size_t old = e->out_ev_carry.size();
+        e->out_ev_carry.resize(old + have);
+        if (have) e->bounce.d2h(e->out_ev_carry.data() + old, e->d_out_ev, (size_t)have * sizeof(OgOutEvent), e->stream);
+        HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, 2 * sizeof(uint32_t), e->stream));
         HIPCK(hipStreamSynchronize(e->stream));
         e->out_ev_overflow += count - have;
+        e->ev_lost_total += counters[1];
         // frame order; within a frame voice order; a voice's events of one frame in push order (the append index of
-        // one lane grows in program order)
-        std::sort(ev.begin(), ev.end(), [](const OgOutEvent& a, const OgOutEvent& b) {
+        // one lane grows in program order).  Events carried over from an earlier call lie on earlier frames.
+        std::sort(e->out_ev_carry.begin() + (ptrdiff_t)old, e->out_ev_carry.end(), [](const OgOutEvent& a, const OgOutEvent& b) {
             if (a.frame != b.frame) return a.frame < b.frame;
             if (a.voice != b.voice) return a.voice < b.voice;
             return a.seq < b.seq;
         });
-        const uint32_t give = std::min(have, cap);
-        for (uint32_t i = 0; i < give; ++i) buf[i] = og_out_event{ev[i].voice, ev[i].output, ev[i].frame, ev[i].value, 0u};
+        const uint32_t give = (uint32_t)std::min<size_t>(e->out_ev_carry.size(), cap);
+        for (uint32_t i = 0; i < give; ++i) {
+            const OgOutEvent& x = e->out_ev_carry[i];
+            buf[i] = og_out_event{x.voice, x.output, x.frame, x.value, 0u};
+        }
+        e->out_ev_carry.erase(e->out_ev_carry.begin(), e->out_ev_carry.begin() + give);
         *n_out = give;
         if (n_overflowed) {
-            *n_overflowed = e->out_ev_overflow + (have - give);
+            *n_overflowed = e->out_ev_overflow;
             e->out_ev_overflow = 0;
         }
         return OG_OK;
@@ -2146,6 +2200,15 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 }
 
 uint64_t og_event_ring_wraps(const og_engine* e) { return e ? e->n_ring_wraps : 0; }
+
+int og_reserve_events(og_engine* e, uint64_t n_events)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (n_events > 0xF0000000ull) return set_err(OG_E_INVALID, "og_reserve_events: at most 2^32 - 2^28 events");
+    e->ev_reserve = (size_t)n_events;
+    e->ev_rebuild = e->ev_rebuild || (e->d_events && e->ev_tail + e->ev_reserve > e->ev_cap); // takes effect with the next rebuild
+    return OG_OK;
+}
 
 int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_timeouts)
 {
@@ -2242,11 +2305,13 @@ extern "C" {
 
 size_t og_state_bytes(const og_engine* e)
 {
+    return ogabi::guard_value<size_t>((size_t)0, [&]() -> size_t {
     // (delay lines are part of the state: their size is known once og_init has sized them)
     if (!e) return 0;
     std::vector<SnapEvent> evs;
     collect_unconsumed(e, evs);
     return dsp_bytes(e) + control_bytes(e, evs.size());
+    });
 }
 
 int og_save_state(og_engine* e, void* dst, size_t cap)

@@ -36,6 +36,8 @@ int CompiledGraph::find_input(const std::string& n) const
 namespace {
 
 [[noreturn]] void fail(const std::string& m) { throw std::runtime_error("oscen graph: " + m); }
+// a well-formed graph that uses something this build lacks: carries OG_E_UNSUPPORTED (og_abi.h)
+[[noreturn]] void fail_unsupported(const std::string& m) { throw ogabi::Unsupported("oscen graph: " + m); }
 
 std::string flit(float v)
 { // exact float literal
@@ -729,7 +731,7 @@ struct Codegen {
             // feedback edge whose producer runs later in the frame: the consumer sees the field the
             // producer wrote on the previous frame (the struct field persists, codegen/emit_node.rs)
             if ((nodes[ni].domain == 1) != (dom == 1))
-                fail("feedback edge from '" + node_name + "' crosses the oversampled region: both ends of a feedback edge must "
+                fail_unsupported("feedback edge from '" + node_name + "' crosses the oversampled region: both ends of a feedback edge must "
                      "run at the same rate in this version");
             auto fit = fb_vars.find(key);
             if (fit == fb_vars.end()) {
@@ -1038,7 +1040,7 @@ struct NodeCtx {
     {
         Val v = in(name);
         if (v.rate > Rate::UBlock || !v.host)
-            fail("node '" + n.decl->name + "': input '" + name +
+            fail_unsupported("node '" + n.decl->name + "': input '" + name +
                  "' must be a block-uniform value (constant or non-ramped broadcast input) in this version");
         return v;
     }
@@ -1423,7 +1425,7 @@ void emit_lp18(NodeCtx& x)
 // Delay (oscen-lib/src/delay/mod.rs): the line itself is an HBM ring per voice (CompiledGraph::rings)
 void emit_delay(NodeCtx& x)
 {
-    if (x.cg.out.lpv != 1) fail("Delay is not supported in array-valued (several lanes per voice) graphs");
+    if (x.cg.out.lpv != 1) fail_unsupported("Delay is not supported in array-valued (several lanes per voice) graphs");
     if (x.cg.out.rings.size() >= 4) fail("at most 4 Delay nodes per graph");
     const Val in = x.in("input");
     const Val ds = x.in("delay_samples");
@@ -2202,7 +2204,7 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
                     }
                     continue;
                 }
-                if (gi.ramp_frames) fail("ramped inputs are not supported inside nested graphs ('" + gi.name + "')");
+                if (gi.ramp_frames) fail_unsupported("ramped inputs are not supported inside nested graphs ('" + gi.name + "')");
                 std::string rep;
                 if (src == sb.in_src.end()) {
                     rep = flit(gi.def);
@@ -2696,7 +2698,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (nd.rate_factor != 2 && nd.rate_factor != 4 && nd.rate_factor != 8)
                 fail("node '" + nd.name + "': oversampling factor must be 1, 2, 4 or 8");
             if (cg.N != 1 && cg.N != (int)nd.rate_factor)
-                fail("all oversampled nodes of a graph must share one factor in this version (node '" + nd.name + "')");
+                fail_unsupported("all oversampled nodes of a graph must share one factor in this version (node '" + nd.name + "')");
             cg.N = (int)nd.rate_factor;
         }
         cg.node_by_name[nd.name] = (int)i;
@@ -2704,8 +2706,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         cg.nodes[i].type = nti;
         cg.nodes[i].id = (int)i;
         if (nd.bus) {
-            if (nd.type != "Tremolo::new") fail("only Tremolo::new is available as a post-mix (bus) node in this version");
-            if (out.bus_tremolo) fail("only one post-mix (bus) node is supported in this version");
+            if (nd.type != "Tremolo::new") fail_unsupported("only Tremolo::new is available as a post-mix (bus) node in this version");
+            if (out.bus_tremolo) fail_unsupported("only one post-mix (bus) node is supported in this version");
             out.bus_tremolo = true;
             out.channels = 2; // Frame<2>
             out.tremolo_rate = [](const UEnv&) { return 5.0f; };  // Tremolo::new() defaults, tremolo.rs:27-37
@@ -3014,8 +3016,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live && !cg.nodes[i].ev_node_edges.empty()) cg.dynamic_events = true;
     if (!ev_out_edges.empty()) cg.dynamic_events = true; // (the per-frame log / clear lives in the ordinary kernel's tick)
-    if (!ev_out_edges.empty() && out.lpv != 1) fail("graph event outputs are not supported in array-valued (several lanes per voice) graphs");
-    if (cg.dynamic_events && out.lpv != 1) fail("node-to-node event edges are not supported in array-valued (several lanes per voice) graphs");
+    if (!ev_out_edges.empty() && out.lpv != 1) fail_unsupported("graph event outputs are not supported in array-valued (several lanes per voice) graphs");
+    if (cg.dynamic_events && out.lpv != 1) fail_unsupported("node-to-node event edges are not supported in array-valued (several lanes per voice) graphs");
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
     std::vector<int> order;
@@ -3307,7 +3309,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 width = w;
                 if (w > 1) {
                     if (out.lpv != 1 || out.bus_tremolo)
-                        fail("a Frame<N> graph output is not supported in array-valued or post-mix graphs yet");
+                        fail_unsupported("a Frame<N> graph output is not supported in array-valued or post-mix graphs yet");
                     if (k == 0) acc.assign((size_t)w, std::string());
                     for (int c = 0; c < w; ++c) acc[(size_t)c] = (k == 0) ? v.ch[(size_t)c].e : "(" + acc[(size_t)c] + " + " + v.ch[(size_t)c].e + ")";
                     continue;
@@ -3362,7 +3364,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
         }
         if (chans.size() > 1 && (out.lpv != 1 || out.bus_tremolo))
-            fail("several bus channels (stream outputs / Frame<2>) are not supported in array-valued or post-mix graphs yet");
+            fail_unsupported("several bus channels (stream outputs / Frame<2>) are not supported in array-valued or post-mix graphs yet");
         if (chans.size() > 4) fail("the mix bus carries at most 4 channels (stream outputs, a Frame<N> counting N)");
         if (chans.size() == 1) {
             cg.os() << "        const float g_out = " << chans[0] << ";\n";

@@ -16,6 +16,7 @@
 // and the result is one fused voice kernel (HIP source) whose per-voice state
 // is laid out as [word][voice] planes.
 #pragma once
+#include "og_abi.h"
 #include <cstdint>
 #include <functional>
 #include <map>

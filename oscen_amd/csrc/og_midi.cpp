@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/oscen_gpu.h"
+#include "og_abi.h"
 
 struct og_midi {
     og_engine* engine = nullptr;
@@ -299,6 +300,7 @@ extern "C" {
 
 int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input, const char* gate_input, og_midi** out)
 {
+    return ogabi::guard([&]() -> int {
     if (!out) return OG_E_INVALID;
     og_midi* m = new og_midi;
     m->engine = e;
@@ -321,12 +323,14 @@ int og_midi_create(og_engine* e, uint32_t n_voices, const char* frequency_input,
     m->queue_cap = 32u * ((m->n + 23u) / 24u);
     *out = m;
     return OG_OK;
+    });
 }
 
 // The same front end over a multi-GPU bank: ONE allocator over the cluster's global voice ids (the LRU / stealing
 // decisions are those of a single bank of that size), every voice message routed to the shard that owns the voice.
 int og_midi_create_cluster(og_cluster* c, const char* frequency_input, const char* gate_input, og_midi** out)
 {
+    return ogabi::guard([&]() -> int {
     if (!out || !c) return OG_E_INVALID;
     if (og_cluster_num_voices(c) > 0xFFFFFFFFull) return OG_E_UNSUPPORTED; // (voice ids of the allocator are 32-bit)
     og_midi* m = new og_midi;
@@ -342,6 +346,7 @@ int og_midi_create_cluster(og_cluster* c, const char* frequency_input, const cha
     m->queue_cap = 32u * ((m->n + 23u) / 24u);
     *out = m;
     return OG_OK;
+    });
 }
 
 void og_midi_destroy(og_midi* m)
@@ -357,6 +362,7 @@ float og_midi_note_to_freq(uint8_t note) { return og_midi::note_to_freq(note); }
 
 int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_offset)
 {
+    return ogabi::guard([&]() -> int {
     if (!m || !bytes) return OG_E_INVALID;
     og_midi::Msg msg;
     memset(&msg, 0, sizeof msg);
@@ -371,10 +377,12 @@ int og_midi_send(og_midi* m, const uint8_t* bytes, uint32_t len, uint32_t frame_
     if (!m->queue.empty() && m->queue.back().frame > msg.frame) m->queue_sorted = false;
     m->queue.push_back(msg);
     return OG_OK;
+    });
 }
 
 int og_midi_send_batch(og_midi* m, const uint8_t* bytes3, const uint32_t* frame_offsets, uint32_t n)
 {
+    return ogabi::guard([&]() -> int {
     if (!m || (n && (!bytes3 || !frame_offsets))) return OG_E_INVALID;
     int rc = OG_OK;
     for (uint32_t i = 0; i < n; ++i) {
@@ -382,46 +390,56 @@ int og_midi_send_batch(og_midi* m, const uint8_t* bytes3, const uint32_t* frame_
         if (r != OG_OK && rc == OG_OK) rc = r;
     }
     return rc;
+    });
 }
 
 int og_midi_set_queue_capacity(og_midi* m, uint32_t capacity)
 {
+    return ogabi::guard([&]() -> int {
     if (!m || capacity == 0) return OG_E_INVALID;
     m->queue_cap = capacity;
     return OG_OK;
+    });
 }
 
 uint64_t og_midi_dropped(const og_midi* m) { return m ? m->dropped : 0; }
 
 int og_midi_flush(og_midi* m)
 {
+    return ogabi::guard([&]() -> int {
     if (!m) return OG_E_INVALID;
     m->last_rc = OG_OK;
     m->flush();
     return m->last_rc;
+    });
 }
 
 int og_midi_process_block(og_midi* m, uint32_t frames, float* out_bus)
 {
+    return ogabi::guard([&]() -> int {
     if (!m || (!m->engine && !m->cluster)) return OG_E_INVALID;
     m->last_rc = OG_OK;
     m->flush(frames);
     const int rc = m->engine ? og_process_block(m->engine, frames, out_bus) : og_cluster_process_block(m->cluster, frames, out_bus);
     return rc != OG_OK ? rc : m->last_rc; // the block was rendered; a non-zero code reports a dropped event
+    });
 }
 
 int og_midi_process_block_async(og_midi* m, uint32_t frames, float* d_out_bus)
 {
+    return ogabi::guard([&]() -> int {
     if (m && m->cluster) return OG_E_UNSUPPORTED; // (a cluster's bus is complete only after the cross-device reduce)
     if (!m || !m->engine) return OG_E_INVALID;
     m->last_rc = OG_OK;
     m->flush(frames);
     const int rc = og_process_block_async(m->engine, frames, d_out_bus);
     return rc != OG_OK ? rc : m->last_rc;
+    });
 }
 
 int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* released, int* note, uint32_t* age)
 {
+    return ogabi::guard([&]() -> int {
     if (!m || voice >= m->n) return OG_E_INVALID;
     const auto& v = m->voices[voice];
     if (active) *active = v.active;
@@ -429,10 +447,12 @@ int og_midi_voice_state(const og_midi* m, uint32_t voice, int* active, int* rele
     if (note) *note = v.note;
     if (age) *age = v.age;
     return OG_OK;
+    });
 }
 
 int og_midi_pop_output(og_midi* m, uint32_t* voice, uint32_t* frame, float* frequency, int* has_frequency, float* gate)
 {
+    return ogabi::guard([&]() -> int {
     if (!m) return OG_E_INVALID;
     if (m->log.empty()) return 0;
     const auto o = m->log.front();
@@ -443,6 +463,7 @@ int og_midi_pop_output(og_midi* m, uint32_t* voice, uint32_t* frame, float* freq
     if (has_frequency) *has_frequency = o.has_frequency;
     if (gate) *gate = o.gate;
     return 1;
+    });
 }
 
 } // extern "C"

@@ -150,9 +150,21 @@ OG_DEV void adsr_gate(Adsr& e, float v, const OgBlockArgs& A, int k)
 }
 
 // process_stage  adsr.rs:206-248, the per-sample part
+//
+// Tolerance mode (default; og_math.h): every moving stage is ONE fused one-pole step towards the stage's
+// target.  Attack / Decay: lv += (tgt - lv) * cf as one subtraction and one fma.  Release -- the reference's
+// `level += -level / samples_remaining` with the increment re-derived every sample (adsr.rs:112-114, 162-173) -- is
+// the same step with target 0 and the time-varying coefficient 1 / samples_remaining: tgt = 0 and cf = 0 in
+// Release (adsr_enter), so the coefficient is cf + rs * rcp(cnt) for every stage and the release arithmetic is a
+// conversion, v_rcp_f32 and one fma in front of the common step (6 VALU per envelope and sample; the
+// operation-for-operation form with its Newton-refined quotient took 11).  Against the reference's correctly
+// rounded quotient the increment differs by <= 2^-23 relative: the step lands on a neighbouring f32 about 2/n of
+// the time, and the recurrence contracts (lv shrinks by 1 - 1/n), so the level stays within a few ulp over a whole
+// release (observed: DESIGN.md section 5).  Nothing here feeds a phase accumulator.
 template <bool RELEASE = true>
 OG_DEV float adsr_tick(Adsr& e)
 {
+#ifdef OG_STRICT
     // Attack: lv += (1 - lv) * attack_coeff; Decay: lv += (sustain_level - lv) * decay_coeff; else cf == 0
     float lv = e.lv + (e.tgt - e.lv) * e.cf;
     // Release: lv += -lv / samples_remaining, increment re-derived every sample (adsr.rs:162-173)
@@ -160,6 +172,12 @@ OG_DEV float adsr_tick(Adsr& e)
     //  than it saves -- the compiler if-converts it into the same arithmetic plus scalar selects)
     // (RELEASE = false: the caller has established rs == 0 in every lane for the whole chunk)
     if (RELEASE) lv = fmaf(e.rs, div_near(-lv, (float)e.cnt), lv);
+#else
+    float cf = e.cf;
+    // (cnt >= 1 while a stage is ticking and ADSR_HOLD otherwise: the reciprocal is finite, rs * rcp is 0 or rcp)
+    if (RELEASE) cf = fmaf(e.rs, __builtin_amdgcn_rcpf((float)e.cnt), cf);
+    const float lv = fmaf(e.tgt - e.lv, cf, e.lv);
+#endif
     e.cnt -= 1u; // samples_remaining -= 1; reaching 0 is handled by adsr_complete()
     e.lv = lv;
     return lv;
@@ -184,12 +202,11 @@ OG_DEV void adsr_complete(Adsr& e, float a_c, float d_c, uint32_t d_n, float& ou
 OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float phase_mod, float feedback,
                               float envelope, float level)
 {
-    const float feedback_mod = prev_output * feedback;
-    const float total_phase_mod = phase_mod + feedback_mod;
+    const float total_phase_mod = OG_FMA(prev_output, feedback, phase_mod); // phase_mod + prev_output * feedback
     const float phase_rad = (phase + total_phase_mod) * F32_TAU;
     const float output = og_sinf(phase_rad) * envelope * level;
     prev_output = output;
-    const float p = phase + inc;
+    const float p = phase + inc; // the phase accumulator keeps the reference's exact operations
     phase = p - truncf(p); // f32::fract
     return output;
 }
@@ -220,7 +237,7 @@ OG_DEV void tpt_update_coefficients(float cutoff, float q, float two_sr, float p
     const float inv_q = 1.0f / q;
     // (rcp + one Newton step: within an ulp of the IEEE quotient, a third of its instructions; the
     //  coefficient already carries og_tanf_q1's few-ulp error)
-    h = div_near(1.0f, 1.0f + inv_q * f + f * f);
+    h = div_near(1.0f, OG_FMA(f, f, OG_FMA(inv_q, f, 1.0f))); // 1 / (1 + inv_q * f + f * f)
     g = f;
     k = f + inv_q;
     cur_c = cutoff;
@@ -276,7 +293,7 @@ OG_DEV void tpt_params_nomod_flat(float cutoff_in, float q_in, float inv_q_in, f
     const float t0 = og_tan_poly(y);
     const float t = big ? div_near(1.0f, t0) : t0;
     const float f = two_sr * t * period;
-    const float nh = div_near(1.0f, 1.0f + inv_q_in * f + f * f);
+    const float nh = div_near(1.0f, OG_FMA(f, f, OG_FMA(inv_q_in, f, 1.0f)));
     h = upd ? nh : h;
     g = upd ? f : g;
     k = upd ? f + inv_q_in : k;
@@ -284,9 +301,11 @@ OG_DEV void tpt_params_nomod_flat(float cutoff_in, float q_in, float inv_q_in, f
     cur_q = upd ? q : cur_q;
 }
 
-// state-variable core :114-122
+// state-variable core :114-122.  The integrators are a stable (contracting) recurrence, not an accumulator:
+// tolerance mode fuses every product into the sum it feeds -- 7 VALU instead of 9.
 OG_DEV float tpt_tick(float in, float& z0, float& z1, float h, float g, float k)
 {
+#ifdef OG_STRICT
     const float high = (in - z0 * k - z1) * h;
     const float hg = high * g;
     const float band = hg + z0;
@@ -294,6 +313,13 @@ OG_DEV float tpt_tick(float in, float& z0, float& z1, float h, float g, float k)
     const float low = bg + z1;
     z0 = hg + band;
     z1 = bg + low;
+#else
+    const float high = (fmaf(-z0, k, in) - z1) * h;
+    const float band = fmaf(high, g, z0);
+    const float low = fmaf(band, g, z1);
+    z0 = fmaf(high, g, band);
+    z1 = fmaf(band, g, low);
+#endif
     return low;
 }
 

@@ -7,15 +7,18 @@
 #include <vector>
 
 #include "../../include/oscen_gpu.h"
+#include "og_abi.h"
 
 namespace {
 void put_u32(std::vector<uint8_t>& b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
 void put_u16(std::vector<uint8_t>& b, uint16_t v) { b.push_back((uint8_t)v); b.push_back((uint8_t)(v >> 8)); }
 } // namespace
 
-extern "C" int og_write_wav(const char* path, const float* interleaved, uint64_t frames, uint32_t channels,
-                            uint32_t sample_rate, uint32_t bits_per_sample)
+extern "C" {
+int og_write_wav(const char* path, const float* interleaved, uint64_t frames, uint32_t channels,
+                 uint32_t sample_rate, uint32_t bits_per_sample)
 {
+    return ogabi::guard([&]() -> int { // (the file image is assembled in a vector: bad_alloc -> OG_E_NOMEM)
     if (!path || (!interleaved && frames) || channels == 0 || (bits_per_sample != 16 && bits_per_sample != 32))
         return OG_E_INVALID;
     const bool f32 = bits_per_sample == 32;
@@ -53,4 +56,6 @@ extern "C" int og_write_wav(const char* path, const float* interleaved, uint64_t
     const bool ok = fwrite(b.data(), 1, b.size(), f) == b.size();
     fclose(f);
     return ok ? OG_OK : OG_E_INVALID;
+    });
 }
+} // extern "C"

@@ -20,13 +20,16 @@ extern "C" void ref_tan_array(const float* x, float* y, long n) { for (long i = 
 '''
 
 
-@pytest.fixture(scope="module")
-def mlib(tmp_path_factory):
-    d = tmp_path_factory.mktemp("ogmath")
+@pytest.fixture(scope="module", params=["tolerance", "strict"])
+def mlib(tmp_path_factory, request):
+    # "tolerance" = the shipped mode (4-coefficient sine polynomial), "strict" = -DOG_STRICT (rounds 1-3)
+    d = tmp_path_factory.mktemp("ogmath_" + request.param)
     src = d / "m.cpp"
     src.write_text(SRC)
     so = d / "libm_test.so"
     flags = ["-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "oscen_amd", "csrc")]
+    if request.param == "strict":
+        flags.append("-DOG_STRICT")
     if "fma" in open("/proc/cpuinfo").read():
         flags.append("-mfma")
     subprocess.run(["g++"] + flags + [str(src), "-o", str(so), "-lm"], check=True)
@@ -50,7 +53,8 @@ def test_sin_matches_glibc_over_fm_range(mlib):
     assert np.max(np.abs(got[small].astype(np.float64) - ref[small])) <= 1.2e-7
     assert np.mean(got[small] == ref[small]) > 0.70  # the rest differ by 1 ulp
     true = np.sin(x[small].astype(np.float64))
-    assert np.max(np.abs(got[small] - true)) <= 1.3e-7
+    # (tolerance mode drops the degree-11 term: approximation error 4.7e-9 on top of the final rounding)
+    assert np.max(np.abs(got[small] - true)) <= 1.45e-7
 
 
 def test_tan_matches_glibc_on_first_quadrant(mlib):
