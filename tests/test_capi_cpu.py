@@ -276,7 +276,7 @@ def test_rust_shim_block_render_constants_and_calls():
     assert "usize::MAX" not in code
     assert re.search(r"impl<const IN: usize> oscen::BlockRender<f32> for GpuGraph<IN>", code)
     assert re.search(r"const NUM_STREAM_INPUTS: usize = IN;", code)
-    assert re.search(r"stream_in_blocks: \[\[f32; MAX_BLOCK_SIZE\]; IN\]", code)
+    assert re.search(r"stream_in_blocks: \[\[f32; MAX_BUS_CHANNELS \* MAX_BLOCK_SIZE\]; IN\]", code)  # room for a Frame<4> input
     assert "og_num_stream_inputs(e) } as usize" in code and "have != IN" in code  # checked against the engine at construction
     sys_rs = open(os.path.join(root, "bindings", "rust", "oscen-gpu-sys", "src", "lib.rs")).read()
     bound = set(re.findall(r"pub fn (og_\w+)\s*\(", sys_rs))
