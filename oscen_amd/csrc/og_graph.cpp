@@ -421,8 +421,8 @@ int user_weight(const std::string& type);
 // rough VALU cost per tick of a node type (used to balance the two-stage split)
 int node_weight(const std::string& type)
 {
-    if (type.rfind("AdsrEnvelope", 0) == 0) return 10;
-    if (type.rfind("FmOperator", 0) == 0) return 24;
+    if (type.rfind("AdsrEnvelope", 0) == 0) return 6;  // tolerance mode: sub, cvt, rcp, 2 fma, countdown (was 11)
+    if (type.rfind("FmOperator", 0) == 0) return 21;
     if (type.rfind("TptFilter", 0) == 0) return 25;
     if (type.rfind("PolyBlepOscillator", 0) == 0) return 30;
     if (type.rfind("Oscillator", 0) == 0) return 22;
@@ -3051,6 +3051,62 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                  "route through a declared Delay node)");
     }
 
+    // ---- schedule order (round 4).  The Kahn order above is the reference's; it front-loads every source node
+    // (FMVoice: the four envelopes, then the operators), which is the worst order for a pipeline cut: values live long,
+    // and the heavy chain sits entirely behind the light sources.  When the graph is a pure per-frame dataflow -- no
+    // feedback edge or delay (those read "the value of the previous frame", which depends on who runs first), no
+    // node-to-node event edge (delivery order), one rate, one lane per voice -- ANY topological order computes the same
+    // values bit for bit, so the nodes are emitted depth first from the sinks instead: a node's producers come right
+    // before it, heaviest producer chain first, light leaves (envelopes) just ahead of their consumer:
+    // FMVoice: env3 op3 route env2 op2 | mixer env1 op1 env_filter gain cutoff_mod filter output_gain -- the contiguous
+    // two-wave cut now balances (56 | 54 estimated VALU per frame; the Kahn order could only offer 47 | 63), every
+    // hand-off value but two stays inside its wave, and the ordinary kernel holds fewer values across nodes.
+    // OGC_ALAP=0 keeps the Kahn order (A/B).
+    {
+        bool any_delay_node = false;
+        for (int ni : order) any_delay_node = any_delay_node || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
+        bool any_rate = false;
+        for (int ni : order) any_rate = any_rate || cg.nodes[ni].decl->rate_factor != 1;
+        const bool reorder = !(getenv("OGC_ALAP") && atoi(getenv("OGC_ALAP")) == 0) && !any_feedback && !cg.dynamic_events && !any_delay_node &&
+                             !any_rate && out.lpv == 1 && order.size() >= 3;
+        if (reorder) {
+            std::vector<int> pos(g.nodes.size(), -1);
+            for (size_t k = 0; k < order.size(); ++k) pos[order[k]] = (int)k;
+            // weight of the not-yet-emitted producer cone of a node (memoised per call: the graphs are small)
+            std::vector<char> done(g.nodes.size(), 0);
+            std::function<int(int, std::set<int>&)> cone = [&](int n, std::set<int>& seen) -> int {
+                if (done[n] || !seen.insert(n).second) return 0;
+                int wsum = node_weight(cg.nodes[n].decl->type);
+                for (int d : deps[n]) wsum += cone(d, seen);
+                return wsum;
+            };
+            std::vector<int> sched;
+            std::function<void(int)> visit = [&](int n) {
+                if (done[n]) return;
+                std::vector<std::pair<int, int>> ds; // (-cone weight, Kahn position): heaviest chain first, ties in Kahn order
+                for (int d : deps[n]) {
+                    if (done[d] || !cg.nodes[d].live) continue;
+                    std::set<int> seen;
+                    ds.push_back({-cone(d, seen), pos[d]});
+                }
+                std::sort(ds.begin(), ds.end());
+                for (auto& pr : ds) visit(order[pr.second]);
+                done[n] = 1;
+                sched.push_back(n);
+            };
+            // sinks (nodes nobody reads) in Kahn order; what feeds the graph outputs comes last among them
+            std::vector<int> n_users(g.nodes.size(), 0);
+            for (int ni : order)
+                for (int d : deps[ni]) n_users[d]++;
+            for (int ni : order)
+                if (n_users[ni] == 0) visit(ni);
+            if (sched.size() == order.size()) {
+                for (int ni : order) out.node_order.push_back(g.nodes[ni].name); // the reference's (Kahn) order, for the record
+                order = sched;
+            }
+        }
+    }
+
     // (feedback edges in graphs with oversampled nodes: allowed when both ends tick at the same rate -- checked where
     //  the consumer reads the previous tick's value, Codegen::eval)
 
@@ -3142,7 +3198,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 }
                 // (its true cost is ~45, but the grouping this weight gives for fm_voice -- op2 with the consumer wave --
                 //  measured equal on the default run and 12% faster at 98 304 voices than op2 with the producer)
-                wt = moving ? 30 : 12;
+                wt = moving ? 25 : 9; // core 7 + parameter test 8 + the coefficient update on the frames whose cutoff moved
             }
             w.push_back(wt);
             total += wt;
@@ -3172,7 +3228,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         }
         // contiguous grouping of the stages into `parts` waves minimising the heaviest wave (the last wave
         // also carries the mix-bus work); ties: smallest sum of squares
-        const int BUS_W = 7;
+        const int BUS_W = 4;
         auto grouping = [&](int parts) {
             const int n = (int)unit_w.size();
             std::vector<int> pre(n + 1, 0);
@@ -3242,7 +3298,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     << (dom == 1 ? " * " + std::to_string(cg.N) : std::string()) << "\n";
             n.type->emit(x);
             cg.emitted[ni] = 1;
-            out.node_order.push_back(n.decl->name);
+            out.schedule_order.push_back(n.decl->name);
         }
         cg.flush_post();
     }
@@ -3860,7 +3916,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                         : std::string())
         << ".\n"
         << "// Node order: ";
+    if (out.node_order.empty()) out.node_order = out.schedule_order; // (not reordered: emitted in the reference's order)
     for (auto& nn : out.node_order) src << nn << " ";
+    if (out.schedule_order != out.node_order) {
+        src << "\n// Schedule (depth first from the sinks; same values, any topological order of a pure dataflow graph): ";
+        for (auto& nn : out.schedule_order) src << nn << " ";
+    }
     if (out.lpv > 1) src << "\n#define OG_HPL " << out.lane_width << " // harmonics per lane (OGC_HPL)";
     if (cg.ev_capacity != 2) src << "\n#define OG_NODE_EVENTS_PER_FRAME " << cg.ev_capacity << " // event_queue_capacity of a node type of this graph";
     src << "\n#include \"og_kernel_rt.hip.h\"\n#include \"og_nodes.hip.h\"\n\n"

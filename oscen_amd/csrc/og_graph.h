@@ -166,7 +166,9 @@ struct CompiledGraph {
     };
     std::vector<OutChan> output_channels; // where every stream output sits in a frame of the bus / of a tap
     uint32_t latency_samples = 0;
-    std::vector<std::string> node_order; // topological order actually emitted (introspection/tests)
+    std::vector<std::string> node_order;     // the reference's topological order (Kahn, ir/lower.rs:1015-1085)
+    std::vector<std::string> schedule_order; // the order the nodes are emitted in (== node_order unless the graph is a pure
+                                             // per-frame dataflow, which is scheduled depth first from its sinks)
     int find_input(const std::string& n) const;
 };
 

@@ -194,7 +194,13 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     import re
     fm = oscen_amd.Graph(builtin="fm_voice").kernel_source()
     assert "voice_block_p2" in fm and "voice_block_p4" in fm
-    assert re.search(r"//   wave 0: env3 env2 env1 env_filter\b", fm)  # a run of envelopes is one stage
+    # round 4: depth-first schedule order (pure dataflow graph: any topological order gives the same bits) -- every
+    # envelope sits right in front of its consumer, the two-wave cut falls between the operator chains
+    assert re.search(r"// Node order: env3 env2 env1 env_filter op3_osc", fm)  # the reference's Kahn order, for the record
+    assert re.search(r"// Schedule \([^)]*\): env3 op3_osc op3_route env2 op2_osc op1_mod_mixer env1 op1_osc env_filter filter_env_gain cutoff_mod filter output_gain", fm)
+    assert re.search(r"//   wave 0: env3 op3_osc op3_route env2 op2_osc\b", fm) and re.search(r"//   wave 1: [a-z0-9_ ]*op1_osc env_filter", fm)
+    sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
+    assert "// Node order:" in sub_src
     for k in ("og_k_", "og_k2_", "og_k4_"):
         assert len(re.findall(r"__global__[^\n]*\b%s[0-9a-f]{16}_(00|10|01|11)\b" % k, fm)) == 4
     # chunk variants: (stage-end checks, release arithmetic[, hand-off prefetch, node steady states])
