@@ -388,7 +388,9 @@ def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device
                             deadline_ms, False, 0))
     # the LOADED bank: every voice plays the synthetic score the throughput lines use, plus the live messages
     loaded = []
-    max_events = min(150e6, _mem_budget_bytes() / 100.0)
+    # (64 M events = 1 GB on the device, ~6 GB of host memory while the timeline is built, ~5 s of set-up per bank: the
+    #  default `python bench.py` has to finish within minutes)
+    max_events = min(64e6, _mem_budget_bytes() / 100.0)
     for V in loaded_voices:
         loaded.append(_rt_bank(graph, V, block, loaded_blocks, 0, midi_per_block, device, deadline_ms, True, max_events))
     paced_rec = None

@@ -220,6 +220,11 @@ int og_set_value(og_engine* e, uint32_t input, float v);
 int og_set_value_ramp(og_engine* e, uint32_t input, float v, uint32_t frames);
 int og_set_value_immediate(og_engine* e, uint32_t input, float v);
 int og_get_value(const og_engine* e, uint32_t input, float* out);
+/* The public fields of a `[ramp: N]` input -- `graph.<input>` is a ValueRampState (oscen-lib/src/graph/types.rs:300-373:
+ * current, target, is_ramping() = frames_remaining > 0) -- and `graph.active_ramps`, the counter tick_ramps() keeps
+ * (oscen-graph-compiler/src/codegen/mod.rs:878-914).  A plain value input reports current == target, 0 frames. */
+int og_ramp_state(const og_engine* e, uint32_t input, float* current, float* target, uint32_t* frames_remaining);
+uint32_t og_active_ramps(const og_engine* e);
 
 /* Per-voice value input (the `voice_handlers.frequency -> voices.frequency`
  * edge, examples/fm-synth/src/lib.rs:88): takes effect at the next block. */

@@ -307,7 +307,7 @@ struct HostEvent { // a push that has not reached the device timeline yet
 
 constexpr int RAMP_RING = 8;
 constexpr int EV_RING = 8;              // pinned staging buffers of the incremental event path
-constexpr size_t EV_STAGE_EVENTS = 32768; // events (and voice updates) one staging buffer holds
+constexpr size_t EV_STAGE_EVENTS = 131072; // events (and voice updates) one staging buffer holds (8 x 2 MB + 8 x 1.5 MB pinned)
 
 } // namespace
 
@@ -707,7 +707,7 @@ struct og_engine {
         if (n + std::max<size_t>(std::min<size_t>(EV_STAGE_EVENTS, 64), ev_reserve) > ev_cap || !d_events) {
             if (d_events) HIPCK(hipFree(d_events));
             d_events = nullptr;
-            size_t headroom = 64 * EV_STAGE_EVENTS; // room for appended segments (32 MB) before the next compaction
+            size_t headroom = (size_t)2 << 20; // room for appended segments (2 M events, 32 MB) before the ring has to wrap
             if (ev_headroom_env) headroom = ev_headroom_env; // OSCEN_GPU_EV_HEADROOM (tests: force compactions), read at og_create
             ev_cap = std::max<size_t>(n + std::max<size_t>(n / 2, ev_reserve), 1024) + headroom;
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
@@ -717,7 +717,7 @@ struct og_engine {
         bounce.h2d(d_ev_end, end.data(), (size_t)V * 4, stream);
         HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
         h_events.swap(evs);
-        h_events.resize(ev_cap); // mirror of the whole ring
+        h_events.reserve(ev_cap); // mirror of the whole ring (grown on demand by the live path: no zero-fill of the room here)
         seg_begin.swap(cursor);
         seg_end.swap(end);
         seg_last.swap(last);
@@ -837,7 +837,7 @@ struct og_engine {
         if (base == SIZE_MAX) return false;
         // commit: host mirror, then the device
         HostProf::Scope pc(prof, HostProf::EV_COMMIT);
-        if (h_events.size() < ev_cap) h_events.resize(ev_cap);
+        if (h_events.size() < base + n_ev) h_events.resize(base + n_ev); // (capacity ev_cap is reserved: no reallocation, no fill of the unused room)
         memcpy(h_events.data() + base, sev, n_ev * sizeof(OgEvent));
         for (size_t i = 0; i < n_upd; ++i) {
             const uint32_t v = upd[3 * i];
@@ -1702,6 +1702,19 @@ int og_get_value(const og_engine* e, uint32_t input, float* out)
     *out = e->values[input];
     return OG_OK;
 }
+
+int og_ramp_state(const og_engine* e, uint32_t input, float* current, float* target, uint32_t* frames_remaining)
+{
+    int rc = check_value_input(e, input, false);
+    if (rc) return rc;
+    const Ramp& r = e->ramps[input];
+    const bool ramped = e->cg->inputs[input].decl.ramp_frames > 0 || r.ramping();
+    if (current) *current = ramped ? r.current : e->values[input];
+    if (target) *target = ramped ? r.target : e->values[input];
+    if (frames_remaining) *frames_remaining = r.frames_remaining;
+    return OG_OK;
+}
+uint32_t og_active_ramps(const og_engine* e) { return e ? e->active_ramps : 0; }
 
 int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t count, const float* v)
 {

@@ -597,8 +597,9 @@ struct Codegen {
             return r;
         }
         if (N <= 1 || v.inner == dst_inner) {
-            if (!policy.empty() && v.rate == Rate::Vary && N <= 1)
-                fail("connection policy [" + policy + "] needs an oversampled (`* N`) node on one side");
+            // (a policy on a same-rate edge is accepted and ignored, like the reference: classify_edge_ir
+            //  `(Same, Same) => EdgeKernel::None` whatever the policy, ir/lower.rs:878 -- the `_1x` variant of
+            //  oversample_variants! keeps its `[sinc]` edge, oscen-lib/tests/oversample_variants.rs:8-23)
             return v;
         }
         const std::string pol = policy.empty() ? "sinc" : policy;
@@ -1188,7 +1189,7 @@ void emit_adsr(NodeCtx& x)
     int w_rem = x.cg.new_state(x.n.decl->name + ".samples_remaining", false, [](const UEnv&) { return 0u; });
     int w_level = x.cg.new_state(x.n.decl->name + ".level", true, [](const UEnv&) { return fbits(0.0f); });
     int w_vel = x.cg.new_state(x.n.decl->name + ".velocity", true, [](const UEnv&) { return fbits(1.0f); });
-    x.cg.S().decl << "    og::Adsr " << E << " = {0u, og::ADSR_HOLD, 0.0f, 1.0f, 0.0f};\n";
+    x.cg.S().decl << "    og::Adsr " << E << " = {0u, og::ADSR_HOLD, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 4294967296.0f};\n";
     x.cg.S().load << "        og::adsr_block_begin(" << E << ", og::ld_u(A, c, " << w_stage << "), og::ld_u(A, c, " << w_rem
               << "), og::ld_f(A, c, " << w_level << "), og::ld_f(A, c, " << w_vel << "), " << K << ");\n";
     x.cg.S().store << "        og::st_u(A, c, " << w_stage << ", " << E << ".stage);\n"
@@ -1196,7 +1197,8 @@ void emit_adsr(NodeCtx& x)
                << "        og::st_f(A, c, " << w_level << ", " << E << ".lv);\n"
                << "        og::st_f(A, c, " << w_vel << ", " << E << ".vel);\n";
     x.on_event("gate", [&](const std::string& val) { return "                og::adsr_gate(" + E + ", " + val + ", " + K + ");\n"; });
-    x.set_out("output", x.n.domain == 1 ? "og::adsr_tick(" + E + ")" : "og::adsr_tick<decltype(chk)::release>(" + E + ")", true);
+    // (outer-rate envelopes: the chunk loops keep <E>.fc == (float)<E>.cnt at their top, see og::Adsr::fc and fc_sync below)
+    x.set_out("output", x.n.domain == 1 ? "og::adsr_tick<true, false>(" + E + ")" : "og::adsr_tick<decltype(chk)::release, true>(" + E + ")", true);
     const std::string fix = "og::adsr_complete(" + E + ", " + x.sf(s_ac) + ", " + x.sf(s_dc) + ", " + x.su(s_dn) + ", " + x.p +
                             "output);\n";
     if (x.n.domain == 1) // oversampled: N ticks per frame, finish a stage end right away
@@ -2204,7 +2206,13 @@ GraphDesc expand_nested(const GraphDesc& g, int depth)
                     }
                     continue;
                 }
-                if (gi.ramp_frames) fail_unsupported("ramped inputs are not supported inside nested graphs ('" + gi.name + "')");
+                // A `[ramp: N]` input of a nested graph is a ValueRampState field of the nested struct, ticked by the nested
+                // process() itself (codegen/mod.rs:559-572).  Nothing in the outer graph can move it: an outer edge into it
+                // has no ConnectEndpoints<f32, ValueRampState> impl (graph/static_context.rs:41-147: a Rust type error), so
+                // it stays at its default -- an idle ramp, `current` = the declared value on every tick.
+                if (gi.ramp_frames && src != sb.in_src.end())
+                    fail("nested graph '" + n.name + "': '" + gi.name + "' is a ramped input (a ValueRampState): an outer connection "
+                         "cannot drive it (the reference has no ConnectEndpoints impl for it)");
                 std::string rep;
                 if (src == sb.in_src.end()) {
                     rep = flit(gi.def);
@@ -3582,7 +3590,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (const auto& r : cg.sec[k].env_rs) m = m.empty() ? r : "(" + m + " + " + r + ")";
         return m;
     };
+    // `<E>.fc = (float)<E>.cnt;` for the envelopes of a group: in front of every loop whose ticks run the release arithmetic
+    // (the release-free chunk variant steps cnt only), see og::Adsr::fc
+    auto fc_sync = [&](const std::vector<int>& st, const std::string& ind) {
+        std::string r;
+        for (int k : st)
+            for (const auto& cexp : cg.sec[k].env_cnts) {
+                const std::string E = cexp.substr(0, cexp.size() - 4); // "<E>.cnt"
+                r += ind + E + ".fc = (float)" + E + ".cnt;\n";
+            }
+        return r;
+    };
     body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> " << (out.voice_channels > 1 ? "og::OutN<" + std::to_string(out.voice_channels) + ">" : std::string("float")) << " {\n"
+         << "        OG_TICK_CONTRACT\n"
          << group_tick({all_stages}, 0);
     if (cg.frame_end.str().empty()) {
         body << "        return " << bus_expr << ";\n    };\n";
@@ -3602,6 +3622,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
         auto variants = [&](const std::string& tail, const std::string& ind0) {
             auto quiet = [&](const std::string& flag, const std::string& ind) {
+                if (flag != "false, false") body << fc_sync(all_stages, ind);
                 body << ind << "#pragma unroll " << unroll << "\n"
                      << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "")
                      << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<" << flag << tail << ">{}));\n";
@@ -3631,6 +3652,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         }
     }
     body << "        } else {\n"
+         << fc_sync(all_stages, "            ")
          << "            for (uint32_t j = 0; j < n; ++j) {\n"
          << "                events(base + j);\n"
          << "                og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "") << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<true>{}));\n"
@@ -3723,6 +3745,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (size_t k : reads) body << "    float xp" << k << "[XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
+                 << "        OG_TICK_CONTRACT\n"
                  << group_tick(groups, gi);
             if (last) body << "        return " << bus_expr << ";\n";
             body << "    };\n";
@@ -3740,6 +3763,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // flags: stage-end checks, release arithmetic, hand-off values prefetched, node steady states
             auto quiet = [&](const char* chk_flag, const char* rel_flag, bool st_flag, const std::string& ind) {
                 const bool pre = !reads.empty();
+                if (std::string(rel_flag) == "true") body << fc_sync(st, ind);
                 if (pre) {
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
@@ -3798,6 +3822,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // the checked chunk: unrolled, stage-end checks and release arithmetic on, events applied on their frame
             auto checked = [&](const std::string& ind) {
                 const bool pre = !reads.empty();
+                body << fc_sync(st, ind);
                 if (pre) {
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
@@ -3873,6 +3898,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 checked("            ");
             }
             body << "        } else {\n"
+                 << fc_sync(st, "            ")
                  << "            for (uint32_t j = 0; j < n; ++j) {\n"
                  << "                const uint32_t f = base + j;\n"
                  << "                events(f);\n"

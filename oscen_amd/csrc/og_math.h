@@ -40,8 +40,15 @@ using __hip_internal::uint32_t;
 // ---------------------------------------------------------------------------
 #ifdef OG_STRICT
 #define OG_FMA(a, b, c) ((a) * (b) + (c))
+#define OG_TICK_CONTRACT
 #else
 #define OG_FMA(a, b, c) fmaf((a), (b), (c))
+// First statement of a generated tick lambda: the expressions the generator writes THERE -- Gain / AddValue / Mixer /
+// Crossfade / Vca bodies, compound connection sources (`osc.output * env + offset -> out`) -- may contract.  Whatever the
+// rate analysis finds constant over a block is formed elsewhere (on the host, or in derive(), both without this pragma),
+// so only per-sample values are touched: their last-bit differences are noise, not a detuning.  The pragma is lexical:
+// the node library's functions keep the -ffp-contract=off they were written under.
+#define OG_TICK_CONTRACT _Pragma("clang fp contract(fast)")
 #endif
 
 // sin(x): Cody-Waite reduction modulo pi with the split of pi carried

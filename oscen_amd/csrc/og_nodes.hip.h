@@ -91,6 +91,12 @@ constexpr uint32_t ADSR_HOLD = 0xFFFFFFFFu;
 struct Adsr {
     uint32_t stage, cnt;
     float lv, tgt, cf, vel, sus, rs;
+    // (float)cnt, kept by the release arithmetic of a chunk so that it costs one subtraction per sample instead of an
+    // integer step and a conversion: adsr_enter() sets it, adsr_tick<.., true> counts it down, and the generated chunk
+    // loops re-derive it from cnt at their top (the release-free chunk variant steps cnt only).  Exact -- identical to
+    // converting cnt every sample -- for stages shorter than 2^24 samples (5.8 minutes at 48 kHz); beyond that the
+    // reciprocal it feeds differs in its last bits, in an increment that is itself below half an ulp of the level.
+    float fc;
 };
 
 OG_DEV void adsr_enter(Adsr& e, uint32_t stage, uint32_t n, float a_c, float d_c)
@@ -101,6 +107,7 @@ OG_DEV void adsr_enter(Adsr& e, uint32_t stage, uint32_t n, float a_c, float d_c
     e.tgt = att ? 1.0f : (dec ? e.sus : 0.0f);
     e.cf = att ? a_c : (dec ? d_c : 0.0f);
     e.rs = (stage == ST_RELEASE) ? 1.0f : 0.0f;
+    e.fc = (float)e.cnt;
 }
 
 // Once per block: load + the part of apply_parameters()/update_sustain_level()
@@ -161,7 +168,8 @@ OG_DEV void adsr_gate(Adsr& e, float v, const OgBlockArgs& A, int k)
 // rounded quotient the increment differs by <= 2^-23 relative: the step lands on a neighbouring f32 about 2/n of
 // the time, and the recurrence contracts (lv shrinks by 1 - 1/n), so the level stays within a few ulp over a whole
 // release (observed: DESIGN.md section 5).  Nothing here feeds a phase accumulator.
-template <bool RELEASE = true>
+// FC: the caller keeps e.fc == (float)e.cnt at the top of the chunk (see Adsr::fc); otherwise cnt is converted here.
+template <bool RELEASE = true, bool FC = false>
 OG_DEV float adsr_tick(Adsr& e)
 {
 #ifdef OG_STRICT
@@ -175,7 +183,10 @@ OG_DEV float adsr_tick(Adsr& e)
 #else
     float cf = e.cf;
     // (cnt >= 1 while a stage is ticking and ADSR_HOLD otherwise: the reciprocal is finite, rs * rcp is 0 or rcp)
-    if (RELEASE) cf = fmaf(e.rs, __builtin_amdgcn_rcpf((float)e.cnt), cf);
+    if (RELEASE) {
+        cf = fmaf(e.rs, __builtin_amdgcn_rcpf(FC ? e.fc : (float)e.cnt), cf);
+        if (FC) e.fc -= 1.0f;
+    }
     const float lv = fmaf(e.tgt - e.lv, cf, e.lv);
 #endif
     e.cnt -= 1u; // samples_remaining -= 1; reaching 0 is handled by adsr_complete()
