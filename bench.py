@@ -604,10 +604,13 @@ def run_cluster(args):
         has_gate = False
     n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if has_gate else 0
     shard0 = cl.shard(0)
+    shards = [cl.shard(s) for s in range(cl.num_shards)]
     if W > 0:
         cl.render(W * block, block)
     torch.cuda.synchronize()
-    shard0.enable_kernel_timing(True)
+    for sh in shards:
+        sh.enable_kernel_timing(True)
+    cl.enable_reduce_timing(True)
     times = []
     mix = None
     for r in range(R):
@@ -618,9 +621,14 @@ def run_cluster(args):
         for d in set(devices):
             torch.cuda.synchronize(d)
         times.append(time.perf_counter() - t0)
-    kern_ms, n_launch = shard0.kernel_time_ms()
-    n_blocks_timed = shard0.kernel_blocks_timed
-    shard0.enable_kernel_timing(False)
+    per_shard = []
+    for sh in shards:  # every shard's own voice-kernel time (HIP events on its stream)
+        ms, n = sh.kernel_time_ms()
+        per_shard.append((ms, n, sh.kernel_blocks_timed))
+        sh.enable_kernel_timing(False)
+    kern_ms, n_launch, n_blocks_timed = per_shard[0]
+    red_total_ms, red_n = cl.reduce_time_ms()
+    cl.enable_reduce_timing(False)
     assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
     elapsed, stats = region_stats(times, total_voices, K, block)
     line = {
@@ -656,6 +664,18 @@ def run_cluster(args):
         "timing": stats,
         "rccl_ranks": cl.num_devices if cl.rccl_reduces else None,
         "cluster": {"shards": cl.num_shards, "devices": cl.num_devices, "rccl_reduces": cl.rccl_reduces},
+        "multi_gpu": {
+            "rccl_ranks": cl.num_devices if cl.rccl_reduces else None,
+            "backend": "RCCL (ncclReduce issued by the library, one communicator per device)" if cl.rccl_reduces else "none (one device)",
+            "per_rank_kernel_ms_avg": [p[0] for p in per_shard],
+            "per_rank_kernel_ms_per_block": [p[0] * p[1] / max(1, p[2]) for p in per_shard],
+            "reduce_ms_total": red_total_ms,
+            "reduces_timed": red_n,
+            "reduce_ms_avg": red_total_ms / red_n if red_n else None,
+            "reduce_share_of_run": (red_total_ms / R) / (elapsed * 1e3) if red_n else None,
+            "note": "reduce = device time between HIP events recorded around each batched ncclReduce on the root's stream "
+                    "(og_cluster_reduce_time_ms); it overlaps the next batch's voice kernels",
+        },
         "offline_voices_at_48k": total_voices * K * block / elapsed / 48000.0,
         "roofline": roofline_record(shard0, V, block, args.graph, kern_ms, n_launch, n_blocks_timed),
         "cpu_baseline": None,
@@ -850,6 +870,7 @@ def main():
         dist.all_reduce(ones)  # every rank of the communicator took part
         rccl_ranks = int(round(float(ones.item())))
     times = []
+    reduce_events, reduce_host_ms = [], []
     kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
     for r in range(R):
         first = W + r * (K + 1)        # first timed block of this region
@@ -867,7 +888,15 @@ def main():
             step(i)
         eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
         if dist is not None:
-            reduce_bus(bus[first:first + K])  # ONE RCCL reduce of the [K, block] mix bus over xGMI
+            # ONE RCCL reduce of the [K, block] mix bus over xGMI, bracketed by events on the stream it runs on (the
+            # engine renders on torch's current stream), so that a scaling record explains its own efficiency
+            t_r0 = time.perf_counter()
+            ev_r0, ev_r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_r0.record(stream)
+            reduce_bus(bus[first:first + K])
+            ev_r1.record(stream)
+            reduce_host_ms.append((time.perf_counter() - t_r0) * 1e3)
+            reduce_events.append((ev_r0, ev_r1))
         torch.cuda.synchronize()
         if dist is not None:
             barrier()
@@ -885,6 +914,31 @@ def main():
         n_blocks_timed += eng.kernel_blocks_timed  # blocks those launches rendered (up to --bus-batch per launch)
         eng.enable_kernel_timing(False)
     kern_ms = kern_total_ms / max(1, n_launch)
+    multi_gpu = None
+    if dist is not None:
+        # per rank: the voice kernel's average launch and per-block time, and what the reduce cost on this rank's stream
+        # (device time between the two events: includes waiting for the slowest rank -- a reduce cannot finish before
+        # every contribution exists) and on its host thread
+        red_dev = [a.elapsed_time(b) for a, b in reduce_events] if args.backend != "gloo" else list(reduce_host_ms)
+        mine = torch.tensor([kern_ms, kern_ms * n_launch / max(1, n_blocks_timed), float(np.median(red_dev)) if red_dev else 0.0,
+                             float(np.median(reduce_host_ms)) if reduce_host_ms else 0.0], dtype=torch.float64,
+                            device="cpu" if args.backend == "gloo" else "cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(allr, mine)
+        rows = [[float(x) for x in t.cpu().tolist()] for t in allr]
+        multi_gpu = {
+            "rccl_ranks": rccl_ranks,
+            "backend": "RCCL" if args.backend == "nccl" else "gloo",
+            "per_rank_kernel_ms_avg": [r[0] for r in rows],
+            "per_rank_kernel_ms_per_block": [r[1] for r in rows],
+            "per_rank_reduce_ms": [r[2] for r in rows],
+            "per_rank_reduce_host_ms": [r[3] for r in rows],
+            "reduce_ms_max": max(r[2] for r in rows),
+            "reduce_bytes": int(K * block * ch * 4),
+            "reduce_share_of_region": max(r[2] for r in rows) / (float(np.median(times)) * 1e3) if times else None,
+            "note": "reduce = one [K x block x channels] f32 sum onto rank 0 per timed region; device time between events "
+                    "recorded around it on the rendering stream (median over the regions)",
+        }
 
     if rank == 0:
         sel = torch.from_numpy(timed_blocks)
@@ -931,6 +985,7 @@ def main():
             },
             "timing": stats,
             "rccl_ranks": rccl_ranks,
+            "multi_gpu": multi_gpu,  # None at N = 1 (no collective on the data path)
             # throughput of the QUEUED path (blocks known ahead, up to 32 per launch) expressed in 48 kHz voices: an
             # offline-render rate.  The real-time figure comes from the blocking entry: realtime.realtime_voices_at_48k
             "offline_voices_at_48k": value / 48000.0,

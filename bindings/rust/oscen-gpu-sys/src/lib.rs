@@ -130,6 +130,8 @@ extern "C" {
     pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
     pub fn og_reserve_events(e: *mut og_engine, n_events: u64) -> c_int;
     pub fn og_sync_event_counters(e: *mut og_engine) -> c_int;
+    pub fn og_cluster_enable_reduce_timing(c: *mut og_cluster, on: c_int) -> c_int;
+    pub fn og_cluster_reduce_time_ms(c: *mut og_cluster, total_ms: *mut f64, n_reduces: *mut u64) -> c_int;
     pub fn og_ramp_state(e: *const og_engine, input: u32, current: *mut c_float, target: *mut c_float, frames_remaining: *mut u32) -> c_int;
     pub fn og_active_ramps(e: *const og_engine) -> u32;
 }

@@ -433,6 +433,10 @@ uint32_t og_cluster_num_devices(const og_cluster* c); /* distinct GPUs = ranks o
 uint64_t og_cluster_num_voices(const og_cluster* c);
 uint32_t og_cluster_channels(const og_cluster* c);
 uint64_t og_cluster_rccl_reduces(const og_cluster* c); /* ncclReduce batches issued so far (0 on a one-device cluster) */
+/* device time of those reduces on the root's stream (HIP events around each batched ncclReduce, includes waiting for the
+ * slowest device): enable, render, then read the sum and count since enabling (reading clears them) */
+int og_cluster_enable_reduce_timing(og_cluster* c, int on);
+int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduces);
 /* event outputs of the graph (og_read_output_events) over all shards: merged into (frame, GLOBAL voice, push order) */
 int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n, uint64_t* n_overflowed);
 uint64_t og_cluster_events_dropped(og_cluster* c); /* og_events_dropped summed over the shards */

@@ -140,6 +140,8 @@ constexpr uint32_t CL_BATCH_BLOCKS = 256; // blocks per reduce
 
 struct og_cluster {
     std::vector<og_engine*> shard;
+    bool time_reduces = false; // og_cluster_enable_reduce_timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reduce_events;
     std::vector<og_out_event> out_ev_carry, out_ev_scratch; // og_cluster_read_output_events: queue (global voice ids) / per-shard scratch
     std::vector<uint64_t> lo; // first global voice of every shard; lo[n] = total
     std::vector<int> devs;    // distinct devices, devs[0] = root
@@ -292,10 +294,22 @@ struct og_cluster {
         // (3) ONE reduce of the whole batch over xGMI (root = devs[0])
         if (use_rccl) {
             Rccl& R = rccl();
+            hipEvent_t t0 = nullptr, t1 = nullptr;
+            if (time_reduces) { // (og_cluster_enable_reduce_timing: device time of the reduce on the ROOT's stream)
+                HIPCK(hipSetDevice(devs[0]));
+                HIPCK(hipEventCreate(&t0));
+                HIPCK(hipEventCreate(&t1));
+                HIPCK(hipEventRecord(t0, dev_stream[0]));
+            }
             R.ck(R.GroupStart(), "ncclGroupStart");
             for (size_t d = 0; d < devs.size(); ++d)
                 R.ck(R.Reduce(dev_acc[b][d], dev_acc[b][d], nf * vc, ncclFloat, ncclSum, 0, comms[d], dev_stream[d]), "ncclReduce");
             R.ck(R.GroupEnd(), "ncclGroupEnd");
+            if (time_reduces) {
+                HIPCK(hipSetDevice(devs[0]));
+                HIPCK(hipEventRecord(t1, dev_stream[0]));
+                reduce_events.push_back({t0, t1});
+            }
             n_reduces += 1;
         }
         // (4) root: post-mix stage, then hand the batch to the host through a pinned staging buffer
@@ -563,6 +577,44 @@ int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap
     *n_out = (uint32_t)give;
     if (n_overflowed) *n_overflowed = over; // (only what a shard's device log could not hold)
     return OG_OK;
+    });
+}
+
+// Device time of the batched ncclReduce on the root's stream (HIP events around it): lets a caller -- bench.py --cluster --
+// say how much of a multi-GPU run is the xGMI reduce.  The time between the two events includes waiting for the slowest
+// device's contribution.  Query after og_cluster_render / og_cluster_synchronize returned (the events are complete then).
+int og_cluster_enable_reduce_timing(og_cluster* c, int on)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    return guard([&] {
+        for (auto& pr : c->reduce_events) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->reduce_events.clear();
+        c->time_reduces = on != 0;
+        return OG_OK;
+    });
+}
+int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduces)
+{
+    if (!c || !total_ms || !n_reduces) return set_err(OG_E_INVALID, "null argument");
+    return guard([&] {
+        double sum = 0.0;
+        uint64_t n = 0;
+        for (auto& pr : c->reduce_events) {
+            float ms = 0.0f;
+            HIPCK(hipEventSynchronize(pr.second));
+            HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            sum += ms;
+            n += 1;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->reduce_events.clear();
+        *total_ms = sum;
+        *n_reduces = n;
+        return OG_OK;
     });
 }
 

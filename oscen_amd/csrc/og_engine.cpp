@@ -1544,12 +1544,18 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // one / two / four waves: 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152:
             // 0.077 / 0.071 / 0.054; 65 536: 0.080 / 0.066 / 0.086; 98 304: 0.104 / 0.084 / -; 131 072: 0.101 / 0.111 /
             // 0.116) and scales with the graph instead of assuming its cost.
+            // Round 4: the SIMD does not retire a wave-instruction every 3.05 cycles whatever it hosts -- that is the figure
+            // with 8+ co-resident waves.  Measured cycles per VALU instruction per SIMD against the waves it interleaves:
+            // 1 wave ~4.9, 2 waves ~4.0, 4 waves ~3.5, 16 waves 3.06 = 3.05 + 1.9 / r.  With that term the
+            // four-wave pipeline wins at 65 536 voices (four waves per SIMD at 3.5 cycles against two at 4.0: measured
+            // 1.04 against 1.19 ms per 20 blocks with the round-4 kernels, whose depth-first schedule also halves the
+            // hand-off traffic of the four-wave cut: ~5 % + 10 instructions instead of 12 % + 16).
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
             const double W = (double)std::max(8, e->cg->valu_estimate);
             auto cycles = [&](int d) {
-                const double I = d == 1 ? W : (d == 2 ? (W + 8.0) / 2.0 : (W * 1.12 + 16.0) / 4.0);
+                const double I = d == 1 ? W : (d == 2 ? (W + 8.0) / 2.0 : (W * 1.05 + 10.0) / 4.0);
                 const double r = std::ceil((double)waves1 * d / (double)simds);
-                return std::max(4.8 * I, 3.05 * r * I);
+                return I * r * (3.05 + 1.9 / r);
             };
             uint32_t depth = 0;
             double best = cycles(1);

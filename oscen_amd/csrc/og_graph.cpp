@@ -937,7 +937,12 @@ struct Codegen {
         }
         Val r;
         r.rate = Rate::Vary;
-        for (int k = 0; k < f->result_channels; ++k) { // (the inlined pure call is evaluated once: common subexpression)
+        // (One textual call per channel: the value is an EXPRESSION that the caller places wherever the edge is evaluated --
+        //  the frame body, the inner loop of an oversampled region, a resampler's capture slot -- so it cannot name a
+        //  temporary of some other scope.  The function is force-inlined and pure by contract (og_register_function: "pure
+        //  function of its arguments"), the identical calls fold into one evaluation; ADVICE r3 asked for a temporary,
+        //  tried in round 4: it broke calls inside `* N` regions.)
+        for (int k = 0; k < f->result_channels; ++k) {
             Val ch = base;
             ch.e = c + ".v[" + std::to_string(k) + "]";
             r.ch.push_back(ch);
@@ -2582,7 +2587,8 @@ void register_user_node(const UserNodeType& t)
     std::set<std::string> names;
     auto uniq = [&](const std::string& n) {
         if (!is_ident(n)) fail("node type '" + t.type + "': '" + n + "' is not an identifier");
-        if (n == "value" || n == "sample_rate") fail("node type '" + t.type + "': '" + n + "' is reserved");
+        if (n == "value" || n == "sample_rate" || n == "frame_offset") // (parameters the generated handlers / process() receive)
+            fail("node type '" + t.type + "': '" + n + "' is reserved");
         if (!names.insert(n).second) fail("node type '" + t.type + "': duplicate field '" + n + "'");
     };
     for (const auto& p : t.inputs) {
@@ -3287,6 +3293,25 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
             const char* ep = getenv("OGC_PARTS");
             if (total >= 80 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(getenv("OGC_K3") ? 3 : 4);
+            if (const char* ec = getenv("OGC_CUTS")) { // experiment knob: "a,b[,c]" = one-past-last stage of every wave but the last (3 or 4 waves)
+                std::vector<int> ends;
+                for (const char* q = ec; *q;) {
+                    ends.push_back(atoi(q));
+                    while (*q && *q != ',') ++q;
+                    if (*q == ',') ++q;
+                }
+                ends.push_back(cg.n_stages);
+                std::vector<std::vector<int>> gr;
+                int lo = 0;
+                bool ok = ends.size() >= 3 && ends.size() <= 4;
+                for (int e : ends) {
+                    ok = ok && e > lo && e <= cg.n_stages;
+                    gr.emplace_back();
+                    for (int k = lo; k < e && ok; ++k) gr.back().push_back(k);
+                    lo = e;
+                }
+                if (ok) cg.groups4 = gr;
+            }
         }
     }
     cg.split = cg.n_stages > 1;
@@ -3602,7 +3627,6 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         return r;
     };
     body << "    auto tick = [&](const uint32_t f, auto chk) __attribute__((always_inline)) -> " << (out.voice_channels > 1 ? "og::OutN<" + std::to_string(out.voice_channels) + ">" : std::string("float")) << " {\n"
-         << "        OG_TICK_CONTRACT\n"
          << group_tick({all_stages}, 0);
     if (cg.frame_end.str().empty()) {
         body << "        return " << bus_expr << ";\n    };\n";
@@ -3745,7 +3769,6 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (size_t k : reads) body << "    float xp" << k << "[XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? " -> float" : "") << " {\n"
-                 << "        OG_TICK_CONTRACT\n"
                  << group_tick(groups, gi);
             if (last) body << "        return " << bus_expr << ";\n";
             body << "    };\n";

@@ -362,6 +362,18 @@ __device__ __forceinline__ og_f2 f2_add(og_f2 x, og_f2 y) { return x + y; }
 __device__ __forceinline__ og_f2 f2_sub(og_f2 x, og_f2 y) { return x - y; }
 #endif
 __device__ __forceinline__ og_f2 f2_mul(og_f2 x, float y) { return f2_mul(x, og_f2{y, y}); }
+// x * y + z: tolerance mode fuses (v_pk_fma_f32: one issue for two harmonics, one rounding each); OG_STRICT keeps the
+// reference's two roundings.  Only used where the result does not feed a recurrence that preserves magnitude (the
+// amplitude interpolation, which is re-anchored on its target every 65 frames, and the output sum -- never the rotation).
+__device__ __forceinline__ og_f2 f2_fma(og_f2 x, og_f2 y, og_f2 z)
+{
+#if defined(OG_STRICT) || defined(OG_EP_SCALAR)
+    return f2_add(f2_mul(x, y), z);
+#else
+    return __builtin_elementwise_fma(x, y, z);
+#endif
+}
+__device__ __forceinline__ og_f2 f2_fma(og_f2 x, float y, og_f2 z) { return f2_fma(x, og_f2{y, y}, z); }
 __device__ __forceinline__ HarmV harm_splat(float x)
 {
     HarmV r;

@@ -40,15 +40,13 @@ using __hip_internal::uint32_t;
 // ---------------------------------------------------------------------------
 #ifdef OG_STRICT
 #define OG_FMA(a, b, c) ((a) * (b) + (c))
-#define OG_TICK_CONTRACT
 #else
 #define OG_FMA(a, b, c) fmaf((a), (b), (c))
-// First statement of a generated tick lambda: the expressions the generator writes THERE -- Gain / AddValue / Mixer /
-// Crossfade / Vca bodies, compound connection sources (`osc.output * env + offset -> out`) -- may contract.  Whatever the
-// rate analysis finds constant over a block is formed elsewhere (on the host, or in derive(), both without this pragma),
-// so only per-sample values are touched: their last-bit differences are noise, not a detuning.  The pragma is lexical:
-// the node library's functions keep the -ffp-contract=off they were written under.
-#define OG_TICK_CONTRACT _Pragma("clang fp contract(fast)")
+// (Not contracted: the expressions the GENERATOR writes into a tick -- Gain / AddValue / Mixer / Crossfade bodies, compound
+//  connection sources.  A `#pragma clang fp contract(fast)` at the top of the tick lambda was tried in round 4: it saves two
+//  instructions per FMVoice frame, but the example crate's nodes written against the plug-in API -- device FUNCTIONS, which a
+//  lexical pragma does not reach, and must not: user code may hold a phase accumulator -- then no longer give the bits of
+//  the built-in kernel (tests/test_plugin_gpu.py).)
 #endif
 
 // sin(x): Cody-Waite reduction modulo pi with the split of pi carried

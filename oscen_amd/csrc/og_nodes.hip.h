@@ -363,9 +363,9 @@ OG_DEV float div_rcp(float a, float b, float rb)
 OG_DEV float poly_blep(float t, float dt, float rdt)
 {
     const float x1 = div_rcp(t, dt, rdt);
-    const float r1 = x1 + x1 - x1 * x1 - 1.0f;
+    const float r1 = OG_FMA(-x1, x1, x1 + x1) - 1.0f; // x1 + x1 - x1 * x1 - 1
     const float x2 = div_rcp(t - 1.0f, dt, rdt);
-    const float r2 = x2 * x2 + x2 + x2 + 1.0f;
+    const float r2 = OG_FMA(x2, x2, x2) + x2 + 1.0f;
     const float res = (t < dt) ? r1 : ((t > 1.0f - dt) ? r2 : 0.0f);
     return (dt > F32_EPSILON) ? res : 0.0f;
 }
@@ -400,7 +400,7 @@ OG_DEV float polyblep_tick(float& phase_state, float frequency, float freq_per_s
     if ((!BELOW_QUARTER && frequency >= sr * 0.25f) || WAVE == PB_SINE) {
         value = og_sinf(phase * F32_TAU);
     } else if (WAVE == PB_SAW) {
-        float y = 2.0f * phase - 1.0f;
+        float y = OG_FMA(2.0f, phase, -1.0f);
         y -= poly_blep(phase, dt, rdt);
         value = y;
     } else if (WAVE == PB_SQUARE) {
@@ -418,7 +418,7 @@ OG_DEV float polyblep_tick(float& phase_state, float frequency, float freq_per_s
         }
         const float t1 = wrap_phase(phase + 0.25f);
         const float t2 = wrap_phase(phase + 0.75f);
-        value = y + 4.0f * dt * (poly_blamp(t1, dt, rdt) - poly_blamp(t2, dt, rdt));
+        value = OG_FMA(4.0f * dt, poly_blamp(t1, dt, rdt) - poly_blamp(t2, dt, rdt), y);
     }
     value = value * amplitude;
     phase_state = wrap_phase(phase_state + freq_per_sample);
@@ -489,9 +489,9 @@ OG_DEV float iir_lowpass_tick(float in, float& v1, float& v2, float b0, float b1
 {
     constexpr float DENORMAL_THRESHOLD = 1e-15f;
     in = (fabsf(in) < DENORMAL_THRESHOLD) ? 0.0f : in;
-    const float out = b0 * in + v1;
-    v1 = b1 * in - a1 * out + v2;
-    v2 = b2 * in - a2 * out;
+    const float out = OG_FMA(b0, in, v1);
+    v1 = OG_FMA(-a1, out, b1 * in) + v2; // b1 * in - a1 * out + v2, same association
+    v2 = OG_FMA(-a2, out, b2 * in);
     v1 = (fabsf(v1) < DENORMAL_THRESHOLD) ? 0.0f : v1;
     v2 = (fabsf(v2) < DENORMAL_THRESHOLD) ? 0.0f : v2;
     return out;
@@ -517,11 +517,11 @@ OG_DEV void lp18_params(float cutoff, float fmod, float resonance, float sr, flo
 OG_DEV float lp18_tick(float in, float& z0, float& z1, float& z2, float g, float h) // :94-106
 {
     const float hp = (in - h * z0 - z1 - z2) / (1.0f + g);
-    const float bp1 = g * hp + z0;
+    const float bp1 = OG_FMA(g, hp, z0);
     z0 = tanhf(bp1);
-    const float bp2 = g * bp1 + z1;
+    const float bp2 = OG_FMA(g, bp1, z1);
     z1 = bp2;
-    const float lp = g * bp2 + z2;
+    const float lp = OG_FMA(g, bp2, z2);
     z2 = lp;
     return lp;
 }
@@ -688,7 +688,7 @@ OG_DEV float hb_down_step(float (&h)[24], float x0, float x1)
     for (int kk = 0; kk < 6; ++kk) {
         const float left = h[2 * kk + 1];
         const float right = h[22 - 2 * kk + 1];
-        acc = acc + (left + right) * HALF[kk];
+        acc = OG_FMA(left + right, HALF[kk], acc); // (taps in the reference's order; tolerance mode drops the product's rounding)
     }
     return acc;
 }
@@ -724,7 +724,7 @@ OG_DEV void hb_up_step(float (&h)[12], float x, float& y0, float& y1)
     y1 = h[5] * CENTER2;
     float acc = 0.0f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) acc = acc + (h[kk] + h[11 - kk]) * HALF[kk];
+    for (int kk = 0; kk < 6; ++kk) acc = OG_FMA(h[kk] + h[11 - kk], HALF[kk], acc);
     y0 = acc * 2.0f;
 }
 
@@ -753,7 +753,7 @@ OG_DEV void sinc_up(float (&h)[Log2<N>::v][12], float x, float (&out)[N])
 OG_DEV float flush_denormal(float x) { return (fabsf(x) < 1e-15f) ? 0.0f : x; }
 OG_DEV float allpass1_step(float a, float& xp, float& yp, float x)
 {
-    const float y = (x - yp) * a + xp;
+    const float y = OG_FMA(x - yp, a, xp);
     xp = flush_denormal(x);
     yp = flush_denormal(y);
     return y;
@@ -820,7 +820,7 @@ OG_DEV void linear_up(float& prev, float x, float (&out)[N])
     const float n_inv = 1.0f / (float)N;
     const float delta = x - prev;
 #pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = prev + delta * ((float)i * n_inv);
+    for (int i = 0; i < N; ++i) out[i] = OG_FMA(delta, (float)i * n_inv, prev);
     prev = x;
 }
 template <int N>
@@ -934,7 +934,7 @@ OG_DEV HarmV ep_amp_tick(EpAmp& a)
         }
     }
 #pragma unroll
-    for (int i = 0; i < OG_HPAIRS; ++i) a.cur.p[i] = f2_add(f2_mul(a.cur.p[i], u), f2_mul(a.tgt.p[i], t));
+    for (int i = 0; i < OG_HPAIRS; ++i) a.cur.p[i] = f2_fma(a.cur.p[i], u, f2_mul(a.tgt.p[i], t)); // current * (1 - t) + target * t
     a.step = ramping ? a.step + 1u : 0u;
     return a.cur;
 }
@@ -1019,8 +1019,7 @@ OG_DEV float ep_bank_tick(EpBank& b, const HarmV& amp)
         const og_f2 im = f2_add(f2_mul(b.re.p[i], b.mim.p[i]), f2_mul(b.im.p[i], b.mre.p[i]));
         b.re.p[i] = re;
         b.im.p[i] = im;
-        const og_f2 w = f2_mul(im, amp.p[i]);
-        acc = (i == 0) ? w : f2_add(acc, w);
+        acc = (i == 0) ? f2_mul(im, amp.p[i]) : f2_fma(im, amp.p[i], acc); // output += im * amplitude (the sum, not the rotation)
     }
     float s = acc.x + acc.y;
     if (VOICE_SUM) {

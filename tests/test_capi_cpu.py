@@ -207,7 +207,6 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false, true>{}" in fm and "og::BoolC<true>{}" in fm
     assert "og::BoolC<false, false, false, false>{}" in fm and "og::BoolC<true, true, true, false>{}" in fm
     assert "og::adsr_tick<decltype(chk)::release, true>" in fm and ".fc = (float)" in fm  # float countdown kept per chunk
-    assert "OG_TICK_CONTRACT" in fm
     assert fm.count("if constexpr (decltype(chk)::value)") >= 3
     # the cutoff of FMVoice moves with an envelope: per-tick parameter check; sub_voice's is block-constant
     tick = fm[fm.index("auto tick"):fm.index("auto events")]

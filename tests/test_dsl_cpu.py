@@ -384,3 +384,35 @@ def test_several_edges_into_a_value_destination_follow_the_reference_kind_propag
         return g.kernel_source()
 
     assert src3("c.output -> g.gain; amount -> g.gain;") == src3("c.output + amount -> g.gain;")
+
+
+def test_round4_front_end_edges_follow_the_reference():
+    """(1) a connection policy on a SAME-rate edge is accepted and ignored: classify_edge_ir `(Same, Same) =>
+    EdgeKernel::None` whatever the policy (oscen-graph-compiler/src/ir/lower.rs:870-880) -- the `_1x` expansion of
+    oversample_variants! keeps its `[sinc]` edge (oscen-lib/tests/oversample_variants.rs:8-23);
+    (2) a `[ramp: N]` input of a NESTED graph is a ValueRampState the nested process() ticks itself
+    (codegen/mod.rs:559-572): nothing outside can move it, it idles at its default; an outer edge into it is an error
+    (no ConnectEndpoints<f32, ValueRampState> impl, graph/static_context.rs:41-147);
+    (3) `frame_offset` is a parameter of the generated handlers: reserved as a port / field name."""
+    plain = oscen_amd.Graph(dsl="name: P; output stream out; nodes { osc = PolyBlepOscillator::saw(440.0, 0.6); } connections { osc.output -> out; }")
+    for pol in ("sinc", "linear", "latch", "sinc_iir"):
+        g = oscen_amd.Graph(dsl="name: P; output stream out; nodes { osc = PolyBlepOscillator::saw(440.0, 0.6); } connections { [%s] osc.output -> out; }" % pol)
+        assert g.kernel_source() == plain.kernel_source()
+    inner_ramped = oscen_amd.Graph(dsl="name: R4Inner; input value level = 0.25 [ramp: 64]; output stream out; "
+                                       "nodes { osc = PolyBlepOscillator::sine(330.0, 1.0); } connections { osc.output * level -> out; }")
+    inner_plain = oscen_amd.Graph(dsl="name: R4InnerP; input value level = 0.25; output stream out; "
+                                      "nodes { osc = PolyBlepOscillator::sine(330.0, 1.0); } connections { osc.output * level -> out; }")
+    oscen_amd.register_graph_type("R4Inner", inner_ramped)
+    oscen_amd.register_graph_type("R4InnerP", inner_plain)
+    try:
+        a = oscen_amd.Graph(dsl="name: O; output stream out; nodes { v = R4Inner; } connections { v.out -> out; }")
+        b = oscen_amd.Graph(dsl="name: O; output stream out; nodes { v = R4InnerP; } connections { v.out -> out; }")
+        assert a.kernel_source() == b.kernel_source()  # the idle ramp is the constant 0.25
+        with pytest.raises(oscen_amd.OscenError, match="ramped input"):
+            oscen_amd.Graph(dsl="name: O2; input value x = 0.5; output stream out; nodes { v = R4Inner; } "
+                                "connections { x -> v.level; v.out -> out; }").kernel_source()
+    finally:
+        oscen_amd.unregister_graph_type("R4Inner")
+        oscen_amd.unregister_graph_type("R4InnerP")
+    with pytest.raises(oscen_amd.OscenError, match="reserved"):
+        oscen_amd.register_node("R4Bad::new", inputs=[("frame_offset", "value", 0.0, -1)], outputs=["out"], process="    out = frame_offset;\n")
