@@ -1531,39 +1531,36 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
                 if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
             }
             e->lanes = lanes;
-            // Pipelined variants for banks too small to put enough ordinary waves on every SIMD.  Which depth (waves per
-            // 64 voices: 1, 2 or 4) is a small cost model, not a table of bank sizes:
-            //   * a wave issues at most one instruction every ~4.8 cycles (dependent-instruction latency; measured with
-            //     one wave per SIMD), so a frame costs a wave 4.8 x its instructions;
-            //   * a SIMD retires one wave-instruction per ~3.05 cycles (the measured scalar-f32 ceiling), and the kernel
-            //     ends with the fullest SIMD: r = ceil(waves / SIMDs) waves share it;
-            //   * cutting the node sequence into d waves adds hand-off work: ~8 instructions per frame for two waves,
-            //     ~12 % + 16 for four (LDS rings, barriers, the per-wave loop and event bookkeeping).
-            // cycles per frame ~ max(4.8 * I_d, 3.05 * r_d * I_d), I_d = instructions per wave.  With the graph's
-            // estimated VALU cost (node weights) this reproduces every measured crossover of fm_voice (256-frame blocks,
-            // one / two / four waves: 16 384 voices 0.091 / 0.073 / 0.045 ms; 32 768: 0.095 / 0.085 / 0.052; 49 152:
-            // 0.077 / 0.071 / 0.054; 65 536: 0.080 / 0.066 / 0.086; 98 304: 0.104 / 0.084 / -; 131 072: 0.101 / 0.111 /
-            // 0.116) and scales with the graph instead of assuming its cost.
-            // Round 4: the SIMD does not retire a wave-instruction every 3.05 cycles whatever it hosts -- that is the figure
-            // with 8+ co-resident waves.  Measured cycles per VALU instruction per SIMD against the waves it interleaves:
-            // 1 wave ~4.9, 2 waves ~4.0, 4 waves ~3.5, 16 waves 3.06 = 3.05 + 1.9 / r.  With that term the
-            // four-wave pipeline wins at 65 536 voices (four waves per SIMD at 3.5 cycles against two at 4.0: measured
-            // 1.04 against 1.19 ms per 20 blocks with the round-4 kernels, whose depth-first schedule also halves the
-            // hand-off traffic of the four-wave cut: ~5 % + 10 instructions instead of 12 % + 16).
+            // Pipelined variants for banks too small to put enough ordinary waves on every SIMD.  Which depth (waves per 64
+            // voices: 1, 2 or 4) runs is decided by a small model of time against waves per SIMD.  (Rounds 1-3 derived it
+            // from two constants -- 4.8 cycles per instruction for a lone wave, 3.05 per SIMD otherwise -- which put the
+            // four-wave pipeline behind the two-wave one at 65 536 voices; with the round-4 kernels it is 12 % ahead.)
+            // Round 4: calibrated on the round-4 kernels instead of derived (profiles/r04_depth_sweep.md: fm_voice, 40
+            // blocks of 256 frames per region, ms per block by bank size and depth).  With r = waves per SIMD
+            // (ceil(workgroups x depth / SIMDs)) every depth is a straight line in r above a latency floor:
+            //   one wave per 64 voices   max(0.074, 0.0365 r + 0.030)   r = 1..4   (16 384 .. 262 144 voices)
+            //   two waves                max(0.058, 0.0255 r + 0.006)   r = 1..8
+            //   four waves               max(0.034, 0.0113 r + 0.0085)  r = 1..16
+            // i.e. a lone wave is bound by its own dependent-issue latency (the floors), and at saturation the pipelines
+            // cost MORE SIMD time per voice than the ordinary kernel (2 x 0.0255 and 4 x 0.0113 against 0.0365: hand-offs,
+            // barriers, per-wave loop and event bookkeeping) -- they win where they raise occupancy: four waves up to
+            // ~131 072 voices (measured 65 536: 0.0535 against 0.0605 / 0.0753; 98 304: 0.076 against 0.097 / 0.101), the
+            // ordinary kernel from ~196 608 on.  Other graphs scale the lines by their estimated cost.
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
-            const double W = (double)std::max(8, e->cg->valu_estimate);
+            const double scale = (double)std::max(8, e->cg->valu_estimate) / 127.0; // fm_voice's estimate
             auto cycles = [&](int d) {
-                const double I = d == 1 ? W : (d == 2 ? (W + 8.0) / 2.0 : (W * 1.05 + 10.0) / 4.0);
                 const double r = std::ceil((double)waves1 * d / (double)simds);
-                return I * r * (3.05 + 1.9 / r);
+                const double t = d == 1 ? std::max(0.074, 0.0365 * r + 0.030)
+                                        : (d == 2 ? std::max(0.058, 0.0255 * r + 0.006) : std::max(0.034, 0.0113 * r + 0.0085));
+                return scale * t;
             };
             uint32_t depth = 0;
             double best = cycles(1);
-            if (e->cg->max_pipeline >= 2 && cycles(2) < 0.95 * best) { // (a deeper pipeline has to pay for itself clearly)
+            if (e->cg->max_pipeline >= 2 && cycles(2) < 0.97 * best) { // (a deeper pipeline has to pay for itself)
                 best = cycles(2);
                 depth = 2;
             }
-            if (e->cg->max_pipeline >= 4 && cycles(4) < 0.95 * best) depth = 4;
+            if (e->cg->max_pipeline >= 4 && cycles(4) < 0.97 * best) depth = 4;
             if (const char* ev = getenv("OSCEN_GPU_SPLIT")) {
                 const int want = atoi(ev);
                 depth = (want >= 4 && e->cg->max_pipeline >= 4) ? 4 : ((want >= 2 && e->cg->max_pipeline >= 2) ? 2 : 0);

@@ -3490,7 +3490,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         t << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
           << "        if (f == c.next_ev) {\n"
           << "            do {\n"
-          << "                const OgEvent ev = A.events[c.ev_cur];\n";
+          << "                const struct { uint32_t target; float value; } ev = {c.nx_target, c.nx_value}; // (prefetched: og::VoiceCtx)\n";
         bool first = true;
         for (size_t i = 0; i < out.inputs.size(); ++i) {
             const InputInfo& in = out.inputs[i];
@@ -3891,7 +3891,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (ev_skip && relevant != "true")
                 body << "        if (!__all((int)(c.next_ev >= base + XCH))) { // consume the events this wave has no handler for\n"
                      << "            while (c.next_ev < base + XCH) {\n"
-                     << "                const uint32_t tgt = A.events[c.ev_cur].target;\n"
+                     << "                const uint32_t tgt = c.nx_target;\n"
                      << "                if (" << relevant << ") break;\n"
                      << "                og::ev_advance(A, c);\n"
                      << "            }\n"

@@ -196,16 +196,41 @@ struct VoiceCtx {
     uint32_t lane;
     // events
     uint32_t ev_cur, ev_cur0, ev_end;
-    uint32_t next_ev; // frame offset inside this block of the next event, or OG_NO_EVENT
+    uint32_t next_ev; // frame offset inside this block of the next event (record ev_cur), or OG_NO_EVENT
+    // Round 4: the next record's payload and the frame of the record after it are PREFETCHED.  Firing an event used to
+    // cost two dependent global loads in the middle of a chunk (the record, then the next record's frame for the
+    // "another one on this frame?" test) -- ~3 us per event and workgroup with only two to four waves per SIMD to hide
+    // them, far more than the handler itself.  Now the handler reads registers, ev_advance() takes next_ev from
+    // `next2` at once and issues the loads for the record after next without waiting for them.
+    uint32_t nx_target; // target of record ev_cur
+    float nx_value;     // value of record ev_cur
+    uint64_t n2_frame;  // absolute frame of record ev_cur + 1 as loaded (~0 = none): turned into a frame offset only when
+                        // that record becomes the next one, so that nothing waits for the load here
     // taps
     int32_t tap;
 };
 
-__device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t idx)
+__device__ __forceinline__ uint32_t ev_rel_of(const OgBlockArgs& a, uint64_t fr)
 {
-    const uint64_t fr = a.events[idx].frame;
     const uint64_t rel = (fr > a.frame0) ? (fr - a.frame0) : 0ull; // late events fire on frame 0
     return (rel < (uint64_t)a.frames) ? (uint32_t)rel : OG_NO_EVENT;
+}
+__device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t idx) { return ev_rel_of(a, a.events[idx].frame); }
+
+// load record ev_cur (frame, target, value) and the frame of the record behind it
+__device__ __forceinline__ void ev_arm(const OgBlockArgs& a, VoiceCtx& c)
+{
+    c.next_ev = OG_NO_EVENT;
+    c.n2_frame = ~0ull;
+    c.nx_target = 0u;
+    c.nx_value = 0.0f;
+    if (c.ev_cur < c.ev_end) {
+        const OgEvent ev = a.events[c.ev_cur];
+        c.next_ev = ev_rel_of(a, ev.frame);
+        c.nx_target = ev.target;
+        c.nx_value = ev.value;
+        if (c.ev_cur + 1u < c.ev_end) c.n2_frame = a.events[c.ev_cur + 1u].frame;
+    }
 }
 
 // LPV = lanes per voice: 1 for ordinary graphs (64 voices per wave).  Graphs whose nodes carry
@@ -222,14 +247,13 @@ __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
     c.lead = c.h == 0;
     c.valid = (threadIdx.x < a.lanes) && (c.v < a.n_voices);
     c.ev_cur = c.ev_end = 0;
-    c.next_ev = OG_NO_EVENT;
     c.tap = -1;
     if (c.valid) {
         c.ev_cur = a.ev_cursor[c.v];
         c.ev_end = a.ev_end[c.v];
-        if (c.ev_cur < c.ev_end) c.next_ev = ev_rel_frame(a, c.ev_cur);
         if (TAPS) c.tap = a.tap_slot[c.v];
     }
+    ev_arm(a, c);
     c.ev_cur0 = c.ev_cur;
 }
 
@@ -243,14 +267,13 @@ __device__ __forceinline__ void voice_begin_split(const OgBlockArgs& a, VoiceCtx
     c.lead = true;
     c.valid = c.v < a.n_voices;
     c.ev_cur = c.ev_end = 0;
-    c.next_ev = OG_NO_EVENT;
     c.tap = -1;
     if (c.valid) {
         c.ev_cur = a.ev_cursor[c.v];
         c.ev_end = a.ev_end[c.v];
-        if (c.ev_cur < c.ev_end) c.next_ev = ev_rel_frame(a, c.ev_cur);
         if (TAPS) c.tap = a.tap_slot[c.v];
     }
+    ev_arm(a, c);
     c.ev_cur0 = c.ev_cur;
 }
 
@@ -284,11 +307,19 @@ __device__ __forceinline__ void ev_out_log(const OgBlockArgs& a, const VoiceCtx&
 #endif
 }
 
-// pop the current event and arm the next one
+// pop the current event: the next one's frame is already known (next2); its payload and the frame of the one behind it
+// are requested here and only waited for when they are used
 __device__ __forceinline__ void ev_advance(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.ev_cur += 1;
-    c.next_ev = (c.ev_cur < c.ev_end) ? ev_rel_frame(a, c.ev_cur) : OG_NO_EVENT;
+    c.next_ev = ev_rel_of(a, c.n2_frame); // (~0: far beyond the launch -> OG_NO_EVENT)
+    c.n2_frame = ~0ull;
+    if (c.ev_cur < c.ev_end) {
+        const OgEvent ev = a.events[c.ev_cur];
+        c.nx_target = ev.target;
+        c.nx_value = ev.value;
+        if (c.ev_cur + 1u < c.ev_end) c.n2_frame = a.events[c.ev_cur + 1u].frame;
+    }
 }
 
 __device__ __forceinline__ float ld_f(const OgBlockArgs& a, const VoiceCtx& c, int w)

@@ -489,9 +489,11 @@ OG_DEV float iir_lowpass_tick(float in, float& v1, float& v2, float b0, float b1
 {
     constexpr float DENORMAL_THRESHOLD = 1e-15f;
     in = (fabsf(in) < DENORMAL_THRESHOLD) ? 0.0f : in;
-    const float out = OG_FMA(b0, in, v1);
-    v1 = OG_FMA(-a1, out, b1 * in) + v2; // b1 * in - a1 * out + v2, same association
-    v2 = OG_FMA(-a2, out, b2 * in);
+    // (NOT contracted, also in tolerance mode: at low cutoffs a1 -> -2, a2 -> 1 and the two state updates cancel almost
+    //  completely -- fusing them moved the output by 2.6e-5 against the oracle, tests/test_n3_gpu.py::test_iir_lowpass)
+    const float out = b0 * in + v1;
+    v1 = b1 * in - a1 * out + v2;
+    v2 = b2 * in - a2 * out;
     v1 = (fabsf(v1) < DENORMAL_THRESHOLD) ? 0.0f : v1;
     v2 = (fabsf(v2) < DENORMAL_THRESHOLD) ? 0.0f : v2;
     return out;
