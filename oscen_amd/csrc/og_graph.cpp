@@ -3192,7 +3192,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (n_stream_outs > 1 && !out.bus_tremolo) stereo_out = true;
         }
         bool want = !(env_split && atoi(env_split) == 0) && cg.N == 1 && out.lpv == 1 && order.size() >= 2 && !any_feedback && !cg.dynamic_events &&
-                    !any_delay && !stereo_out;
+                    !any_delay; // (round 4: several bus channels -- Frame<N> / several stream outputs -- run in the pipelines too)
+        (void)stereo_out;
         // estimated per-tick VALU cost of every node, in emission order
         int total = 0;
         std::vector<int> w;
@@ -3303,7 +3304,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 ends.push_back(cg.n_stages);
                 std::vector<std::vector<int>> gr;
                 int lo = 0;
-                bool ok = ends.size() >= 3 && ends.size() <= 4;
+                bool ok = ends.size() >= 3 && ends.size() <= 6;
                 for (int e : ends) {
                     ok = ok && e > lo && e <= cg.n_stages;
                     gr.emplace_back();
@@ -3705,7 +3706,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         }
         body << "template <bool RAMPS, bool TAPS>\n"
              << "__device__ __forceinline__ void voice_block_p" << tag << "(const OgBlockArgs& A)\n{\n"
-             << "    __shared__ og::BusLds bus;\n";
+             << "    __shared__ og::" << (out.voice_channels > 1 ? "BusLdsN<" + std::to_string(out.voice_channels) + ">" : std::string("BusLds")) << " bus;\n";
         {
             // frames per hand-off: 8.  16 (OGC_XCH16, two-wave pipeline only) measured +2% on a 94-block run at
             // 65 536 voices but -1.5% on the 188-block default run, and its doubled LDS rings leave room for only
@@ -3768,7 +3769,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
             for (size_t k : reads) body << "    float xp" << k << "[XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
-                 << (last ? " -> float" : "") << " {\n"
+                 << (last ? (out.voice_channels > 1 ? " -> og::OutN<" + std::to_string(out.voice_channels) + ">" : std::string(" -> float")) : std::string()) << " {\n"
                  << group_tick(groups, gi);
             if (last) body << "        return " << bus_expr << ";\n";
             body << "    };\n";
@@ -3816,9 +3817,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // event falls by a third, nearly all of it from (1)) -- but (2) inlines the handlers into every frame of the
             // checked body (two-wave kernel 26.8 -> 35.9 KB) and the QUIET path pays for it: idle bank 0.0514 -> 0.0528,
             // sustaining 0.0536 -> 0.0553.  At the benchmark's event density the two cancel (2.73e11 either way), so
-            // (1) is on and (2) is off by default: OGC_EVUNROLL=1 turns it on, OGC_EVSKIP=0 turns (1) off.
+            // (1) was on and (2) off through round 3: OGC_EVSKIP=0 turns (1) off.
             const bool ev_skip = !(getenv("OGC_EVSKIP") && atoi(getenv("OGC_EVSKIP")) == 0);
-            const bool ev_unroll = getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) != 0;
+            // (round 4: (2) is ON -- with the event records prefetched into registers (og::VoiceCtx::nx_*) the handlers inlined
+            //  into the checked body no longer carry loads and waits; four-wave kernel at 65 536 voices, interleaved A/B:
+            //  3.07e11 either way at the driver's command, 3.57e11 against 3.44e11 on the 188-block run; OGC_EVUNROLL=0 turns it off)
+            const bool ev_unroll = !(getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) == 0);
             std::string relevant; // condition on `tgt`: this wave has a handler for the event
             {
                 const std::string code = cat(st, &Codegen::Sect::derive) + group_tick(groups, gi) + cat(st, &Codegen::Sect::decl);

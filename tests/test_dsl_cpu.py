@@ -283,7 +283,7 @@ def test_calls_on_a_connection_parse_and_report_like_the_reference():
 def test_calls_on_a_connection_compile_in_every_kernel_shape():
     """named functions, methods and frame constructors inside the shapes the generator treats differently -- across a
     rate boundary, in array broadcasts, inside a nested graph, feeding a Frame<2> output of a graph whose nodes would
-    otherwise get the pipelined kernels (a frame-valued output is summed by the ordinary kernel only) -- each compiled
+    also get the pipelined kernels (round 4: the last wave keeps one bus tile per channel) -- each compiled
     for gfx950 (og_graph_jit_check)"""
     oscen_amd.register_function("half", ["x"], "return x * 0.5f;")
     oscen_amd.register_function("ms", [("v", 2)], "og::Frame<2> o; o.v[0] = v.v[0] - v.v[1]; o.v[1] = v.v[0] + v.v[1]; return o;",
@@ -306,8 +306,8 @@ def test_calls_on_a_connection_compile_in_every_kernel_shape():
             g = oscen_amd.Graph(dsl=f"name: DxT; input cutoff: value = 800.0; output out: {ty}; nodes {{ {nodes} }} connections {{ {conns} }}")
             src = g.kernel_source()
             assert "og_fn_half(" in src or "og_fn_ms(" in src
-            if ty != "stream":
-                assert "voice_block_p2" not in src  # no pipelined kernels for a frame-valued output
+            if ty != "stream":  # round 4: a frame-valued output runs in the pipelined kernels too (N bus tiles in the last wave)
+                assert "voice_block_p2" in src and "og::BusLdsN<2> bus" in src[src.index("voice_block_p2"):]
             assert g.jit_check() > 1000, conns
     finally:
         oscen_amd.unregister_graph_type("DxInnerFn")
