@@ -443,8 +443,18 @@ struct og_engine {
     // where `n` events can be appended, or SIZE_MAX when the ring is full
     size_t ring_alloc(size_t n)
     {
+        size_t at = ring_alloc_bounded(n, 4096);
+        if (at == SIZE_MAX) at = ring_alloc_bounded(n, SIZE_MAX); // (no room behind a bounded sweep: finish it, then decide)
+        return at;
+    }
+    // `sweep` bounds how many dead segments one call retires.  When a long resident score runs out, the segments of ALL
+    // voices die within a few blocks: retiring millions of them in one call was a 10-15 ms stall on the real-time path
+    // (round 4, the loaded bank: one block near the end of every run at 4-8 M voices); the room they occupy is not needed
+    // at once, so the sweep is spread over the following calls.
+    size_t ring_alloc_bounded(size_t n, size_t sweep)
+    {
         const uint64_t hz = consumed_horizon();
-        while (!ring_live.empty()) {
+        while (!ring_live.empty() && sweep-- > 0) {
             const RingSeg& f = ring_live.front();
             const bool dead = seg_begin[f.voice] != f.begin || seg_end[f.voice] != f.end || seg_last[f.voice] < hz;
             if (!dead) break;

@@ -1,7 +1,10 @@
 """Where does a 20-30 ms block of the blocking entry at 4 M voices come from?  (Seen once per ~15 000-30 000 blocks,
 back to back at full load: bench.py's realtime record.)
 
-    python scripts/dbg_rt_hiccup.py [voices] [blocks] [paced]
+    python scripts/dbg_rt_hiccup.py [voices] [blocks] [paced|back] [loaded]
+
+`loaded`: the synthetic score of the throughput lines (every voice plays its cyclic 1 s note plan) is resident for the
+whole run, on top of the live messages -- the loaded bank of bench.py's real-time record.
 
 Windows of 50 blocks; per window the host latency of every block and the kernel time the engine's HIP events saw.
 A window with a slow block prints both: kernel time up by the same amount = the GPU ran the kernel slowly (clock /
@@ -17,9 +20,20 @@ import oscen_amd
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 4194304
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 paced = len(sys.argv) > 3 and sys.argv[3] == "paced"
+loaded = len(sys.argv) > 4 and sys.argv[4] == "loaded"
 block, W = 256, 50
 eng = oscen_amd.Engine("fm_voice", V, sample_rate=48000.0)
-eng.set_voice_values("frequency", oscen_amd.note_plans(V)["frequency"])
+if loaded:
+    plans = oscen_amd.note_plans(V)
+    total_frames = (50 + N + 2) * block
+    ev_v, ev_f0, ev_x = plans["events"]
+    reps = -(-total_frames // 48000)
+    plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
+    eng.reserve_events(int(1000 * (50 + N) * 3.0 * total_frames / 48000.0) + (1 << 20))
+    print("resident score events:", oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames), flush=True)
+    del plans
+else:
+    eng.set_voice_values("frequency", oscen_amd.note_plans(V)["frequency"])
 midi = oscen_amd.Midi(eng)
 midi.set_queue_capacity(1000)
 rng = np.random.default_rng(1)

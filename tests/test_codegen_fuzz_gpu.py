@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests.graph_interp import VoiceInterp
 from tests.test_codegen_fuzz_cpu import random_graph
 
@@ -48,6 +49,7 @@ def test_random_graph_matches_the_node_interpreter(seed):
     got = np.concatenate(got, axis=1)
     assert np.isfinite(ref).all()
     err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5, (seed, err, desc["order"])
 
 
@@ -85,6 +87,7 @@ def test_random_multirate_graph_matches_the_node_interpreter(seed):
     got = np.concatenate(got, axis=1)
     assert np.isfinite(ref).all() and np.abs(ref).max() > 1e-3
     err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5, (seed, err, desc["order"], desc["rates"], desc["policies"])
 
 
@@ -242,6 +245,7 @@ def test_random_connection_expressions_match_numpy_over_the_oracle_oscillators(s
                         assert np.isfinite(ref), (seed, text)
                         worst = max(worst, abs(float(got[v, i, c]) - ref) / max(1.0, abs(ref)))
                         c += 1
+        observed.note(worst)
         assert worst <= 1e-5, (seed, worst, text)
     finally:
         oscen_amd.unregister_function("fx::half")

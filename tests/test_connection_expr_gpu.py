@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 
 pytestmark = pytest.mark.gpu
 SR = 48000.0
@@ -165,6 +166,7 @@ def test_f32_methods_against_numpy_on_a_per_voice_sweep():
             got = taps[:, -1, i]
             err = float(np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))))
             worst[expr] = err
+            observed.note(err)
             assert err <= 1e-5, (expr, err, got[:4], want[:4])
             assert np.array_equal(taps[:, 0, i], got)  # constant over the block
     assert len(worst) == len(METHODS)

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +98,7 @@ def test_graph_outputs_as_connection_sources_with_two_policies():
             ref_a[v, i], ref_b[v, i] = out_a, out_b
         worst = max(worst, rel_err(got[v], ref), rel_err(got3[v, :, 0], ref_a[v]), rel_err(got3[v, :, 1], ref_b[v]))
         assert np.abs(ref).max() > 0.2
+    observed.note(worst)
     assert worst <= 1e-5, worst
     # the bus: every channel is the sum over the voices
     for c, r in ((0, ref_a), (1, ref_b)):
@@ -164,6 +166,7 @@ def test_frame_edge_across_a_rate_boundary_up_and_down():
                 ref[i] = f32(outs[0] - f32(outs[1] * f32(0.5)))
             worst = max(worst, rel_err(got[v], ref))
             assert np.abs(ref).max() > 0.05
+        observed.note(worst)
         assert worst <= 1e-5, worst
     finally:
         for t in ("R3Spread::new", "R3StereoClip::new", "R3Diff::new"):
@@ -215,6 +218,7 @@ def test_nested_graph_oversampled_as_a_whole():
             outs.append(render_taps(eng, n, frames, blocks))
         assert np.array_equal(outs[0], outs[1])  # the nested form is the flat graph
         worst = max(rel_err(outs[0][v], _oracle_chain(lib, frames * blocks, float(freqs[v]), "sinc", "sinc", 4)) for v in range(n))
+        observed.note(worst)
         assert worst <= 1e-5, worst
     finally:
         oscen_amd.unregister_graph_type("R3ClipInner")
@@ -284,6 +288,7 @@ def test_oversampled_array_fans_into_an_outer_output_through_one_resampler():
             ref[i] = lib.oo_sinc_down_process(C.byref(dn), ol.fptr(buf))
         assert np.abs(ref).max() > 0.2
         worst = max(worst, rel_err(got[v], ref))
+    observed.note(worst)
     assert worst <= 1e-5, worst
 
 

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -47,6 +48,7 @@ def test_epiano_bank_parity_and_stereo_bus():
         worst_bus = max(worst_bus, float(np.max(np.abs(bus - ref_bus))) / scale)
         f0 += frames
     assert np.max(np.abs(ref_taps)) > 1e-3
+    observed.note(worst)
     assert worst <= 1e-5, worst
     assert worst_bus <= 1e-5, worst_bus
     assert np.max(np.abs(bus[:, 0] - bus[:, 1])) > 1e-4  # the tremolo really pans

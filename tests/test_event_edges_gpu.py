@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 from tests.graph_interp import _make
 
@@ -84,6 +85,7 @@ def render(g, freqs, periods, frames, blocks=(256, 300, 212)):
 
 def close(got, ref):
     err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5 and float(np.abs(ref).max()) > 0.1, err
 
 

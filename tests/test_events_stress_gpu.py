@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -113,4 +114,5 @@ def test_bulk_incremental_and_queued_event_paths_agree(n, monkeypatch):
         ref.append(t)
     ref = np.concatenate(ref, axis=1)
     err = float(np.max(np.abs(taps_a - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5 and np.abs(ref).max() > 1e-2, err

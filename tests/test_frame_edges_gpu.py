@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 from tests.graph_interp import _make
 
@@ -106,6 +107,7 @@ def test_frame_edges_and_the_stereo_filter(split, monkeypatch):
     assert eng.pipeline_depth == max(1, split)
     ref = model(freqs, cutoffs, gates, frames)
     err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5 and float(np.abs(ref).max()) > 0.05, err
 
 

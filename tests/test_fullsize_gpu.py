@@ -21,6 +21,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -105,6 +106,7 @@ def test_full_size_bank_against_the_oracle(graph, kind, n, total):
     # (1) sampled voices vs the oracle
     ref = oracle_taps(kind, taps, total, 256)
     err = np.abs(tp - ref) / np.maximum(1.0, np.abs(ref))
+    observed.note(float(err.max()))
     assert float(err.max()) <= TOL, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
     assert np.abs(ref).max() > 1e-3  # the sampled voices do sound
 
@@ -250,6 +252,7 @@ def test_the_timed_path_equals_the_checked_path_bit_for_bit(graph, kind, n, bloc
     bus_ref, tp, state_ref = render_blocking_with_taps(graph, n, total, block, taps)
     ref = oracle_taps(kind, taps, total, block)
     err = np.abs(tp - ref) / np.maximum(1.0, np.abs(ref))
+    observed.note(float(err.max()))
     assert float(err.max()) <= TOL, float(err.max())
     # the timed path: the engine's own blocks-per-launch pick, the pick's pipelined kernel and the ordinary kernel
     for env, want_depth in ((None, None), ({"OSCEN_GPU_SPLIT": "0"}, 1), ({"OSCEN_GPU_SPLIT": "2"}, 2)):
@@ -283,5 +286,6 @@ def test_the_largest_real_time_bank_sampled_voices_against_the_oracle():
     assert info["passes"] > 1 and info["depth"] == 1, info
     ref = oracle_taps(ol.BANK_FM, taps, total, block)
     err = np.abs(tp - ref) / np.maximum(1.0, np.abs(ref))
+    observed.note(float(err.max()))
     assert float(err.max()) <= TOL, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
     assert np.abs(ref).max() > 1e-3 and np.isfinite(bus).all() and np.abs(bus).max() > 1.0

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +59,7 @@ def test_custom_graph_is_jit_compiled_and_matches_oracle_nodes():
                 lib.oo_tpt_process(C.byref(f))
                 ref[v, i] = f.output[0]
         worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+    observed.note(worst)
     assert worst <= 1e-5, worst
 
 
@@ -107,6 +109,7 @@ def test_polyblep_waveforms(wave, ctor):
 
     worst, r = _run_nodes(g, setup, ref, n=n)
     assert np.max(np.abs(r)) > 0.5
+    observed.note(worst)
     assert worst <= 1e-5, worst
 
 
@@ -139,6 +142,7 @@ def test_static_simple_graph_shape():
             return out
 
         worst, r = _run_nodes(g, lambda e: e.set_voice_values("frequency", freqs), ref, n=n, sr=44100.0, blocks=2)
+        observed.note(worst)
         assert worst <= 1e-5, (ctor, worst)
 
 
@@ -194,6 +198,7 @@ def test_static_complex_graph_shape():
                 lib.oo_static_complex_process(C.byref(c))
                 ref[v, i] = c.vca.output
         worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+    observed.note(worst)
     assert worst <= 1e-5, worst
 
 
@@ -286,4 +291,5 @@ def test_custom_graph_pipelined_variants_through_hiprtc(depth, monkeypatch):
     r = np.stack([ref(v) for v in range(n)])
     assert np.max(np.abs(r)) > 0.05
     err = float(np.max(np.abs(got - r) / np.maximum(1.0, np.abs(r))))
+    observed.note(err)
     assert err <= 1e-5, err

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -80,6 +81,7 @@ def test_iir_lowpass(per_voice_cutoff):
     err, got, r, _ = _run(g, lambda e: e.set_voice_values("frequency", freqs), ref, n, frames=250,  # 250: the 32-tick
                           per_block=lambda e, b: e.set_value("cutoff", cut[b]))                    # counter straddles blocks
     assert np.max(np.abs(r)) > 0.2
+    observed.note(err)
     assert err <= TOL, err
 
 
@@ -135,6 +137,7 @@ def test_lp18_filter_with_envelope_fmod():
 
     err, got, r, _ = _run(g, setup, ref, n, per_block=lambda e, b: e.set_value("res", res[b]))
     assert np.max(np.abs(r)) > 0.05
+    observed.note(err)
     assert err <= TOL, err
 
 
@@ -164,6 +167,7 @@ def test_lp18_unconnected_parameters_match_prepare():
         return out
 
     err, _, r, _ = _run(g, lambda e: e.set_voice_values("frequency", freqs), ref, n, blocks=2)
+    observed.note(err)
     assert err <= TOL, err
 
 
@@ -203,6 +207,7 @@ def test_delay_line(delay_samples, feedback):
         return out
 
     err, got, r, eng = _run(g, lambda e: e.set_voice_values("frequency", freqs), ref, n, frames=128, blocks=5)
+    observed.note(err)
     assert err <= TOL, err
     assert eng.state_bytes >= 131072 * n * 4  # the delay lines are part of the saved state
 
@@ -242,6 +247,7 @@ def test_modulated_delay_time():
 
     err, _, r, _ = _run(g, lambda e: e.set_voice_values("frequency", freqs), ref, n, frames=256, blocks=3)
     assert np.max(np.abs(r)) > 0.2
+    observed.note(err)
     assert err <= TOL, err
 
 
@@ -310,6 +316,7 @@ def test_feedback_edge_through_delay_node():
     err, got, r, _ = _run(g, setup, ref, n, frames=256, blocks=4)
     # the echoes are there: energy after the envelope has died (0.03 s decay to sustain 0)
     assert np.max(np.abs(r[:, 600:])) > 1e-3
+    observed.note(err)
     assert err <= TOL, err
 
 

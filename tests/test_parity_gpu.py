@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -112,6 +113,7 @@ def test_fm_voice_config1_one_voice_one_second():
     worst, got, ref = run_script(p, events, [256] * 187 + [128])
     assert got.shape == (1, 48000)
     assert np.max(np.abs(ref)) > 0.05
+    observed.note(worst)
     assert worst <= TOL, worst
 
 
@@ -122,6 +124,7 @@ def test_fm_bank_default_params_ragged_voice_count():
     events = random_note_script(n, 4096, 2)
     worst, got, ref = run_script(p, events, [256] * 16)
     assert np.max(np.abs(ref)) > 0.05
+    observed.note(worst)
     assert worst <= TOL, worst
 
 
@@ -160,6 +163,7 @@ def test_fm_bank_every_pipeline_depth(depth, monkeypatch):
         scale = max(1.0, float(np.max(np.sum(np.abs(ref_taps), axis=0))))
         assert np.max(np.abs(bus[:, 0] - ref64)) <= TOL * scale
         f0 += frames
+    observed.note(worst)
     assert worst <= TOL, worst
 
 
@@ -174,6 +178,7 @@ def test_fm_bank_fast_envelopes_all_stages():
     p.set_freqs(midi_freqs(n, 3))
     events = random_note_script(n, 3072, 4, span=(500, 1200))
     worst, got, ref = run_script(p, events, [256] * 12)
+    observed.note(worst)
     assert worst <= TOL, worst
 
 
@@ -204,6 +209,7 @@ def test_fm_bank_variant_feedback_route_envamount_and_ramps():
         bus, taps, ref_bus, ref_taps, ref64 = p.block(256)
         worst = max(worst, rel_err(taps, ref_taps))
         f0 += 256
+    observed.note(worst)
     assert worst <= TOL, worst
     assert abs(p.eng.get_value("filter_cutoff") - 6000.0) < 1e-3
 
@@ -252,6 +258,7 @@ def test_event_edge_cases():
         bus, taps, ref_bus, ref_taps, _ = p.block(256)
         worst = max(worst, rel_err(taps, ref_taps))
         assert np.all(taps[4] == 0.0) and np.all(ref_taps[4] == 0.0)
+    observed.note(worst)
     assert worst <= TOL, worst
     assert p.eng.events_dropped == 1
     # 33rd event on one voice/input in one block overflows like ArrayVec<_, 32>
@@ -278,6 +285,7 @@ def test_sub_voice_parity():
         bus, taps, ref_bus, ref_taps, ref64 = p.block(256)
         worst = max(worst, rel_err(taps, ref_taps))
         f0 += 256
+    observed.note(worst)
     assert worst <= TOL, worst
 
 
@@ -395,6 +403,7 @@ def test_full_size_properties():
                 bank.push_event(i, on - f0, ol.EV_GATE, float(plans["gate"][v]))
         _, ref = bank.process_block(block, taps=list(range(len(sample))))
         worst = max(worst, rel_err(taps_a[:, f0:f0 + block], ref))
+    observed.note(worst)
     assert worst <= TOL, worst
     # nothing sounds before the first note-on, and the bus is alive afterwards
     first_on = int(plans["on_frame"].min())

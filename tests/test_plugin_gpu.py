@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import oscen_amd
+from tests import observed
 from tests import plugin_nodes
 from tests.graph_interp import VoiceInterp
 from tests.test_plugin_cpu import ARRAY_DSL, FLAT_DSL, INNER_DSL, OUTER_DSL
@@ -150,6 +151,7 @@ def test_node_arrays_match_the_hand_expanded_graph_and_the_interpreter():
             gates = [("gate", 0.8)] if f == 5 + 7 * v else ([("gate", 0.0)] if f == 400 + 3 * v else [])
             ref[v, f] = vi.frame(gates)
     err = float(np.max(np.abs(outs[0] - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5 and np.abs(ref).max() > 1e-2, err
 
 
@@ -236,6 +238,7 @@ def test_stream_input_block_and_render_with_inputs():
             vi.set_value("audio_in", float(xp[f]))
             ref[v, f] = vi.frame([])
     err = float(np.max(np.abs(taps - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
     assert err <= 1e-5 and np.abs(ref).max() > 1e-2, err
     want = ref.astype(np.float64).sum(axis=0)
     assert np.max(np.abs(bus[:, 0] - want)) <= 1e-5 * max(1.0, float(np.abs(want).max()))
