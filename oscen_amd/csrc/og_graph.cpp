@@ -477,6 +477,10 @@ struct Codegen {
         // per-frame code, multirate layout of emit_frame.rs:114-176:
         //   s_pre (outer nodes) | s_up (upsamplers) | for j<N { s_inner ; s_cap } | s_down (downsamplers) | s_post
         std::ostringstream s_pre, s_up, s_inner, s_log, s_cap, s_down, s_post; // (s_log: graph event outputs of inner nodes, logged before s_cap clears them)
+        // step 6a of the reference's multirate body (codegen/emit_frame.rs:150-160): the event handlers of an INNER node fed
+        // by another inner node run once per OUTER tick, in front of the inner loop, over everything the producer pushed
+        // during the previous outer tick; the producer's queue is cleared there, not per inner tick
+        std::ostringstream s_ev6a, s_ev6a_clear;
         std::map<int, std::ostringstream> ev_handlers; // per graph event input
     };
     Sect sec[16];
@@ -488,6 +492,8 @@ struct Codegen {
     std::map<std::string, std::string> user_fns; // device functions of the user node types this graph uses
     int blk_slot0 = -1;  // first of the 32 slots holding the block starts of a launch (allocated when a handler reads frame_offset)
     int ev_capacity = 2; // OG_NODE_EVENTS_PER_FRAME of this graph: the largest event_queue_capacity among its node types
+    std::set<std::pair<int, std::string>> inner_ev_sources; // (node id, event output) read by another node of the oversampled region
+    std::set<std::pair<int, std::string>> outer_ev_sources; // (inner node id, event output) read by an outer node behind the region
     int N = 1;        // oversampling factor of the `* N` nodes (1 = none)
     int n_cross = 0;  // cross-rate edges emitted so far
     bool any_derive = false;
@@ -1138,14 +1144,28 @@ void NodeCtx::on_event(const std::string& port, const std::function<std::string(
     auto nv = n.ev_node_edges.find(port);
     if (nv == n.ev_node_edges.end()) return;
     const NodeInst& src = cg.nodes[nv->second.first];
-    if (src.domain != n.domain)
+    // Across a rate boundary (round 4; the reference's drains, codegen/emit_frame.rs:341-374): outer -> inner events are
+    // copied in front of the inner loop (step 5.5) and handled at step 6a of the SAME outer frame; inner -> outer events
+    // -- everything the N inner ticks pushed -- are copied after the loop (step 7a) and handled when the outer node
+    // runs (step 7.5).  An outer node that feeds the inner loop cannot read an inner node (it would have to run twice).
+    if (src.domain != n.domain && !((src.domain == 0 && n.domain >= 1) || (src.domain == 1 && n.domain == 2)))
         fail("event edge '" + src.decl->name + "." + nv->second.second + " -> " + n.decl->name + "." + port +
-             "' crosses a rate boundary (cross-rate event drains are not built)");
+             "' runs against the rate schedule (an outer node in front of the oversampled region cannot read a node of it)");
     if (cg.stage_of.size() > (size_t)n.id && cg.stage_of[n.id] != cg.stage_of[src.id])
         fail("internal: event edge across pipeline stages");
     const std::string q = "n" + std::to_string(src.id) + "_" + nv->second.second;
-    cg.os() << "        if (__any((int)(" << q << ".n != 0u))) { // events '" << src.decl->name << "." << nv->second.second
-            << "' pushed on this frame\n"
+    // both ends in the oversampled region: the reference copies the producer's queue into the consumer's on every inner
+    // tick but runs the consumer's handlers (process_event_inputs) once per OUTER tick, in front of the inner loop --
+    // i.e. at the start of the NEXT outer frame, over everything the producer pushed during this one (step 6a,
+    // codegen/emit_frame.rs:150-160; oscen-macros/src/lib.rs:266-285: process_event_inputs clears the node's own outputs,
+    // then dispatches its input queues)
+    const bool inner_pair = n.domain == 1 && src.domain <= 1; // the handler runs at step 6a, in front of the inner loop
+    if (inner_pair && gen("evv").find("[j]") != std::string::npos)
+        fail_unsupported("node '" + n.decl->name + "': a handler fed by another oversampled node runs in front of the inner loop; "
+                         "its value inputs cannot come through a resampled edge in this version");
+    (inner_pair ? cg.S().s_ev6a : cg.os())
+            << "        if (__any((int)(" << q << ".n != 0u))) { // events '" << src.decl->name << "." << nv->second.second
+            << (inner_pair && src.domain == 1 ? "' pushed during the previous outer frame\n" : "' pushed on this frame\n")
             << "            OG_EV_LOOP_PRAGMA\n" // (unrolled up to a capacity of 4, a rolled loop above: the handler is inlined per copy)
             << "            for (uint32_t evk = 0; evk < OG_NODE_EVENTS_PER_FRAME; ++evk)\n"
             << "                if (OG_NODE_EVENTS_PER_FRAME > 4 && !__any((int)(evk < " << q << ".n))) break;\n"
@@ -1755,9 +1775,21 @@ void emit_user(NodeCtx& x)
     for (const std::string& o : u.ev_outputs) {
         evo.push_back(x.p + o);
         x.cg.S().decl << "    og::EvOut " << x.p << o << ";\n";
-        (x.n.domain == 1 ? x.cg.S().s_cap : x.cg.frame_end)
+        const bool to_inner = x.n.domain == 1 && x.cg.inner_ev_sources.count({x.n.id, o}) > 0;
+        const bool to_outer = x.n.domain == 1 && x.cg.outer_ev_sources.count({x.n.id, o}) > 0; // collects the frame's N ticks for an outer node
+        (to_inner ? x.cg.S().s_ev6a_clear : ((x.n.domain == 1 && !to_outer) ? x.cg.S().s_cap : x.cg.frame_end))
             << "        if (__any((int)(" << x.p << o << ".lost != 0u))) og::ev_report_lost(A, c, " << x.p << o << ");\n"
             << "        " << x.p << o << ".clear();\n";
+        if (to_inner) { // the queue outlives the frame -- and the launch: it is part of the voice's state
+            const int wn = x.cg.new_state(x.n.decl->name + "." + o + ".n", false, [](const UEnv&) { return 0u; });
+            x.cg.S().load << "        " << x.p << o << ".n = og::ld_u(A, c, " << wn << ");\n";
+            x.cg.S().store << "        og::st_u(A, c, " << wn << ", " << x.p << o << ".n);\n";
+            for (int k = 0; k < x.cg.ev_capacity; ++k) {
+                const int wv = x.cg.new_state(x.n.decl->name + "." + o + ".v" + std::to_string(k), true, [](const UEnv&) { return fbits(0.0f); });
+                x.cg.S().load << "        " << x.p << o << ".v[" << k << "] = og::ld_f(A, c, " << wv << ");\n";
+                x.cg.S().store << "        og::st_f(A, c, " << wv << ", " << x.p << o << ".v[" << k << "]);\n";
+            }
+        }
         x.cg.out.has_node_event_outputs = true;
     }
     // event handlers: value inputs must be known when the event fires (before the frame's nodes run)
@@ -3318,6 +3350,29 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     cg.split = cg.n_stages > 1;
 
 
+    // ---- event outputs read inside the oversampled region (step 6a, see Sect::s_ev6a): which they are, and the queue
+    // capacity of the graph BEFORE any node is emitted (such a queue collects the pushes of all N inner ticks of a frame
+    // and is a state plane per slot)
+    for (int ni : order) {
+        const NodeInst& n = cg.nodes[ni];
+        if (n.type->user && !n.type->user->ev_outputs.empty() && n.type->user->event_capacity > cg.ev_capacity)
+            cg.ev_capacity = std::min(32, n.type->user->event_capacity);
+    }
+    for (int ni : order) {
+        const NodeInst& n = cg.nodes[ni];
+        if (n.domain == 0) continue;
+        for (const auto& kv : n.ev_node_edges) {
+            const NodeInst& src = cg.nodes[kv.second.first];
+            if (src.domain != 1) continue;
+            (n.domain == 1 ? cg.inner_ev_sources : cg.outer_ev_sources).insert({src.id, kv.second.second});
+            const int per_tick = src.type->user && src.type->user->event_capacity > 0 ? src.type->user->event_capacity : 2;
+            cg.ev_capacity = std::max(cg.ev_capacity, std::min(32, per_tick * cg.N)); // the reference's queue holds 32
+            for (const auto& eo : ev_out_edges)
+                if (eo.second.first == src.id && eo.second.second == kv.second.second)
+                    fail_unsupported("event output '" + src.decl->name + "." + kv.second.second + "' feeds both an oversampled node and a graph event output");
+        }
+    }
+
     // ---- emit nodes: outer (pre), inner, outer (post), each in topological order -------------
     for (int dom = 0; dom < 3; ++dom) {
         cg.dom = dom;
@@ -3478,7 +3533,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     auto tick_code = [&](int st) {
         Codegen::Sect& S = cg.sec[st];
         std::ostringstream t;
-        t << S.s_pre.str() << S.s_up.str();
+        t << S.s_pre.str() << S.s_up.str() << S.s_ev6a.str() << S.s_ev6a_clear.str();
         if (cg.N > 1)
             t << "#pragma unroll\n        for (int j = 0; j < " << cg.N << "; ++j) { // oversampled inner loop\n"
               << S.s_inner.str() << S.s_log.str() << S.s_cap.str() << "        }\n";

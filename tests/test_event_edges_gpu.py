@@ -370,3 +370,111 @@ def test_event_output_of_an_oversampled_node():
             assert eng.events_dropped == 0
     finally:
         oscen_amd.unregister_node("OsBurst::new")
+
+
+def test_event_edge_between_two_oversampled_nodes_is_delivered_once_per_outer_tick():
+    """Both ends of an event edge inside the oversampled region (round 4).  The reference copies the producer's queue into
+    the consumer's on every inner tick but runs the consumer's handlers -- process_event_inputs() -- once per OUTER tick,
+    in front of the inner loop (step 6a of the multirate body, oscen-graph-compiler/src/codegen/emit_frame.rs:150-160), and
+    the producer's queue is cleared there too (oscen-macros/src/lib.rs:266-285): what an inner node pushes during outer
+    frame f reaches an inner consumer at the START of frame f + 1, all of it, in push order.  (Rounds 2-3 delivered on
+    the same inner tick.)  The queue is part of the voice's state: a block boundary between push and delivery changes
+    nothing."""
+    oscen_amd.register_node(
+        "R4Clock::new", inputs=[("every", "value", 3.0, 0)], outputs=[], n_ctor_args=1, state=[("t", "u32", 0, -1)], event_outputs=["tick"],
+        process="    t += 1u;\n    if ((float)(t % (uint32_t)every) == 0.0f) tick.push((float)t);\n")
+    oscen_amd.register_node(
+        "R4Counter::new", inputs=[("trig", "event", 0.0, -1)], outputs=["out"],
+        state=[("received", "u32", 0, -1), ("sum", "f32", 0.0, -1), ("seen_at", "u32", 0, -1), ("ticks", "u32", 0, -1)],
+        handlers={"trig": "    received += 1u;\n    sum += value;\n    seen_at = ticks;\n"},
+        process="    ticks += 1u;\n    out = sum;\n")
+    try:
+        for factor in (2, 4):
+            g = oscen_amd.Graph(dsl=f"""name: InnerEv; input every: value = 3.0; output out: stream;
+                nodes {{ clk = R4Clock::new(3.0) * {factor}; cnt = R4Counter::new() * {factor}; }}
+                connections {{ every -> clk.every; clk.tick -> cnt.trig; [latch] cnt.out -> out; }}""", per_voice=["every"])
+            n, frames = 12, 64
+            every = (1 + np.arange(n) % 5).astype(np.float32)  # 1: a push on every inner tick (factor pushes per outer frame)
+            # model: per outer frame -- 6a: deliver last frame's pushes, clear; then `factor` inner ticks
+            want_out = np.zeros((n, frames), dtype=np.float32)
+            want = []
+            for v in range(n):
+                t, ticks, received, ssum, seen_at, queue = 0, 0, 0, np.float32(0.0), 0, []
+                for f in range(frames):
+                    for x in queue:
+                        received += 1
+                        ssum = np.float32(ssum + np.float32(x))
+                        seen_at = ticks
+                    queue = []
+                    for _ in range(factor):
+                        t += 1
+                        if t % int(every[v]) == 0:
+                            queue.append(t)
+                        ticks += 1
+                    want_out[v, f] = ssum
+                want.append((received, ssum, seen_at, ticks))
+
+            def run(blocks):
+                eng = oscen_amd.Engine(g, n, sample_rate=SR)
+                eng.set_voice_values("every", every)
+                eng.set_voice_taps(list(range(n)))
+                got = []
+                for b in blocks:
+                    eng.process_block(b)
+                    got.append(eng.read_voice_taps(b))
+                return eng, np.concatenate(got, axis=1)
+
+            eng, got = run([frames])
+            assert np.array_equal(got, want_out), factor
+            assert np.array_equal(eng.read_state_field("cnt.received", dtype=np.uint32), np.array([w[0] for w in want], dtype=np.uint32))
+            assert np.array_equal(eng.read_state_field("cnt.seen_at", dtype=np.uint32), np.array([w[2] for w in want], dtype=np.uint32))
+            assert np.array_equal(eng.read_state_field("cnt.ticks", dtype=np.uint32), np.full(n, factor * frames, dtype=np.uint32))
+            assert eng.events_dropped == 0
+            # delivery happens a whole outer frame after the push: with a push on every tick the first frame still reads 0
+            assert want_out[0, 0] == 0.0 and want_out[0, 1] > 0.0
+            # block boundaries between push and delivery (the queue travels in the state planes)
+            _, got2 = run([1, 7, 1, 23, 32])
+            assert np.array_equal(got2, got), factor
+        # ACROSS the rate boundary (the reference's event drains, emit_frame.rs:341-374): an outer node's events reach an
+        # inner node at step 6a of the SAME outer frame (outer nodes run first); an inner node's events -- all N ticks' --
+        # reach an outer node behind the region when it runs, in the same frame
+        factor, n, frames = 4, 12, 48
+        every = (1 + np.arange(n) % 5).astype(np.float32)
+        for shape in ("outer_to_inner", "inner_to_outer"):
+            ck, ct = ("", " * 4") if shape == "outer_to_inner" else (" * 4", "")
+            pol = "[latch] " if shape == "outer_to_inner" else ""
+            g = oscen_amd.Graph(dsl=f"""name: CrossEv; input every: value = 3.0; output out: stream;
+                nodes {{ clk = R4Clock::new(3.0){ck}; cnt = R4Counter::new(){ct}; }}
+                connections {{ every -> clk.every; clk.tick -> cnt.trig; {pol}cnt.out -> out; }}""", per_voice=["every"])
+            want_out = np.zeros((n, frames), dtype=np.float32)
+            want_recv, want_seen = [], []
+            for v in range(n):
+                t, ticks, received, ssum, seen_at = 0, 0, 0, np.float32(0.0), 0
+                for f in range(frames):
+                    queue = []
+                    for _ in range(1 if shape == "outer_to_inner" else factor):  # the clock's ticks of this outer frame
+                        t += 1
+                        if t % int(every[v]) == 0:
+                            queue.append(t)
+                    for x in queue:  # delivered in the same outer frame, before the counter's own ticks
+                        received += 1
+                        ssum = np.float32(ssum + np.float32(x))
+                        seen_at = ticks
+                    ticks += factor if shape == "outer_to_inner" else 1
+                    want_out[v, f] = ssum
+                want_recv.append(received)
+                want_seen.append(seen_at)
+            eng = oscen_amd.Engine(g, n, sample_rate=SR)
+            eng.set_voice_values("every", every)
+            eng.set_voice_taps(list(range(n)))
+            got = []
+            for b in (5, 11, 32):
+                eng.process_block(b)
+                got.append(eng.read_voice_taps(b))
+            assert np.array_equal(np.concatenate(got, axis=1), want_out), shape
+            assert np.array_equal(eng.read_state_field("cnt.received", dtype=np.uint32), np.array(want_recv, dtype=np.uint32)), shape
+            assert np.array_equal(eng.read_state_field("cnt.seen_at", dtype=np.uint32), np.array(want_seen, dtype=np.uint32)), shape
+            assert eng.events_dropped == 0
+    finally:
+        oscen_amd.unregister_node("R4Clock::new")
+        oscen_amd.unregister_node("R4Counter::new")
