@@ -3541,12 +3541,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         return t.str();
     };
     // per-voice events due on frame f (sub-block splitting of process_block, codegen/mod.rs:836-871)
-    auto events_code = [&](const std::vector<int>& stages) {
+    auto events_code = [&](const std::vector<int>& stages, bool prefetch = true) {
+        const std::string PRE = prefetch ? "true" : "false"; // (the ordinary kernel reads the record when it fires: og::ev_arm)
         std::ostringstream t;
         t << "    auto events = [&](const uint32_t f) __attribute__((always_inline)) {\n"
           << "        if (f == c.next_ev) {\n"
           << "            do {\n"
-          << "                const struct { uint32_t target; float value; } ev = {c.nx_target, c.nx_value}; // (prefetched: og::VoiceCtx)\n";
+          << "                const og::EvRec ev = og::ev_record<" << PRE << ">(A, c);\n";
         bool first = true;
         for (size_t i = 0; i < out.inputs.size(); ++i) {
             const InputInfo& in = out.inputs[i];
@@ -3564,7 +3565,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
               << "                }\n";
             first = false;
         }
-        t << "                og::ev_advance(A, c);\n"
+        t << "                og::ev_advance<" << PRE << ">(A, c);\n"
           << "            } while (c.next_ev <= f);\n"
           << "        }\n    };\n";
         return t.str();
@@ -3689,7 +3690,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     } else { // clear_event_outputs(): the frame's node-to-node events have been delivered (and the graph's event outputs logged)
         body << "        const auto g_bus = " << bus_expr << ";\n" << cg.frame_log.str() << cg.frame_end.str() << "        return g_bus;\n    };\n";
     }
-    body << events_code(all_stages);
+    body << events_code(all_stages, false);
     body << "    for (uint32_t base = 0; base < A.frames; base += OG_BUS_CHUNK) {\n"
          << "        const uint32_t n = min((uint32_t)OG_BUS_CHUNK, A.frames - base);\n"
          << (out.rings.empty() ? std::string() : "        cbase = base;\n" + cat(all_stages, &Codegen::Sect::chunk_begin))

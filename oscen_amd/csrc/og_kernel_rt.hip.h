@@ -217,7 +217,11 @@ __device__ __forceinline__ uint32_t ev_rel_of(const OgBlockArgs& a, uint64_t fr)
 }
 __device__ __forceinline__ uint32_t ev_rel_frame(const OgBlockArgs& a, uint32_t idx) { return ev_rel_of(a, a.events[idx].frame); }
 
-// load record ev_cur (frame, target, value) and the frame of the record behind it
+// load record ev_cur (frame, target, value) and the frame of the record behind it.
+// PRE = false (the ordinary one-wave kernel): only the frame is read here and the record itself when it fires -- that
+// kernel runs with 4 to 16 waves per SIMD, which hide the two loads, and sits at the 128-VGPR cap of four waves per SIMD:
+// the four registers of the prefetch cost it 19 spills around its chunk loop (profiles/r04h_fm262144_summary.md).
+template <bool PRE = true>
 __device__ __forceinline__ void ev_arm(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.next_ev = OG_NO_EVENT;
@@ -225,12 +229,28 @@ __device__ __forceinline__ void ev_arm(const OgBlockArgs& a, VoiceCtx& c)
     c.nx_target = 0u;
     c.nx_value = 0.0f;
     if (c.ev_cur < c.ev_end) {
-        const OgEvent ev = a.events[c.ev_cur];
-        c.next_ev = ev_rel_of(a, ev.frame);
-        c.nx_target = ev.target;
-        c.nx_value = ev.value;
-        if (c.ev_cur + 1u < c.ev_end) c.n2_frame = a.events[c.ev_cur + 1u].frame;
+        if (PRE) {
+            const OgEvent ev = a.events[c.ev_cur];
+            c.next_ev = ev_rel_of(a, ev.frame);
+            c.nx_target = ev.target;
+            c.nx_value = ev.value;
+            if (c.ev_cur + 1u < c.ev_end) c.n2_frame = a.events[c.ev_cur + 1u].frame;
+        } else {
+            c.next_ev = ev_rel_frame(a, c.ev_cur);
+        }
     }
+}
+// the record that fires now: {target, value}
+struct EvRec {
+    uint32_t target;
+    float value;
+};
+template <bool PRE = true>
+__device__ __forceinline__ EvRec ev_record(const OgBlockArgs& a, const VoiceCtx& c)
+{
+    if (PRE) return EvRec{c.nx_target, c.nx_value};
+    const OgEvent ev = a.events[c.ev_cur];
+    return EvRec{ev.target, ev.value};
 }
 
 // LPV = lanes per voice: 1 for ordinary graphs (64 voices per wave).  Graphs whose nodes carry
@@ -253,7 +273,7 @@ __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
         c.ev_end = a.ev_end[c.v];
         if (TAPS) c.tap = a.tap_slot[c.v];
     }
-    ev_arm(a, c);
+    ev_arm<false>(a, c);
     c.ev_cur0 = c.ev_cur;
 }
 
@@ -309,9 +329,14 @@ __device__ __forceinline__ void ev_out_log(const OgBlockArgs& a, const VoiceCtx&
 
 // pop the current event: the next one's frame is already known (next2); its payload and the frame of the one behind it
 // are requested here and only waited for when they are used
+template <bool PRE = true>
 __device__ __forceinline__ void ev_advance(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.ev_cur += 1;
+    if (!PRE) {
+        c.next_ev = (c.ev_cur < c.ev_end) ? ev_rel_frame(a, c.ev_cur) : OG_NO_EVENT;
+        return;
+    }
     c.next_ev = ev_rel_of(a, c.n2_frame); // (~0: far beyond the launch -> OG_NO_EVENT)
     c.n2_frame = ~0ull;
     if (c.ev_cur < c.ev_end) {
