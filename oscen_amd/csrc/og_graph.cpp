@@ -2796,7 +2796,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             t.erase(std::remove_if(t.begin(), t.end(), [](char ch) { return isspace((unsigned char)ch); }), t.end());
             return t;
         };
-        std::map<std::string, K> known; // "node.port"
+        // "node.port", keyed by the ROOT node of an expanded array element (`voices__3.cutoff` -> `voices.cutoff`): the
+        // reference infers one kind per (root node, field) and every element shares it (infer_endpoint_types runs before
+        // the array is unrolled, ir/lower.rs:233-338) -- ADVICE r3
+        auto canon = [](const std::string& key) {
+            const size_t dot = key.find('.');
+            std::string node = dot == std::string::npos ? key : key.substr(0, dot);
+            const size_t us = node.rfind("__");
+            if (us != std::string::npos && us + 2 < node.size() &&
+                std::all_of(node.begin() + (long)us + 2, node.end(), [](char ch) { return isdigit((unsigned char)ch); }))
+                node.erase(us);
+            return dot == std::string::npos ? node : node + key.substr(dot);
+        };
+        std::map<std::string, K> known;
         auto decl_kind = [](Kind k) { return k == Kind::Stream ? Stream : (k == Kind::Value ? Value : Event); };
         std::function<K(const ExprP&)> kind_of = [&](const ExprP& e) -> K {
             if (!e) return Unknown;
@@ -2809,7 +2821,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     auto oi = cg.output_by_name.find(e->node);
                     return oi != cg.output_by_name.end() ? decl_kind(g.outputs[oi->second].kind) : Unknown;
                 }
-                auto it = known.find(e->node + "." + e->port);
+                auto it = known.find(canon(e->node + "." + e->port));
                 return it == known.end() ? Unknown : it->second;
             }
             case Expr::Chan:
@@ -2843,8 +2855,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             st.dst_is_node = st.dst.find('.') != std::string::npos;
             if (st.src->t == Expr::Ref && !st.src->port.empty()) st.src_endpoint = st.src->node + "." + st.src->port;
             if (e.policy == "linear" || e.policy == "sinc" || e.policy == "sinc_iir") { // stream-only kernels: both ends are streams
-                if (st.dst_is_node) known.emplace(st.dst, Stream);
-                if (!st.src_endpoint.empty()) known.emplace(st.src_endpoint, Stream);
+                if (st.dst_is_node) known.emplace(canon(st.dst), Stream);
+                if (!st.src_endpoint.empty()) known.emplace(canon(st.src_endpoint), Stream);
             }
             stmts.push_back(st);
         }
@@ -2852,20 +2864,20 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             bool changed = false;
             for (const Stmt& st : stmts) {
                 const K sk = kind_of(st.src);
-                if (sk != Unknown && st.dst_is_node && !known.count(st.dst)) {
-                    known[st.dst] = sk;
+                if (sk != Unknown && st.dst_is_node && !known.count(canon(st.dst))) {
+                    known[canon(st.dst)] = sk;
                     changed = true;
                 }
                 K dk = Unknown;
                 if (st.dst_is_node) {
-                    auto it = known.find(st.dst);
+                    auto it = known.find(canon(st.dst));
                     dk = it == known.end() ? Unknown : it->second;
                 } else {
                     auto oi = cg.output_by_name.find(st.dst);
                     if (oi != cg.output_by_name.end()) dk = decl_kind(g.outputs[oi->second].kind);
                 }
-                if (dk != Unknown && !st.src_endpoint.empty() && !known.count(st.src_endpoint)) {
-                    known[st.src_endpoint] = dk;
+                if (dk != Unknown && !st.src_endpoint.empty() && !known.count(canon(st.src_endpoint))) {
+                    known[canon(st.src_endpoint)] = dk;
                     changed = true;
                 }
             }
@@ -2878,7 +2890,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             if (kv.second.size() < 2) continue;
             K dk = Unknown;
             if (kv.first.find('.') != std::string::npos) {
-                auto it = known.find(kv.first);
+                auto it = known.find(canon(kv.first));
                 dk = it == known.end() ? Unknown : it->second;
             } else {
                 auto oi = cg.output_by_name.find(kv.first);

@@ -384,6 +384,16 @@ def test_several_edges_into_a_value_destination_follow_the_reference_kind_propag
         return g.kernel_source()
 
     assert src3("c.output -> g.gain; amount -> g.gain;") == src3("c.output + amount -> g.gain;")
+    # one kind per (ROOT node, field): a typed value input wired to ONE element of an array makes the port a value endpoint
+    # of every element (the reference infers kinds before it unrolls the array) -- two edges into another element: last wins
+    def src4(conns):
+        g = oscen_amd.Graph(dsl="""name: DxK3; input cutoff: value = 900.0; output out: stream;
+            nodes { osc = PolyBlepOscillator::saw(220.0, 0.5); lfo = PolyBlepOscillator::sine(3.0, 200.0); lfo2 = PolyBlepOscillator::sine(5.0, 100.0);
+                    fs = [TptFilter::new(1000.0, 0.7); 2]; }
+            connections { osc.output -> fs.input; fs.output -> out; cutoff -> fs[0].cutoff; """ + conns + " }")
+        return g.kernel_source()
+
+    assert src4("lfo.output -> fs[1].cutoff; lfo2.output -> fs[1].cutoff;") == src4("lfo2.output -> fs[1].cutoff;")
 
 
 def test_round4_front_end_edges_follow_the_reference():
