@@ -4056,10 +4056,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
     // register budget of the ordinary kernel: 4 waves per SIMD = 128 VGPRs.  The 4-lanes-per-voice e-piano form
-    // (OG_HPL = 8) keeps eight harmonics of nine arrays per lane: it is given the two-waves-per-SIMD budget and takes
-    // 156 VGPRs of it without a spill -- which still makes three waves per SIMD resident.  (Forcing the three-wave budget,
-    // 168 VGPRs, measured 1.7 % faster but the allocator then spills 80 registers around the chunk loop: not taken.)
-    int waves_eu = (out.lpv > 1 && out.lane_width == 8) ? 2 : 4;
+    // (OG_HPL = 8) keeps eight harmonics of nine arrays per lane.  Round 3 gave it the two-waves-per-SIMD budget (201
+    // VGPRs, no spill; the three-wave budget measured +1.7 % with 80 spills and was not taken).  Round 4: with the
+    // packed-fma bodies the three-wave budget (168 VGPRs) spills 76 registers, all of them around the chunk loop (25
+    // scratch instructions per 16-frame chunk, none in the frame loop: scripts/isa_mix.py epiano_voice OGC_WAVES_EU=3)
+    // and is 3.3 % faster in an interleaved A/B (1.57e11 -> 1.62e11 at 262 144 voices): taken.  Four waves (128 VGPRs)
+    // spill inside the frame loop.
+    int waves_eu = (out.lpv > 1 && out.lane_width == 8) ? 3 : 4;
     if (const char* ew = getenv("OGC_WAVES_EU")) waves_eu = std::max(1, std::min(8, atoi(ew)));
     for (auto& v : variants)
         src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(" << waves_eu << "))) void og_k_" << hs << "_" << v[0]
