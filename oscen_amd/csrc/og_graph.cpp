@@ -3815,7 +3815,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 // the straggler its consumers wait for at the hand-off barrier.  Measured, fm_voice: two waves at
                 // 65 536 voices 0.0741 -> 0.0660 ms; four waves at 32 768 voices 0.0500 -> 0.0484 ms; raising the
                 // other waves as well (2,1 / 3,2,1,0) is no better.  OGC_PRIO="p0,p1[,p2,p3]" overrides.
-                std::vector<int> pr = {1, 0, 0, 0};
+                // Round 4, four waves (depth-first order): the LAST wave (filter, bus) lowest, the first highest, the middle
+                // ones between -- 2,1,1,0.  Interleaved A/B at the driver's command, 65 536 voices: 1,0,0,0 3.08e11; 0,0,0,0
+                // 3.00e11; 0,0,1,0 3.20e11; 1,1,1,0 3.16e11; 2,1,1,0 3.26e11; 3,2,1,0 3.27e11; 3,2,2,0 3.28e11; 2,1,2,0 3.28e11;
+                // 3,2,1,1 3.14e11 -- whatever is upstream must not wait for the wave that closes the chunk; the exact levels
+                // above it are within noise.  (Neutral on the 188-block run, +1 % at 32 768 and 131 072 voices.)
+                std::vector<int> pr = K >= 3 ? std::vector<int>{2, 1, 1, 0} : std::vector<int>{1, 0, 0, 0};
+                if (K >= 3) {
+                    pr.assign((size_t)K, 1);
+                    pr.front() = 2;
+                    pr.back() = 0;
+                }
                 if (const char* ep = getenv("OGC_PRIO")) {
                     pr.clear();
                     for (const char* q = ep; *q; ++q)

@@ -199,6 +199,9 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert re.search(r"// Node order: env3 env2 env1 env_filter op3_osc", fm)  # the reference's Kahn order, for the record
     assert re.search(r"// Schedule \([^)]*\): env3 op3_osc op3_route env2 op2_osc op1_mod_mixer env1 op1_osc env_filter filter_env_gain cutoff_mod filter output_gain", fm)
     assert re.search(r"//   wave 0: env3 op3_osc op3_route env2 op2_osc\b", fm) and re.search(r"//   wave 1: [a-z0-9_ ]*op1_osc env_filter", fm)
+    # wave priorities of the four-wave workgroup: first wave 2, middle waves 1, the wave that closes the chunk 0
+    p4 = fm[fm.index("voice_block_p4"):]
+    assert p4.count("__builtin_amdgcn_s_setprio(2);") == 1 and p4.count("__builtin_amdgcn_s_setprio(1);") == 2
     sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     assert "// Node order:" in sub_src
     for k in ("og_k_", "og_k2_", "og_k4_"):
