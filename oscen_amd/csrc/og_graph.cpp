@@ -3808,6 +3808,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         for (int gi = 0; gi < K; ++gi) {
             const std::vector<int>& st = groups[gi];
             const bool last = gi == K - 1;
+            int base_prio = 0;
             body << (gi == 0 ? "    if (stage == 0) {\n" : "    } else if (stage == " + std::to_string(gi) + ") {\n");
             {
                 // VALU issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md).  The first wave of
@@ -3832,6 +3833,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                         if (isdigit((unsigned char)*q)) pr.push_back(*q - '0');
                 }
                 if (gi < (int)pr.size() && pr[gi] > 0) body << "    __builtin_amdgcn_s_setprio(" << pr[gi] << ");\n";
+                base_prio = gi < (int)pr.size() ? pr[gi] : 0;
             }
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
             body << "    auto derive = [&]() __attribute__((always_inline)) {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
@@ -3978,6 +3980,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << "                og::ev_advance(A, c);\n"
                      << "            }\n"
                      << "        }\n";
+            // A wave that meets an event or an envelope stage end runs the checked body for that chunk -- about twice the
+            // work of a quiet one -- and the other waves of its workgroup wait for it at the hand-off barrier: it runs
+            // that chunk at the highest priority and drops back afterwards.  Interleaved A/B, fm_voice, 65 536 voices,
+            // 94-block runs, nine pairs: +0.9 .. +5.8 %, mean +2.1 % (3.68e11 -> 3.76e11); level 2 instead of 3 gives a
+            // third of it; neutral at 32 768 and 262 144 voices; raising the release-arithmetic variant as well loses
+            // the gain.  (The two-wave kernel carries it too although it does nothing for it -- forced with
+            // OSCEN_GPU_SPLIT=2 at 65 536 voices: 3.16e11 with, 3.19e11 without; the engine does not pick that kernel at
+            // any bank size of the bench.)  OGC_SLOWPRIO=-1 turns it off.
+            const int slow_prio = getenv("OGC_SLOWPRIO") ? atoi(getenv("OGC_SLOWPRIO")) : 3;
             const bool one_checked = ev_unroll && !mc.empty() && !force; // events and stage ends share ONE unrolled, checked body
             if (one_checked)
                 body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH)) && __all((int)(" << mc
@@ -4000,7 +4011,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
             if (one_checked) {
                 body << "        } else if (n == XCH) { // an event or a stage end in this chunk: the checked, unrolled body\n";
+                if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << slow_prio << "); // the wave on the slow path is the straggler\n";
                 checked("            ");
+                if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << base_prio << ");\n";
             }
             body << "        } else {\n"
                  << fc_sync(st, "            ")

@@ -201,7 +201,11 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert re.search(r"//   wave 0: env3 op3_osc op3_route env2 op2_osc\b", fm) and re.search(r"//   wave 1: [a-z0-9_ ]*op1_osc env_filter", fm)
     # wave priorities of the four-wave workgroup: first wave 2, middle waves 1, the wave that closes the chunk 0
     p4 = fm[fm.index("voice_block_p4"):]
-    assert p4.count("__builtin_amdgcn_s_setprio(2);") == 1 and p4.count("__builtin_amdgcn_s_setprio(1);") == 2
+    assert p4.count("\n    __builtin_amdgcn_s_setprio(2);") == 1 and p4.count("\n    __builtin_amdgcn_s_setprio(1);") == 2
+    # ... and a wave runs a chunk that holds an event or a stage end (the checked body) at priority 3, then drops back
+    # (three of the four waves hold an envelope; the last one -- filter and bus -- has no checked body)
+    assert p4.count("__builtin_amdgcn_s_setprio(3); // the wave on the slow path") == 3
+    assert len(re.findall(r"\n {8,}__builtin_amdgcn_s_setprio\([012]\);", p4)) == 3
     sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     assert "// Node order:" in sub_src
     for k in ("og_k_", "og_k2_", "og_k4_"):
