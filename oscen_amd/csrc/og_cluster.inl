@@ -141,7 +141,36 @@ constexpr uint32_t CL_BATCH_BLOCKS = 256; // blocks per reduce
 struct og_cluster {
     std::vector<og_engine*> shard;
     bool time_reduces = false; // og_cluster_enable_reduce_timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> reduce_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reduce_events; // recorded, not yet read (bounded: fold_reduce_events)
+    double reduce_ms_folded = 0.0; // device time of the pairs already read and destroyed
+    uint64_t reduce_n_folded = 0;
+    // reads and destroys the event pairs (all of them, or only the completed ones at the front)
+    void fold_reduce_events(bool wait)
+    {
+        size_t k = 0;
+        for (; k < reduce_events.size(); ++k) {
+            auto& pr = reduce_events[k];
+            if (wait) HIPCK(hipEventSynchronize(pr.second));
+            else if (hipEventQuery(pr.second) != hipSuccess) break;
+            float ms = 0.0f;
+            HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            reduce_ms_folded += ms;
+            reduce_n_folded += 1;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        reduce_events.erase(reduce_events.begin(), reduce_events.begin() + (ptrdiff_t)k);
+    }
+    void drop_reduce_events()
+    {
+        for (auto& pr : reduce_events) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        reduce_events.clear();
+        reduce_ms_folded = 0.0;
+        reduce_n_folded = 0;
+    }
     std::vector<og_out_event> out_ev_carry, out_ev_scratch; // og_cluster_read_output_events: queue (global voice ids) / per-shard scratch
     std::vector<uint64_t> lo; // first global voice of every shard; lo[n] = total
     std::vector<int> devs;    // distinct devices, devs[0] = root
@@ -177,6 +206,7 @@ struct og_cluster {
                 (void)hipSetDevice(e->device);
                 (void)hipStreamSynchronize(e->stream);
             }
+        drop_reduce_events();
         for (size_t d = 0; d < devs.size(); ++d) {
             (void)hipSetDevice(devs[d]);
             if (d < dev_stream.size() && dev_stream[d]) {
@@ -297,8 +327,10 @@ struct og_cluster {
             hipEvent_t t0 = nullptr, t1 = nullptr;
             if (time_reduces) { // (og_cluster_enable_reduce_timing: device time of the reduce on the ROOT's stream)
                 HIPCK(hipSetDevice(devs[0]));
+                if (reduce_events.size() >= 256) fold_reduce_events(false); // (a caller that never asks must not pile up events)
                 HIPCK(hipEventCreate(&t0));
                 HIPCK(hipEventCreate(&t1));
+                reduce_events.push_back({t0, t1}); // (owned by the list from here on: an error below does not leak them)
                 HIPCK(hipEventRecord(t0, dev_stream[0]));
             }
             R.ck(R.GroupStart(), "ncclGroupStart");
@@ -308,7 +340,6 @@ struct og_cluster {
             if (time_reduces) {
                 HIPCK(hipSetDevice(devs[0]));
                 HIPCK(hipEventRecord(t1, dev_stream[0]));
-                reduce_events.push_back({t0, t1});
             }
             n_reduces += 1;
         }
@@ -587,11 +618,7 @@ int og_cluster_enable_reduce_timing(og_cluster* c, int on)
 {
     if (!c) return set_err(OG_E_INVALID, "null cluster");
     return guard([&] {
-        for (auto& pr : c->reduce_events) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        c->reduce_events.clear();
+        c->drop_reduce_events();
         c->time_reduces = on != 0;
         return OG_OK;
     });
@@ -600,20 +627,12 @@ int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduc
 {
     if (!c || !total_ms || !n_reduces) return set_err(OG_E_INVALID, "null argument");
     return guard([&] {
-        double sum = 0.0;
-        uint64_t n = 0;
-        for (auto& pr : c->reduce_events) {
-            float ms = 0.0f;
-            HIPCK(hipEventSynchronize(pr.second));
-            HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second));
-            sum += ms;
-            n += 1;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        c->reduce_events.clear();
-        *total_ms = sum;
-        *n_reduces = n;
+        if (!c->devs.empty()) HIPCK(hipSetDevice(c->devs[0]));
+        c->fold_reduce_events(true);
+        *total_ms = c->reduce_ms_folded;
+        *n_reduces = c->reduce_n_folded;
+        c->reduce_ms_folded = 0.0;
+        c->reduce_n_folded = 0;
         return OG_OK;
     });
 }

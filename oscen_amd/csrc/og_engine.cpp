@@ -2179,9 +2179,14 @@ int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_
         const uint32_t have = std::min(count, e->out_ev_cap);
         const size_t old = e->out_ev_carry.size();
         e->out_ev_carry.resize(old + have);
-        if (have) e->bounce.d2h(e->out_ev_carry.data() + old, e->d_out_ev, (size_t)have * sizeof(OgOutEvent), e->stream);
-        HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, 2 * sizeof(uint32_t), e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
+        try {
+            if (have) e->bounce.d2h(e->out_ev_carry.data() + old, e->d_out_ev, (size_t)have * sizeof(OgOutEvent), e->stream);
+            HIPCK(hipMemsetAsync(e->d_out_ev_count, 0, 2 * sizeof(uint32_t), e->stream));
+            HIPCK(hipStreamSynchronize(e->stream));
+        } catch (...) {
+            e->out_ev_carry.resize(old); // (a failed copy leaves no half-filled records in the queue)
+            throw;
+        }
         e->out_ev_overflow += count - have;
         e->ev_lost_total += counters[1];
         // frame order; within a frame voice order; a voice's events of one frame in push order (the append index of
