@@ -3865,8 +3865,41 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             for (int k : st)
                 for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
             // flags: stage-end checks, release arithmetic, hand-off values prefetched, node steady states
-            auto quiet = [&](const char* chk_flag, const char* rel_flag, bool st_flag, const std::string& ind) {
+            // `stay` (sticky chunks): the condition -- on the NEXT chunk, `base1` -- under which this very variant runs again.
+            // The wave then stays in a loop of its own around the variant's body (hand-off barrier inside) instead of
+            // going back through the chunk loop's head.  Why: the chunk loop merges four bodies (two quiet variants, the
+            // checked one, the rolled one) and the compiler brings every loop-carried value (envelope, phases, event
+            // cursor: ~20 registers) back to one place after each of them -- 30 v_mov + ~40 SALU per wave and chunk, a sixth
+            // of a quiet chunk's instructions (scripts/isa_blocks.py).  A loop with ONE body keeps its values where they are.
+            // Static count, fm_voice four-wave kernel, release-free quiet chunk of waves 0-2: 231 + 230 + 222 -> 195 + 181 + 188
+            // VALU per 8 frames (-15 VALU per 64-voice frame of ~117).  Interleaved A/B on one MI355X, 65 536 voices: 94-block
+            // runs 3.73e11 -> 4.01e11, the driver's command 3.29e11 -> 3.54e11, 131 072 voices 3.90e11 -> 4.20e11 (+7.5 % each);
+            // parity subset of the GPU suite green with the variant before it became the default.  OGC_STICKY=0 turns it off.
+            const bool sticky = !(getenv("OGC_STICKY") && atoi(getenv("OGC_STICKY")) == 0) && !getenv("OGC_FORCE_PATH");
+            std::string stay_path; // conditions of the enclosing branches, on the next chunk
+            const std::string sync_line = getenv("OGC_NOSYNC") ? "// (experiment: hand-off barrier removed -- results are wrong, timing only)"
+                                                               : "__syncthreads(); // hand-off: every wave stays one chunk ahead of the next one";
+            const std::string bus_tail_fmt = // %B = first frame of the finished chunk, %N = its length
+                "{ // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / XCH hand-offs\n"
+                "%I    const uint32_t lastf = %B + %N - 1;\n"
+                "%I    if ((lastf % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || lastf + 1 == A.frames)\n"
+                "%I        og::bus_chunk_reduce(A, c, bus, lastf - (lastf % OG_BUS_CHUNK), (lastf % OG_BUS_CHUNK) + 1);\n"
+                "%I}\n";
+            auto bus_tail = [&](const std::string& ind, const std::string& n_expr) {
+                std::string o = ind + bus_tail_fmt;
+                auto sub = [&](const std::string& k, const std::string& v) {
+                    for (size_t q = o.find(k); q != std::string::npos; q = o.find(k, q + v.size())) o.replace(q, k.size(), v);
+                };
+                sub("%I", ind);
+                sub("%B", "base");
+                sub("%N", n_expr);
+                return o;
+            };
+            auto quiet = [&](const char* chk_flag, const char* rel_flag, bool st_flag, const std::string& ind0, const std::string& stay = std::string()) {
                 const bool pre = !reads.empty();
+                const bool loop = sticky && !stay.empty();
+                const std::string ind = loop ? ind0 + "    " : ind0;
+                if (loop) body << ind0 << "for (;;) { // sticky: this variant again while its conditions hold\n";
                 if (std::string(rel_flag) == "true") body << fc_sync(st, ind);
                 if (pre) {
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
@@ -3880,6 +3913,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                      << ind << "    const uint32_t f = base + j;\n"
                      << ind << "    " << call(flag) << "\n"
                      << ind << "}\n";
+                if (loop) {
+                    body << ind << "const uint32_t ch1 = ch + 1u, base1 = base + XCH;\n"
+                         << ind << "if (!(ch1 < n_chunks && A.frames - base1 >= (uint32_t)XCH && " << stay_path << (stay == "1" ? "" : " && " + stay)
+                         << ")) break;\n";
+                    if (last) body << bus_tail(ind, "XCH");
+                    body << ind << sync_line << "\n"
+                         << ind << "++t;\n" << ind << "ch = ch1;\n" << ind << "base = base1;\n"
+                         << ind0 << "}\n";
+                }
             };
             const std::string mc = min_cnt(st);
             // ---- events in the pipelined kernels -----------------------------------------------------------------
@@ -3947,13 +3989,14 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (force && force[0] == 'c') {
                     quiet("true", "true", st_flag, ind0);
                 } else if (mc.empty()) {
-                    quiet("true", "true", st_flag, ind0);
+                    quiet("true", "true", st_flag, ind0, "1");
                 } else {
-                    body << ind0 << "if (__all((int)(" << mc << " > (uint32_t)XCH))) { // no envelope stage ends in this chunk\n"
-                         << ind0 << "    if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // ... and no lane is in Release\n";
-                    quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "        ");
+                    const std::string no_end = "__all((int)(" + mc + " > (uint32_t)XCH))", no_rel = "__all((int)(" + rs_sum(st) + " == 0.0f))";
+                    body << ind0 << "if (" << no_end << ") { // no envelope stage ends in this chunk\n"
+                         << ind0 << "    if (" << no_rel << ") { // ... and no lane is in Release\n";
+                    quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "        ", no_end + " && " + no_rel);
                     body << ind0 << "    } else {\n";
-                    quiet("false", "true", st_flag, ind0 + "        ");
+                    quiet("false", "true", st_flag, ind0 + "        ", no_end + " && !" + no_rel);
                     body << ind0 << "    }\n" << ind0 << "} else {\n";
                     quiet("true", "true", st_flag, ind0 + "    ");
                     body << ind0 << "}\n";
@@ -3961,16 +4004,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             };
             // the two straight-line variants only (the caller has established that no countdown ends in the chunk)
             auto fast_variants = [&](bool st_flag, const std::string& ind0) {
-                body << ind0 << "if (__all((int)(" << rs_sum(st) << " == 0.0f))) { // no lane is in Release\n";
-                quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "    ");
+                const std::string no_rel = "__all((int)(" + rs_sum(st) + " == 0.0f))";
+                body << ind0 << "if (" << no_rel << ") { // no lane is in Release\n";
+                quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "    ", no_rel);
                 body << ind0 << "} else {\n";
-                quiet("false", "true", st_flag, ind0 + "    ");
+                quiet("false", "true", st_flag, ind0 + "    ", "!" + no_rel);
                 body << ind0 << "}\n";
             };
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
-                 << "        const uint32_t ch = t - " << gi << "u;\n"
+                 << "        " << (sticky ? "" : "const ") << "uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"
-                 << "        const uint32_t base = ch * XCH;\n"
+                 << "        " << (sticky ? "" : "const ") << "uint32_t base = ch * XCH;\n"
                  << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n";
             if (ev_skip && relevant != "true")
                 body << "        if (!__all((int)(c.next_ev >= base + XCH))) { // consume the events this wave has no handler for\n"
@@ -3999,13 +4043,19 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (one_checked) fast_variants(st_flag, ind);
                 else variants(st_flag, ind);
             };
+            const std::string stay_entry = std::string("__all((int)(c.next_ev >= base1 + XCH))") +
+                                           (one_checked ? " && __all((int)(" + mc + " > (uint32_t)XCH))" : std::string());
             if (steady.empty()) {
+                stay_path = stay_entry;
                 pick(false, "            ");
             } else {
+                const std::string all_steady = "__all((int)(!c.valid || (" + steady + ")))";
                 body << "            constexpr uint32_t CHUNK = XCH;\n"
-                     << "            if (__all((int)(!c.valid || (" << steady << ")))) { // node steady states hold for the whole chunk\n";
+                     << "            if (" << all_steady << ") { // node steady states hold for the whole chunk\n";
+                stay_path = stay_entry + " && " + all_steady;
                 pick(true, "                ");
                 body << "            } else {\n";
+                stay_path = stay_entry + " && !" + all_steady;
                 pick(false, "                ");
                 body << "            }\n";
             }
@@ -4023,15 +4073,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                  << "                " << call("true") << "\n"
                  << "            }\n"
                  << "        }\n";
-            if (last)
-                body << "        { // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / XCH hand-offs\n"
-                     << "            const uint32_t lastf = base + n - 1;\n"
-                     << "            if ((lastf % OG_BUS_CHUNK) == OG_BUS_CHUNK - 1 || lastf + 1 == A.frames)\n"
-                     << "                og::bus_chunk_reduce(A, c, bus, lastf - (lastf % OG_BUS_CHUNK), (lastf % OG_BUS_CHUNK) + 1);\n"
-                     << "        }\n";
+            if (last) body << bus_tail("        ", "n");
             body << "        }\n"
-                 << (getenv("OGC_NOSYNC") ? "        // (experiment: hand-off barrier removed -- results are wrong, timing only)\n"
-                                          : "        __syncthreads(); // hand-off: every wave stays one chunk ahead of the next one\n")
+                 << "        " << sync_line << "\n"
                  << "    }\n";
             if (last) body << "    og::bus_flush(A, c, bus);\n";
             body << cat(st, &Codegen::Sect::pre_store) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::store)
