@@ -3713,33 +3713,56 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         std::string steady;
         for (int k : all_stages)
             for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
+        // Sticky chunks in the ordinary kernel (OGC_STICKY1=1; experiment of late round 4, NOT yet measured on the GPU -- off by
+        // default): as in the pipelined kernels (emit_pipeline below), a wave stays in the quiet variant it is in while that
+        // variant's conditions hold on the next chunk, instead of going back through the chunk loop's head, where the
+        // compiler reconciles the register assignments of the four chunk bodies (fm_voice: 57 v_mov per 16-frame chunk).
+        const bool sticky1 = getenv("OGC_STICKY1") && atoi(getenv("OGC_STICKY1")) != 0;
+        std::string stay_path1;
         auto variants = [&](const std::string& tail, const std::string& ind0) {
-            auto quiet = [&](const std::string& flag, const std::string& ind) {
+            auto quiet = [&](const std::string& flag, const std::string& ind1, const std::string& stay = std::string()) {
+                const bool loop = sticky1 && !stay.empty();
+                const std::string ind = loop ? ind1 + "    " : ind1;
+                if (loop) body << ind1 << "for (;;) { // sticky: this variant again while its conditions hold\n";
                 if (flag != "false, false") body << fc_sync(all_stages, ind);
                 body << ind << "#pragma unroll " << unroll << "\n"
                      << ind << "for (uint32_t j = 0; j < OG_BUS_CHUNK; ++j) og::bus_put<TAPS" << (cg.bus_all_lanes ? ", !TAPS" : "")
                      << ">(A, c, bus, base + j, j, tick(base + j, og::BoolC<" << flag << tail << ">{}));\n";
+                if (loop) {
+                    body << ind << "const uint32_t base1 = base + OG_BUS_CHUNK;\n"
+                         << ind << "if (!(base1 + OG_BUS_CHUNK <= A.frames && " << stay_path1 << (stay == "1" ? "" : " && " + stay) << ")) break;\n"
+                         << ind << "og::bus_chunk_reduce(A, c, bus, base, OG_BUS_CHUNK);\n"
+                         << ind << "base = base1;\n"
+                         << (out.rings.empty() ? std::string() : ind + "cbase = base;\n" + cat(all_stages, &Codegen::Sect::chunk_begin))
+                         << ind1 << "}\n";
+                }
             };
             if (mc.empty()) {
-                quiet("true, true", ind0);
+                quiet("true, true", ind0, "1");
             } else {
-                body << ind0 << "if (__all((int)(" << mc << " > (uint32_t)OG_BUS_CHUNK))) { // no envelope stage ends in this chunk\n"
-                     << ind0 << "    if (__all((int)(" << rs_sum(all_stages) << " == 0.0f))) { // ... and no lane is in Release\n";
-                quiet("false, false", ind0 + "        ");
+                const std::string no_end = "__all((int)(" + mc + " > (uint32_t)OG_BUS_CHUNK))", no_rel = "__all((int)(" + rs_sum(all_stages) + " == 0.0f))";
+                body << ind0 << "if (" << no_end << ") { // no envelope stage ends in this chunk\n"
+                     << ind0 << "    if (" << no_rel << ") { // ... and no lane is in Release\n";
+                quiet("false, false", ind0 + "        ", no_end + " && " + no_rel);
                 body << ind0 << "    } else {\n";
-                quiet("false, true", ind0 + "        ");
+                quiet("false, true", ind0 + "        ", no_end + " && !" + no_rel);
                 body << ind0 << "    }\n" << ind0 << "} else {\n";
                 quiet("true, true", ind0 + "    ");
                 body << ind0 << "}\n";
             }
         };
+        const std::string stay_entry1 = "__all((int)(c.next_ev >= base1 + OG_BUS_CHUNK))";
         if (steady.empty()) {
+            stay_path1 = stay_entry1;
             variants("", "            ");
         } else {
+            const std::string all_steady = "__all((int)(!c.valid || (" + steady + ")))";
             body << "            constexpr uint32_t CHUNK = OG_BUS_CHUNK;\n"
-                 << "            if (__all((int)(!c.valid || (" << steady << ")))) { // node steady states hold for the whole chunk\n";
+                 << "            if (" << all_steady << ") { // node steady states hold for the whole chunk\n";
+            stay_path1 = stay_entry1 + " && " + all_steady;
             variants(", false, true", "                ");
             body << "            } else {\n";
+            stay_path1 = stay_entry1 + " && !" + all_steady;
             variants("", "                ");
             body << "            }\n";
         }
