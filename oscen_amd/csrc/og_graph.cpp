@@ -3894,8 +3894,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // checked one, the rolled one) and the compiler brings every loop-carried value (envelope, phases, event
             // cursor: ~20 registers) back to one place after each of them -- 30 v_mov + ~40 SALU per wave and chunk, a sixth
             // of a quiet chunk's instructions (scripts/isa_blocks.py).  A loop with ONE body keeps its values where they are.
-            // Static count, fm_voice four-wave kernel, release-free quiet chunk of waves 0-2: 231 + 230 + 222 -> 195 + 181 + 188
-            // VALU per 8 frames (-15 VALU per 64-voice frame of ~117).  Interleaved A/B on one MI355X, 65 536 voices: 94-block
+            // Static count, fm_voice four-wave kernel, release-free quiet chunk of waves 0-2: 231 + 230 + 222 -> ~201 + 187 + 194
+            // VALU per 8 frames; rocprofv3 SQ_INSTS_VALU per 64-voice frame at the driver's command 120.7 -> 107.4.  Interleaved A/B on one MI355X, 65 536 voices: 94-block
             // runs 3.73e11 -> 4.01e11, the driver's command 3.29e11 -> 3.54e11, 131 072 voices 3.90e11 -> 4.20e11 (+7.5 % each);
             // parity subset of the GPU suite green with the variant before it became the default.  OGC_STICKY=0 turns it off.
             const bool sticky = !(getenv("OGC_STICKY") && atoi(getenv("OGC_STICKY")) == 0) && !getenv("OGC_FORCE_PATH");

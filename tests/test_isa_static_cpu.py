@@ -1,0 +1,74 @@
+"""Static guard on the generated fm-synth kernels (CPU: hipcc cross-compiles gfx950 here, nothing runs).
+
+The pipelined kernels owe ~7.5 % of their throughput ("sticky chunks") to the fact that a quiet chunk's
+loop carries its ~20 live values in place: no v_mov register shuffles, a handful of scalar instructions around the
+unrolled 8-frame body.  That is a property of generator + compiler, invisible to parity tests; this test reads it off the
+assembly with scripts/isa_loops.py's span finder."""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oscen_amd  # noqa: E402
+from oscen_amd import build as b  # noqa: E402
+
+
+def _innermost_loops(asm, kern):
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(kern + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    ins, label_at = [], {}
+    for l in lines[start + 1:end]:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            label_at[m.group(1)] = len(ins)
+            continue
+        if not t or t[0] in ";.":
+            continue
+        ins.append(t.split(";")[0].strip())
+    spans = []
+    for i, t in enumerate(ins):
+        op = t.split()[0]
+        if (op.startswith("s_cbranch") or op == "s_branch") and t.split()[1] in label_at and label_at[t.split()[1]] <= i:
+            spans.append((label_at[t.split()[1]], i))
+    inner = [s for s in spans if not any(o is not s and s[0] <= o[0] and o[1] <= s[1] for o in spans)]
+    out = []
+    for a, e in inner:
+        c = collections.Counter()
+        for t in ins[a:e + 1]:
+            op = t.split()[0]
+            if op in ("v_mov_b32_e32", "v_mov_b64_e32"): c["v_mov"] += 1
+            elif op.startswith("v_"): c["valu"] += 1
+            elif op == "s_barrier": c["barrier"] += 1
+            elif op.startswith("s_cbranch") or op == "s_branch": c["branch"] += 1
+        c["n"] = e - a + 1
+        out.append(c)
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_sticky_chunk_loops_of_the_four_wave_kernel_carry_their_values_in_place(tmp_path):
+    src = oscen_amd.Graph(builtin="fm_voice").kernel_source()
+    kern = re.search(r"\b(og_k4_[0-9a-f]{16}_00)\b", src).group(1)
+    hip, asm = tmp_path / "fm.hip", tmp_path / "fm.s"
+    hip.write_text(src)
+    r = subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-x", "hip", "-S", "--cuda-device-only", str(hip), "-o", str(asm)] + b.COMMON,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    loops = _innermost_loops(asm.read_text(), kern)
+    # the six sticky loops of the three envelope waves, as far as the layout keeps them contiguous (the unrolled 8-frame
+    # body up to the first backward branch; the rest of the stay test and the barrier sit in a block placed elsewhere):
+    # two branches (leave / repeat) -- and NO register shuffles
+    sticky = [c for c in loops if c["branch"] == 2 and c["n"] >= 150]
+    assert len(sticky) == 6, [dict(c) for c in loops if c["n"] >= 100]
+    for c in sticky:
+        assert c["v_mov"] <= 2, dict(c)
+        assert c["valu"] <= 240, dict(c)  # 181 .. 229 VALU per 8 frames today (release-free / release variant)
+    # all three waves' release-free variants together: < 25 VALU per frame and wave
+    assert sum(sorted(c["valu"] for c in sticky)[:3]) <= 3 * 8 * 25
