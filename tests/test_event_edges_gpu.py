@@ -382,7 +382,7 @@ def test_event_edge_between_two_oversampled_nodes_is_delivered_once_per_outer_ti
     nothing."""
     oscen_amd.register_node(
         "R4Clock::new", inputs=[("every", "value", 3.0, 0)], outputs=[], n_ctor_args=1, state=[("t", "u32", 0, -1)], event_outputs=["tick"],
-        process="    t += 1u;\n    if ((float)(t % (uint32_t)every) == 0.0f) tick.push((float)t);\n")
+        process="    t += 1u;\n    if ((float)(t % max((uint32_t)every, 1u)) == 0.0f) tick.push((float)t);\n")  # (max: lanes beyond the bank hold every = 0)
     oscen_amd.register_node(
         "R4Counter::new", inputs=[("trig", "event", 0.0, -1)], outputs=["out"],
         state=[("received", "u32", 0, -1), ("sum", "f32", 0.0, -1), ("seen_at", "u32", 0, -1), ("ticks", "u32", 0, -1)],
