@@ -129,6 +129,8 @@ extern "C" {
     pub fn og_blocking_stats(e: *const og_engine, calls: *mut u64, marker_timeouts: *mut u64) -> c_int;
     pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
     pub fn og_reserve_events(e: *mut og_engine, n_events: u64) -> c_int;
+    pub fn og_group_voices(e: *mut og_engine, policy: u32) -> c_int;
+    pub fn og_voice_slot(e: *const og_engine, voice: u32, slot: *mut u32) -> c_int;
     pub fn og_sync_event_counters(e: *mut og_engine) -> c_int;
     pub fn og_cluster_enable_reduce_timing(c: *mut og_cluster, on: c_int) -> c_int;
     pub fn og_cluster_reduce_time_ms(c: *mut og_cluster, total_ms: *mut f64, n_reduces: *mut u64) -> c_int;
@@ -153,6 +155,7 @@ extern "C" {
 extern "C" {
     pub fn og_cluster_read_output_events(c: *mut og_cluster, buf: *mut og_out_event, cap: u32, n: *mut u32, n_overflowed: *mut u64) -> c_int;
     pub fn og_cluster_events_dropped(c: *mut og_cluster) -> u64;
+    pub fn og_cluster_group_voices(c: *mut og_cluster, policy: u32) -> c_int;
 }
 
 // ---- the rest of include/oscen_gpu.h: event outputs of the graph, taps, introspection, statistics ----

@@ -380,6 +380,17 @@ uint64_t og_event_ring_wraps(const og_engine* e);
  * sizes the room once, before the score goes to the device.  No counterpart in the reference (its queues are the
  * fixed 32-deep ArrayVecs of graph/types.rs:18; the score there is the caller's own loop). */
 int og_reserve_events(og_engine* e, uint64_t n_events);
+/* Voice grouping for resident scores (no counterpart in the reference, whose `voices[i]` are one array in one loop:
+ * fm-synth/src/lib.rs:22-131).  A wave renders 64 consecutive voice SLOTS and takes, chunk by chunk, the cheapest body all
+ * of its lanes allow; policy 1 re-orders the slots so that voices whose notes end at about the same time share waves (by
+ * the frame of the voice's first scheduled note-off -- an event with a value <= 0 --, then by its first event), policy 0
+ * restores the identity.  Voice NUMBERS do not change: every entry point keeps taking and handing out the caller's
+ * numbers (events, per-voice values, taps, state fields, event outputs, MIDI voices); per-voice samples are bit for bit
+ * those of the ungrouped bank, the bus differs by the association of the sum.  Call after og_init and after scheduling
+ * the score, before the first block and before og_set_voice_taps (OG_E_STATE otherwise); og_init restores the identity;
+ * og_save_state blobs of a grouped engine carry the order and og_load_state adopts it. */
+int og_group_voices(og_engine* e, uint32_t policy);
+int og_voice_slot(const og_engine* e, uint32_t voice, uint32_t* slot); /* the physical slot of a voice (== voice when not grouped) */
 /* the blocking entry (og_process_block / og_midi_process_block): calls that waited on the completion word, and how
  * many of those waits ended because the stream was found finished (hipStreamQuery, asked every 128 us from 256 us on)
  * before the completion word was seen -- 0 in the ordinary case */
@@ -440,6 +451,7 @@ int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduc
 /* event outputs of the graph (og_read_output_events) over all shards: merged into (frame, GLOBAL voice, push order) */
 int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n, uint64_t* n_overflowed);
 uint64_t og_cluster_events_dropped(og_cluster* c); /* og_events_dropped summed over the shards */
+int og_cluster_group_voices(og_cluster* c, uint32_t policy); /* og_group_voices on every shard (voices never change shard) */
 /* the engine of shard s (owned by the cluster) and its first global voice: taps, state snapshots, statistics */
 og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice);
 

@@ -637,6 +637,16 @@ int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduc
     });
 }
 
+int og_cluster_group_voices(og_cluster* c, uint32_t policy)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    for (og_engine* e : c->shard) {
+        const int rc = og_group_voices(e, policy);
+        if (rc != OG_OK) return rc;
+    }
+    return OG_OK;
+}
+
 uint64_t og_cluster_events_dropped(og_cluster* c)
 {
     uint64_t d = 0;

@@ -421,7 +421,12 @@ struct og_engine {
     // for each voice that received events -- its unconsumed old events merged with the new ones -- at the
     // tail of d_events and repoints that voice's (cursor, end) with a tiny kernel: O(#pushes) host work,
     // one async copy from a pinned staging ring, no stream synchronisation.
-    std::vector<HostEvent> pending;      // pushes not yet on the device timeline
+    std::vector<HostEvent> pending;      // pushes not yet on the device timeline (PHYSICAL voice slots)
+    // og_group_voices: logical voice (what every entry point takes and hands out) -> physical slot (what the device arrays
+    // and everything below the entry points index).  Empty = identity.
+    std::vector<uint32_t> phys_of, logical_of;
+    uint32_t phys(uint32_t v) const { return phys_of.empty() ? v : phys_of[v]; }
+    uint32_t logical(uint32_t p) const { return logical_of.empty() ? p : logical_of[p]; }
     std::vector<OgEvent> h_events;       // host mirror of d_events (the whole ring)
     std::vector<uint32_t> seg_begin, seg_end; // per voice: its current segment (empty vectors = all segments empty)
     std::vector<uint64_t> seg_last;           // per voice: frame of the segment's last event (< frame_now: all consumed)
@@ -1163,6 +1168,7 @@ int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, flo
     if (!e) return set_err(OG_E_INVALID, "null engine");
     if (input >= e->cg->inputs.size()) return set_err(OG_E_INVALID, "input index out of range");
     if (voice >= e->V) return set_err(OG_E_INVALID, "voice index out of range");
+    voice = e->phys(voice);
     const auto& in = e->cg->inputs[input];
     uint32_t target;
     if (setvalue) {
@@ -1638,6 +1644,8 @@ int og_init(og_engine* e, float sample_rate)
         e->out_ev_overflow = 0;
         e->out_ev_carry.clear();
         e->ev_lost_total = 0;
+        e->phys_of.clear(); // (og_group_voices: a fresh state has no voice order to keep)
+        e->logical_of.clear();
         e->frame_now = 0;
         e->inited = true;
         return OG_OK;
@@ -1738,7 +1746,17 @@ int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t c
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
         const size_t w = (size_t)e->cg->inputs[input].state_word;
-        e->bounce.h2d(e->d_state + w * e->V + first, v, (size_t)count * 4, e->stream);
+        if (e->phys_of.empty()) {
+            e->bounce.h2d(e->d_state + w * e->V + first, v, (size_t)count * 4, e->stream);
+        } else { // grouped voices: the range is scattered over the plane
+            std::vector<float> plane(e->V);
+            if (count < e->V) {
+                e->bounce.d2h(plane.data(), e->d_state + w * e->V, (size_t)e->V * 4, e->stream);
+                HIPCK(hipStreamSynchronize(e->stream));
+            }
+            for (uint32_t i = 0; i < count; ++i) plane[e->phys_of[first + i]] = v[i];
+            e->bounce.h2d(e->d_state + w * e->V, plane.data(), (size_t)e->V * 4, e->stream);
+        }
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -1783,7 +1801,7 @@ int og_schedule_voice_events(og_engine* e, uint32_t input, uint32_t n, const uin
         if (voices[i] >= e->V) return set_err(OG_E_INVALID, "voice index out of range");
     e->pending.reserve(e->pending.size() + n);
     for (uint32_t i = 0; i < n; ++i)
-        e->pending.push_back(HostEvent{voices[i], std::max(abs_frames[i], e->frame_now), target, values[i], e->seq++, false});
+        e->pending.push_back(HostEvent{e->phys(voices[i]), std::max(abs_frames[i], e->frame_now), target, values[i], e->seq++, false});
     return OG_OK;
     });
 }
@@ -2042,7 +2060,14 @@ int og_read_state_field(og_engine* e, const char* path, uint32_t first_voice, ui
     return guard([&] {
         HIPCK(hipSetDevice(e->device));
         e->flush_bus();
-        if (n) e->bounce.d2h(out, e->d_state + (size_t)w * e->V + first_voice, (size_t)n * 4, e->stream);
+        if (n && e->phys_of.empty()) {
+            e->bounce.d2h(out, e->d_state + (size_t)w * e->V + first_voice, (size_t)n * 4, e->stream);
+        } else if (n) { // grouped voices: gather
+            std::vector<uint32_t> plane(e->V);
+            e->bounce.d2h(plane.data(), e->d_state + (size_t)w * e->V, (size_t)e->V * 4, e->stream);
+            HIPCK(hipStreamSynchronize(e->stream));
+            for (uint32_t i = 0; i < n; ++i) ((uint32_t*)out)[i] = plane[e->phys_of[first_voice + i]];
+        }
         HIPCK(hipStreamSynchronize(e->stream));
         return OG_OK;
     });
@@ -2058,7 +2083,7 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
         std::vector<int32_t> slot(e->V, -1);
         for (uint32_t i = 0; i < n; ++i) {
             if (voices[i] >= e->V) throw std::runtime_error("tap voice out of range");
-            slot[voices[i]] = (int32_t)i;
+            slot[e->phys(voices[i])] = (int32_t)i;
         }
         e->bounce.h2d(e->d_tap_slot, slot.data(), (size_t)e->V * 4, e->stream);
         HIPCK(hipStreamSynchronize(e->stream));
@@ -2189,6 +2214,8 @@ int og_read_output_events(og_engine* e, og_out_event* buf, uint32_t cap, uint32_
         }
         e->out_ev_overflow += count - have;
         e->ev_lost_total += counters[1];
+        if (!e->logical_of.empty()) // grouped voices: the log holds physical slots
+            for (size_t i = old; i < e->out_ev_carry.size(); ++i) e->out_ev_carry[i].voice = e->logical_of[e->out_ev_carry[i].voice];
         // frame order; within a frame voice order; a voice's events of one frame in push order (the append index of
         // one lane grows in program order).  Events carried over from an earlier call lie on earlier frames.
         std::sort(e->out_ev_carry.begin() + (ptrdiff_t)old, e->out_ev_carry.end(), [](const OgOutEvent& a, const OgOutEvent& b) {
@@ -2238,6 +2265,79 @@ int og_reserve_events(og_engine* e, uint64_t n_events)
     if (n_events > 0xF0000000ull) return set_err(OG_E_INVALID, "og_reserve_events: at most 2^32 - 2^28 events");
     e->ev_reserve = (size_t)n_events;
     e->ev_rebuild = e->ev_rebuild || (e->d_events && e->ev_tail + e->ev_reserve > e->ev_cap); // takes effect with the next rebuild
+    return OG_OK;
+}
+
+// Voice grouping for resident scores.  A wave renders 64 consecutive voice slots and takes, chunk by chunk, the cheapest body
+// ALL of its lanes allow: one releasing lane puts the whole wave on the release arithmetic, one event or envelope stage end
+// on the checked body.  With the voices of a bank in arbitrary order nearly every wave holds a releasing lane nearly all
+// the time.  og_group_voices re-orders the SLOTS so that voices whose notes end at about the same time share waves --
+// policy 1: by the frame of the voice's first scheduled note-off (an event-input event with a value <= 0), then by its
+// first event of any kind -- and keeps a logical -> physical table: every entry point still takes and hands out the
+// caller's voice numbers, per-voice samples are bit for bit those of the ungrouped bank, the summed bus differs by the
+// association of the sum only.  Policy 0 restores the identity.  To be called after og_init and after the score has been
+// scheduled, before the first block (the only per-voice state then are the per-voice value inputs, which move along).
+int og_group_voices(og_engine* e, uint32_t policy)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (policy > 1u) return set_err(OG_E_INVALID, "og_group_voices: policy 0 (identity) or 1 (by first note-off)");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before og_group_voices");
+    if (e->frame_now != 0 || !e->queue.empty() || !e->h_events.empty() || e->n_block_local != 0)
+        return set_err(OG_E_STATE, "og_group_voices: only before the first block (and before block-local pushes)");
+    if (e->n_taps != 0) return set_err(OG_E_STATE, "og_group_voices: set the voice taps after grouping");
+    return guard([&] {
+        HIPCK(hipSetDevice(e->device));
+        const uint32_t V = e->V;
+        std::vector<uint32_t> new_phys(V);
+        if (policy == 0u) {
+            for (uint32_t v = 0; v < V; ++v) new_phys[v] = v;
+        } else {
+            const uint64_t NONE = ~(uint64_t)0;
+            std::vector<uint64_t> first_off(V, NONE), first_any(V, NONE);
+            for (const HostEvent& h : e->pending) {
+                const uint32_t v = e->logical(h.voice);
+                first_any[v] = std::min(first_any[v], h.frame);
+                if (!(h.target & OG_EV_SETVALUE) && h.value <= 0.0f) first_off[v] = std::min(first_off[v], h.frame);
+            }
+            std::vector<uint32_t> order(V);
+            for (uint32_t v = 0; v < V; ++v) order[v] = v;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                if (first_off[a] != first_off[b]) return first_off[a] < first_off[b];
+                return first_any[a] < first_any[b];
+            });
+            for (uint32_t r = 0; r < V; ++r) new_phys[order[r]] = r;
+        }
+        // the per-voice value inputs move with their voices
+        std::vector<float> plane(V), moved(V);
+        for (size_t i = 0; i < e->cg->inputs.size(); ++i) {
+            const auto& in = e->cg->inputs[i];
+            if (!(in.decl.kind == ogc::Kind::Value && in.decl.per_voice)) continue;
+            float* d = reinterpret_cast<float*>(e->d_state) + (size_t)in.state_word * V;
+            e->bounce.d2h(plane.data(), d, (size_t)V * 4, e->stream);
+            HIPCK(hipStreamSynchronize(e->stream));
+            for (uint32_t v = 0; v < V; ++v) moved[new_phys[v]] = plane[e->phys(v)];
+            e->bounce.h2d(d, moved.data(), (size_t)V * 4, e->stream);
+            HIPCK(hipStreamSynchronize(e->stream));
+        }
+        for (HostEvent& h : e->pending) h.voice = new_phys[e->logical(h.voice)];
+        bool identity = true;
+        for (uint32_t v = 0; v < V && identity; ++v) identity = new_phys[v] == v;
+        if (identity) {
+            e->phys_of.clear();
+            e->logical_of.clear();
+        } else {
+            e->logical_of.assign(V, 0u);
+            for (uint32_t v = 0; v < V; ++v) e->logical_of[new_phys[v]] = v;
+            e->phys_of.swap(new_phys);
+        }
+        return OG_OK;
+    });
+}
+int og_voice_slot(const og_engine* e, uint32_t voice, uint32_t* slot)
+{
+    if (!e || !slot) return set_err(OG_E_INVALID, "null argument");
+    if (voice >= e->V) return set_err(OG_E_INVALID, "voice index out of range");
+    *slot = e->phys(voice);
     return OG_OK;
 }
 
@@ -2326,10 +2426,14 @@ void collect_unconsumed(const og_engine* e, std::vector<SnapEvent>& out)
     for (const HostEvent& h : e->pending)
         if (h.frame >= hz) out.push_back(SnapEvent{h.voice, h.target, h.frame, h.value, h.block_local ? 1u : 0u});
 }
-size_t control_bytes(const og_engine* e, size_t n_events)
+// (a blob of an engine with grouped voices -- og_group_voices -- is version 3: the state planes and the events are in
+//  PHYSICAL order, and the logical -> physical table follows the events; loading it adopts the table)
+size_t control_bytes(const og_engine* e, size_t n_events, bool grouped)
 {
-    return sizeof(SnapHeader) + e->cg->inputs.size() * (sizeof(float) + sizeof(SnapRamp)) + n_events * sizeof(SnapEvent);
+    return sizeof(SnapHeader) + e->cg->inputs.size() * (sizeof(float) + sizeof(SnapRamp)) + n_events * sizeof(SnapEvent) +
+           (grouped ? (size_t)e->V * sizeof(uint32_t) : 0);
 }
+size_t control_bytes(const og_engine* e, size_t n_events) { return control_bytes(e, n_events, !e->phys_of.empty()); }
 } // namespace
 
 extern "C" {
@@ -2366,7 +2470,7 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
         }
         HIPCK(hipStreamSynchronize(e->stream));
         char* p = (char*)dst + off;
-        const SnapHeader h{SNAP_MAGIC, 2u, e->frame_now, (uint32_t)e->cg->inputs.size(), e->active_ramps, (uint64_t)evs.size()};
+        const SnapHeader h{SNAP_MAGIC, e->phys_of.empty() ? 2u : 3u, e->frame_now, (uint32_t)e->cg->inputs.size(), e->active_ramps, (uint64_t)evs.size()};
         memcpy(p, &h, sizeof h);
         p += sizeof h;
         memcpy(p, e->values.data(), e->values.size() * sizeof(float));
@@ -2377,6 +2481,8 @@ int og_save_state(og_engine* e, void* dst, size_t cap)
             p += sizeof sr;
         }
         if (!evs.empty()) memcpy(p, evs.data(), evs.size() * sizeof(SnapEvent));
+        p += evs.size() * sizeof(SnapEvent);
+        if (!e->phys_of.empty()) memcpy(p, e->phys_of.data(), (size_t)e->V * sizeof(uint32_t));
         return OG_OK;
     });
 }
@@ -2390,12 +2496,23 @@ int og_load_state(og_engine* e, const void* src, size_t len)
     memcpy(&h, (const char*)src + dsp, sizeof h);
     // (n_events is checked against the bytes that are there BEFORE it enters any size arithmetic: a crafted count must
     //  not wrap control_bytes() around to a matching length)
-    const size_t fixed = control_bytes(e, 0);
-    if (h.magic != SNAP_MAGIC || h.version != 2u || h.n_inputs != e->cg->inputs.size() || len < dsp + fixed ||
-        h.n_events > (uint64_t)((len - dsp - fixed) / sizeof(SnapEvent)) || len != dsp + control_bytes(e, (size_t)h.n_events))
+    const bool grouped = h.version == 3u;
+    const size_t fixed = control_bytes(e, 0, grouped);
+    if (h.magic != SNAP_MAGIC || (h.version != 2u && h.version != 3u) || h.n_inputs != e->cg->inputs.size() || len < dsp + fixed ||
+        h.n_events > (uint64_t)((len - dsp - fixed) / sizeof(SnapEvent)) || len != dsp + control_bytes(e, (size_t)h.n_events, grouped))
         return set_err(OG_E_INVALID, "state blob does not belong to this graph / voice count (or is from another version)");
+    std::vector<uint32_t> new_phys, new_logical;
+    if (grouped) { // the voice order must be a permutation before anything is changed
+        new_phys.resize(e->V);
+        new_logical.assign(e->V, 0xFFFFFFFFu);
+        memcpy(new_phys.data(), (const char*)src + len - (size_t)e->V * sizeof(uint32_t), (size_t)e->V * sizeof(uint32_t));
+        for (uint32_t v = 0; v < e->V; ++v) {
+            if (new_phys[v] >= e->V || new_logical[new_phys[v]] != 0xFFFFFFFFu) return set_err(OG_E_INVALID, "state blob: the voice order is not a permutation");
+            new_logical[new_phys[v]] = v;
+        }
+    }
     { // validate the events before anything is changed: the kernel indexes handlers / per-voice inputs by `target`
-        const char* q = (const char*)src + dsp + fixed;
+        const char* q = (const char*)src + dsp + control_bytes(e, 0, false);
         for (uint64_t i = 0; i < h.n_events; ++i, q += sizeof(SnapEvent)) {
             SnapEvent ev;
             memcpy(&ev, q, sizeof ev);
@@ -2424,6 +2541,15 @@ int og_load_state(og_engine* e, const void* src, size_t len)
         }
         e->reset_timeline();
         HIPCK(hipStreamSynchronize(e->stream));
+        const bool order_changed = e->phys_of != new_phys;
+        e->phys_of.swap(new_phys); // (version 2: identity)
+        e->logical_of.swap(new_logical);
+        if (order_changed && e->n_taps) { // taps were resolved to physical slots under the old order: set them again
+            std::vector<int32_t> none(e->V, -1);
+            e->bounce.h2d(e->d_tap_slot, none.data(), (size_t)e->V * 4, e->stream);
+            HIPCK(hipStreamSynchronize(e->stream));
+            e->n_taps = 0;
+        }
         const char* p = (const char*)src + off + sizeof h;
         memcpy(e->values.data(), p, e->values.size() * sizeof(float));
         p += e->values.size() * sizeof(float);
