@@ -86,6 +86,21 @@ assert np.max(np.abs(bus - one)) <= 2e-6 * float(abs_sum.max()) + 1e-6
 cl2 = oscen_amd.Cluster("fm_voice", n, list(range(n_dev)), sample_rate=SR)
 oscen_amd.schedule_note_plans(cl2, plans, total_frames=total)
 assert np.array_equal(cl2.render(total, block=block).reshape(total, -1), bus)
+# every built-in graph, and device lists with several shards per device / in no particular order: the cluster's bus is the
+# single engine's (the e-piano's Tremolo runs once, on the root, after the reduce; the echo voice carries delay lines)
+for graph, nv in (("epiano_voice", 8 * 24), ("sat4x_voice", 8 * 40), ("echo_voice", 8 * 30)):
+    tot, blk = 512, 128
+    pl = oscen_amd.note_plans(nv, span=tot)
+    single = oscen_amd.Engine(graph, nv, sample_rate=SR)
+    oscen_amd.schedule_note_plans(single, pl, total_frames=tot)
+    want = single.render(tot, block=blk).reshape(tot, -1)
+    for devs in ([0, 1, 2, 3, 4, 5, 6, 7], [0, 0, 1, 1, 2, 2, 3, 3], [3, 1, 2]):
+        c = oscen_amd.Cluster(graph, nv, devs, sample_rate=SR)
+        assert c.num_devices == len(set(devs))
+        oscen_amd.schedule_note_plans(c, pl, total_frames=tot)
+        got = np.concatenate([c.process_block(blk).copy() for _ in range(tot // blk)], axis=0).reshape(tot, -1)
+        assert got.shape == want.shape and c.rccl_reduces > 0
+        assert np.abs(got - want).max() <= 4e-7 * max(1.0, float(np.abs(want).max())) * 4, (graph, devs)
 print("cluster8 ok", cl.rccl_reduces, float(np.abs(bus).max()))
 """
 
