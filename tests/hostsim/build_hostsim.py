@@ -12,7 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oscen_amd import build as b  # noqa: E402  (source lists and the generator; nothing of the product is changed)
 
-OUT = os.path.join(HERE, "_build")
+# OG_HOSTSIM_ASAN=1: an AddressSanitizer build in its own directory (device memory is host memory here, so an out-of-bounds
+# access of a KERNEL is a heap overflow ASan sees).  Run the tests with LD_PRELOAD=<libclang_rt.asan-x86_64.so> and
+# ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 (the fibres' stacks are not ASan's).
+ASAN = bool(os.environ.get("OG_HOSTSIM_ASAN"))
+OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
 LIB = os.path.join(OUT, "liboscen_gpu_hostsim.so")
 
 
@@ -29,6 +33,9 @@ FLAGS = ["-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mfma", "-mavx2", "
 
 
 def build(force=False):
+    if ASAN and "-fsanitize=address" not in FLAGS:
+        FLAGS.extend(["-fsanitize=address", "-fno-omit-frame-pointer", "-g1", '-DOG_HOSTSIM_JIT_FLAGS=" -fsanitize=address -fno-omit-frame-pointer -g1"',
+                      '-DOG_HOSTSIM_BUILD="_build_asan"'])
     os.makedirs(OUT, exist_ok=True)
     gens = b.generate()
     srcs = [os.path.join(b.CSRC, f) for f in b.HOST_SRCS if f != "og_jit.cpp"]
@@ -52,7 +59,7 @@ def build(force=False):
         import shutil
 
         shutil.rmtree(os.path.join(OUT, "jit"), ignore_errors=True)  # (kernels compiled at run time against the old headers)
-        b._run([cxx(), "-shared", "-o", LIB] + objs + ["-Wl,--allow-multiple-definition", "-ldl", "-lpthread"])  # (a noinline __device__ function of og_nodes.hip.h is emitted by every generated unit)
+        b._run([cxx(), "-shared", "-o", LIB] + objs + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) + ["-Wl,--allow-multiple-definition", "-ldl", "-lpthread"])  # (a noinline __device__ function of og_nodes.hip.h is emitted by every generated unit)
     # the stand-in for librccl.so.1 (clusters of several simulated devices): found through LD_LIBRARY_PATH by the test process
     fake_dir = os.path.join(OUT, "fake_rccl")
     os.makedirs(fake_dir, exist_ok=True)

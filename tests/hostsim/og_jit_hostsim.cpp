@@ -14,6 +14,12 @@
 
 #include "og_jit.h"
 
+#ifndef OG_HOSTSIM_JIT_FLAGS
+#define OG_HOSTSIM_JIT_FLAGS ""
+#endif
+#ifndef OG_HOSTSIM_BUILD
+#define OG_HOSTSIM_BUILD "_build"
+#endif
 #ifndef OG_HOSTSIM_DIR
 #error "build with -DOG_HOSTSIM_DIR=... -DOG_CSRC_DIR=... -DOG_HOSTSIM_CXX=... (tests/hostsim/build_hostsim.py)"
 #endif
@@ -32,7 +38,7 @@ std::string hash_hex(uint64_t h)
 // compiles the unit (once per kernel hash: the objects are kept under _build/jit) and returns the path of the shared object
 std::string compile_unit(const ogc::CompiledGraph& cg)
 {
-    const std::string dir = std::string(OG_HOSTSIM_DIR) + "/_build/jit";
+    const std::string dir = std::string(OG_HOSTSIM_DIR) + "/" OG_HOSTSIM_BUILD "/jit";
     (void)mkdir(dir.c_str(), 0777);
     const std::string base = dir + "/" + hash_hex(cg.hash);
     const std::string so = base + ".so";
@@ -45,7 +51,7 @@ std::string compile_unit(const ogc::CompiledGraph& cg)
           << "extern \"C\" void og_hostsim_set_api(void* a) { simt::api_slot() = (simt::Api*)a; }\n";
     }
     const bool debug = getenv("OG_HOSTSIM_DEBUG") != nullptr; // keep the unit and compile it with line tables
-    const std::string cmd = std::string(OG_HOSTSIM_CXX) + (debug ? " -g" : "") + " -x c++ -shared -O1 -std=c++17 -ffp-contract=off -fPIC -mfma -mavx2 -DOG_HOSTSIM=1 -DOG_JIT=1"
+    const std::string cmd = std::string(OG_HOSTSIM_CXX) + (debug ? " -g" : "") + OG_HOSTSIM_JIT_FLAGS + " -x c++ -shared -O1 -std=c++17 -ffp-contract=off -fPIC -mfma -mavx2 -DOG_HOSTSIM=1 -DOG_JIT=1"
                             " -Wno-unknown-attributes -Wno-unused-value -Wno-pass-failed -Wno-unknown-pragmas -I" OG_HOSTSIM_DIR " -I" OG_CSRC_DIR " -o " + tmp + " " + src +
                             " > " + log + " 2>&1";
     const int rc = system(cmd.c_str());

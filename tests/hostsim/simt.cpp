@@ -135,9 +135,19 @@ void run_block(Sched& s, unsigned n)
         L.op = OP_NONE;
     }
     const unsigned n_waves = (n + WAVE - 1) / WAVE;
+    // The order in which ready lanes run between rendezvous points is the simulator's choice; a kernel that is correct on
+    // the hardware gives the same result under any of them.  OG_HOSTSIM_SCHEDULE=reverse runs the waves (and the lanes) last
+    // first, =rotate starts one wave further on every pass: a hand-off that lacks a barrier shows up as a changed result.
+    static const int sched = [] {
+        const char* e = getenv("OG_HOSTSIM_SCHEDULE");
+        return !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "rotate") ? 2 : 0));
+    }();
+    unsigned pass = 0;
     while (alive) {
         bool progress = false;
-        for (unsigned l = 0; l < n; ++l) {
+        ++pass;
+        for (unsigned k = 0; k < n; ++k) {
+            const unsigned l = sched == 1 ? n - 1 - k : (sched == 2 ? (k + pass * WAVE) % n : k);
             Lane& L = s.lanes[l];
             if (L.state != READY) continue;
             s.cur = &L;

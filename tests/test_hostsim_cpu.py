@@ -55,6 +55,22 @@ def test_gpu_parity_tests_on_the_host_simulator(hostsim_env):
     assert "%d passed" % len(ids) in tail, tail
 
 
+@pytest.mark.timeout(900)
+def test_pipelined_kernels_do_not_depend_on_the_order_the_waves_run_in(hostsim_env):
+    """Between rendezvous points the simulator may run the ready lanes in any order.  It normally runs wave 0 first; here
+    the waves run last-first: the producer wave of a pipelined kernel then reaches every hand-off AFTER its consumers are
+    waiting.  A missing or misplaced hand-off barrier (the sticky chunk loops keep theirs inside the loop) changes a result."""
+    ids = [t for t in subset() if t.split("::")[0] in ("tests/test_parity_gpu.py", "tests/test_jit_gpu.py", "tests/test_multirate_gpu.py",
+                                                       "tests/test_event_edges_gpu.py", "tests/test_voice_grouping_gpu.py")]
+    assert len(ids) >= 35
+    env = dict(hostsim_env)
+    env["OG_HOSTSIM_SCHEDULE"] = "reverse"
+    workers = str(max(2, min(8, (os.cpu_count() or 2) // 2)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-n", workers, "--timeout", "300", "-p", "no:cacheprovider"] + ids,
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "%d passed" % len(ids) in r.stdout[-4000:], r.stdout[-4000:]
+
+
 CLUSTER8 = r"""
 import sys
 import numpy as np
