@@ -36,7 +36,7 @@ def make_score(n, blocks, block, seed):
 @pytest.mark.parametrize("n", [130, 5000])
 def test_bulk_incremental_and_queued_event_paths_agree(n, monkeypatch):
     blocks, block = 40, 192
-    score = make_score(n, blocks, block, seed=n)
+    score = make_score(n, blocks, block, seed=int(os.environ.get("OSCEN_STRESS_SEED", n)))  # (soak runs: other scores)
     freqs = oscen_amd.midi_note_to_freq(np.random.default_rng(3).integers(36, 97, n)).astype(np.float32)
     probe = np.unique(np.linspace(0, n - 1, 24).astype(np.uint32))
 
