@@ -3810,7 +3810,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (depth > 1) slots += (size_t)depth;
             }
             const bool wide = K == 2 && slots * 16 * 64 * 4 <= 36 * 1024 && getenv("OGC_XCH16");
-            body << "    constexpr uint32_t XCH = " << (wide ? 16 : 8) << "; // frames per hand-off between the waves\n";
+            int xch = wide ? 16 : 8;
+            // OGC_XCH=4|16: experiment for the next round -- with the sticky chunk loops a hand-off costs ~9 VALU + ~17 SALU
+            // and a barrier instead of ~45 + ~40, so the trade between hand-off overhead (longer chunks) and lock-step wait /
+            // LDS footprint (shorter ones) has moved since the measurements above.  OG_BUS_CHUNK (16) must stay a multiple.
+            if (const char* ex = getenv("OGC_XCH")) {
+                const int want = atoi(ex);
+                if ((want == 4 || want == 8 || want == 16) && slots * (size_t)want * 64 * 4 <= 60 * 1024) xch = want;
+            }
+            body << "    constexpr uint32_t XCH = " << xch << "; // frames per hand-off between the waves\n";
         }
         for (size_t k = 0; k < cg.xvals.size(); ++k) {
             const auto& xv = cg.xvals[k];

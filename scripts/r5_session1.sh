@@ -36,5 +36,7 @@ else
   echo "(build it first: python scripts/build_variant.py s1 OGC_STICKY1=1)"
 fi
 echo "== (4) cut and priority sweep of the four-wave kernel now that waves 0-2 are lighter (build the variants first: scripts/build_variant.py c<tag> OGC_CUTS=...)"
-TAGS=$(ls oscen_amd/_build/liboscen_gpu_c*.so oscen_amd/_build/liboscen_gpu_p*.so 2>/dev/null | sed 's/.*liboscen_gpu_//; s/\.so//' | tr '\n' ' ')
+# (and the hand-off length: scripts/build_variant.py x4 OGC_XCH=4; scripts/build_variant.py x16 OGC_XCH=16 -- with the sticky
+#  loops the static VALU per frame is the same at 4 / 8 / 16 frames per hand-off: 23.3-24.8 / 22.6-24.4 / 22.3-24.2)
+TAGS=$(ls oscen_amd/_build/liboscen_gpu_c*.so oscen_amd/_build/liboscen_gpu_p*.so oscen_amd/_build/liboscen_gpu_x*.so 2>/dev/null | sed 's/.*liboscen_gpu_//; s/\.so//' | tr '\n' ' ')
 [ -n "$TAGS" ] && bash scripts/ab_bench.sh "base $TAGS" 2 --no-realtime --steps 20 --warmup 5
