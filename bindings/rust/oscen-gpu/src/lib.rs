@@ -223,6 +223,10 @@ impl<const IN: usize> GpuGraph<IN> {
     /// `graph.<node>.<field>` of every voice in `first_voice .. first_voice + n` (the generated struct's node fields are
     /// public in the reference; here a node's persistent fields are planes of the state image): "node.field",
     /// "array[i].field", "nested.node.field"
+    /// `og_group_voices`: after the score has been scheduled and before the first block, order the voice SLOTS so that voices
+    /// whose notes end together share waves (policy 1; 0 = identity).  Voice numbers -- the `voices[i]` of the generated
+    /// struct -- do not change anywhere on this surface.
+    pub fn group_voices(&mut self, policy: u32) -> Result<(), GpuError> { ck(unsafe { sys::og_group_voices(self.e, policy) }).map(|_| ()) }
     pub fn read_state_field(&mut self, path: &str, first_voice: u32, n: u32) -> Result<Vec<f32>, GpuError> {
         let c_path = CString::new(path).unwrap();
         let mut out = vec![0.0f32; n as usize];
@@ -272,6 +276,7 @@ impl GpuCluster {
     pub fn num_devices(&self) -> u32 { unsafe { sys::og_cluster_num_devices(self.c) } }
     /// RCCL reduces issued so far (0 on a one-device cluster: the shards are added on the device)
     pub fn rccl_reduces(&self) -> u64 { unsafe { sys::og_cluster_rccl_reduces(self.c) } }
+    pub fn group_voices(&mut self, policy: u32) -> Result<(), GpuError> { ck(unsafe { sys::og_cluster_group_voices(self.c, policy) }).map(|_| ()) }
     pub fn input(&self, name: &str) -> Result<InputId, GpuError> {
         let n = CString::new(name).map_err(|_| GpuError(-1, "input name holds a NUL byte".into()))?;
         Ok(InputId(ck(unsafe { sys::og_cluster_input_index(self.c, n.as_ptr()) })? as u32))
