@@ -4034,12 +4034,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 }
             };
             // the two straight-line variants only (the caller has established that no countdown ends in the chunk)
+            const int rel_prio = getenv("OGC_RELPRIO") ? atoi(getenv("OGC_RELPRIO")) : -1;
             auto fast_variants = [&](bool st_flag, const std::string& ind0) {
                 const std::string no_rel = "__all((int)(" + rs_sum(st) + " == 0.0f))";
                 body << ind0 << "if (" << no_rel << ") { // no lane is in Release\n";
                 quiet("false", force && force[0] == 'b' ? "true" : "false", st_flag, ind0 + "    ", no_rel);
                 body << ind0 << "} else {\n";
+                // OGC_RELPRIO=n (experiment for grouped banks, og_group_voices: the waves that release are then few and
+                // whole, and their workgroups are the ones a launch waits for; measured WITHOUT grouping in round 4: loses)
+                if (rel_prio >= 0) body << ind0 << "    __builtin_amdgcn_s_setprio(" << rel_prio << ");\n";
                 quiet("false", "true", st_flag, ind0 + "    ", "!" + no_rel);
+                if (rel_prio >= 0) body << ind0 << "    __builtin_amdgcn_s_setprio(" << base_prio << ");\n";
                 body << ind0 << "}\n";
             };
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"

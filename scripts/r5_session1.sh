@@ -24,6 +24,13 @@ python bench.py --no-cpu-baseline --no-realtime --voices-per-gpu 131072 2>/dev/n
 python bench.py --no-cpu-baseline --no-realtime --voices-per-gpu 131072 --group-voices 2>/dev/null | one "131072   grouped"
 python bench.py --no-cpu-baseline --no-realtime --voices-per-gpu 1048576 2>/dev/null | one "1048576  plain  "
 python bench.py --no-cpu-baseline --no-realtime --voices-per-gpu 1048576 --group-voices 2>/dev/null | one "1048576  grouped"
+echo "== (2b) grouped bank + release-variant priority (build first: scripts/build_variant.py rp3 OGC_RELPRIO=3)"
+if [ -f oscen_amd/_build/liboscen_gpu_rp3.so ]; then
+  for r in 1 2 3; do
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --group-voices 2>/dev/null | one "driver grouped         "
+    ( set -a; . oscen_amd/_build/liboscen_gpu_rp3.env; set +a; OSCEN_GPU_LIB=$ROOT/oscen_amd/_build/liboscen_gpu_rp3.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --group-voices 2>/dev/null | one "driver grouped relprio3" )
+  done
+fi
 echo "== (3) sticky chunks in the ordinary kernel (OGC_STICKY1): 262 144 / 1 M voices, e-piano, saturator"
 if [ -f oscen_amd/_build/liboscen_gpu_s1.so ]; then
   bash scripts/ab_bench.sh "base s1" 3 --no-realtime --voices-per-gpu 262144
