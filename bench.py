@@ -736,7 +736,7 @@ def main():
     ap.add_argument("--midi-live", type=int, default=0, metavar="N",
                     help="live path: N MIDI messages per block through og_midi_send_batch; the block is enqueued with "
                          "og_midi_process_block_async (the host parses block k+1 while block k renders)")
-    ap.add_argument("--group-voices", action="store_true",
+    ap.add_argument("--group-voices", type=int, nargs="?", const=1, default=0, metavar="POLICY",
                     help="og_group_voices(1) after the score is scheduled: voice slots ordered by first note-off (same voices, same "
                          "samples; the bus differs by the association of the sum).  Built and verified on the host simulator late "
                          "in round 4, not yet measured on the GPU: off by default")
@@ -828,7 +828,7 @@ def main():
             plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
         oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
         if args.group_voices:  # (og_group_voices: voices whose notes end together share waves; off by default in round 4)
-            eng.group_voices(1)
+            eng.group_voices(args.group_voices)
         ev_f = plans["events"][1]
         if "gate" in eng.input_names:
             inside = ev_f < total_frames
@@ -997,7 +997,7 @@ def main():
                 "events_in_timed_region": n_events_timed // R,
                 "note_plan_span_frames": span if span else 48000,
                 "blocks_per_launch_limit": args.bus_batch if args.bus_batch else "engine's choice (8..32 by bank size)",
-                "voice_slots": "grouped by first note-off (og_group_voices)" if (args.group_voices and midi is None) else "in voice order",
+                "voice_slots": ("grouped by first note-off (og_group_voices policy %d)" % args.group_voices) if (args.group_voices and midi is None) else "in voice order",
                 "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
                                ("og_midi_process_block, blocking" if args.midi_blocking else "og_midi_process_block_async"))
                               if midi is not None

@@ -383,8 +383,9 @@ int og_reserve_events(og_engine* e, uint64_t n_events);
 /* Voice grouping for resident scores (no counterpart in the reference, whose `voices[i]` are one array in one loop:
  * fm-synth/src/lib.rs:22-131).  A wave renders 64 consecutive voice SLOTS and takes, chunk by chunk, the cheapest body all
  * of its lanes allow; policy 1 re-orders the slots so that voices whose notes end at about the same time share waves (by
- * the frame of the voice's first scheduled note-off -- an event with a value <= 0 --, then by its first event), policy 0
- * restores the identity.  Voice NUMBERS do not change: every entry point keeps taking and handing out the caller's
+ * the frame of the voice's first scheduled note-off -- an event with a value <= 0 --, then by its first event), policy 2
+ * additionally deals those groups of 64 slots out so that the workgroups a CU is handed carry about the same number of
+ * events (banks of >= 32 768 voices; experimental), policy 0 restores the identity.  Voice NUMBERS do not change: every entry point keeps taking and handing out the caller's
  * numbers (events, per-voice values, taps, state fields, event outputs, MIDI voices); per-voice samples are bit for bit
  * those of the ungrouped bank, the bus differs by the association of the sum.  Call after og_init and after scheduling
  * the score, before the first block and before og_set_voice_taps (OG_E_STATE otherwise); og_init restores the identity;

@@ -2280,7 +2280,7 @@ int og_reserve_events(og_engine* e, uint64_t n_events)
 int og_group_voices(og_engine* e, uint32_t policy)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");
-    if (policy > 1u) return set_err(OG_E_INVALID, "og_group_voices: policy 0 (identity) or 1 (by first note-off)");
+    if (policy > 2u) return set_err(OG_E_INVALID, "og_group_voices: policy 0 (identity), 1 (by first note-off) or 2 (1 + waves dealt out by weight)");
     if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before og_group_voices");
     if (e->frame_now != 0 || !e->queue.empty() || !e->h_events.empty() || e->n_block_local != 0)
         return set_err(OG_E_STATE, "og_group_voices: only before the first block (and before block-local pushes)");
@@ -2305,7 +2305,44 @@ int og_group_voices(og_engine* e, uint32_t policy)
                 if (first_off[a] != first_off[b]) return first_off[a] < first_off[b];
                 return first_any[a] < first_any[b];
             });
-            for (uint32_t r = 0; r < V; ++r) new_phys[order[r]] = r;
+            if (policy == 2u && V >= 2u * 256u * OG_WAVE) {
+                // Policy 2 (experiment, not measured): the same waves, DEALT OUT.  With every workgroup of a launch resident
+                // at once (65 536 voices = 1 024 workgroups = 4 per CU) a launch ends with the busiest CU; policy 1 leaves
+                // the waves that hold the score's events next to each other in dispatch order.  Here the groups of 64 slots
+                // are ranked by the number of events they hold and placed boustrophedon over rows of 256 groups -- row 0
+                // left to right, row 1 right to left, ... -- so that groups i, i + 256, i + 512, ... (which share a CU if
+                // workgroups are handed to the 256 CUs round robin: an assumption) add up to about the same weight.
+                const uint32_t W = (V + OG_WAVE - 1) / OG_WAVE, ROW = 256u;
+                std::vector<uint32_t> weight(W, 0u), rank(W);
+                std::vector<uint32_t> slot_of(V);
+                for (uint32_t r = 0; r < V; ++r) slot_of[order[r]] = r;
+                for (const HostEvent& h : e->pending) weight[slot_of[e->logical(h.voice)] / OG_WAVE] += 1u;
+                for (uint32_t w = 0; w < W; ++w) rank[w] = w;
+                std::stable_sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+                std::vector<uint32_t> place(W); // place[k] = position of the k-th heaviest group
+                for (uint32_t k = 0; k < W; ++k) {
+                    const uint32_t row = k / ROW, col = k % ROW;
+                    const uint32_t row_len = std::min(ROW, W - row * ROW);
+                    place[k] = row * ROW + ((row & 1u) ? (row_len - 1u - std::min(col, row_len - 1u)) : col);
+                }
+                std::vector<uint32_t> group_pos(W);
+                for (uint32_t k = 0; k < W; ++k) group_pos[rank[k]] = place[k];
+                // (a last, partial group stays last: it is the lightest or is forced there)
+                const bool partial = (V % OG_WAVE) != 0u;
+                if (partial && group_pos[W - 1] != W - 1) {
+                    for (uint32_t w = 0; w < W; ++w)
+                        if (group_pos[w] == W - 1) {
+                            group_pos[w] = group_pos[W - 1];
+                            break;
+                        }
+                    group_pos[W - 1] = W - 1;
+                }
+                std::vector<uint32_t> dealt(V);
+                for (uint32_t r = 0; r < V; ++r) dealt[r] = group_pos[r / OG_WAVE] * OG_WAVE + r % OG_WAVE;
+                for (uint32_t r = 0; r < V; ++r) new_phys[order[r]] = dealt[r];
+            } else {
+                for (uint32_t r = 0; r < V; ++r) new_phys[order[r]] = r;
+            }
         }
         // the per-voice value inputs move with their voices
         std::vector<float> plane(V), moved(V);

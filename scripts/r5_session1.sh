@@ -17,6 +17,7 @@ echo "== (2) og_group_voices: driver's command, default run, 131 072 voices (int
 for r in 1 2 3; do
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime 2>/dev/null | one "driver   plain  "
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --group-voices 2>/dev/null | one "driver   grouped"
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --group-voices 2 2>/dev/null | one "driver   policy2"
   python bench.py --no-cpu-baseline --no-realtime 2>/dev/null | one "default  plain  "
   python bench.py --no-cpu-baseline --no-realtime --group-voices 2>/dev/null | one "default  grouped"
 done

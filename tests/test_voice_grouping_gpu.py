@@ -69,6 +69,33 @@ def test_grouped_bank_gives_the_same_voices_and_bus_as_the_ungrouped_bank():
         assert np.array_equal(a[40:90], grouped.read_state_field(path, first=40, n=50)), path
 
 
+def test_policy_two_deals_the_waves_out_and_changes_no_voice():
+    """policy 2 = policy 1 + the groups of 64 slots placed so that groups i, i + 256, ... carry about the same number of
+    events (banks of >= 32 768 voices); still a permutation, still the same voices"""
+    n, block, blocks = 33000, 128, 2
+    total = block * blocks
+    plans = oscen_amd.note_plans(n, span=total, fold="slice")
+    engs = []
+    for policy in (0, 1, 2):
+        e = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+        oscen_amd.schedule_note_plans(e, plans, total_frames=total)
+        e.group_voices(policy)
+        engs.append(e)
+    probe = np.unique(np.linspace(0, n - 1, 200).astype(np.uint32))
+    slots = [np.array([e.voice_slot(int(v)) for v in range(0, n, 7)]) for e in engs]
+    assert np.array_equal(slots[0], np.arange(0, n, 7)) and not np.array_equal(slots[1], slots[2])
+    all2 = np.array([engs[2].voice_slot(v) for v in range(n)])
+    assert np.array_equal(np.sort(all2), np.arange(n))
+    for e in engs:
+        e.set_voice_taps(probe)
+    for _ in range(blocks):
+        buses = [e.process_block(block) for e in engs]
+        taps = [e.read_voice_taps(block) for e in engs]
+        assert np.array_equal(taps[0], taps[1]) and np.array_equal(taps[0], taps[2])
+        scale = max(1.0, float(np.abs(buses[0]).max()))
+        assert np.max(np.abs(buses[0] - buses[1])) <= 1e-4 * scale and np.max(np.abs(buses[0] - buses[2])) <= 1e-4 * scale
+
+
 def test_grouped_bank_against_the_oracle():
     from tests import oracle_lib as ol
     from tests.test_fullsize_gpu import oracle_taps
