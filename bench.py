@@ -314,6 +314,8 @@ def _rt_bank(graph, V, block, n_blocks, paced_blocks, midi_per_block, device, de
         per_voice = 3.0 * total_frames / 48000.0
         eng.reserve_events(int(midi_per_block * (warm + n_blocks + paced_blocks) * per_voice) + (1 << 20))
         n_resident = oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+        if os.environ.get("OSCEN_BENCH_GROUP_VOICES"):  # (--group-voices reaches the real-time child through the environment)
+            eng.group_voices(int(os.environ["OSCEN_BENCH_GROUP_VOICES"]))
         plans["events"] = None
     else:
         eng.set_voice_values("frequency", plans["frequency"])
@@ -750,6 +752,8 @@ def main():
                          "ranks on one GPU ('Duplicate GPU detected'), so this is how a one-GPU box exercises it")
     ap.add_argument("--realtime-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.group_voices:
+        os.environ["OSCEN_BENCH_GROUP_VOICES"] = str(args.group_voices)
 
     if args.realtime_child:
         # the real-time record in a process of its own: numpy + the engine, nothing else -- like a host application.  (In
