@@ -43,6 +43,8 @@ if [ -f oscen_amd/_build/liboscen_gpu_s1.so ]; then
 else
   echo "(build it first: python scripts/build_variant.py s1 OGC_STICKY1=1)"
 fi
+echo "== (3b) the hardware sine: accuracy and cost (DESIGN section 8, item 5)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -I oscen_amd/csrc -o /tmp/vsin scripts/ubench/vsin.hip 2>/dev/null && /tmp/vsin
 echo "== (4) cut and priority sweep of the four-wave kernel now that waves 0-2 are lighter (build the variants first: scripts/build_variant.py c<tag> OGC_CUTS=...)"
 # (and the hand-off length: scripts/build_variant.py x4 OGC_XCH=4; scripts/build_variant.py x16 OGC_XCH=16 -- with the sticky
 #  loops the static VALU per frame is the same at 4 / 8 / 16 frames per hand-off: 23.3-24.8 / 22.6-24.4 / 22.3-24.2)
