@@ -190,6 +190,7 @@ struct hipDeviceProp_t {
     int maxThreadsPerBlock;
 };
 
+extern "C" { // (C linkage like the real runtime: a test reaches hipMalloc & co. through the loaded library's handle)
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
@@ -198,18 +199,8 @@ hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipMalloc(void** p, size_t n);
-template <class T>
-static inline hipError_t hipMalloc(T** p, size_t n)
-{
-    return hipMalloc((void**)p, n);
-}
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
-template <class T>
-static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0)
-{
-    return hipHostMalloc((void**)p, n, flags);
-}
 hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind k, hipStream_t s);
@@ -233,6 +224,18 @@ hipError_t hipModuleUnload(hipModule_t m);
 hipError_t hipModuleGetFunction(hipFunction_t* f, hipModule_t m, const char* name);
 hipError_t hipModuleLaunchKernel(hipFunction_t f, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned shmem,
                                  hipStream_t s, void** params, void** extra);
+
+} // extern "C"
+template <class T>
+static inline hipError_t hipMalloc(T** p, size_t n)
+{
+    return hipMalloc((void**)p, n);
+}
+template <class T>
+static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0)
+{
+    return hipHostMalloc((void**)p, n, flags);
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     simt::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
