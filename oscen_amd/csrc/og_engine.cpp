@@ -1748,6 +1748,8 @@ int og_set_voice_values(og_engine* e, uint32_t input, uint32_t first, uint32_t c
         const size_t w = (size_t)e->cg->inputs[input].state_word;
         if (e->phys_of.empty()) {
             e->bounce.h2d(e->d_state + w * e->V + first, v, (size_t)count * 4, e->stream);
+        } else if (count <= 64u) { // grouped voices, a few values: one word each
+            for (uint32_t i = 0; i < count; ++i) e->bounce.h2d(e->d_state + w * e->V + e->phys_of[first + i], v + i, 4, e->stream);
         } else { // grouped voices: the range is scattered over the plane
             std::vector<float> plane(e->V);
             if (count < e->V) {

@@ -50,9 +50,10 @@ def test_grouped_bank_gives_the_same_voices_and_bus_as_the_ungrouped_bank():
             for v in rng.choice(n, 40, replace=False):
                 for e in (plain, grouped):
                     e.push_voice_event("gate", int(v), int(v) % block, 0.7)
-            f_new = (220.0 + 3.0 * np.arange(50)).astype(np.float32)
+            f_new = (220.0 + 3.0 * np.arange(150)).astype(np.float32)
             for e in (plain, grouped):
-                e.set_voice_values("frequency", f_new, first=100)
+                e.set_voice_values("frequency", f_new, first=100)       # a range: scattered over the slots
+                e.set_voice_values("frequency", f_new[:3] * 2.0, first=5)  # a few values: word by word
         bus_a = plain.process_block(block)
         bus_b = grouped.process_block(block)
         ta, tb = plain.read_voice_taps(block), grouped.read_voice_taps(block)
