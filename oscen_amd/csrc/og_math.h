@@ -101,10 +101,57 @@ OG_HD float og_sinf(float x)
 #else
     (void)PI_C; // |k| * 3.4e-15: below half an ulp of r for |x| < 1e5
 #endif
-    // (-1)^k: flip the sign of r (odd polynomial) when k is odd
+    // (-1)^k: flip the sign of r (odd polynomial) when k is odd.  Adding (k & 1) << 31 to the bit pattern flips exactly
+    // the sign bit (the carry leaves the word), and a shift-and-add is ONE instruction (v_lshl_add_u32).
     b.f = r;
-    b.u ^= t.u << 31;
+    b.u += t.u << 31;
     return og_sin_reduced(b.f);
+}
+
+// sin(2 pi t) for an argument in TURNS (what an FM operator's phase + modulation is: fm_operator.rs:62-66 forms
+// `(phase + mod) * TAU` and takes the sine).  Reduction in half-turns: k = rint(2t) by the magic-number trick, r = 2t - k
+// EXACTLY (one fma: 2t is exact, and so is the difference of two neighbours), sign = parity of k, then an odd minimax
+// polynomial of sin(pi r) on [-1/2, 1/2] (fit of (sin(pi r) - pi r) / r^3 in r^2, max error 4.9e-9).  Ten instructions
+// against the thirteen of `og_sinf(t * TAU)`.  Against sin(2 pi t) the error is <= 1.5e-7 for ANY |t| < 2^21; against the
+// reference's f32 `(t * TAU).sin()` the two differ by the rounding of the reference's own product, <= |t| * 3.8e-7
+// (1.2e-7 * 2 pi per turn of argument: 4.2e-7 / 7.4e-7 / 1.5e-6 observed at modulation depths 0 / 1 / 4 turns) -- part
+// of the tolerance budget (OG_SIN_TURNS).
+OG_HD float og_sin_turns_poly(float t)
+{
+    const float MAGIC = 12582912.0f;
+    const float C0 = 0x1.921fb6p+1f;    //  pi
+    const float C1 = -0x1.4abbb6p+2f;   // -5.16770697
+    const float C2 = 0x1.4666b6p+1f;    //  2.55000949
+    const float C3 = -0x1.321cp-1f;     // -0.597869873
+    const float C4 = 0x1.3abd92p-4f;    //  0.0768409446
+    union { float f; uint32_t u; } m, b;
+    m.f = fmaf(t, 2.0f, MAGIC);
+    const float k = m.f - MAGIC;
+    b.f = fmaf(t, 2.0f, -k);
+    b.u += m.u << 31;
+    const float r = b.f, u = r * r;
+    float q = fmaf(u, C4, C3);
+    q = fmaf(u, q, C2);
+    q = fmaf(u, q, C1);
+    q = fmaf(u, q, C0);
+    return r * q;
+}
+
+// OG_SIN_TURNS: how an FM operator takes its sine.  0 = og_sinf((phase + mod) * TAU) -- follows the reference's f32
+// product; 1 = og_sin_turns_poly(phase + mod); 2 = the hardware's v_sin_f32 (argument in turns, valid for |t| <= 256),
+// host builds (tests/test_og_math.py, the host simulator) take the polynomial.
+#ifndef OG_SIN_TURNS
+#define OG_SIN_TURNS 0
+#endif
+OG_HD float og_sin_turns(float t)
+{
+#if OG_SIN_TURNS == 2 && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sinf(t);
+#elif OG_SIN_TURNS >= 1
+    return og_sin_turns_poly(t);
+#else
+    return og_sinf(t * 6.28318548202514648f);
+#endif
 }
 
 // tan(x) for x in [0, pi/2): used by the TPT coefficient update

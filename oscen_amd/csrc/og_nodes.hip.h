@@ -214,8 +214,7 @@ OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float
                               float envelope, float level)
 {
     const float total_phase_mod = OG_FMA(prev_output, feedback, phase_mod); // phase_mod + prev_output * feedback
-    const float phase_rad = (phase + total_phase_mod) * F32_TAU;
-    const float output = og_sinf(phase_rad) * envelope * level;
+    const float output = og_sin_turns(phase + total_phase_mod) * envelope * level; // ((phase + mod) * TAU).sin(): og_math.h, OG_SIN_TURNS
     prev_output = output;
     const float p = phase + inc; // the phase accumulator keeps the reference's exact operations
     phase = p - truncf(p); // f32::fract
@@ -227,8 +226,7 @@ OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float
 OG_DEV float fm_operator_tick_nofb(float& phase, float& prev_output, float inc, float phase_mod, float envelope,
                                    float level)
 {
-    const float phase_rad = (phase + phase_mod) * F32_TAU;
-    const float output = og_sinf(phase_rad) * envelope * level;
+    const float output = og_sin_turns(phase + phase_mod) * envelope * level;
     prev_output = output;
     const float p = phase + inc;
     phase = p - truncf(p);

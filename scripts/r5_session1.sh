@@ -12,7 +12,7 @@ for l in sys.stdin:
     print('$1', 'value %.4g' % d['value'], 'kernel_ms %.4f' % d['roofline']['kernel_ms_avg'], d['roofline'].get('kernel_variant'))
 "; }
 echo "== (1) the new GPU tests of round 4's last commits: voice grouping on the device"
-timeout 300 python -m pytest tests/test_voice_grouping_gpu.py -m gpu -q -x 2>&1 | tail -3
+timeout 300 python -m pytest tests/test_voice_grouping_gpu.py tests/test_hard_regime_gpu.py -m gpu -q -x 2>&1 | tail -3
 echo "== (2) og_group_voices: driver's command, default run, 131 072 voices (interleaved)"
 for r in 1 2 3; do
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-realtime 2>/dev/null | one "driver   plain  "
@@ -50,3 +50,17 @@ echo "== (4) cut and priority sweep of the four-wave kernel now that waves 0-2 a
 #  loops the static VALU per frame is the same at 4 / 8 / 16 frames per hand-off: 23.3-24.8 / 22.6-24.4 / 22.3-24.2)
 TAGS=$(ls oscen_amd/_build/liboscen_gpu_c*.so oscen_amd/_build/liboscen_gpu_p*.so oscen_amd/_build/liboscen_gpu_x*.so 2>/dev/null | sed 's/.*liboscen_gpu_//; s/\.so//' | tr '\n' ' ')
 [ -n "$TAGS" ] && bash scripts/ab_bench.sh "base $TAGS" 2 --no-realtime --steps 20 --warmup 5
+echo "== (5) the FM sine in turns: st1 = half-turn polynomial (10 VALU), st2 = v_sin_f32 (build: scripts/build_variant.py st1 -- -DOG_SIN_TURNS=1)"
+if [ -f oscen_amd/_build/liboscen_gpu_st1.so ]; then
+  bash scripts/ab_bench.sh "base st1 st2" 3 --no-realtime --steps 20 --warmup 5
+  bash scripts/ab_bench.sh "base st1 st2" 1 --no-realtime
+  bash scripts/ab_bench.sh "base st1 st2 s1 st1s1 st2s1" 2 --no-realtime --voices-per-gpu 262144
+  for t in base st1 st2; do
+    echo "-- parity + observed errors: $t"
+    rm -f $OUT/observed_$t.jsonl
+    if [ "$t" = "base" ]; then unset OSCEN_GPU_LIB; else export OSCEN_GPU_LIB=$ROOT/oscen_amd/_build/liboscen_gpu_$t.so; fi
+    OSCEN_OBSERVED=$OUT/observed_$t.jsonl timeout 500 python -m pytest tests/test_hard_regime_gpu.py tests/test_parity_gpu.py tests/test_fullsize_gpu.py tests/test_midi_gpu.py -m gpu -q -k "not fm1048576 and not is_jit and not poly_wrapper and not largest_real_time" 2>&1 | tail -4
+    python scripts/observed_errors.py $OUT/observed_$t.jsonl | head -8
+    unset OSCEN_GPU_LIB
+  done
+fi

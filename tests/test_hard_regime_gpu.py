@@ -1,0 +1,117 @@
+"""One second of the FM voice in the regime where errors grow: operator self-feedback with a loop gain just under one,
+the modulation routed both ways, an envelope-modulated filter cutoff (per-sample tan) and the ramped cutoff of SURVEY
+8(d) config 2's variant -- against the oracle, with the error written out over time.
+
+Reference: examples/fm-synth/src/nodes/fm_operator.rs:58-76 (phase feedback: `prev_output * feedback` re-enters the
+phase), examples/fm-synth/src/fm_voice.rs:10-48 (parameters), oscen-lib/src/filters/tpt/mod.rs:85-101 (the coefficient
+branch a moving cutoff takes every sample).  A second test pins the one documented deviation of the clamps
+(og_nodes.hip.h `clampf` = v_med3_f32: a NaN input clamps to `lo`, Rust's f32::clamp propagates it)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import observed
+from tests import oracle_lib as ol
+from tests.test_parity_gpu import Pair, rel_err, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def hard_regime_pair(n):
+    p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
+    # SURVEY 8(d), config 2's variant.  Loop gain of an operator's self-feedback = 2 pi * feedback * level * envelope *
+    # velocity: 2 pi * 0.3 * 0.5 = 0.94 at full envelope and velocity -- just under 1 (beyond 1 phase-feedback FM is
+    # chaotic and two implementations differing by an ulp part ways without bound: not a parity regime).
+    p.set_value_immediate("op3_feedback", 0.3)
+    p.set_value_immediate("op2_feedback", 0.2)
+    p.set_value_immediate("route", 0.5)
+    p.set_value_immediate("filter_env_amount", 2000.0)
+    return p
+
+
+def test_fm_voice_variant_one_second():
+    n, total = 64, 48000
+    p = hard_regime_pair(n)
+    plans = oscen_amd.note_plans(n)  # the synthetic score of SURVEY 8(d): on in block 0, off in [12000, 36000], retrigger after 36000
+    p.set_freqs(plans["frequency"])
+    ev_v, ev_f, ev_x = plans["events"]
+    order = np.argsort(ev_f, kind="stable")
+    ev_v, ev_f, ev_x = ev_v[order], ev_f[order], ev_x[order]
+    # block sizes: a boundary on frame 4800, where the cutoff ramp starts (setters act at block boundaries)
+    blocks = [256] * 18 + [192]
+    while sum(blocks) + 256 <= total:
+        blocks.append(256)
+    if sum(blocks) < total:
+        blocks.append(total - sum(blocks))
+    assert sum(blocks) == total
+    f0, k, curve, worst, peak = 0, 0, [], 0.0, 0.0
+    for frames in blocks:
+        if f0 == 4800:
+            p.set_value("filter_cutoff", 6000.0)  # `[ramp: 2205]`: 2000 -> 6000 over 2205 frames
+        while k < len(ev_f) and ev_f[k] < f0 + frames:
+            p.gate(int(ev_v[k]), int(ev_f[k]) - f0, float(ev_x[k]))
+            k += 1
+        bus, taps, ref_bus, ref_taps, ref64 = p.block(frames)
+        e = rel_err(taps, ref_taps)
+        assert np.isfinite(taps).all()
+        curve.append((f0, e))
+        worst = max(worst, e)
+        peak = max(peak, float(np.abs(ref_taps).max()))
+        scale = max(1.0, float(np.max(np.sum(np.abs(ref_taps), axis=0))))
+        assert np.max(np.abs(bus[:, 0] - ref64)) <= TOL * scale
+        f0 += frames
+    assert k == len(ev_f) and peak > 0.3  # every event was delivered; the voices sound
+    observed.note(worst)
+    path = os.environ.get("OSCEN_OBSERVED")
+    if path:  # the error-vs-time curve for profiles/r05_observed_errors.md (max over 64 voices per block)
+        with open(path + ".hard_regime_curve.json", "w") as f:
+            json.dump({"voices": n, "frames": total, "curve": curve, "worst": worst, "ref_peak": peak}, f)
+    assert worst <= TOL, (worst, max(curve, key=lambda c: c[1]))
+    assert abs(p.eng.get_value("filter_cutoff") - 6000.0) < 1e-3
+
+
+def test_nan_parameter_takes_the_lower_clamp_bound_where_rust_would_keep_the_nan():
+    """og::clampf is v_med3_f32 (one instruction instead of compare + select twice).  For every non-NaN input it is
+    f32::clamp; for a NaN input the median-of-three returns `lo`, where Rust's `clamp` returns the NaN (core::f32
+    clamp: `if self < min { min } else if self > max { max } else { self }`).  What that means on the path in scope:
+    TptFilter::apply_parameter_updates (filters/tpt/mod.rs:85-101) clamps cutoff and q and updates the coefficients
+    only `if (cutoff - self.current_cutoff).abs() > EPSILON || ...` -- with a NaN cutoff the comparison is false and the
+    reference KEEPS ITS PREVIOUS COEFFICIENTS (the NaN never reaches tan); here the NaN clamps to 20 Hz (resp. q = 0.1),
+    which differs from the current value, and the filter moves there.  Both stay finite; they differ.  Documented in
+    og_nodes.hip.h and DESIGN.md section 5; this pins it."""
+    n, frames = 64, 256
+    freqs = oscen_amd.midi_note_to_freq(np.arange(40, 40 + n)).astype(np.float32)
+
+    def gpu(param, value):
+        eng = oscen_amd.Engine("fm_voice", n, sample_rate=48000.0)
+        eng.set_voice_values("frequency", freqs)
+        eng.set_voice_taps(list(range(n)))
+        if param:
+            eng.set_value_immediate(param, value)
+        for v in range(n):
+            eng.push_voice_event("gate", v, v % 7, 0.8)
+        eng.process_block(frames)
+        return eng.read_voice_taps(frames).copy()
+
+    def cpu(param, value):
+        bank = ol.Bank(ol.BANK_FM, n, 48000.0)
+        for v in range(n):
+            bank.set_voice_frequency(v, float(freqs[v]))
+            bank.push_event(v, v % 7, ol.EV_GATE, 0.8)
+        if param:
+            bank.set_value_immediate(ol.FM_PARAMS.index(param), value)
+        return bank.process_block(frames, taps=list(range(n)))[1].copy()
+
+    plain_gpu, plain_cpu = gpu(None, 0.0), cpu(None, 0.0)
+    assert rel_err(plain_gpu, plain_cpu) <= TOL and np.abs(plain_cpu).max() > 0.0
+    for param, lo in (("filter_cutoff", 20.0), ("filter_resonance", 0.1)):
+        got = gpu(param, float("nan"))
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, gpu(param, lo)), param           # here: NaN -> the lower bound
+        assert not np.array_equal(got, plain_gpu), param
+        ref = cpu(param, float("nan"))
+        assert np.isfinite(ref).all()
+        assert np.array_equal(ref, plain_cpu), param                # the reference: the update is skipped
