@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def pmc_profile(voices, block, graph, kernel_hash, blocks_per_launch=None):
+def pmc_profile(voices, block, graph, kernel_hash, blocks_per_launch=None, variant=None):
     """The committed rocprofv3 PMC summary (profiles/*_summary.json, scripts/prof_summary.py) of THIS kernel:
     same graph, bank size, block and kernel hash.  FETCH_SIZE / WRITE_SIZE / SQ_* come from separate --pmc
     runs, so they cannot be measured in-process; a summary of another kernel build is never mixed in --
@@ -49,7 +49,7 @@ def pmc_profile(voices, block, graph, kernel_hash, blocks_per_launch=None):
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("voices") != voices or d.get("frames") != block or d.get("graph", "fm_voice") != graph:
+        if d.get("voices") != voices or d.get("frames") != block or d.get("graph", "fm_voice") != graph or d.get("variant") != variant:
             continue
         if d.get("kernel_hash") == kernel_hash and "hbm_traffic" in d:
             # several summaries of this kernel: the one whose command queued the same number of blocks per launch
@@ -491,7 +491,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed):
+def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed, variant=None):
     """The HBM roofline object of the contract for the voice kernel of `eng` (one shard of V voices)."""
     words = eng.state_words_per_voice
     lanes = eng.voices_per_wave * eng.lanes_per_voice
@@ -506,7 +506,7 @@ def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed):
     blocks_per_launch = n_blocks_timed / float(max(1, n_launch))
     bytes_per_launch = bytes_per_block * blocks_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    prof = pmc_profile(V, block, graph, eng.kernel_hash, blocks_per_launch)
+    prof = pmc_profile(V, block, graph, eng.kernel_hash, blocks_per_launch, variant)
     pmc_bytes, pmc_valu, pmc_src = prof["bytes"], prof["valu"], prof["source"]
     pmc_note = None
     if pmc_src and abs(prof["blocks_per_launch"] - blocks_per_launch) > 0.02 * blocks_per_launch:
@@ -567,6 +567,251 @@ def roofline_record(eng, V, block, graph, kern_ms, n_launch, n_blocks_timed):
             "source": pmc_src,
         },
     }
+
+
+# The other BASELINE.json configurations on one GPU (graph, bank size, frames rendered), measured by the
+# same timed_bank() as the headline after it, so that the driver's one command records every configuration.
+OTHER_CONFIGS = [
+    # (name, graph, voices, blocks per timed region, variant)
+    ("2-variant: fm-synth 65 536 voices, feedback .3/.2, route .5, env amount 2000, cutoff ramp", "fm_voice", 65536, 188, "survey2"),
+    ("4-shard: fm-synth 262 144 voices (config 4's per-GPU shard)", "fm_voice", 262144, 188, None),
+    ("3a: electric-piano 262 144 voices -> Tremolo, stereo", "epiano_voice", 262144, 94, None),
+    ("3b: osc+env+TptFilter 262 144 voices", "sub_voice", 262144, 94, None),
+    ("5: SatGraph_4x 131 072 voices (multirate)", "sat4x_voice", 131072, 94, None),
+]
+
+
+def config_records(args, local_rank):
+    """One compact record per entry of OTHER_CONFIGS (N = 1 only): value, ms per step, the kernel and its roofline figures."""
+    import copy
+
+    import numpy as np
+    import torch
+
+    out = []
+    a = copy.copy(args)
+    a.midi_live, a.midi_blocking, a.sparse_events, a.bus_batch = 0, False, False, 0
+    W, R = 8, 3
+    for name, graph, V, K, variant in OTHER_CONFIGS:
+        if args.test_scale > 1:
+            V, K, W, R = max(64, V // args.test_scale), (24 if variant else 4), 2, 2
+        try:
+            m = timed_bank(a, graph, V, K, W, R, 0, local_rank, 1, None, variant)
+            mix = m.bus[torch.from_numpy(m.timed_blocks).to(m.bus.device)].float().cpu().numpy()
+            assert np.isfinite(mix).all() and np.abs(mix).max() > 0.0, "bus is silent or non-finite"
+            elapsed, _ = region_stats(m.times, V, K, m.block)
+            rf = roofline_record(m.eng, V, m.block, graph, m.kern_ms, m.n_launch, m.n_blocks_timed, variant)
+            vi = rf.get("valu_issue") or {}
+            out.append({
+                "config": name, "graph": graph, "voices": V, "steps": K, "repeats": R, "variant": variant,
+                "value": V * K * m.block / elapsed, "ms_per_step": elapsed / K * 1e3,
+                "kernel": rf["kernel_variant"], "kernel_hash": rf["kernel_hash"], "kernel_ms_per_block": rf["kernel_ms_per_block"],
+                "blocks_per_launch": rf["blocks_per_launch"], "bytes_per_voice_sample": rf["bytes_per_voice_sample"],
+                "roofline_frac": rf["frac"], "valu_issue_frac": vi.get("frac"),
+                "valu_per_64_voices_per_frame": vi.get("valu_wave_inst_per_64_voices_per_frame"),
+                "dram_gbs": rf["dram_gbs"], "profile": rf["traffic_source"], "stale_profile": rf["stale_profile"],
+                "events_in_timed_region": m.n_events_timed // R,
+            })
+            m.eng.close()
+            del m
+            torch.cuda.empty_cache()
+        except Exception as e:  # (a side record never costs the headline line)
+            out.append({"config": name, "graph": graph, "voices": V, "error": str(e)[:200]})
+    return out
+
+
+SURVEY2 = {"op3_feedback": 0.3, "op2_feedback": 0.2, "route": 0.5, "filter_env_amount": 2000.0}
+
+
+def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, variant=None):
+    """The measurement proper: this rank's shard of a bank of V voices per GPU, W warm-up blocks, then R timed regions of K
+    blocks each (barrier + synchronize on both sides).  Used for the headline line and, at N = 1, once more for every other
+    BASELINE configuration (`configs`)."""
+    import types
+
+    import numpy as np
+    import torch
+
+    import oscen_amd
+    from oscen_amd import distributed as ogd
+
+    rccl_ranks = None
+    total_voices = V * world_size
+    lo, hi = ogd.shard_range(rank, world_size, total_voices)
+    block = args.block
+    # block sequence: W warm-up blocks (the last one runs after the barrier, see below), then R regions of K timed
+    # blocks, regions 1.. each preceded by ONE untimed block that plays the same role as that last warm-up block
+    n_blocks = W + R * K + (R - 1)
+    total_frames = n_blocks * block
+    span = 0 if args.sparse_events else min(total_frames, 48000)
+
+    eng = oscen_amd.Engine(graph, hi - lo, device=local_rank, sample_rate=48000.0)
+    # global voice ids keep their note streams; a run shorter than the 1 s score sees a slice of it at its real density
+    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="slice")
+    midi = None
+    ramp_blocks = {}
+    if variant == "survey2":
+        # SURVEY 8(d), config 2's VARIANT: operator feedback, the modulation routed both ways, an envelope-modulated cutoff
+        # (a per-sample tan: filters/tpt/mod.rs:85-101 is the branch the defaults never take) and the ramped filter_cutoff
+        # 2 000 -> 6 000 over 2 205 frames at frame 4 800 of each timed second (block 19 of a region; the next region
+        # ramps back, the same work)
+        for name, val in SURVEY2.items():
+            eng.set_value_immediate(name, val)
+        for r in range(R):
+            if K > 19:
+                ramp_blocks[W + r * (K + 1) + 19] = 6000.0 if r % 2 == 0 else 2000.0
+    timed_blocks = np.zeros(n_blocks, dtype=bool)
+    for r in range(R):
+        b0 = W + r * (K + 1)
+        timed_blocks[b0:b0 + K] = True
+    if args.midi_live:
+        eng.set_voice_values("frequency", plans["frequency"])
+        midi = oscen_amd.Midi(eng)
+        midi.set_queue_capacity(max(32, args.midi_live))
+        n_events_timed = args.midi_live * K * R
+    else:
+        if total_frames > 48000:  # a run longer than the 1 s score plays it again and again (same density throughout)
+            ev_v, ev_f0, ev_x = plans["events"]
+            reps = -(-total_frames // 48000)
+            plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
+        oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
+        if args.group_voices:  # (og_group_voices: voices whose notes end together share waves; off by default in round 4)
+            eng.group_voices(args.group_voices)
+        ev_f = plans["events"][1]
+        if "gate" in eng.input_names:
+            inside = ev_f < total_frames
+            n_events_timed = int(np.count_nonzero(timed_blocks[(ev_f[inside] // block).astype(np.int64)]))
+        else:
+            n_events_timed = 0
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    if args.bus_batch != 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
+        eng.set_bus_batching(args.bus_batch)
+    ch = eng.channels
+    bus = torch.zeros((n_blocks, block * ch), dtype=torch.float32, device="cuda")
+    base = bus.data_ptr()
+    host_bus = np.zeros((n_blocks, block * ch), dtype=np.float32)
+    rng = np.random.default_rng(0x05CE2026 + rank)
+    live = []
+    if midi is not None:  # messages built once: the timed loop pays for the engine's live path, not for numpy
+        live_notes = rng.integers(36, 97, size=(n_blocks, args.midi_live)).astype(np.uint8)
+        live_frames = np.sort(rng.integers(0, block, size=(n_blocks, args.midi_live)), axis=1).astype(np.uint32)
+        for i in range(n_blocks):  # even blocks play notes, odd blocks release the notes of the block before
+            live.append(midi.pack_messages(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0)))
+
+    def step(i):
+        if i in ramp_blocks:
+            eng.set_value("filter_cutoff", ramp_blocks[i])  # `[ramp: 2205]` (fm_voice.rs); launches what is queued first
+        if midi is None:
+            eng.process_block_async(block, base + i * block * ch * 4)
+        else:
+            midi.send_packed(live[i])
+            if args.midi_blocking:
+                host_bus[i] = midi.process_block(block).reshape(-1)
+            else:
+                midi.process_block_async(block, base + i * block * ch * 4)
+
+    def reduce_bus(t):
+        if args.backend == "gloo":  # CPU collective (plumbing check only)
+            h = t.cpu()
+            ogd.reduce_bus(h)
+            t.copy_(h)
+        else:
+            ogd.reduce_bus(t)
+
+    def barrier():
+        if args.backend == "gloo":
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local_rank])
+
+    # Warm-up: W - 1 blocks, the communicator set-up, the barrier -- and then the LAST warm-up block, so that the voice
+    # kernel is the most recent thing every CU ran when the clock starts.  Measured on MI355X: the first launch of the
+    # voice kernel after OTHER kernels (RCCL's, or any torch kernel) is ~35 % slower than in a steady stream of blocks
+    # (same instruction count, +57 % instruction-fetch wait: its code has to come back from HBM), and with one launch per
+    # 20-32 blocks that launch is the whole timed region -- a measurement artefact of the barrier, not of the path.
+    for i in range(max(0, W - 1)):
+        step(i)
+    eng.flush()
+    if dist is not None:  # communicator set-up (lazy in RCCL) must not land in the timed region
+        reduce_bus(bus[:max(1, W - 1)] if W > 1 else torch.zeros((1, block * ch), dtype=torch.float32, device="cuda"))
+        ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
+        dist.all_reduce(ones)  # every rank of the communicator took part
+        rccl_ranks = int(round(float(ones.item())))
+    times = []
+    reduce_events, reduce_host_ms = [], []
+    kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
+    for r in range(R):
+        first = W + r * (K + 1)        # first timed block of this region
+        torch.cuda.synchronize()
+        if dist is not None:
+            barrier()
+        torch.cuda.synchronize()
+        if first > 0 and (r > 0 or W > 0):  # the untimed block right in front of the region
+            step(first - 1)
+            eng.flush()
+            torch.cuda.synchronize()
+        eng.enable_kernel_timing(True)  # (per region: the untimed block in front of it is not part of the launch average)
+        t0 = time.perf_counter()
+        for i in range(first, first + K):
+            step(i)
+        eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
+        if dist is not None:
+            # ONE RCCL reduce of the [K, block] mix bus over xGMI, bracketed by events on the stream it runs on (the
+            # engine renders on torch's current stream), so that a scaling record explains its own efficiency
+            t_r0 = time.perf_counter()
+            ev_r0, ev_r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_r0.record(stream)
+            reduce_bus(bus[first:first + K])
+            ev_r1.record(stream)
+            reduce_host_ms.append((time.perf_counter() - t_r0) * 1e3)
+            reduce_events.append((ev_r0, ev_r1))
+        torch.cuda.synchronize()
+        if dist is not None:
+            barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times.append(elapsed)
+        ms, n = eng.kernel_time_ms()               # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
+        kern_total_ms += ms * n
+        n_launch += n
+        n_blocks_timed += eng.kernel_blocks_timed  # blocks those launches rendered (up to --bus-batch per launch)
+        eng.enable_kernel_timing(False)
+    kern_ms = kern_total_ms / max(1, n_launch)
+    multi_gpu = None
+    if dist is not None:
+        # per rank: the voice kernel's average launch and per-block time, and what the reduce cost on this rank's stream
+        # (device time between the two events: includes waiting for the slowest rank -- a reduce cannot finish before
+        # every contribution exists) and on its host thread
+        red_dev = [a.elapsed_time(b) for a, b in reduce_events] if args.backend != "gloo" else list(reduce_host_ms)
+        mine = torch.tensor([kern_ms, kern_ms * n_launch / max(1, n_blocks_timed), float(np.median(red_dev)) if red_dev else 0.0,
+                             float(np.median(reduce_host_ms)) if reduce_host_ms else 0.0], dtype=torch.float64,
+                            device="cpu" if args.backend == "gloo" else "cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(allr, mine)
+        rows = [[float(x) for x in t.cpu().tolist()] for t in allr]
+        multi_gpu = {
+            "rccl_ranks": rccl_ranks,
+            "backend": "RCCL" if args.backend == "nccl" else "gloo",
+            "per_rank_kernel_ms_avg": [r[0] for r in rows],
+            "per_rank_kernel_ms_per_block": [r[1] for r in rows],
+            "per_rank_reduce_ms": [r[2] for r in rows],
+            "per_rank_reduce_host_ms": [r[3] for r in rows],
+            "reduce_ms_max": max(r[2] for r in rows),
+            "reduce_bytes": int(K * block * ch * 4),
+            "reduce_share_of_region": max(r[2] for r in rows) / (float(np.median(times)) * 1e3) if times else None,
+            "note": "reduce = one [K x block x channels] f32 sum onto rank 0 per timed region; device time between events "
+                    "recorded around it on the rendering stream (median over the regions)",
+        }
+
+    return types.SimpleNamespace(eng=eng, times=times, kern_ms=kern_ms, n_launch=n_launch, n_blocks_timed=n_blocks_timed, multi_gpu=multi_gpu,
+                                 rccl_ranks=rccl_ranks, timed_blocks=timed_blocks, bus=bus, host_bus=host_bus, midi=midi,
+                                 n_events_timed=n_events_timed, span=span, total_voices=total_voices, block=block, ch=ch)
 
 
 def region_stats(times, total_voices, K, block):
@@ -713,18 +958,23 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--graph", default="fm_voice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default=None, choices=["survey2"],
+                    help="survey2 = SURVEY 8(d) config 2's variant of the fm-synth bank: op3_feedback .3, op2_feedback .2, route .5, "
+                         "filter_env_amount 2000 (per-sample tan) and the 2 205-frame filter_cutoff ramp at frame 4 800 of every timed second")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` array (the other BASELINE configurations, measured after the headline at N = 1)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the blocking-path real-time latency record")
-    ap.add_argument("--rt-blocks", type=int, default=2000, help="blocks per bank size of the real-time record")
-    ap.add_argument("--rt-paced-blocks", type=int, default=1500,
+    ap.add_argument("--rt-blocks", type=int, default=1000, help="blocks per bank size of the real-time record")
+    ap.add_argument("--rt-paced-blocks", type=int, default=750,
                     help="blocks of the paced run (one call per 5.33 ms block period) on the largest bank of the real-time record")
-    ap.add_argument("--rt-voices", default="65536,131072,1048576,4194304,8388608",
+    ap.add_argument("--rt-voices", default="65536,1048576,8388608",
                     help="bank sizes of the real-time record (comma separated)")
     ap.add_argument("--rt-midi", type=int, default=1000, help="live MIDI messages per block in the real-time record")
-    ap.add_argument("--rt-loaded-voices", default="1048576,4194304,6291456,8388608",
+    ap.add_argument("--rt-loaded-voices", default="4194304,6291456,8388608",
                     help="bank sizes of the LOADED real-time record: the synthetic score resident on every voice + the live "
                          "messages (empty: skip)")
-    ap.add_argument("--rt-loaded-blocks", type=int, default=2000, help="back-to-back blocks per loaded bank")
-    ap.add_argument("--rt-loaded-paced-blocks", type=int, default=1500, help="paced blocks on the largest loaded bank that met every deadline")
+    ap.add_argument("--rt-loaded-blocks", type=int, default=1000, help="back-to-back blocks per loaded bank")
+    ap.add_argument("--rt-loaded-paced-blocks", type=int, default=750, help="paced blocks on the largest loaded bank that met every deadline")
     ap.add_argument("--cluster", action="store_true",
                     help="multi-GPU through the C-ABI cluster (og_cluster_*, one process) instead of one rank per GPU; "
                          "with --gpus 1 the plain engine path runs (identical to the default)")
@@ -751,6 +1001,7 @@ def main():
                     help="run the RCCL leg (process group, reduce, barrier) with a one-rank communicator: RCCL refuses two "
                          "ranks on one GPU ('Duplicate GPU detected'), so this is how a one-GPU box exercises it")
     ap.add_argument("--realtime-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--test-scale", type=int, default=1, help=argparse.SUPPRESS)  # tests/test_bench_line_cpu.py: banks and runs of `configs` divided by this
     args = ap.parse_args()
     if args.group_voices:
         os.environ["OSCEN_BENCH_GROUP_VOICES"] = str(args.group_voices)
@@ -802,166 +1053,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, rank=rank, world_size=world_size)
 
-    V = args.voices_per_gpu
-    total_voices = V * world_size
-    lo, hi = ogd.shard_range(rank, world_size, total_voices)
-    block, K, W, R = args.block, args.steps, args.warmup, max(1, args.repeats)
-    # block sequence: W warm-up blocks (the last one runs after the barrier, see below), then R regions of K timed
-    # blocks, regions 1.. each preceded by ONE untimed block that plays the same role as that last warm-up block
-    n_blocks = W + R * K + (R - 1)
-    total_frames = n_blocks * block
-    span = 0 if args.sparse_events else min(total_frames, 48000)
-
-    eng = oscen_amd.Engine(args.graph, hi - lo, device=local_rank, sample_rate=48000.0)
-    # global voice ids keep their note streams; a run shorter than the 1 s score sees a slice of it at its real density
-    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="slice")
-    midi = None
-    timed_blocks = np.zeros(n_blocks, dtype=bool)
-    for r in range(R):
-        b0 = W + r * (K + 1)
-        timed_blocks[b0:b0 + K] = True
-    if args.midi_live:
-        eng.set_voice_values("frequency", plans["frequency"])
-        midi = oscen_amd.Midi(eng)
-        midi.set_queue_capacity(max(32, args.midi_live))
-        n_events_timed = args.midi_live * K * R
-    else:
-        if total_frames > 48000:  # a run longer than the 1 s score plays it again and again (same density throughout)
-            ev_v, ev_f0, ev_x = plans["events"]
-            reps = -(-total_frames // 48000)
-            plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
-        oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
-        if args.group_voices:  # (og_group_voices: voices whose notes end together share waves; off by default in round 4)
-            eng.group_voices(args.group_voices)
-        ev_f = plans["events"][1]
-        if "gate" in eng.input_names:
-            inside = ev_f < total_frames
-            n_events_timed = int(np.count_nonzero(timed_blocks[(ev_f[inside] // block).astype(np.int64)]))
-        else:
-            n_events_timed = 0
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
-    if args.bus_batch != 1:  # queued blocks share a launch; every bus is complete before the timed region closes (flush below)
-        eng.set_bus_batching(args.bus_batch)
-    ch = eng.channels
-    bus = torch.zeros((n_blocks, block * ch), dtype=torch.float32, device="cuda")
-    base = bus.data_ptr()
-    host_bus = np.zeros((n_blocks, block * ch), dtype=np.float32)
-    rng = np.random.default_rng(0x05CE2026 + rank)
-    live = []
-    if midi is not None:  # messages built once: the timed loop pays for the engine's live path, not for numpy
-        live_notes = rng.integers(36, 97, size=(n_blocks, args.midi_live)).astype(np.uint8)
-        live_frames = np.sort(rng.integers(0, block, size=(n_blocks, args.midi_live)), axis=1).astype(np.uint32)
-        for i in range(n_blocks):  # even blocks play notes, odd blocks release the notes of the block before
-            live.append(midi.pack_messages(live_notes[i - (i % 2)], live_frames[i], on=(i % 2 == 0)))
-
-    def step(i):
-        if midi is None:
-            eng.process_block_async(block, base + i * block * ch * 4)
-        else:
-            midi.send_packed(live[i])
-            if args.midi_blocking:
-                host_bus[i] = midi.process_block(block).reshape(-1)
-            else:
-                midi.process_block_async(block, base + i * block * ch * 4)
-
-    def reduce_bus(t):
-        if args.backend == "gloo":  # CPU collective (plumbing check only)
-            h = t.cpu()
-            ogd.reduce_bus(h)
-            t.copy_(h)
-        else:
-            ogd.reduce_bus(t)
-
-    def barrier():
-        if args.backend == "gloo":
-            dist.barrier()
-        else:
-            dist.barrier(device_ids=[local_rank])
-
-    # Warm-up: W - 1 blocks, the communicator set-up, the barrier -- and then the LAST warm-up block, so that the voice
-    # kernel is the most recent thing every CU ran when the clock starts.  Measured on MI355X: the first launch of the
-    # voice kernel after OTHER kernels (RCCL's, or any torch kernel) is ~35 % slower than in a steady stream of blocks
-    # (same instruction count, +57 % instruction-fetch wait: its code has to come back from HBM), and with one launch per
-    # 20-32 blocks that launch is the whole timed region -- a measurement artefact of the barrier, not of the path.
-    for i in range(max(0, W - 1)):
-        step(i)
-    eng.flush()
-    if dist is not None:  # communicator set-up (lazy in RCCL) must not land in the timed region
-        reduce_bus(bus[:max(1, W - 1)] if W > 1 else torch.zeros((1, block * ch), dtype=torch.float32, device="cuda"))
-        ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(ones)  # every rank of the communicator took part
-        rccl_ranks = int(round(float(ones.item())))
-    times = []
-    reduce_events, reduce_host_ms = [], []
-    kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
-    for r in range(R):
-        first = W + r * (K + 1)        # first timed block of this region
-        torch.cuda.synchronize()
-        if dist is not None:
-            barrier()
-        torch.cuda.synchronize()
-        if first > 0 and (r > 0 or W > 0):  # the untimed block right in front of the region
-            step(first - 1)
-            eng.flush()
-            torch.cuda.synchronize()
-        eng.enable_kernel_timing(True)  # (per region: the untimed block in front of it is not part of the launch average)
-        t0 = time.perf_counter()
-        for i in range(first, first + K):
-            step(i)
-        eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
-        if dist is not None:
-            # ONE RCCL reduce of the [K, block] mix bus over xGMI, bracketed by events on the stream it runs on (the
-            # engine renders on torch's current stream), so that a scaling record explains its own efficiency
-            t_r0 = time.perf_counter()
-            ev_r0, ev_r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev_r0.record(stream)
-            reduce_bus(bus[first:first + K])
-            ev_r1.record(stream)
-            reduce_host_ms.append((time.perf_counter() - t_r0) * 1e3)
-            reduce_events.append((ev_r0, ev_r1))
-        torch.cuda.synchronize()
-        if dist is not None:
-            barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        elapsed = t1 - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        times.append(elapsed)
-        ms, n = eng.kernel_time_ms()               # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
-        kern_total_ms += ms * n
-        n_launch += n
-        n_blocks_timed += eng.kernel_blocks_timed  # blocks those launches rendered (up to --bus-batch per launch)
-        eng.enable_kernel_timing(False)
-    kern_ms = kern_total_ms / max(1, n_launch)
-    multi_gpu = None
-    if dist is not None:
-        # per rank: the voice kernel's average launch and per-block time, and what the reduce cost on this rank's stream
-        # (device time between the two events: includes waiting for the slowest rank -- a reduce cannot finish before
-        # every contribution exists) and on its host thread
-        red_dev = [a.elapsed_time(b) for a, b in reduce_events] if args.backend != "gloo" else list(reduce_host_ms)
-        mine = torch.tensor([kern_ms, kern_ms * n_launch / max(1, n_blocks_timed), float(np.median(red_dev)) if red_dev else 0.0,
-                             float(np.median(reduce_host_ms)) if reduce_host_ms else 0.0], dtype=torch.float64,
-                            device="cpu" if args.backend == "gloo" else "cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world_size)]
-        dist.all_gather(allr, mine)
-        rows = [[float(x) for x in t.cpu().tolist()] for t in allr]
-        multi_gpu = {
-            "rccl_ranks": rccl_ranks,
-            "backend": "RCCL" if args.backend == "nccl" else "gloo",
-            "per_rank_kernel_ms_avg": [r[0] for r in rows],
-            "per_rank_kernel_ms_per_block": [r[1] for r in rows],
-            "per_rank_reduce_ms": [r[2] for r in rows],
-            "per_rank_reduce_host_ms": [r[3] for r in rows],
-            "reduce_ms_max": max(r[2] for r in rows),
-            "reduce_bytes": int(K * block * ch * 4),
-            "reduce_share_of_region": max(r[2] for r in rows) / (float(np.median(times)) * 1e3) if times else None,
-            "note": "reduce = one [K x block x channels] f32 sum onto rank 0 per timed region; device time between events "
-                    "recorded around it on the rendering stream (median over the regions)",
-        }
+    V, K, W, R = args.voices_per_gpu, args.steps, args.warmup, max(1, args.repeats)
+    m = timed_bank(args, args.graph, V, K, W, R, rank, local_rank, world_size, dist, args.variant)
+    eng, times, kern_ms, n_launch, n_blocks_timed, multi_gpu = m.eng, m.times, m.kern_ms, m.n_launch, m.n_blocks_timed, m.multi_gpu
+    rccl_ranks, timed_blocks, bus, host_bus, midi = m.rccl_ranks, m.timed_blocks, m.bus, m.host_bus, m.midi
+    n_events_timed, span, total_voices, block = m.n_events_timed, m.span, m.total_voices, m.block
 
     if rank == 0:
         sel = torch.from_numpy(timed_blocks)
@@ -1013,8 +1109,13 @@ def main():
             # throughput of the QUEUED path (blocks known ahead, up to 32 per launch) expressed in 48 kHz voices: an
             # offline-render rate.  The real-time figure comes from the blocking entry: realtime.realtime_voices_at_48k
             "offline_voices_at_48k": value / 48000.0,
-            "roofline": roofline_record(eng, V, block, args.graph, kern_ms, n_launch, n_blocks_timed),
+            "roofline": roofline_record(eng, V, block, args.graph, kern_ms, n_launch, n_blocks_timed, args.variant),
         }
+        # the bound that applies (VALU issue) next to the contract's HBM object, so that nobody reads
+        # the charged-bytes fraction as a bandwidth
+        line["valu_issue"] = line["roofline"].get("valu_issue")
+        if args.variant:
+            line["config"]["variant"] = args.variant
         if midi is not None:
             line["config"]["midi_messages_per_block"] = args.midi_live
             line["event_stats"] = eng.event_stats
@@ -1024,7 +1125,16 @@ def main():
         barrier()
         dist.destroy_process_group()
     if line is not None:
-        if world_size == 1 and not args.no_realtime and "gate" in eng.input_names and args.graph == "fm_voice":
+        configs = None
+        if world_size == 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant:
+            has_gate = "gate" in eng.input_names
+            eng.close()
+            torch.cuda.synchronize()
+            configs = config_records(args, local_rank)
+            line["roofline"]["configs"] = configs
+        else:
+            has_gate = "gate" in eng.input_names
+        if world_size == 1 and not args.no_realtime and has_gate and args.graph == "fm_voice":
             torch.cuda.synchronize()
             env = dict(os.environ)
             env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "").split(",")[local_rank] if env.get("HIP_VISIBLE_DEVICES") else str(local_rank)
@@ -1056,6 +1166,16 @@ def main():
         import ctypes
 
         ctypes.CDLL(None).fflush(None)
+        if configs is not None:
+            # LAST key of the line, compact, so that the tail a log keeps still shows every configuration:
+            # [name, voices, value, ms_per_step, kernel, roofline.frac, valu_issue.frac, dram GB/s, stale profile]
+            def sig(x):
+                return None if x is None else float("%.4g" % x)
+
+            line["configs"] = [[c["config"].split(":")[0], c["voices"], sig(c.get("value")), sig(c.get("ms_per_step")), c.get("kernel"),
+                                sig(c.get("roofline_frac")), sig(c.get("valu_issue_frac")), sig(c.get("dram_gbs")), c.get("stale_profile"),
+                                c.get("error")] for c in configs]
+            line["configs_keys"] = "name, voices, voices*samples/s, ms_per_step, kernel, roofline.frac (charged), valu_issue.frac, dram GB/s, stale_profile, error"
         print(json.dumps(line), flush=True)
 
 
