@@ -675,7 +675,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
             reps = -(-total_frames // 48000)
             plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
         oscen_amd.schedule_note_plans(eng, plans, total_frames=total_frames)
-        if args.group_voices:  # (og_group_voices: voices whose notes end together share waves; off by default in round 4)
+        if args.group_voices:  # (og_group_voices: voices whose notes end together share waves)
             eng.group_voices(args.group_voices)
         ev_f = plans["events"][1]
         if "gate" in eng.input_names:
@@ -829,27 +829,28 @@ def region_stats(times, total_voices, K, block):
     }
 
 
-def run_cluster(args):
-    """--cluster: ONE process drives every GPU through the C-ABI cluster (og_cluster_create over devices 0..N-1,
-    og_cluster_render of the K blocks inside the timed region: per-shard host threads, one batched ncclReduce over
-    xGMI).  This is what a Rust / C caller of liboscen_gpu.so gets on a multi-GPU node."""
+def cluster_record(args, N, V, K, W, R, graph=None):
+    """The workload through the C-ABI cluster (og_cluster_create over devices 0..N-1, og_cluster_render of the K blocks inside
+    the timed region: per-shard host threads, one batched ncclReduce over xGMI): what a Rust / C caller of liboscen_gpu.so
+    gets on a multi-GPU node.  Returns the record; `--cluster` prints it as the line, a `--gpus N` run without the flag
+    carries it as the `og_cluster` sub-record."""
     import numpy as np
     import torch
 
     import oscen_amd
 
+    graph = graph or args.graph
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
     n_dev = torch.cuda.device_count()
-    N = args.gpus
     devices = [0] * N if args.single_device else list(range(N))
     if not args.single_device and n_dev < N:
         sys.exit("bench.py --cluster --gpus %d: only %d device(s) visible" % (N, n_dev))
-    V, block, K, W, R = args.voices_per_gpu, args.block, args.steps, args.warmup, max(1, args.repeats)
+    block = args.block
     total_voices = V * N
     total_frames = (W + R * K) * block
     span = 0 if args.sparse_events else min(total_frames, 48000)
-    cl = oscen_amd.Cluster(args.graph, total_voices, devices, sample_rate=48000.0)
+    cl = oscen_amd.Cluster(graph, total_voices, devices, sample_rate=48000.0)
     plans = oscen_amd.note_plans(total_voices, span=span, fold="slice")
     cl.set_voice_values("frequency", plans["frequency"])
     ev_v, ev_f, ev_x = plans["events"]
@@ -863,6 +864,8 @@ def run_cluster(args):
     except oscen_amd.OscenError:
         has_gate = False
     n_events_timed = int(np.count_nonzero((ev_f >= W * block) & (ev_f < total_frames))) if has_gate else 0
+    if has_gate and args.group_voices:
+        cl.group_voices(args.group_voices)
     shard0 = cl.shard(0)
     shards = [cl.shard(s) for s in range(cl.num_shards)]
     if W > 0:
@@ -911,7 +914,7 @@ def run_cluster(args):
                         % (V, len(set(devices)), block, n_events_timed,
                            "mix bus of each launch batch summed with one ncclReduce over xGMI" if cl.rccl_reduces
                            else "one device: no collective on the data path"),
-            "graph": args.graph,
+            "graph": graph,
             "voices_per_gpu": V,
             "total_voices": total_voices,
             "block": block,
@@ -937,9 +940,18 @@ def run_cluster(args):
                     "(og_cluster_reduce_time_ms); it overlaps the next batch's voice kernels",
         },
         "offline_voices_at_48k": total_voices * K * block / elapsed / 48000.0,
-        "roofline": roofline_record(shard0, V, block, args.graph, kern_ms, n_launch, n_blocks_timed),
+        "roofline": roofline_record(shard0, V, block, graph, kern_ms, n_launch, n_blocks_timed),
         "cpu_baseline": None,
     }
+    if not args.single_device and N > 1:
+        assert cl.rccl_reduces and cl.num_devices == N, "the cluster's RCCL leg did not span %d devices" % N
+    cl.close()
+    return line
+
+
+def run_cluster(args):
+    """--cluster: ONE process drives every GPU through the C-ABI cluster."""
+    line = cluster_record(args, args.gpus, args.voices_per_gpu, args.steps, args.warmup, max(1, args.repeats))
     import ctypes
 
     ctypes.CDLL(None).fflush(None)
@@ -988,10 +1000,11 @@ def main():
     ap.add_argument("--midi-live", type=int, default=0, metavar="N",
                     help="live path: N MIDI messages per block through og_midi_send_batch; the block is enqueued with "
                          "og_midi_process_block_async (the host parses block k+1 while block k renders)")
-    ap.add_argument("--group-voices", type=int, nargs="?", const=1, default=0, metavar="POLICY",
-                    help="og_group_voices(1) after the score is scheduled: voice slots ordered by first note-off (same voices, same "
-                         "samples; the bus differs by the association of the sum).  Built and verified on the host simulator late "
-                         "in round 4, not yet measured on the GPU: off by default")
+    ap.add_argument("--group-voices", type=int, nargs="?", const=1, default=1, metavar="POLICY",
+                    help="og_group_voices(POLICY) after the score is scheduled (default 1; 0 = off): voice slots ordered by first "
+                         "note-off, so that the voices of a wave release together and the wave takes the cheaper chunk bodies more "
+                         "often -- same voices, same per-voice samples bit for bit; the bus differs by the association of the sum.  "
+                         "Measured round 5: +2.5 % at the driver's command, +5 % at 131 072 voices, +10 % at 1 048 576")
     ap.add_argument("--midi-blocking", action="store_true",
                     help="with --midi-live: the blocking drop-in entry og_midi_process_block (= process_block + bus to host)")
     # plumbing checks of the multi-rank path on a 1-GPU box (not a benchmark configuration):
@@ -1059,6 +1072,28 @@ def main():
     rccl_ranks, timed_blocks, bus, host_bus, midi = m.rccl_ranks, m.timed_blocks, m.bus, m.host_bus, m.midi
     n_events_timed, span, total_voices, block = m.n_events_timed, m.span, m.total_voices, m.block
 
+    # N > 1: BASELINE config 4's per-GPU shard (262 144 voices per GPU, 1 s of audio per region) through the same ranks and
+    # the same RCCL reduce, as a sub-record of the line (the driver's command does not pass --voices-per-gpu)
+    config4 = None
+    V4 = max(64, 262144 // args.test_scale)
+    if world_size > 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant and V4 != V:
+        K4, W4, R4 = (188, 8, 3) if args.test_scale == 1 else (4, 2, 2)
+        m4 = timed_bank(args, "fm_voice", V4, K4, W4, R4, rank, local_rank, world_size, dist, None)
+        if rank == 0:
+            e4, _ = region_stats(m4.times, m4.total_voices, K4, block)
+            rf4 = roofline_record(m4.eng, V4, block, "fm_voice", m4.kern_ms, m4.n_launch, m4.n_blocks_timed)
+            config4 = {"config": "4: fm-synth %d voices sharded over %d GPUs (%d per GPU), one reduce of the [K x block] mix bus per region"
+                                 % (m4.total_voices, world_size, V4),
+                       "total_voices": m4.total_voices, "voices_per_gpu": V4, "steps": K4, "repeats": R4,
+                       "value": m4.total_voices * K4 * block / e4, "ms_per_step": e4 / K4 * 1e3, "rccl_ranks": m4.rccl_ranks,
+                       "multi_gpu": m4.multi_gpu, "kernel": rf4["kernel_variant"], "kernel_ms_per_block": rf4["kernel_ms_per_block"],
+                       "roofline_frac": rf4["frac"], "valu_issue_frac": (rf4.get("valu_issue") or {}).get("frac"),
+                       "dram_gbs": rf4["dram_gbs"], "stale_profile": rf4["stale_profile"]}
+        m4.eng.close()
+        del m4
+    if world_size > 1 and args.backend == "nccl" and not args.single_device:
+        assert rccl_ranks == world_size, "RCCL communicator spans %s ranks, expected %d" % (rccl_ranks, world_size)
+
     if rank == 0:
         sel = torch.from_numpy(timed_blocks)
         mix = host_bus[timed_blocks] if (midi is not None and args.midi_blocking) else bus[sel.to(bus.device)].float().cpu().numpy()
@@ -1122,18 +1157,34 @@ def main():
     else:
         line = None
     if dist is not None:
-        barrier()
+        if args.backend == "gloo":
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if line is not None:
+        has_gate = "gate" in eng.input_names
+        if config4 is not None:
+            line["config4"] = config4
+        if world_size > 1 and not args.no_configs and not args.midi_live and not args.variant:
+            # the SAME workload through the product's own multi-GPU leg: one process, og_cluster_* over all N devices, the
+            # library's ncclReduce (the ranks above used torch.distributed's communicator).  Rank 0 runs it after the
+            # process group is gone; the other ranks have finished.
+            eng.close()
+            try:
+                c = cluster_record(args, world_size, V, K, W, R)
+                line["og_cluster"] = {k: c[k] for k in ("value", "ms_per_step", "rccl_ranks", "cluster", "multi_gpu", "timing")}
+                line["og_cluster"]["entry"] = "og_cluster_create + og_cluster_render (C ABI, one process, the library's own RCCL communicator)"
+                rf = c["roofline"]
+                line["og_cluster"]["kernel"], line["og_cluster"]["kernel_ms_per_block"] = rf["kernel_variant"], rf["kernel_ms_per_block"]
+            except (Exception, SystemExit) as e:
+                line["og_cluster"] = {"error": str(e)[:300]}
         configs = None
         if world_size == 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant:
-            has_gate = "gate" in eng.input_names
             eng.close()
             torch.cuda.synchronize()
             configs = config_records(args, local_rank)
             line["roofline"]["configs"] = configs
-        else:
-            has_gate = "gate" in eng.input_names
         if world_size == 1 and not args.no_realtime and has_gate and args.graph == "fm_voice":
             torch.cuda.synchronize()
             env = dict(os.environ)

@@ -41,9 +41,15 @@ struct Rccl {
     void load()
     {
         if (lib) return;
+        // OSCEN_GPU_RCCL_LIB = path of the RCCL build to bind (an explicit path is loaded even when another library of
+        // the same soname is already in the process -- e.g. the one a host application links)
+        if (const char* forced = getenv("OSCEN_GPU_RCCL_LIB")) {
+            lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) throw HipError(std::string("cannot load OSCEN_GPU_RCCL_LIB=") + forced + ": " + dlerror());
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!lib) throw HipError(std::string("cannot load RCCL (librccl.so.1): ") + dlerror());
         auto sym = [&](const char* s) {

@@ -3713,11 +3713,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         std::string steady;
         for (int k : all_stages)
             for (const auto& fc : cg.sec[k].fast_conds) steady += (steady.empty() ? "" : " && ") + fc;
-        // Sticky chunks in the ordinary kernel (OGC_STICKY1=1; experiment of late round 4, NOT yet measured on the GPU -- off by
-        // default): as in the pipelined kernels (emit_pipeline below), a wave stays in the quiet variant it is in while that
+        // Sticky chunks in the ordinary kernel (OGC_STICKY1=0 turns them off): as in the pipelined kernels (emit_pipeline below), a wave stays in the quiet variant it is in while that
         // variant's conditions hold on the next chunk, instead of going back through the chunk loop's head, where the
         // compiler reconciles the register assignments of the four chunk bodies (fm_voice: 57 v_mov per 16-frame chunk).
-        const bool sticky1 = getenv("OGC_STICKY1") && atoi(getenv("OGC_STICKY1")) != 0;
+        const bool sticky1 = !(getenv("OGC_STICKY1") && atoi(getenv("OGC_STICKY1")) == 0); // round 5: on (+4.5 % at 262 144 voices, +6 % at 1 M, +3.4 % saturator; profiles/r05a_session1.md)
         std::string stay_path1;
         auto variants = [&](const std::string& tail, const std::string& ind0) {
             auto quiet = [&](const std::string& flag, const std::string& ind1, const std::string& stay = std::string()) {

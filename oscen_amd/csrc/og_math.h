@@ -141,7 +141,11 @@ OG_HD float og_sin_turns_poly(float t)
 // product; 1 = og_sin_turns_poly(phase + mod); 2 = the hardware's v_sin_f32 (argument in turns, valid for |t| <= 256),
 // host builds (tests/test_og_math.py, the host simulator) take the polynomial.
 #ifndef OG_SIN_TURNS
+#ifdef OG_STRICT
 #define OG_SIN_TURNS 0
+#else
+#define OG_SIN_TURNS 2
+#endif
 #endif
 OG_HD float og_sin_turns(float t)
 {

@@ -21,8 +21,13 @@ torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a, **k: None
 torch.cuda.empty_cache = lambda: None
-torch.cuda.device_count = lambda: 1
+torch.cuda.device_count = lambda: int(__import__("os").environ.get("OG_HOSTSIM_DEVICES", "1"))
 torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=0)
+class _Event:  # (the reduce of a multi-rank run is bracketed by torch events)
+    def __init__(self, *a, **k): pass
+    def record(self, *a, **k): pass
+    def elapsed_time(self, other): return 0.0
+torch.cuda.Event = _Event
 _zeros = torch.zeros
 torch.zeros = lambda *a, **k: _zeros(*a, **{**k, "device": "cpu"})
 sys.argv = ["bench.py"] + %(argv)r
@@ -88,3 +93,42 @@ def test_variant_line(hostsim_env):
                                 "--variant", "survey2"])
     assert d["config"]["variant"] == "survey2" and "configs" not in d
     assert d["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_line_carries_config4_and_the_og_cluster_leg(hostsim_env, tmp_path):
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one rank per device; gloo here) on the
+    simulator's eight devices: the line has the rank-per-GPU headline, the `config4` sub-record (262 144 voices per GPU,
+    scaled down here) through the same ranks, and the `og_cluster` sub-record -- the product's own multi-GPU leg
+    (og_cluster_*, the library's ncclReduce over a stand-in librccl) over all eight devices, asserted to span them."""
+    script = tmp_path / "bench_harness.py"
+    argv = ["--gpus", "8", "--steps", "4", "--warmup", "2", "--repeats", "2", "--voices-per-gpu", "64", "--backend", "gloo", "--test-scale", "2048"]
+    script.write_text(HARNESS % {"root": ROOT, "argv": argv, "bench": os.path.join(ROOT, "bench.py")})
+    env = dict(hostsim_env)
+    env["OG_HOSTSIM_DEVICES"] = "8"
+    env["OMP_NUM_THREADS"] = "1"
+    # torch has the real librccl.so.1 in the process already: bind the simulator's stand-in by path
+    env["OSCEN_GPU_RCCL_LIB"] = os.path.join(os.path.dirname(env["OSCEN_GPU_LIB"]), "fake_rccl", "librccl.so.1")
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                         # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["config"]["total_voices"] == 8 * 64 and d["scaling"] == "weak"
+    assert d["multi_gpu"]["rccl_ranks"] == 8 and len(d["multi_gpu"]["per_rank_kernel_ms_avg"]) == 8
+    c4 = d["config4"]
+    assert c4["voices_per_gpu"] == 128 and c4["total_voices"] == 8 * 128 and c4["rccl_ranks"] == 8 and c4["value"] > 0
+    assert len(c4["multi_gpu"]["per_rank_kernel_ms_avg"]) == 8
+    oc = d["og_cluster"]
+    assert "error" not in oc, oc
+    assert oc["rccl_ranks"] == 8 and oc["cluster"]["devices"] == 8 and oc["cluster"]["rccl_reduces"] > 0 and oc["value"] > 0
+    assert "configs" not in d and d["cpu_baseline"] is None       # N = 1 extras stay at N = 1

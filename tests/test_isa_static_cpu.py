@@ -65,10 +65,16 @@ def test_sticky_chunk_loops_of_the_four_wave_kernel_carry_their_values_in_place(
     # the six sticky loops of the three envelope waves, as far as the layout keeps them contiguous (the unrolled 8-frame
     # body up to the first backward branch; the rest of the stay test and the barrier sit in a block placed elsewhere):
     # two branches (leave / repeat) -- and NO register shuffles
-    sticky = [c for c in loops if c["branch"] == 2 and c["n"] >= 150]
-    assert len(sticky) == 6, [dict(c) for c in loops if c["n"] >= 100]
+    sticky = [c for c in loops if c["branch"] == 2 and c["n"] >= 100]
+    assert len(sticky) == 6, [dict(c) for c in loops if c["n"] >= 80]
     for c in sticky:
         assert c["v_mov"] <= 2, dict(c)
-        assert c["valu"] <= 240, dict(c)  # 181 .. 229 VALU per 8 frames today (release-free / release variant)
-    # all three waves' release-free variants together: < 25 VALU per frame and wave
-    assert sum(sorted(c["valu"] for c in sticky)[:3]) <= 3 * 8 * 25
+        # round 5 (the operators' sine is one v_sin_f32): 85 .. 133 VALU per 8 frames (release-free / release variant);
+        # round 4's polynomial sine: 181 .. 229
+        assert c["valu"] <= 140, dict(c)
+    # all three waves' release-free variants together: < 13 VALU per frame and wave (round 4: < 25)
+    assert sum(sorted(c["valu"] for c in sticky)[:3]) <= 3 * 8 * 13
+    # and the sine really is the hardware's: 8 v_sin_f32 per unrolled chunk of every operator wave
+    asm_text = asm.read_text()
+    k0 = asm_text.index(kern + ":")
+    assert asm_text[k0:asm_text.index(".Lfunc_end", k0)].count("v_sin_f32") >= 3 * 8
