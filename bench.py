@@ -643,11 +643,15 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
     # blocks, regions 1.. each preceded by ONE untimed block that plays the same role as that last warm-up block
     n_blocks = W + R * K + (R - 1)
     total_frames = n_blocks * block
-    span = 0 if args.sparse_events else min(total_frames, 48000)
+    # the score: regions of a second or more play the 1 s plan of SURVEY 8(d) as it is (note-ons in block 0 of every second);
+    # shorter regions see every voice's CYCLIC plan from a per-voice offset (fold="slice"), i.e. the plan's real event
+    # density -- 3 events per voice per 48 000 frames, all three kinds -- in every region, however many regions there are
+    short_regions = K * block < 48000
+    span = 0 if args.sparse_events else (total_frames if short_regions else min(total_frames, 48000))
 
     eng = oscen_amd.Engine(graph, hi - lo, device=local_rank, sample_rate=48000.0)
     # global voice ids keep their note streams; a run shorter than the 1 s score sees a slice of it at its real density
-    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="slice")
+    plans = oscen_amd.note_plans(hi - lo, first_voice=lo, span=span, fold="cyclic" if short_regions else "slice")
     midi = None
     ramp_blocks = {}
     if variant == "survey2":
@@ -670,7 +674,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
         midi.set_queue_capacity(max(32, args.midi_live))
         n_events_timed = args.midi_live * K * R
     else:
-        if total_frames > 48000:  # a run longer than the 1 s score plays it again and again (same density throughout)
+        if total_frames > 48000 and not (short_regions and span):  # a run longer than the 1 s score plays it again and again
             ev_v, ev_f0, ev_x = plans["events"]
             reps = -(-total_frames // 48000)
             plans["events"] = (np.tile(ev_v, reps), np.concatenate([ev_f0 + 48000 * k for k in range(reps)]), np.tile(ev_x, reps))
@@ -738,7 +742,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
         ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(ones)  # every rank of the communicator took part
         rccl_ranks = int(round(float(ones.item())))
-    times = []
+    times, sclk = [], []
     reduce_events, reduce_host_ms = [], []
     kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
     for r in range(R):
@@ -777,6 +781,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         times.append(elapsed)
+        sclk.append(eng.shader_clock_ghz())        # (after the clock has stopped: a 20 us probe of the shader clock as the region left it)
         ms, n = eng.kernel_time_ms()               # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
         kern_total_ms += ms * n
         n_launch += n
@@ -809,7 +814,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
                     "recorded around it on the rendering stream (median over the regions)",
         }
 
-    return types.SimpleNamespace(eng=eng, times=times, kern_ms=kern_ms, n_launch=n_launch, n_blocks_timed=n_blocks_timed, multi_gpu=multi_gpu,
+    return types.SimpleNamespace(eng=eng, times=times, sclk=sclk, kern_ms=kern_ms, n_launch=n_launch, n_blocks_timed=n_blocks_timed, multi_gpu=multi_gpu,
                                  rccl_ranks=rccl_ranks, timed_blocks=timed_blocks, bus=bus, host_bus=host_bus, midi=midi,
                                  n_events_timed=n_events_timed, span=span, total_voices=total_voices, block=block, ch=ch)
 
@@ -826,6 +831,8 @@ def region_stats(times, total_voices, K, block):
         "value_min": total_voices * K * block / float(t.max()),
         "value_max": total_voices * K * block / float(t.min()),
         "value_first_region": total_voices * K * block / float(t[0]),
+        # what five regions alone would have reported (rounds 1-4): the governor's cold figure
+        "value_median_first5": total_voices * K * block / float(np.median(t[:5])),
     }
 
 
@@ -951,7 +958,7 @@ def cluster_record(args, N, V, K, W, R, graph=None):
 
 def run_cluster(args):
     """--cluster: ONE process drives every GPU through the C-ABI cluster."""
-    line = cluster_record(args, args.gpus, args.voices_per_gpu, args.steps, args.warmup, max(1, args.repeats))
+    line = cluster_record(args, args.gpus, args.voices_per_gpu, args.steps, args.warmup, args.repeats if args.repeats > 0 else 5)
     import ctypes
 
     ctypes.CDLL(None).fflush(None)
@@ -963,8 +970,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=188)   # 188 x 256 frames = 1 s of audio
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--repeats", type=int, default=5,
-                    help="how many times the K-step timed region is run (value = the median region)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed region is run (value = the median region; every region is in the line).  "
+                         "0 = as many as make ~40 ms of timed work, at least 5 and at most 48: the GPU's clock governor needs tens of "
+                         "milliseconds of load to settle (measured round 5: forty-eight 0.75 ms regions in a row go 0.76 -> 0.68 ms, "
+                         "the cycle count per frame of the kernel is the same throughout -- GRBM_GUI_ACTIVE), so five regions of 20 "
+                         "blocks measure the governor, not the kernel")
     ap.add_argument("--voices-per-gpu", type=int, default=65536,
                     help="65536 = BASELINE configs[1]; 262144 with --gpus 8 = configs[3] (2 097 152 voices)")
     ap.add_argument("--block", type=int, default=256)
@@ -1066,7 +1077,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, rank=rank, world_size=world_size)
 
-    V, K, W, R = args.voices_per_gpu, args.steps, args.warmup, max(1, args.repeats)
+    V, K, W = args.voices_per_gpu, args.steps, args.warmup
+    if args.repeats > 0:
+        R, repeats_rule = args.repeats, "--repeats %d" % args.repeats
+    else:
+        est_region_ms = max(1e-3, K * 0.045 * V / 65536.0)  # ~0.045 ms per 256-frame block of 65 536 fm voices
+        R = int(max(5, min(48, -(-40.0 // est_region_ms))))
+        repeats_rule = "auto: ~40 ms of timed work (5..48 regions) so that the clock governor has settled by the median region"
     m = timed_bank(args, args.graph, V, K, W, R, rank, local_rank, world_size, dist, args.variant)
     eng, times, kern_ms, n_launch, n_blocks_timed, multi_gpu = m.eng, m.times, m.kern_ms, m.n_launch, m.n_blocks_timed, m.multi_gpu
     rccl_ranks, timed_blocks, bus, host_bus, midi = m.rccl_ranks, m.timed_blocks, m.bus, m.host_bus, m.midi
@@ -1117,8 +1134,8 @@ def main():
                 "workload": "fm-synth voice bank (FMVoice graph), %d voices/GPU, block=%d frames, 48 kHz, f32; "
                             "synthetic note streams splitmix64(0x05CE2026 ^ voice) resident in HBM%s; "
                             "%d note events (on / off / retrigger) fall inside the %d timed regions; %s"
-                            % (V, block, "" if not span or span >= 48000 else
-                               ", the %d-frame run shows a per-voice slice of the cyclic 1 s note plan at its real event density" % span,
+                            % (V, block, "" if not span or span == 48000 else
+                               ", the %d-frame run plays every voice's cyclic 1 s note plan from a per-voice offset: the plan's real event density in every region" % span,
                                n_events_timed, R,
                                "one GPU: no collective on the data path" if dist is None else
                                "the [K x block] mix bus of a region reduced once over %s (%d rank%s)"
@@ -1138,7 +1155,8 @@ def main():
                               if midi is not None
                               else "resident timeline (og_schedule_voice_events)",
             },
-            "timing": stats,
+            # sclk_ghz_after_region: the shader clock each region left behind (og_shader_clock_ghz) -- region times follow it
+            "timing": dict(stats, repeats_rule=repeats_rule, sclk_ghz_after_region=[None if x is None else round(x, 3) for x in m.sclk]),
             "rccl_ranks": rccl_ranks,
             "multi_gpu": multi_gpu,  # None at N = 1 (no collective on the data path)
             # throughput of the QUEUED path (blocks known ahead, up to 32 per launch) expressed in 48 kHz voices: an
@@ -1210,7 +1228,8 @@ def main():
         else:
             line["realtime"] = None
         if world_size == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span)
+            # (the oracle folds the plan the same way; a rotated plan of more than a second reads the same in any window)
+            line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span if span <= 48000 else 47999)
         else:
             line["cpu_baseline"] = None
         # RCCL writes a version banner through C stdio: push it out first, so that the JSON is the LAST line of stdout

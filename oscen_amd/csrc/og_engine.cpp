@@ -74,6 +74,28 @@ __device__ __forceinline__ void og_bus_reduce_body(const float* __restrict__ par
     }
 }
 
+// og_shader_clock_ghz: one wave spins for `ticks` of the constant 100 MHz counter (s_memrealtime) and counts shader cycles
+// (s_memtime: one tick per shader clock, MI355X_MICROARCH.md) over the same span
+__global__ __launch_bounds__(64) void og_clock_probe(unsigned long long* out, unsigned ticks)
+{
+#ifndef OG_HOSTSIM
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r1;
+    do {
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < ticks);
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+#else
+    if (threadIdx.x == 0) out[0] = out[1] = 0ull; // (the host simulator has no shader clock)
+    (void)ticks;
+#endif
+}
+
 __global__ __launch_bounds__(1024) void og_bus_reduce(const float* __restrict__ partials, uint32_t n_rows,
                                                       uint32_t frames, float* __restrict__ out, uint32_t out_stride, uint32_t out_off)
 {
@@ -2414,6 +2436,25 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
     const double avg = e->t_used ? total / (double)e->t_used : 0.0;
     e->t_used = 0;
     return avg;
+}
+
+int og_shader_clock_ghz(og_engine* e, double* ghz)
+{
+    if (!e || !ghz) return set_err(OG_E_INVALID, "null argument");
+    return guard([&]() -> int {
+        HIPCK(hipSetDevice(e->device));
+        unsigned long long* h = nullptr;
+        HIPCK(hipHostMalloc((void**)&h, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        h[0] = h[1] = 0ull;
+        hipLaunchKernelGGL(og_clock_probe, dim3(1), dim3(64), 0, e->stream, h, 2000u); // 20 us
+        const hipError_t rc = hipStreamSynchronize(e->stream);
+        const unsigned long long cyc = h[0], ref = h[1];
+        (void)hipHostFree(h);
+        if (rc != hipSuccess) throw HipError(std::string("og_clock_probe: ") + hipGetErrorString(rc));
+        if (ref == 0ull) return set_err(OG_E_UNSUPPORTED, "no shader clock counter on this device");
+        *ghz = (double)cyc / (double)ref * 0.1; // cycles per 10 ns tick
+        return OG_OK;
+    });
 }
 
 } // extern "C"

@@ -1093,6 +1093,13 @@ struct NodeCtx {
                      << ", " << var << ");\n";
         return var;
     }
+    // an array field that stays in its state plane (read-mostly: touched by event handlers, not by the frame loop): the
+    // expression of this lane's pointer to its OG_HPL words
+    std::string state_lane_plane(const std::string& name, float init)
+    {
+        cg.out.lane_state.push_back({n.decl->name + "." + name + "[h]", true, [init](const UEnv&) { return fbits(init); }, true});
+        return "og::lane_plane<LPV>(A, c, " + std::to_string((int)cg.out.lane_state.size() - 1) + ")";
+    }
     std::string state_u(const std::string& name, uint32_t init)
     {
         std::string var = p + name;
@@ -1519,18 +1526,19 @@ void emit_ep_amp(NodeCtx& x)
         ks = x.in("key_scaling"), rr = x.in("release_rate");
     (void)x.in("frequency"); // routed to the node but never read by its process()
     const std::string A = x.p + "a";
-    // decay / release only change when a note starts: read-mostly planes, written back in blocks that rewrote them
-    std::string cur = x.state_lane_h("current_value", 0.0f), tgt = x.state_lane_h("target_value", 0.0f),
-                dec = x.state_lane_h("decay", 0.0f, A + ".tables_dirty"), rel = x.state_lane_h("release", 0.0f, A + ".tables_dirty");
+    // decay / release only change when a note starts and are read only by the gate handler: they stay in their state planes
+    // (og_nodes.hip.h, EpAmp); the table the next ramp target uses sits in an LDS column
+    std::string cur = x.state_lane_h("current_value", 0.0f), tgt = x.state_lane_h("target_value", 0.0f);
+    const std::string dec = x.state_lane_plane("decay", 0.0f), rel = x.state_lane_plane("release", 0.0f);
     std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
     std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
     x.cg.S().decl << "    og::EpAmp " << A << " = {};\n";
-    x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << dec << ", " << rel << ", og::harm_select(" << released
-              << " != 0u, " << rel << ", " << dec << "), " << released << ", " << step << ", " << vel << ", false};\n";
+    x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << released << ", " << step << ", " << vel
+              << ", nullptr, nullptr, nullptr};\n";
+    x.cg.S().pre << "    og::ep_amp_begin(" << A << ", " << dec << ", " << rel << ", c.valid);\n";
     // stores run before the generic store section reads the mirrors back
-    x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << dec << " = " << A
-                   << ".decay; " << rel << " = " << A << ".release; " << released << " = " << A << ".released; " << step
-                   << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
+    x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << released << " = " << A
+                   << ".released; " << step << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
     x.on_event("gate", [&](const std::string& val) {
         return "                og::ep_amp_gate(" + A + ", c.h * OG_HPL, " + val + ", " + br.e + ", " + vs.e + ", " + dr.e + ", " + hd.e +
                ", " + ks.e + ", " + rr.e + ");\n";
@@ -4159,7 +4167,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                                   {"11", "true", "true"}};
     // register budget of the ordinary kernel: 4 waves per SIMD = 128 VGPRs.  The 4-lanes-per-voice e-piano form
     // (OG_HPL = 8) keeps eight harmonics of nine arrays per lane.  Round 3 gave it the two-waves-per-SIMD budget (201
-    // VGPRs, no spill; the three-wave budget measured +1.7 % with 80 spills and was not taken).  Round 4: with the
+    // VGPRs, no spill; the three-wave budget measured +1.7 % with 80 spills and was not taken).  Round 5: decay / release /
+    // mult are no longer register state (og_nodes.hip.h, EpAmp) -- see scripts/isa_mix.py epiano_voice.  Round 4: with the
     // packed-fma bodies the three-wave budget (168 VGPRs) spills 76 registers, all of them around the chunk loop (25
     // scratch instructions per 16-frame chunk, none in the frame loop: scripts/isa_mix.py epiano_voice OGC_WAVES_EU=3)
     // and is 3.3 % faster in an interleaved A/B (1.57e11 -> 1.62e11 at 262 144 voices): taken.  Four waves (128 VGPRs)

@@ -462,6 +462,12 @@ __device__ __forceinline__ HarmV ldl_h(const OgBlockArgs& a, const VoiceCtx& c, 
 #endif
     return r;
 }
+// this lane's OG_HPL words of lane-state plane k (arrays that stay in memory: read and written by event handlers only)
+template <int LPV>
+__device__ __forceinline__ float* lane_plane(const OgBlockArgs& a, const VoiceCtx& c, int k)
+{
+    return reinterpret_cast<float*>(a.lane_state) + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL;
+}
 template <int LPV>
 __device__ __forceinline__ void stl_h(const OgBlockArgs& a, const VoiceCtx& c, int k, const HarmV& x)
 {

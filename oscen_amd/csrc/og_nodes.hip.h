@@ -857,13 +857,83 @@ __device__ const float EP_VEL127[EP_HARMONICS] = {
     9.33705e-05f, 0.000177973f, 0.0002545f, 0.000323602f, 0.000779045f, 0.000116569f, 0.000772873f, 0.000364486f,
     0.000248027f, 0.00018236f, 3.27292e-05f, 6.64988e-05f, 0.0f, 0.0f, 0.0f, 0.0f};
 
+// Round 5: the read-mostly tables of AmplitudeSource are not register state any more.  `decay` and `release` (32 + 32 words
+// per voice) are read only by the gate handler and `mult` (= released ? release : decay) only when a new ramp target is
+// formed, once per 65 frames of a voice; held in registers they were what the three-waves-per-SIMD budget spilled around
+// every chunk (76 registers, 144 B of scratch per lane).  Now decay / release stay in their state planes (the gate
+// handler writes them there when a note starts and reads `release` back when it ends) and `mult` lives in an LDS column
+// per lane: the frame loop keeps cur / tgt and the oscillator bank's four arrays, nothing else of OG_HPL words.
 struct EpAmp {
-    HarmV cur, tgt, decay, release; // this lane's harmonics
-    HarmV mult;                     // released ? release : decay (what the next target is formed with)
-    uint32_t released, step;        // per voice
+    HarmV cur, tgt;          // this lane's harmonics
+    uint32_t released, step; // per voice
     float velocity;
-    bool tables_dirty;              // decay / release were rewritten in this block (they are read-mostly state)
+    float4* mult;            // this lane's column of the wave's LDS copy of (released ? release : decay): element q at mult[q * OG_WAVE]
+    float* decay;            // this lane's OG_HPL words of the `decay` state plane
+    float* release;          // ... of the `release` state plane
 };
+
+OG_DEV void ep_mult_put(EpAmp& a, const HarmV& m)
+{
+#if OG_HPL >= 4
+#pragma unroll
+    for (int q = 0; q < OG_HPL / 4; ++q) a.mult[q * OG_WAVE] = make_float4(m.p[2 * q].x, m.p[2 * q].y, m.p[2 * q + 1].x, m.p[2 * q + 1].y);
+#else
+    reinterpret_cast<float2*>(a.mult)[0] = make_float2(m.p[0].x, m.p[0].y);
+#endif
+}
+OG_DEV HarmV ep_mult_get(const EpAmp& a)
+{
+    HarmV m;
+#if OG_HPL >= 4
+#pragma unroll
+    for (int q = 0; q < OG_HPL / 4; ++q) {
+        const float4 v = a.mult[q * OG_WAVE];
+        m.p[2 * q] = og_f2{v.x, v.y};
+        m.p[2 * q + 1] = og_f2{v.z, v.w};
+    }
+#else
+    const float2 v = reinterpret_cast<const float2*>(a.mult)[0];
+    m.p[0] = og_f2{v.x, v.y};
+#endif
+    return m;
+}
+OG_DEV HarmV ep_plane_get(const float* p)
+{
+    HarmV r;
+#if OG_HPL >= 4
+#pragma unroll
+    for (int i = 0; i < OG_HPL / 4; ++i) {
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        r.p[2 * i] = og_f2{q.x, q.y};
+        r.p[2 * i + 1] = og_f2{q.z, q.w};
+    }
+#else
+    const float2 q = *reinterpret_cast<const float2*>(p);
+    r.p[0] = og_f2{q.x, q.y};
+#endif
+    return r;
+}
+OG_DEV void ep_plane_put(float* p, const HarmV& x)
+{
+#if OG_HPL >= 4
+#pragma unroll
+    for (int i = 0; i < OG_HPL / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(x.p[2 * i].x, x.p[2 * i].y, x.p[2 * i + 1].x, x.p[2 * i + 1].y);
+#else
+    *reinterpret_cast<float2*>(p) = make_float2(x.p[0].x, x.p[0].y);
+#endif
+}
+
+// block start: bind the lane's planes and its LDS column, bring the table the next target will be formed with
+OG_DEV void ep_amp_begin(EpAmp& a, float* decay_plane, float* release_plane, bool valid)
+{
+    __shared__ float4 ep_mult[OG_HPL >= 4 ? OG_HPL / 4 : 1][OG_WAVE]; // (one-wave workgroups: column = lane)
+    a.mult = &ep_mult[0][threadIdx.x % OG_WAVE];
+    a.decay = decay_plane;
+    a.release = release_plane;
+    HarmV m = harm_splat(0.0f);
+    if (valid) m = ep_plane_get(a.released != 0u ? release_plane : decay_plane);
+    ep_mult_put(a, m);
+}
 
 // on_gate :308-318 -> trigger_note :292-299 (get_decay :244-268, get_release :270-274,
 // get_initial_amplitudes :276-290; note_pitch stays 60.0) or release_note :301-304.   h0 = first harmonic of the lane
@@ -894,17 +964,18 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
             amp *= 1.0f + brightness_scaling * (float)h;
             cur[j] = amp;
         }
-        a.decay = harm_make(dec);
-        a.release = harm_splat(rel);
+        const HarmV decay = harm_make(dec);
+        ep_plane_put(a.decay, decay); // self.decay = get_decay(..), self.release = get_release(..): the state planes
+        ep_plane_put(a.release, harm_splat(rel));
+        ep_mult_put(a, decay);
         a.cur = harm_make(cur);
         a.released = 0u;
         a.step = 0u;
-        a.tables_dirty = true;
     } else {
         a.released = 1u;
         a.step = 0u;
+        ep_mult_put(a, ep_plane_get(a.release)); // (this lane's own earlier stores, if any, are visible to its loads)
     }
-    a.mult = harm_select(a.released != 0u, a.release, a.decay); // (by value: see harm_select)
 }
 
 // AmplitudeSource::process :321-351 for the lane's harmonics, written without branches: with eight voices per wave
@@ -913,7 +984,7 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
 //   step < 64            -> current = current * (1 - t) + target * t, t = (step + 1) / 64; step += 1
 //   step == 64           -> current = target; step = 0: the same lerp with t = 1 (x * 0 + y * 1 == y for the finite,
 //                           non-negative amplitudes here)
-// `mult` is the table the next target uses (release or decay): it only changes in the gate handler.
+// The table the next target uses (release or decay) only changes in the gate handler; it is read from LDS.
 OG_DEV HarmV ep_amp_tick(EpAmp& a)
 {
     const bool fresh = a.step == 0u;
@@ -924,11 +995,13 @@ OG_DEV HarmV ep_amp_tick(EpAmp& a)
 #define OG_EP_FRESH_BRANCH 1
 #endif
     // A new target is formed once per 65 frames of a voice.  With 16 voices in a wave no lane needs one on ~78 % of the
-    // frames: one wave-uniform test skips the products and selects there (a per-lane `if` would cost both sides).
+    // frames: one wave-uniform test skips the LDS reads, the products and the selects there (a per-lane `if` would cost
+    // both sides).
     if (!OG_EP_FRESH_BRANCH || __any((int)fresh)) {
+        const HarmV mult = ep_mult_get(a);
 #pragma unroll
         for (int i = 0; i < OG_HPAIRS; ++i) {
-            const og_f2 tn = f2_mul(a.cur.p[i], a.mult.p[i]);
+            const og_f2 tn = f2_mul(a.cur.p[i], mult.p[i]);
             a.tgt.p[i].x = fresh ? tn.x : a.tgt.p[i].x;
             a.tgt.p[i].y = fresh ? tn.y : a.tgt.p[i].y;
         }

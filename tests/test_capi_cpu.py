@@ -280,6 +280,27 @@ def test_note_event_streams_match_the_oracle_generator_in_both_fold_modes():
             assert (ev_x[win] > 0).sum() > 0 and (ev_x[win] == 0).sum() > 0
 
 
+def test_cyclic_fold_is_the_slice_fold_repeated():
+    """fold="cyclic" (bench.py, regions shorter than the 1 s score): below 48 000 frames it IS the slice fold; beyond, the
+    rotated plan repeats with the period of the score and only the first period carries the held voices' initial note-on"""
+    import oscen_amd
+
+    n = 400
+    a = oscen_amd.note_plans(n, first_voice=123, span=6400, fold="slice")["events"]
+    b = oscen_amd.note_plans(n, first_voice=123, span=6400, fold="cyclic")["events"]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    v, f, x = oscen_amd.note_plans(n, first_voice=123, span=48000 * 2 + 5000, fold="cyclic")["events"]
+    assert np.all(np.diff(v) >= 0) and f.max() < 3 * 48000
+    per = [np.sort(f[(f >= 48000 * k) & (f < 48000 * (k + 1))] - 48000 * k) for k in range(3)]
+    assert len(per[1]) == 3 * n and np.array_equal(per[1], per[2])       # 3 events per voice per second, every second alike
+    assert len(per[0]) > 3 * n                                            # + the note-on of the voices sounding at the cut
+    for voice in range(0, n, 37):                                         # per voice: frames ascending, on / off alternate
+        m = v == voice
+        assert np.all(np.diff(f[m]) >= 0)
+        g = x[m] > 0
+        assert not np.any(~g[1:] & ~g[:-1])                               # never two note-offs in a row
+
+
 def test_rust_shim_block_render_constants_and_calls():
     """bindings/rust/oscen-gpu (source only: no rustc here): BlockRender::NUM_STREAM_INPUTS must be a real constant --
     the trait's default render() asserts `inputs.len() == NUM_STREAM_INPUTS` and loops over it

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = r'''
 #include "og_math.h"
 extern "C" void og_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sinf(x[i]); }
+extern "C" void og_sin_turns_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sin_turns_poly(x[i]); }
+extern "C" void og_sin_turns_dflt(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sin_turns(x[i]); }
 extern "C" void og_tan_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_tanf_q1(x[i]); }
 extern "C" void ex_sin_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_sinf_exact(x[i]); }
 extern "C" void ex_cos_array(const float* x, float* y, long n) { for (long i = 0; i < n; ++i) y[i] = og_cosf_exact(x[i]); }
@@ -55,6 +57,32 @@ def test_sin_matches_glibc_over_fm_range(mlib):
     true = np.sin(x[small].astype(np.float64))
     # (tolerance mode drops the degree-11 term: approximation error 4.7e-9 on top of the final rounding)
     assert np.max(np.abs(got[small] - true)) <= 1.45e-7
+
+
+def test_sin_in_turns(mlib):
+    """og_sin_turns_poly(t) = sin(2 pi t): the half-turn reduction is exact, so the error against the TRUE sine is the
+    polynomial's (4.9e-9) plus the final roundings at ANY argument size; against the reference's f32
+    `((t) * TAU).sin()` the two differ by the rounding of the reference's own product (|t| * 2 pi * 6e-8).  On the GPU the
+    shipped operator takes v_sin_f32 (OG_SIN_TURNS = 2; measured on MI355X: 4.6e-7 / 7.6e-7 / 1.5e-6 against the
+    reference's form at modulation depths 0 / 1 / 4 turns, profiles/r05a_session1.log); host builds of og_sin_turns
+    take this polynomial (strict builds: og_sinf(t * TAU))."""
+    rng = np.random.default_rng(2)
+    for depth, bound_ref in ((0.0, 4.5e-7), (1.0, 8e-7), (4.0, 1.6e-6), (16.0, 3.7e-6)):
+        t = (rng.random(1_000_000) + (rng.random(1_000_000) - 0.5) * depth).astype(np.float32)
+        got = _apply(mlib, "og_sin_turns_array", t).astype(np.float64)
+        true = np.sin(2.0 * np.pi * t.astype(np.float64))
+        assert np.max(np.abs(got - true)) <= 1.6e-7
+        x = (t * np.float32(6.28318548202514648)).astype(np.float32)
+        assert np.max(np.abs(got - _apply(mlib, "ref_sin_array", x))) <= bound_ref
+    big = rng.uniform(-2.0e6, 2.0e6, 200_000).astype(np.float32)  # |2t| < 2^22: the magic-number rounding still holds
+    assert np.max(np.abs(_apply(mlib, "og_sin_turns_array", big) - np.sin(2.0 * np.pi * big.astype(np.float64)))) <= 1.6e-7
+    exact = np.array([0.0, 0.5, 1.0, -0.5, 2.5, 0.25, -0.25, 0.75], dtype=np.float32)
+    want = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0, -1.0, -1.0])
+    assert np.max(np.abs(_apply(mlib, "og_sin_turns_array", exact) - want)) <= 1.2e-7
+    # the dispatching form: strict builds keep the radian polynomial on the reference's product
+    t = rng.random(100_000).astype(np.float32)
+    d = _apply(mlib, "og_sin_turns_dflt", t)
+    assert np.max(np.abs(d - np.sin(2.0 * np.pi * t.astype(np.float64)))) <= 5e-7
 
 
 def test_tan_matches_glibc_on_first_quadrant(mlib):
