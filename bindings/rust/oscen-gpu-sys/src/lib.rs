@@ -155,6 +155,7 @@ extern "C" {
 extern "C" {
     pub fn og_cluster_read_output_events(c: *mut og_cluster, buf: *mut og_out_event, cap: u32, n: *mut u32, n_overflowed: *mut u64) -> c_int;
     pub fn og_cluster_events_dropped(c: *mut og_cluster) -> u64;
+    pub fn og_cluster_sync_event_counters(c: *mut og_cluster) -> c_int;
     pub fn og_cluster_group_voices(c: *mut og_cluster, policy: u32) -> c_int;
 }
 

@@ -456,6 +456,9 @@ int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduc
 /* event outputs of the graph (og_read_output_events) over all shards: merged into (frame, GLOBAL voice, push order) */
 int og_cluster_read_output_events(og_cluster* c, og_out_event* buf, uint32_t cap, uint32_t* n, uint64_t* n_overflowed);
 uint64_t og_cluster_events_dropped(og_cluster* c); /* og_events_dropped summed over the shards */
+/* og_sync_event_counters on every shard; returns the first error (og_cluster_events_dropped folds the counters the same way
+ * but can only leave an error in og_last_error) */
+int og_cluster_sync_event_counters(og_cluster* c);
 int og_cluster_group_voices(og_cluster* c, uint32_t policy); /* og_group_voices on every shard (voices never change shard) */
 /* the engine of shard s (owned by the cluster) and its first global voice: taps, state snapshots, statistics */
 og_engine* og_cluster_shard(og_cluster* c, uint32_t s, uint64_t* first_voice);

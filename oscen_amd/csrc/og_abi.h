@@ -27,6 +27,7 @@ struct DeviceError : Error {
 
 // records `msg` as this thread's og_last_error() and returns `code` (defined in og_engine.cpp)
 int set_error(int code, const std::string& msg);
+int set_error(int code, const char* msg) noexcept; // (no std::string temporary at the call site: what guard() calls)
 
 template <class F>
 int guard(F&& f) noexcept

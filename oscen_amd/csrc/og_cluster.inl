@@ -646,20 +646,45 @@ int og_cluster_reduce_time_ms(og_cluster* c, double* total_ms, uint64_t* n_reduc
 int og_cluster_group_voices(og_cluster* c, uint32_t policy)
 {
     if (!c) return set_err(OG_E_INVALID, "null cluster");
-    for (og_engine* e : c->shard) {
-        const int rc = og_group_voices(e, policy);
-        if (rc != OG_OK) return rc;
-    }
-    return OG_OK;
+    return guard([&]() -> int {
+        for (size_t s = 0; s < c->shard.size(); ++s) {
+            const int rc = og_group_voices(c->shard[s], policy);
+            if (rc != OG_OK) { // all shards or none: the ones already re-ordered go back to the identity (og_last_error keeps the cause)
+                const std::string why = og_last_error();
+                for (size_t k = 0; k < s; ++k) (void)og_group_voices(c->shard[k], 0u);
+                return set_err(rc, why);
+            }
+        }
+        return OG_OK;
+    });
+}
+
+// fold the device-side drop counts of every shard into the counters og_cluster_events_dropped reads; the first error is
+// reported (and the remaining shards are still synchronised)
+int og_cluster_sync_event_counters(og_cluster* c)
+{
+    if (!c) return set_err(OG_E_INVALID, "null cluster");
+    return guard([&]() -> int {
+        int first = OG_OK;
+        std::string why;
+        for (og_engine* e : c->shard) {
+            const int rc = og_sync_event_counters(e);
+            if (rc != OG_OK && first == OG_OK) {
+                first = rc;
+                why = og_last_error();
+            }
+        }
+        return first == OG_OK ? OG_OK : set_err(first, why);
+    });
 }
 
 uint64_t og_cluster_events_dropped(og_cluster* c)
 {
     uint64_t d = 0;
-    for (size_t s = 0; c && s < c->shard.size(); ++s) {
-        (void)og_sync_event_counters(c->shard[s]); // (the caller is the rendering thread: og_cluster* is not const here)
-        d += og_events_dropped(c->shard[s]);
-    }
+    // (the caller is the rendering thread: og_cluster* is not const here.  A device error while the counters are folded
+    //  stays in og_last_error(); og_cluster_sync_event_counters is the call that RETURNS it)
+    if (c) (void)og_cluster_sync_event_counters(c);
+    for (size_t s = 0; c && s < c->shard.size(); ++s) d += og_events_dropped(c->shard[s]);
     return d;
 }
 

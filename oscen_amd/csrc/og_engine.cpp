@@ -184,6 +184,17 @@ int set_error(int code, const std::string& m)
     }
     return code;
 }
+// the form guard()'s catch handlers use: the std::string is built INSIDE the try (guard is noexcept: a bad_alloc while
+// copying e.what() must not become std::terminate)
+int set_error(int code, const char* m) noexcept
+{
+    try {
+        g_err.assign(m ? m : "");
+    } catch (...) {
+        g_err.clear();
+    }
+    return code;
+}
 } // namespace ogabi
 
 namespace {
@@ -406,6 +417,7 @@ struct og_engine {
     // state loaded and stored once, one inter-kernel gap, one bus reduce per tree level -- instead of one launch each.
     // A queued block has had its ramps ticked and its stream samples captured; anything that touches engine state
     // launches the queue first.  Results are those of block-by-block processing, bit for bit.
+    std::vector<uint32_t> tap_voices; // og_set_voice_taps: the tapped voices by the caller's numbers (slots are resolved from them)
     uint32_t bus_batch = 1; // queue limit (blocks per launch)
     uint32_t batch_cap = 1; // what the buffers are sized for
     struct QueuedBlock {
@@ -747,6 +759,11 @@ struct og_engine {
             size_t headroom = (size_t)2 << 20; // room for appended segments (2 M events, 32 MB) before the ring has to wrap
             if (ev_headroom_env) headroom = ev_headroom_env; // OSCEN_GPU_EV_HEADROOM (tests: force compactions), read at og_create
             ev_cap = std::max<size_t>(n + std::max<size_t>(n / 2, ev_reserve), 1024) + headroom;
+            // ring positions (seg_begin / seg_end, the device cursor and end words) are 32-bit: the ring never grows past
+            // what they address -- the slack shrinks first, and a score that does not fit with its reserve is refused
+            const size_t EV_CAP_MAX = 0xFFFFFFF0ull;
+            if (ev_cap > EV_CAP_MAX) ev_cap = EV_CAP_MAX;
+            if (n + ev_reserve > ev_cap) throw ogabi::Error(OG_E_NOMEM, "event timeline + og_reserve_events exceed the 32-bit event ring");
             HIPCK(hipMalloc(&d_events, ev_cap * sizeof(OgEvent)));
         }
         if (n) bounce.h2d(d_events, evs.data(), n * sizeof(OgEvent), stream);
@@ -754,7 +771,10 @@ struct og_engine {
         bounce.h2d(d_ev_end, end.data(), (size_t)V * 4, stream);
         HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
         h_events.swap(evs);
-        h_events.reserve(ev_cap); // mirror of the whole ring (grown on demand by the live path: no zero-fill of the room here)
+        // mirror of the whole ring, reserved up front so that the live path never reallocates while playing (grown on demand:
+        // no zero-fill of the room here) -- up to 2^28 events (4 GB of host memory); a ring larger than that mirrors what is
+        // resident plus the promised reserve and grows on demand beyond it
+        h_events.reserve(ev_cap <= ((size_t)1 << 28) ? ev_cap : std::min(ev_cap, h_events.size() + std::max<size_t>(ev_reserve, (size_t)1 << 28)));
         seg_begin.swap(cursor);
         seg_end.swap(end);
         seg_last.swap(last);
@@ -2119,6 +2139,7 @@ int og_set_voice_taps(og_engine* e, const uint32_t* voices, uint32_t n)
             HIPCK(hipMemset(e->d_taps, 0, (size_t)n * OG_MAX_BLOCK * 4 * e->cg->voice_channels));
         }
         e->n_taps = n;
+        e->tap_voices.assign(voices, voices + n); // the caller's voice numbers: og_load_state re-resolves them when it adopts another slot order
         return OG_OK;
     });
 }
@@ -2624,11 +2645,11 @@ int og_load_state(og_engine* e, const void* src, size_t len)
         const bool order_changed = e->phys_of != new_phys;
         e->phys_of.swap(new_phys); // (version 2: identity)
         e->logical_of.swap(new_logical);
-        if (order_changed && e->n_taps) { // taps were resolved to physical slots under the old order: set them again
-            std::vector<int32_t> none(e->V, -1);
-            e->bounce.h2d(e->d_tap_slot, none.data(), (size_t)e->V * 4, e->stream);
+        if (order_changed && e->n_taps) { // taps were resolved to physical slots under the old order: resolve the SAME voices again
+            std::vector<int32_t> slot(e->V, -1);
+            for (uint32_t i = 0; i < e->n_taps; ++i) slot[e->phys(e->tap_voices[i])] = (int32_t)i;
+            e->bounce.h2d(e->d_tap_slot, slot.data(), (size_t)e->V * 4, e->stream);
             HIPCK(hipStreamSynchronize(e->stream));
-            e->n_taps = 0;
         }
         const char* p = (const char*)src + off + sizeof h;
         memcpy(e->values.data(), p, e->values.size() * sizeof(float));

@@ -1999,6 +1999,15 @@ GraphDesc expand_arrays(const GraphDesc& g)
     std::map<std::string, uint32_t> arr;
     for (const GNode& n : g.nodes)
         if (n.array_len) arr[n.name] = n.array_len;
+    // `<name>__<digits>` is how the elements of an expanded array are named, and the endpoint-kind inference further down
+    // shares one kind per array ROOT by stripping that suffix (canon()): a user node that merely looks like an element
+    // would share kinds with an unrelated node of the root's name -- the spelling is reserved
+    for (const GNode& n : g.nodes) {
+        const size_t us = n.name.rfind("__");
+        if (us != std::string::npos && us > 0 && us + 2 < n.name.size() &&
+            std::all_of(n.name.begin() + (long)us + 2, n.name.end(), [](char ch) { return isdigit((unsigned char)ch); }))
+            fail("node '" + n.name + "': names ending in __<digits> are reserved for the elements of node arrays");
+    }
     if (arr.empty()) return g;
     GraphDesc o;
     o.name = g.name;

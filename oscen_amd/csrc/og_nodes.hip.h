@@ -32,6 +32,46 @@ constexpr float F32_TAU = 6.28318548202514648f;
 OG_DEV float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 OG_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
+// f32::fract(x) / `x % 1.0`: x - trunc(x) is that value exactly; sign(x) * (|x| - floor(|x|)) is the same number in two
+// instructions (v_fract_f32 with an |x| input modifier, v_bfi_b32) instead of three -- the subtraction inside v_fract is
+// exact for a non-negative argument, the hardware's clamp below 1.0 never engages there.  (Differs from x - trunc(x) only
+// in the sign of a zero result for negative whole x.)
+OG_DEV float fract_keep_sign(float x)
+{
+#ifndef OG_HOSTSIM
+    return __builtin_copysignf(__builtin_amdgcn_fractf(__builtin_fabsf(x)), x);
+#else
+    return x - truncf(x);
+#endif
+}
+// f32::rem_euclid(1.0): r = x % 1.0; if r < 0 { r + 1.0 } else { r } -- ONE v_fract_f32 (x - floor(x), rounded once: r is
+// exact, so r + 1.0 rounds to the same number).  The single difference: where r + 1.0 rounds UP to 1.0 (-6e-8 < x < 0) the
+// reference returns 1.0 and v_fract its clamp 0.99999994.
+OG_DEV float fract_floor(float x)
+{
+#ifndef OG_HOSTSIM
+    return __builtin_amdgcn_fractf(x);
+#else
+    const float r = x - truncf(x);
+    const float w = (r < 0.0f) ? r + 1.0f : r;
+    return w >= 1.0f ? 0.99999994f : w;
+#endif
+}
+
+// The phase accumulator of an FM operator: `self.phase = (self.phase + inc).fract()` (fm_operator.rs:68-70).  The phase only
+// ever enters sin(2 pi (phase + mod)), which has period 1, so the representative in [0, 1) -- ONE v_fract_f32 -- gives the
+// same output as the reference's sign-keeping fract; for inc >= 0 (every graph in scope) the two are the same number, bit
+// for bit; for a negative increment the state word reads phase + 1 where the reference holds a negative phase.
+// OG_STRICT: x - trunc(x).
+OG_DEV float fract_phase(float p)
+{
+#ifdef OG_STRICT
+    return p - truncf(p);
+#else
+    return fract_floor(p);
+#endif
+}
+
 // a / b for finite a and b >= 1: v_rcp_f32 plus one Newton step on the
 // quotient (q' = q + (a - q*b) * rcp(b)).  Correctly rounded except for rare
 // 1-ulp misses; 5 VALU ops instead of the 12 of the IEEE expansion.  Only
@@ -217,7 +257,7 @@ OG_DEV float fm_operator_tick(float& phase, float& prev_output, float inc, float
     const float output = og_sin_turns(phase + total_phase_mod) * envelope * level; // ((phase + mod) * TAU).sin(): og_math.h, OG_SIN_TURNS
     prev_output = output;
     const float p = phase + inc; // the phase accumulator keeps the reference's exact operations
-    phase = p - truncf(p); // f32::fract
+    phase = fract_phase(p); // f32::fract
     return output;
 }
 
@@ -229,7 +269,7 @@ OG_DEV float fm_operator_tick_nofb(float& phase, float& prev_output, float inc, 
     const float output = og_sin_turns(phase + phase_mod) * envelope * level;
     prev_output = output;
     const float p = phase + inc;
-    phase = p - truncf(p);
+    phase = fract_phase(p);
     return output;
 }
 
@@ -340,13 +380,9 @@ enum : uint32_t { PB_SINE = 0, PB_SAW = 1, PB_SQUARE = 2, PB_TRIANGLE = 3 };
 // x % 1.0 (Rust `%` = C fmod): x - trunc(x) is that value exactly (the subtraction is exact: both
 // operands share the exponent range of x and the result has fewer significant bits).  Two VALU ops
 // instead of the general fmod loop.  (Differs from fmod only in the sign of a zero result for -0.0.)
-OG_DEV float fmod1(float x) { return x - truncf(x); }
+OG_DEV float fmod1(float x) { return fract_keep_sign(x); }
 
-OG_DEV float wrap_phase(float p) // rem_euclid(1.0) :171-173
-{
-    const float r = fmod1(p);
-    return (r < 0.0f) ? r + 1.0f : r;
-}
+OG_DEV float wrap_phase(float p) { return fract_floor(p); } // rem_euclid(1.0) :171-173
 
 // poly_blep :139-153 and poly_blamp :155-169, written without branches: in a bank some lane is next to
 // a discontinuity on almost every sample, so both sides are evaluated and selected.  rdt = rcp(dt) is

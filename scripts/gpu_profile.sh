@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (one timed region, no real-time record: the LAST launches of the voice kernel are then exactly the timed ones,
 #  which is what scripts/prof_summary.py averages)
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-realtime --repeats 1 $EXTRA"
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-realtime --no-configs --repeats 1 $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE")
 [ -n "${PROF_FULL:-}" ] && PASSES+=("SQ_INSTS_VALU_TRANS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES")

@@ -19,7 +19,10 @@ try:  # the exact command scripts/gpu_profile.sh ran
     cmd = _re.sub(r"python \S*/bench.py", "python bench.py", cmd)
 except OSError:
     pass
-out = {"tag": tag, "command": cmd, "graph": GRAPH, "voices": V, "frames": FR}
+import re as _re2
+_vm = _re2.search(r"--variant\s+(\w+)", cmd)
+VARIANT = _vm.group(1) if _vm else None  # bench.py --variant survey2: matched by bench.py's pmc_profile()
+out = {"tag": tag, "command": cmd, "graph": GRAPH, "voices": V, "frames": FR, "variant": VARIANT}
 con = sqlite3.connect(os.path.join(base, "stats", "stats_results.db"))
 out["kernel_stats"] = [dict(name=r[0], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4])
                        for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 6")]
@@ -43,12 +46,15 @@ def _arg(name, default):
 auto_batch = min(32, max(8, (32 << 20) // (max(1, waves) * 256 * 4)))
 steps, warm, batch = _arg("--steps", 188), _arg("--warmup", 8), (_arg("--bus-batch", 0) or auto_batch)
 timed_launches = (steps + batch - 1) // batch
+if VARIANT == "survey2" and steps > 19:  # the cutoff ramp is set in front of block 19 of the region: og_set_value launches what is queued
+    timed_launches = (19 + batch - 1) // batch + (steps - 19 + batch - 1) // batch
 out["timed_launches"] = timed_launches
 out["blocks_per_launch"] = steps / float(timed_launches)
 # the timed region comes last: its launches are the last `timed_launches` dispatches of the voice kernel (the warm-up
 # blocks in front of it take 2-3 launches: a bulk-scheduled score is uploaded after the first block, and bench.py runs
 # the last warm-up block after the barrier)
-durs = [r[0] for r in con.execute("select (end - start) from kernels where name = ? order by start", (out.get("kernel_name", ""),))]
+# (all variants of the kernel -- _00 plain, _10 ramp table, ... -- of this hash)
+durs = [r[0] for r in con.execute("select (end - start) from kernels where name like ? order by start", ("og_k%" + out.get("kernel_hash", "?") + "%",))]
 out["warmup_launches"] = max(0, len(durs) - timed_launches)
 if len(durs) >= timed_launches:
     out["timed_avg_us"] = sum(durs[-timed_launches:]) / 1e3 / max(1, timed_launches)

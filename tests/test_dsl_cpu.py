@@ -110,6 +110,12 @@ def test_dsl_diagnostics():
         oscen_amd.Graph(dsl="name: X; output o: stream; nodes { a = Gain::new(1.0); b = Gain::new(1.0); } "
                             "connections { a.output -> [b] -> a.input; a.output -> o; }").kernel_source()
     assert "AllowsFeedback" in str(e.value)
+    # `<name>__<digits>` is the spelling of an expanded array element (the endpoint-kind inference shares kinds per array
+    # root by that suffix): a user node spelled like one is refused instead of silently sharing kinds with `osc`
+    with pytest.raises(oscen_amd.OscenError) as e:
+        oscen_amd.Graph(dsl="name: X; output o: stream; nodes { osc = Gain::new(1.0); osc__1 = Gain::new(1.0); } "
+                            "connections { osc.output -> osc__1.input; osc__1.output -> o; }").kernel_source()
+    assert "reserved for the elements of node arrays" in str(e.value)
 
 
 def test_dsl_feedback_through_delay():

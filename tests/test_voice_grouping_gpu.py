@@ -165,6 +165,29 @@ def test_a_snapshot_of_a_grouped_bank_carries_the_voice_order():
         fresh.load_state(bad)
 
 
+def test_voice_taps_survive_a_load_that_changes_the_slot_order():
+    """og_load_state adopts the blob's voice order; taps set BEFORE the load keep reading the same voice numbers (ADVICE r4:
+    round 4 silently cleared them when the order changed)."""
+    n, block = 150, 128
+    total = block * 8
+    plans, plain, grouped = fm_pair(n, total)
+    taps = np.arange(3, n, 11, dtype=np.uint32)
+    for _ in range(3):
+        grouped.process_block(block)
+    blob = grouped.save_state()
+    grouped.set_voice_taps(taps)
+    want = [(grouped.process_block(block).copy(), grouped.read_voice_taps(block)) for _ in range(4)]
+    fresh = oscen_amd.Engine("fm_voice", n, sample_rate=SR)   # identity order
+    fresh.set_voice_taps(taps)                                # ... taps resolved under the identity
+    fresh.load_state(blob)                                    # the order changes under them
+    assert fresh.voice_slot(int(taps[1])) == grouped.voice_slot(int(taps[1]))
+    for bus, tp in want:
+        b2 = fresh.process_block(block)
+        assert np.array_equal(b2, bus)
+        assert np.array_equal(fresh.read_voice_taps(block), tp)
+    assert np.abs(want[0][1]).max() > 0.0
+
+
 def test_event_outputs_and_cluster_shards_keep_voice_numbers_under_grouping():
     oscen_amd.register_node(
         "GvBurst::new", inputs=[("period", "value", 100.0, 0), ("trig", "event", 0.0, -1)], outputs=["level"], n_ctor_args=1,
