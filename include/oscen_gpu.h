@@ -80,8 +80,12 @@ int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type
  * them every stream/value input is a `const float <name>`, every private field a `float& <name>` (or `uint32_t&`),
  * every output a `float& <name>` to assign, plus `const float sample_rate`; an event handler also sees
  * `const float value` (the scalar payload) -- and, if its source names it, `const uint32_t frame_offset`
- * (EventInstance::frame_offset: the offset inside the process_block call, times N for a `* N` node) -- but only the VALUE inputs (streams do not exist yet when an event
- * fires).  og_math.h / og_nodes.hip.h helpers (og_sinf, og::clampf, ...) are in scope.  The bodies are compiled into
+ * (EventInstance::frame_offset, oscen-lib/src/graph/types.rs:129-132: for an event of a GRAPH input the offset inside the
+ * process_block call, times N for a `* N` node; for an event pushed by another NODE the offset its producer gave it --
+ * `<event_output>.push_at(frame_offset, value)`, plain `push(value)` = offset 0 -- multiplied (saturating) by N on an
+ * outer -> inner edge and divided by N on an inner -> outer edge, codegen/emit_edge.rs:86-99) -- but only the VALUE inputs
+ * (streams do not exist yet when an event fires).  og_math.h / og_nodes.hip.h helpers (og_sin_turns, og_sinf, og::clampf,
+ * ...) are in scope.  The bodies are compiled into
  * the fused voice kernel by hiprtc when an engine is created for a graph that uses the type.  Process-wide registry. */
 typedef struct {
     const char* name;

@@ -1145,9 +1145,18 @@ constexpr float ADSR_CURVE_K = 4.6051702f;
 
 void NodeCtx::on_event(const std::string& port, const std::function<std::string(const std::string&)>& gen)
 {
+    // `@OFF@` in the generated call = the EventInstance::frame_offset the handler receives: for an event of a GRAPH input the
+    // offset inside its process_block call (times N for a node of the oversampled region: compute_event_rescale,
+    // ir/lower.rs:846-852); for an event pushed by another NODE the offset the producer gave it, rescaled across a rate
+    // boundary like the reference's drains (codegen/emit_edge.rs:86-99: outer -> inner saturating_mul(N), inner -> outer / N)
+    auto with_off = [](std::string call, const std::string& off) {
+        for (size_t pos = call.find("@OFF@"); pos != std::string::npos; pos = call.find("@OFF@", pos)) call.replace(pos, 5, off);
+        return call;
+    };
     auto ev = n.ev_edges.find(port);
     if (ev != n.ev_edges.end())
-        for (int ei : ev->second) cg.S().ev_handlers[ei] << gen("ev.value");
+        for (int ei : ev->second)
+            cg.S().ev_handlers[ei] << with_off(gen("ev.value"), n.domain == 1 ? "blk_off(f) * " + std::to_string(cg.N) + "u" : "blk_off(f)");
     auto nv = n.ev_node_edges.find(port);
     if (nv == n.ev_node_edges.end()) return;
     const NodeInst& src = cg.nodes[nv->second.first];
@@ -1166,6 +1175,10 @@ void NodeCtx::on_event(const std::string& port, const std::function<std::string(
     // i.e. at the start of the NEXT outer frame, over everything the producer pushed during this one (step 6a,
     // codegen/emit_frame.rs:150-160; oscen-macros/src/lib.rs:266-285: process_event_inputs clears the node's own outputs,
     // then dispatches its input queues)
+    const std::string Ns = std::to_string(cg.N) + "u";
+    const std::string node_off = (src.domain == 0 && n.domain == 1) ? "og::sat_mul_u32(" + q + ".off(evk), " + Ns + ")"
+                                 : (src.domain == 1 && n.domain == 2) ? "(" + q + ".off(evk) / " + Ns + ")"
+                                                                      : q + ".off(evk)";
     const bool inner_pair = n.domain == 1 && src.domain <= 1; // the handler runs at step 6a, in front of the inner loop
     if (inner_pair && gen("evv").find("[j]") != std::string::npos)
         fail_unsupported("node '" + n.decl->name + "': a handler fed by another oversampled node runs in front of the inner loop; "
@@ -1178,7 +1191,7 @@ void NodeCtx::on_event(const std::string& port, const std::function<std::string(
             << "                if (OG_NODE_EVENTS_PER_FRAME > 4 && !__any((int)(evk < " << q << ".n))) break;\n"
             << "                else if (evk < " << q << ".n) {\n"
             << "                const float evv = " << q << ".get(evk);\n"
-            << gen("evv") << "                }\n"
+            << with_off(gen("evv"), node_off) << "                }\n"
             << "        }\n";
 }
 
@@ -1459,7 +1472,8 @@ void emit_lp18(NodeCtx& x)
 // Delay (oscen-lib/src/delay/mod.rs): the line itself is an HBM ring per voice (CompiledGraph::rings)
 void emit_delay(NodeCtx& x)
 {
-    if (x.cg.out.lpv != 1) fail_unsupported("Delay is not supported in array-valued (several lanes per voice) graphs");
+    // (array-valued graphs: the line stays one ring per VOICE; the lanes of a voice hold the same per-voice scalars, read
+    //  the same slots and write the same value to the same slot -- each lane's loads see its own stores)
     if (x.cg.out.rings.size() >= 4) fail("at most 4 Delay nodes per graph");
     const Val in = x.in("input");
     const Val ds = x.in("delay_samples");
@@ -1792,10 +1806,16 @@ void emit_user(NodeCtx& x)
             const int wn = x.cg.new_state(x.n.decl->name + "." + o + ".n", false, [](const UEnv&) { return 0u; });
             x.cg.S().load << "        " << x.p << o << ".n = og::ld_u(A, c, " << wn << ");\n";
             x.cg.S().store << "        og::st_u(A, c, " << wn << ", " << x.p << o << ".n);\n";
+            bool sets_offsets = u.process_src.find("push_at") != std::string::npos;
+            for (const auto& h : u.handlers) sets_offsets = sets_offsets || h.second.find("push_at") != std::string::npos;
             for (int k = 0; k < x.cg.ev_capacity; ++k) {
                 const int wv = x.cg.new_state(x.n.decl->name + "." + o + ".v" + std::to_string(k), true, [](const UEnv&) { return fbits(0.0f); });
                 x.cg.S().load << "        " << x.p << o << ".v[" << k << "] = og::ld_f(A, c, " << wv << ");\n";
                 x.cg.S().store << "        og::st_f(A, c, " << wv << ", " << x.p << o << ".v[" << k << "]);\n";
+                if (!sets_offsets) continue; // (every push is push(x): all offsets are 0)
+                const int wo = x.cg.new_state(x.n.decl->name + "." + o + ".o" + std::to_string(k), false, [](const UEnv&) { return 0u; });
+                x.cg.S().load << "        " << x.p << o << ".o[" << k << "] = og::ld_u(A, c, " << wo << ");\n";
+                x.cg.S().store << "        og::st_u(A, c, " << wo << ", " << x.p << o << ".o[" << k << "]);\n";
             }
         }
         x.cg.out.has_node_event_outputs = true;
@@ -1816,8 +1836,7 @@ void emit_user(NodeCtx& x)
         for (const std::string& v : evo) args << ", " << v;
         args << ", " << x.sf(s_sr) << ");\n";
         const std::string tail = args.str(), name = fn + "_on_" + h.first;
-        const std::string off = !uses_offset ? std::string()
-                                             : (x.n.domain == 1 ? ", blk_off(f) * " + std::to_string(x.cg.N) + "u" : std::string(", blk_off(f)"));
+        const std::string off = !uses_offset ? std::string() : std::string(", @OFF@"); // (NodeCtx::on_event: by the event's source)
         x.on_event(h.first, [&](const std::string& val) { return "                " + name + "(" + val + off + tail; });
     }
     for (const auto& kv : x.n.ev_edges)
@@ -3091,8 +3110,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     for (size_t i = 0; i < g.nodes.size(); ++i)
         if (cg.nodes[i].live && !cg.nodes[i].ev_node_edges.empty()) cg.dynamic_events = true;
     if (!ev_out_edges.empty()) cg.dynamic_events = true; // (the per-frame log / clear lives in the ordinary kernel's tick)
-    if (!ev_out_edges.empty() && out.lpv != 1) fail_unsupported("graph event outputs are not supported in array-valued (several lanes per voice) graphs");
-    if (cg.dynamic_events && out.lpv != 1) fail_unsupported("node-to-node event edges are not supported in array-valued (several lanes per voice) graphs");
+    // (array-valued graphs -- several lanes per voice: the per-voice scalars, event queues included, are replicated on the
+    //  voice's lanes, every lane runs the handlers, and only the voice's lead lane logs a graph event output or counts a
+    //  dropped push: og_kernel_rt.hip.h, VoiceCtx::lead)
 
     // ---- Kahn topological sort (ir/lower.rs:1015-1085), ready set in declaration order
     std::vector<int> order;

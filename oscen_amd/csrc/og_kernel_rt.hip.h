@@ -171,12 +171,27 @@ struct EvOut {
     uint32_t n = 0u;
     uint32_t lost = 0u; // pushes past the capacity on this frame (reported through OgBlockArgs::ev_lost, og_events_dropped)
     float v[OG_NODE_EVENTS_PER_FRAME] = {};
-    __device__ __forceinline__ void push(float x) // try_push: dropped when the frame's queue is full
+    // EventInstance::frame_offset (graph/types.rs:129-132) as the producer set it: carried along the edge, multiplied / divided
+    // by N across a rate boundary (codegen/emit_edge.rs:86-99), handed to a handler that names `frame_offset`.  Nobody
+    // reading it, the compiler drops the array.
+    uint32_t o[OG_NODE_EVENTS_PER_FRAME] = {};
+    __device__ __forceinline__ void push_at(uint32_t frame_offset, float x) // try_push(EventInstance { frame_offset, Scalar(x) }): dropped when the frame's queue is full
     {
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++k) v[k] = (n == k) ? x : v[k];
+        for (uint32_t k = 0; k < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++k) {
+            v[k] = (n == k) ? x : v[k];
+            o[k] = (n == k) ? frame_offset : o[k];
+        }
         lost += (n >= (uint32_t)OG_NODE_EVENTS_PER_FRAME) ? 1u : 0u;
         n = min(n + 1u, (uint32_t)OG_NODE_EVENTS_PER_FRAME);
+    }
+    __device__ __forceinline__ void push(float x) { push_at(0u, x); } // frame_offset 0: "now", what the reference's per-frame producers push
+    __device__ __forceinline__ uint32_t off(uint32_t k) const
+    {
+        uint32_t r = o[0];
+#pragma unroll
+        for (uint32_t j = 1; j < (uint32_t)OG_NODE_EVENTS_PER_FRAME; ++j) r = (k == j) ? o[j] : r;
+        return r;
     }
     __device__ __forceinline__ float get(uint32_t k) const
     {
@@ -187,6 +202,13 @@ struct EvOut {
     }
     __device__ __forceinline__ void clear() { n = 0u; lost = 0u; }
 };
+
+// u32::saturating_mul (the reference's outer -> inner rescale of an event's frame_offset)
+__device__ __forceinline__ uint32_t sat_mul_u32(uint32_t a, uint32_t b)
+{
+    const unsigned long long p = (unsigned long long)a * (unsigned long long)b;
+    return p > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p;
+}
 
 struct VoiceCtx {
     uint32_t v;     // voice index

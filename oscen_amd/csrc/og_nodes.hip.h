@@ -964,8 +964,10 @@ OG_DEV void ep_amp_begin(EpAmp& a, float* decay_plane, float* release_plane, boo
 {
     __shared__ float4 ep_mult[OG_HPL >= 4 ? OG_HPL / 4 : 1][OG_WAVE]; // (one-wave workgroups: column = lane)
     a.mult = &ep_mult[0][threadIdx.x % OG_WAVE];
-    a.decay = decay_plane;
-    a.release = release_plane;
+    // (a lane beyond the bank's last voice owns no planes: a node-to-node event can reach its handler -- every lane runs the
+    //  tick -- and must not write through these)
+    a.decay = valid ? decay_plane : nullptr;
+    a.release = valid ? release_plane : nullptr;
     HarmV m = harm_splat(0.0f);
     if (valid) m = ep_plane_get(a.released != 0u ? release_plane : decay_plane);
     ep_mult_put(a, m);
@@ -1001,8 +1003,10 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
             cur[j] = amp;
         }
         const HarmV decay = harm_make(dec);
-        ep_plane_put(a.decay, decay); // self.decay = get_decay(..), self.release = get_release(..): the state planes
-        ep_plane_put(a.release, harm_splat(rel));
+        if (a.decay) { // self.decay = get_decay(..), self.release = get_release(..): the state planes
+            ep_plane_put(a.decay, decay);
+            ep_plane_put(a.release, harm_splat(rel));
+        }
         ep_mult_put(a, decay);
         a.cur = harm_make(cur);
         a.released = 0u;
@@ -1010,7 +1014,7 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
     } else {
         a.released = 1u;
         a.step = 0u;
-        ep_mult_put(a, ep_plane_get(a.release)); // (this lane's own earlier stores, if any, are visible to its loads)
+        if (a.release) ep_mult_put(a, ep_plane_get(a.release)); // (this lane's own earlier stores, if any, are visible to its loads)
     }
 }
 

@@ -478,3 +478,64 @@ def test_event_edge_between_two_oversampled_nodes_is_delivered_once_per_outer_ti
     finally:
         oscen_amd.unregister_node("R4Clock::new")
         oscen_amd.unregister_node("R4Counter::new")
+
+
+def test_a_node_to_node_event_carries_the_frame_offset_its_producer_gave_it():
+    """EventInstance::frame_offset (oscen-lib/src/graph/types.rs:129-132) on IN-VOICE events: the producer's value travels
+    with the event -- not the frame the handler happens to run on -- and a rate boundary rescales it like the reference's
+    drains (oscen-graph-compiler/src/codegen/emit_edge.rs:86-99: outer -> inner `saturating_mul(N)`, inner -> outer `/ N`).
+    `out.push_at(offset, value)` = try_push(EventInstance { frame_offset, Scalar(value) }); `push(value)` leaves it 0."""
+    oscen_amd.register_node(
+        "OffSrc::new", inputs=[("period", "value", 10.0, 0), ("base", "value", 0.0, -1)], outputs=[], n_ctor_args=1,
+        state=[("count", "u32", 0, -1), ("fired", "u32", 0, -1)], event_outputs=["trig"],
+        process="""
+    count += 1u;
+    if ((float)count >= period) { count = 0u; fired += 1u; trig.push_at((uint32_t)base + 3u * fired, 0.25f * (float)fired); }
+""")
+    oscen_amd.register_node(
+        "OffCap::new", inputs=[("input", "event", 0.0, -1)], outputs=["seen"],
+        state=[("cap", "f32", -1.0, -1), ("val", "f32", 0.0, -1), ("hits", "f32", 0.0, -1)],
+        handlers={"input": "    cap = (float)frame_offset;\n    val = value;\n    hits += 1.0f;\n"}, process="    seen = cap;\n")
+    # a forwarding handler: what it pushes with push() starts again at offset 0, with push_at(frame_offset, ..) it passes on
+    oscen_amd.register_node(
+        "OffFwd::new", inputs=[("input", "event", 0.0, -1)], outputs=[], event_outputs=["same", "zero"],
+        handlers={"input": "    same.push_at(frame_offset, value);\n    zero.push(value);\n"}, process="")
+    try:
+        n, frames = 67, 96
+        periods = (7 + np.arange(n) % 13).astype(np.float32)
+        bases = (100 * (np.arange(n) % 5)).astype(np.float32)
+        fired = frames // periods.astype(np.int64)          # pushes per voice in `frames` frames
+        last_off = bases.astype(np.int64) + 3 * fired        # the producer's offset of its LAST push
+        for src_rate, dst_rate, scale in (("", "", lambda o: o), ("", " * 4", lambda o: np.minimum(o * 4, 0xFFFFFFFF)), (" * 4", "", lambda o: o // 4)):
+            inner_src = bool(src_rate)
+            g = oscen_amd.Graph(dsl=f"""name: OffEdge; input period: value = 10.0; input base: value = 0.0; output out: stream;
+                nodes {{ src = OffSrc::new(10.0){src_rate}; fwd = OffFwd::new(){src_rate}; a = OffCap::new(){dst_rate}; b = OffCap::new(){dst_rate}; z = OffCap::new(){dst_rate}; }}
+                connections {{ period -> src.period; base -> src.base; src.trig -> a.input; src.trig -> fwd.input; fwd.same -> b.input; fwd.zero -> z.input;
+                               {'[latch] ' if dst_rate else ''}a.seen + b.seen + z.seen -> out; }}""",
+                                per_voice=["period", "base"])
+            eng = oscen_amd.Engine(g, n, sample_rate=SR)
+            # an oversampled producer ticks N times per frame: its counter reaches `period` N times as often
+            eng.set_voice_values("period", periods * (4 if inner_src else 1))
+            eng.set_voice_values("base", bases)
+            for b in (64, 32):
+                eng.process_block(b)
+            hits = eng.read_state_field("a.hits")
+            assert np.array_equal(hits, fired.astype(np.float32)), (src_rate, dst_rate)
+            want = scale(last_off).astype(np.float32)
+            want[fired == 0] = -1.0
+            assert np.array_equal(eng.read_state_field("a.cap"), want), (src_rate, dst_rate)   # the straight edge
+            # ... and through the forwarding handler.  With BOTH src and fwd in the oversampled region the handler runs at
+            # step 6a of the NEXT outer frame (codegen/emit_frame.rs:150-160), so b has not seen a push of the last frame yet
+            fired_b = fired
+            if inner_src:
+                p4 = (periods * 4).astype(np.int64)
+                fired_b = np.array([sum(1 for k in range(1, int(fired[v]) + 1) if (k * p4[v] - 1) // 4 <= frames - 2) for v in range(n)])
+            want_b = scale(bases.astype(np.int64) + 3 * fired_b).astype(np.float32)
+            want_b[fired_b == 0] = -1.0
+            assert np.array_equal(eng.read_state_field("b.cap"), want_b), (src_rate, dst_rate, "through the forwarder")
+            zero = np.where(fired_b > 0, 0.0, -1.0).astype(np.float32)
+            assert np.array_equal(eng.read_state_field("z.cap"), zero)  # push(): frame_offset 0
+            assert np.array_equal(eng.read_state_field("a.val"), (0.25 * fired).astype(np.float32))
+    finally:
+        for t in ("OffSrc::new", "OffCap::new", "OffFwd::new"):
+            oscen_amd.unregister_node(t)
