@@ -742,7 +742,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
         ones = torch.ones(1, dtype=torch.float32, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(ones)  # every rank of the communicator took part
         rccl_ranks = int(round(float(ones.item())))
-    times, sclk = [], []
+    times, sclk, kclk = [], [], []
     reduce_events, reduce_host_ms = [], []
     kern_total_ms, n_launch, n_blocks_timed = 0.0, 0, 0
     for r in range(R):
@@ -783,6 +783,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
         times.append(elapsed)
         sclk.append(eng.shader_clock_ghz())        # (after the clock has stopped: a 20 us probe of the shader clock as the region left it)
         ms, n = eng.kernel_time_ms()               # average duration of a voice-kernel LAUNCH (HIP events on the engine's stream)
+        kclk.append(eng.kernel_clock_ghz or None)  # ... and the shader clock those launches ran at, read by the kernel itself
         kern_total_ms += ms * n
         n_launch += n
         n_blocks_timed += eng.kernel_blocks_timed  # blocks those launches rendered (up to --bus-batch per launch)
@@ -814,7 +815,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
                     "recorded around it on the rendering stream (median over the regions)",
         }
 
-    return types.SimpleNamespace(eng=eng, times=times, sclk=sclk, kern_ms=kern_ms, n_launch=n_launch, n_blocks_timed=n_blocks_timed, multi_gpu=multi_gpu,
+    return types.SimpleNamespace(eng=eng, times=times, sclk=sclk, kclk=kclk, kern_ms=kern_ms, n_launch=n_launch, n_blocks_timed=n_blocks_timed, multi_gpu=multi_gpu,
                                  rccl_ranks=rccl_ranks, timed_blocks=timed_blocks, bus=bus, host_bus=host_bus, midi=midi,
                                  n_events_timed=n_events_timed, span=span, total_voices=total_voices, block=block, ch=ch)
 
@@ -1155,8 +1156,11 @@ def main():
                               if midi is not None
                               else "resident timeline (og_schedule_voice_events)",
             },
-            # sclk_ghz_after_region: the shader clock each region left behind (og_shader_clock_ghz) -- region times follow it
-            "timing": dict(stats, repeats_rule=repeats_rule, sclk_ghz_after_region=[None if x is None else round(x, 3) for x in m.sclk]),
+            # kernel_sclk_ghz: the shader clock the voice kernel ran at in each region, measured by the kernel itself (workgroup
+            # 0: shader cycles / 100 MHz ticks between its first and last instruction, og_kernel_clock_ghz) -- region times
+            # follow it; sclk_ghz_after_region: what an idle-GPU probe reads right after the region (og_shader_clock_ghz)
+            "timing": dict(stats, repeats_rule=repeats_rule, kernel_sclk_ghz=[None if not x else round(x, 3) for x in m.kclk],
+                           sclk_ghz_after_region=[None if x is None else round(x, 3) for x in m.sclk]),
             "rccl_ranks": rccl_ranks,
             "multi_gpu": multi_gpu,  # None at N = 1 (no collective on the data path)
             # throughput of the QUEUED path (blocks known ahead, up to 32 per launch) expressed in 48 kHz voices: an

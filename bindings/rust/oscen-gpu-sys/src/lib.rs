@@ -180,6 +180,7 @@ extern "C" {
     pub fn og_enable_kernel_timing(e: *mut og_engine, on: c_int) -> c_int;
     pub fn og_kernel_time_ms(e: *mut og_engine, n_launches: *mut u32) -> f64;
     pub fn og_shader_clock_ghz(e: *mut og_engine, ghz: *mut f64) -> c_int;
+    pub fn og_kernel_clock_ghz(e: *const og_engine) -> f64;
     pub fn og_kernel_blocks_timed(e: *const og_engine) -> u64;
     pub fn og_kernel_is_jit(e: *const og_engine) -> c_int;
     pub fn og_kernel_name(e: *const og_engine) -> *const c_char;

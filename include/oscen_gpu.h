@@ -405,6 +405,10 @@ int og_blocking_stats(const og_engine* e, uint64_t* calls, uint64_t* marker_time
 int og_enable_kernel_timing(og_engine* e, int on);
 double og_kernel_time_ms(og_engine* e, uint32_t* n_launches);
 uint64_t og_kernel_blocks_timed(const og_engine* e); /* blocks those launches covered (> launches with og_set_bus_batching) */
+/* the shader clock the launches averaged by the LAST og_kernel_time_ms call ran at, measured by the voice kernel itself: its
+ * first workgroup reads the shader-cycle counter and the constant 100 MHz counter at its first and last instruction (0 when
+ * timing was off or the device has no such counters) */
+double og_kernel_clock_ghz(const og_engine* e);
 /* the shader clock the device runs at NOW: a one-wave probe on the engine's stream counts shader cycles (s_memtime) over
  * 20 us of the constant 100 MHz counter (s_memrealtime); blocks until it has run.  A measurement aid: the clock governor
  * takes tens of milliseconds of load to settle, so short bursts of blocks run slower than a steady stream of them. */

@@ -571,8 +571,11 @@ struct og_engine {
 
     bool timing = false;
     std::vector<hipEvent_t> t_start, t_stop;
+    unsigned long long* h_clock = nullptr; // pinned, [T_CLOCK][4]: {cycles, ticks} at the start and at the end of timed launch i
+    static constexpr size_t T_CLOCK = 8192;
     size_t t_used = 0;
     size_t t_blocks = 0; // blocks the timed launches covered
+    double last_clock_ghz = 0.0;
 
     ~og_engine()
     {
@@ -609,6 +612,7 @@ struct og_engine {
         }
         if (h_progress) (void)hipHostFree((void*)h_progress);
         if (h_bus_pinned) (void)hipHostFree(h_bus_pinned);
+        if (h_clock) (void)hipHostFree(h_clock);
         for (auto ev : t_start) (void)hipEventDestroy(ev);
         for (auto ev : t_stop) (void)hipEventDestroy(ev);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -1130,6 +1134,11 @@ struct og_engine {
                 t_stop.push_back(b);
             }
             HIPCK(hipEventRecord(t_start[t_used], stream));
+            if (!h_clock) {
+                HIPCK(hipHostMalloc((void**)&h_clock, T_CLOCK * 4 * sizeof(unsigned long long), hipHostMallocDefault));
+                memset(h_clock, 0, T_CLOCK * 4 * sizeof(unsigned long long));
+            }
+            A.clock_out = h_clock + 4 * t_used; // (pinned host memory is device-visible: four 8-byte stores per launch)
         }
         if (launch)
             launch(A, ramps_on, taps_on, stream);
@@ -2455,9 +2464,23 @@ double og_kernel_time_ms(og_engine* e, uint32_t* n_launches)
     }
     if (n_launches) *n_launches = (uint32_t)e->t_used;
     const double avg = e->t_used ? total / (double)e->t_used : 0.0;
+    // the shader clock of those launches: total cycles / total 100 MHz ticks between the marks of workgroup 0
+    double cyc = 0.0, ticks = 0.0;
+    for (size_t i = 0; e->h_clock && i < e->t_used; ++i) {
+        const unsigned long long* q = e->h_clock + 4 * i;
+        if (q[3] > q[1] && q[2] > q[0]) {
+            cyc += (double)(q[2] - q[0]);
+            ticks += (double)(q[3] - q[1]);
+        }
+    }
+    e->last_clock_ghz = ticks > 0.0 ? cyc / ticks * 0.1 : 0.0;
     e->t_used = 0;
     return avg;
 }
+
+/* the shader clock the launches of the LAST og_kernel_time_ms call ran at, measured by the voice kernel itself (0 where the
+ * device has no such counters) */
+double og_kernel_clock_ghz(const og_engine* e) { return e ? e->last_clock_ghz : 0.0; }
 
 int og_shader_clock_ghz(og_engine* e, double* ghz)
 {

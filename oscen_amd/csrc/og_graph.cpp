@@ -3502,8 +3502,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                          " and " + (w > 1 ? "Frame<" + std::to_string(w) + ">" : std::string("f32")) + " sources");
                 width = w;
                 if (w > 1) {
-                    if (out.lpv != 1 || out.bus_tremolo)
-                        fail_unsupported("a Frame<N> graph output is not supported in array-valued or post-mix graphs yet");
+                    if (out.bus_tremolo) // (array-valued voices: the voice's lead lane puts every channel, og::bus_put)
+                        fail_unsupported("a Frame<N> graph output is not supported in post-mix graphs yet");
                     if (k == 0) acc.assign((size_t)w, std::string());
                     for (int c = 0; c < w; ++c) acc[(size_t)c] = (k == 0) ? v.ch[(size_t)c].e : "(" + acc[(size_t)c] + " + " + v.ch[(size_t)c].e + ")";
                     continue;
@@ -3557,8 +3557,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 chans.push_back(var);
             }
         }
-        if (chans.size() > 1 && (out.lpv != 1 || out.bus_tremolo))
-            fail_unsupported("several bus channels (stream outputs / Frame<2>) are not supported in array-valued or post-mix graphs yet");
+        if (chans.size() > 1 && out.bus_tremolo)
+            fail_unsupported("several bus channels (stream outputs / Frame<2>) are not supported in post-mix graphs yet");
         if (chans.size() > 4) fail("the mix bus carries at most 4 channels (stream outputs, a Frame<N> counting N)");
         if (chans.size() == 1) {
             cg.os() << "        const float g_out = " << chans[0] << ";\n";

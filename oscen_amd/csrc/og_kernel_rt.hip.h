@@ -90,6 +90,9 @@ struct OgBlockArgs {
     uint32_t out_ev_cap;
     uint32_t _pad0;
     uint32_t* ev_lost;         // pushes an in-voice event queue could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output)
+    // timed launches only (og_enable_kernel_timing), else null: workgroup 0 writes {shader cycles, 100 MHz ticks} at its first
+    // and last instruction -- the shader clock the launch ran at UNDER ITS OWN LOAD (og_kernel_clock_ghz)
+    unsigned long long* clock_out; // [4]
     float* rings[OG_MAX_RINGS];        // delay lines: [capacity][n_voices] each (slot-major, voices contiguous)
     uint32_t ring_cap[OG_MAX_RINGS];   // capacity in samples (a power of two, ring_buffer/mod.rs:35-41)
     uint32_t slots[OG_MAX_SLOTS]; // block-uniform values (f32 or u32 bits)
@@ -203,6 +206,21 @@ struct EvOut {
     __device__ __forceinline__ void clear() { n = 0u; lost = 0u; }
 };
 
+// s_memtime ticks once per shader cycle, s_memrealtime at a constant 100 MHz (MI355X_MICROARCH.md): the two, read at the first
+// and the last instruction of workgroup 0, give the clock the launch really ran at.  One scalar branch per call.
+__device__ __forceinline__ void clock_mark(const OgBlockArgs& a, int which)
+{
+#ifndef OG_HOSTSIM
+    if (a.clock_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.clock_out[2 * which] = __builtin_readcyclecounter();
+        a.clock_out[2 * which + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#else
+    (void)a;
+    (void)which;
+#endif
+}
+
 // u32::saturating_mul (the reference's outer -> inner rescale of an event's frame_offset)
 __device__ __forceinline__ uint32_t sat_mul_u32(uint32_t a, uint32_t b)
 {
@@ -297,6 +315,7 @@ __device__ __forceinline__ void voice_begin(const OgBlockArgs& a, VoiceCtx& c)
     }
     ev_arm<false>(a, c);
     c.ev_cur0 = c.ev_cur;
+    clock_mark(a, 0);
 }
 
 // two-wave pipeline kernel: both waves of the workgroup see the same 64 voices
@@ -317,11 +336,13 @@ __device__ __forceinline__ void voice_begin_split(const OgBlockArgs& a, VoiceCtx
     }
     ev_arm(a, c);
     c.ev_cur0 = c.ev_cur;
+    clock_mark(a, 0);
 }
 
 __device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
 {
     if (c.valid && c.lead && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
+    clock_mark(a, 1);
 }
 
 // end of a frame, before the queues are cleared: count the pushes an event output had to drop ...

@@ -164,3 +164,54 @@ def test_delay_line_behind_an_array_valued_voice(delay_samples, feedback):
         worst = max(worst, float(np.max(np.abs(wet[v] - ref) / np.maximum(1.0, np.abs(ref)))))
     assert np.abs(dry).max() > 0.5 and not np.array_equal(dry, wet)
     assert worst <= 1e-5, worst
+
+
+def test_several_bus_channels_of_an_array_valued_voice():
+    """Two stream outputs / a Frame<2> output of a voice whose nodes are array-valued: every channel is summed over the
+    VOICES (emit_node.rs:463-466 `voices.out -> out` per output) -- the voice's lead lane contributes, not each of its four
+    lanes.  Checked against the one-output graph: channel 0 is its bus, channel 1 the scaled copy; taps likewise."""
+    n, blocks = 53, (256, 100)
+    freqs = np.linspace(80.0, 900.0, n).astype(np.float32)
+    vs, fs, xs = clock_events((61 + 7 * np.arange(n)).astype(np.float32), sum(blocks))
+
+    def graph(kind):
+        g = oscen_amd.Graph("ep_" + kind)
+        g.input_value("frequency", 220.0, per_voice=True)
+        g.input_event("gate")
+        if kind == "two":
+            g.output_stream("out_a")
+            g.output_stream("out_b")
+        elif kind == "frame":
+            g.output_stream("out")  # (fed a Frame(..): a Frame<2> voice output)
+        else:
+            g.output_stream("out")
+        g.node("amp", "AmplitudeSource::new")
+        g.node("bank", "OscillatorBank::new")
+        for s, d in (("frequency", "amp.frequency"), ("frequency", "bank.frequency"), ("gate", "amp.gate"), ("gate", "bank.gate"),
+                     ("amp.amplitudes", "bank.amplitudes")):
+            g.connect(s, d)
+        if kind == "two":
+            g.connect("bank.output", "out_a")
+            g.connect("bank.output * 0.5", "out_b")
+        elif kind == "frame":
+            g.connect("Frame(bank.output, bank.output * 0.5)", "out")
+        else:
+            g.connect("bank.output", "out")
+        return g
+
+    res = {}
+    for kind in ("one", "two", "frame"):
+        e = oscen_amd.Engine(graph(kind), n, sample_rate=SR)
+        assert e.lanes_per_voice == 4 and e.channels == (1 if kind == "one" else 2)
+        e.set_voice_values("frequency", freqs)
+        e.schedule_voice_events("gate", vs, fs, xs)
+        res[kind] = render(e, blocks)
+    taps1, bus1 = res["one"]
+    assert np.abs(taps1).max() > 0.5
+    for kind in ("two", "frame"):
+        taps, bus = res[kind]
+        assert taps.shape == taps1.shape + (2,) and bus.shape == (sum(blocks), 2)
+        assert np.array_equal(taps[..., 0], taps1) and np.array_equal(taps[..., 1], taps1 * np.float32(0.5))
+        scale = max(1.0, float(np.abs(taps1).sum(axis=0).max()))
+        assert np.allclose(bus[:, 0], bus1[:, 0], rtol=0, atol=1e-5 * scale)
+        assert np.allclose(bus[:, 1], 0.5 * bus1[:, 0], rtol=0, atol=1e-5 * scale)
