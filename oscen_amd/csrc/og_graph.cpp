@@ -2019,13 +2019,22 @@ GraphDesc expand_arrays(const GraphDesc& g)
     for (const GNode& n : g.nodes)
         if (n.array_len) arr[n.name] = n.array_len;
     // `<name>__<digits>` is how the elements of an expanded array are named, and the endpoint-kind inference further down
-    // shares one kind per array ROOT by stripping that suffix (canon()): a user node that merely looks like an element
-    // would share kinds with an unrelated node of the root's name -- the spelling is reserved
-    for (const GNode& n : g.nodes) {
-        const size_t us = n.name.rfind("__");
-        if (us != std::string::npos && us > 0 && us + 2 < n.name.size() &&
-            std::all_of(n.name.begin() + (long)us + 2, n.name.end(), [](char ch) { return isdigit((unsigned char)ch); }))
-            fail("node '" + n.name + "': names ending in __<digits> are reserved for the elements of node arrays");
+    // shares one kind per array ROOT by stripping that suffix (canon()).  A graph written out element by element
+    // (`oscs__0`, `oscs__1`, ...: what to_dsl prints for an expanded array) is fine -- the elements share their root's kinds,
+    // as in the array form; a node spelled like an element of ANOTHER node of the graph (`osc__1` next to `osc`) would
+    // share kinds with an unrelated node: refused
+    {
+        std::set<std::string> names;
+        for (const GNode& n : g.nodes) names.insert(n.name);
+        for (const GNode& n : g.nodes) {
+            const size_t us = n.name.rfind("__");
+            if (n.array_len || us == std::string::npos || us == 0 || us + 2 >= n.name.size() ||
+                !std::all_of(n.name.begin() + (long)us + 2, n.name.end(), [](char ch) { return isdigit((unsigned char)ch); }))
+                continue;
+            if (names.count(n.name.substr(0, us)))
+                fail("node '" + n.name + "': names ending in __<digits> are reserved for the elements of node arrays (the graph also has a node '" +
+                     n.name.substr(0, us) + "')");
+        }
     }
     if (arr.empty()) return g;
     GraphDesc o;
