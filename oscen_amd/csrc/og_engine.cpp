@@ -170,6 +170,12 @@ OgLaunchFn og_find_kernel(uint64_t hash)
         if (e->hash == hash) return e->launch;
     return nullptr;
 }
+OgOccupancyFn og_find_occupancy(uint64_t hash)
+{
+    for (OgKernelEntry* e = og_kernel_registry_head(); e; e = e->next)
+        if (e->hash == hash) return e->occupancy;
+    return nullptr;
+}
 
 namespace {
 thread_local std::string g_err;
@@ -1613,13 +1619,44 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // barriers, per-wave loop and event bookkeeping) -- they win where they raise occupancy: four waves up to
             // ~131 072 voices (measured 65 536: 0.0535 against 0.0605 / 0.0753; 98 304: 0.076 against 0.097 / 0.101), the
             // ordinary kernel from ~196 608 on.  Other graphs scale the lines by their estimated cost.
+            // Round 5: re-calibrated on the round-5 kernels (profiles/r05e_depth_sweep.md) and made aware of RESIDENCY.  A CU
+            // holds only so many workgroups of a shape at once (registers, LDS: 16 / 8 / 6 for fm_voice's three shapes --
+            // asked of the runtime per kernel, hipOccupancyMaxActiveBlocksPerMultiprocessor); a bank of more workgroups per CU
+            // runs in rounds, and a short last round costs almost a full one: at 131 072 voices the four-wave shape (8
+            // workgroups per CU, 6 resident) took 0.070 ms per block against 0.057 for two waves, at 196 608 (12 = two full
+            // rounds) 0.086 against 0.096 and 0.094 -- the straight lines of round 4 could not see that.  Per round, time
+            // against w = workgroups per CU (ms per 256-frame block, fm_voice; other graphs scale by their estimated cost,
+            // which does not change the choice):
+            //   one wave per 64 voices   w <= 4: 0.058; 8: 0.072; 12: 0.094; 16: 0.116
+            //   two waves                w <= 4: 0.043; 6..8: 0.057
+            //   four waves               1: 0.0318; 2: 0.0329; 3: 0.0345; 4: 0.0370; 6: 0.0438
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
+            const double cus = std::max(1, prop.multiProcessorCount);
             const double scale = (double)std::max(8, e->cg->valu_estimate) / 127.0; // fm_voice's estimate
+            auto interp = [](const double* xs, const double* ys, int n, double x) {
+                if (x <= xs[0]) return ys[0];
+                for (int k = 1; k < n; ++k)
+                    if (x <= xs[k]) return ys[k - 1] + (ys[k] - ys[k - 1]) * (x - xs[k - 1]) / (xs[k] - xs[k - 1]);
+                return ys[n - 1] * x / xs[n - 1];
+            };
+            auto round_ms = [&](int d, double w) {
+                static const double x1[] = {4, 8, 12, 16}, y1[] = {0.058, 0.072, 0.094, 0.116};
+                static const double x2[] = {4, 6, 8}, y2[] = {0.043, 0.057, 0.057};
+                static const double x4[] = {1, 2, 3, 4, 6}, y4[] = {0.0318, 0.0329, 0.0345, 0.0370, 0.0438};
+                return d == 1 ? interp(x1, y1, 4, w) : (d == 2 ? interp(x2, y2, 3, w) : interp(x4, y4, 5, w));
+            };
+            auto resident = [&](int d) { // workgroups of this shape a CU holds at once
+                int n = 0;
+                if (OgOccupancyFn occ = og_find_occupancy(e->cg->hash)) n = occ(d);
+                else if (e->jit) n = e->jit->occupancy(d);
+                if (n <= 0) n = d == 4 ? 6 : (d == 2 ? 8 : 16);
+                return (double)n;
+            };
             auto cycles = [&](int d) {
-                const double r = std::ceil((double)waves1 * d / (double)simds);
-                const double t = d == 1 ? std::max(0.074, 0.0365 * r + 0.030)
-                                        : (d == 2 ? std::max(0.058, 0.0255 * r + 0.006) : std::max(0.034, 0.0113 * r + 0.0085));
-                return scale * t;
+                const double w = std::ceil((double)waves1 / cus); // workgroups per CU (every shape: one workgroup per 64 voices)
+                const double cap = resident(d);
+                const double full = std::floor(w / cap), rest = w - full * cap;
+                return scale * (full * round_ms(d, cap) + (rest > 0.0 ? round_ms(d, rest) : 0.0));
             };
             uint32_t depth = 0;
             double best = cycles(1);

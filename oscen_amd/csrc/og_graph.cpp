@@ -4238,8 +4238,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << "    else if (ramps && !taps) hipLaunchKernelGGL(og_k_" << hs << "_10, grid, block, 0, s, A);\n"
         << "    else if (!ramps && taps) hipLaunchKernelGGL(og_k_" << hs << "_01, grid, block, 0, s, A);\n"
         << "    else hipLaunchKernelGGL(og_k_" << hs << "_11, grid, block, 0, s, A);\n}\n"
+        << "static int og_occ_" << hs << "(int depth) // resident workgroups per CU of each shape (registers, LDS)\n{\n    int n = 0;\n";
+    for (auto [K, W] : depths)
+        src << "    if (depth == " << K << ") { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, og_k" << K << "_" << hs << "_00, " << 64 * W
+            << ", 0); return n; }\n";
+    src << "    if (depth <= 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, og_k_" << hs << "_00, OG_WAVE, 0);\n    return n;\n}\n"
         << "static const OgKernelRegistrar og_reg_" << hs << "(0x" << hs << "ull, \"" << g.name << "\", &og_launch_"
-        << hs << ");\n#endif\n";
+        << hs << ", &og_occ_" << hs << ");\n#endif\n";
     out.source = src.str();
     return cgp;
 }

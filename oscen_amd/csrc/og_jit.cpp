@@ -98,6 +98,13 @@ struct JitImpl : OgJitKernel {
                                              stream, nullptr, cfg);
         if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));
     }
+    int occupancy(int depth) override
+    {
+        hipFunction_t f = depth == 4 ? fn4[0] : (depth == 2 ? fn2[0] : fn[0]);
+        int n = 0;
+        if (!f || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, (depth >= 2 ? depth : 1) * OG_WAVE, 0) != hipSuccess) return 0;
+        return n;
+    }
 };
 
 } // namespace

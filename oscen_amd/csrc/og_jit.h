@@ -12,6 +12,7 @@
 struct OgJitKernel {
     virtual ~OgJitKernel() {}
     virtual void launch(const OgBlockArgs& args, bool ramps, bool taps, hipStream_t stream) = 0;
+    virtual int occupancy(int depth) = 0; // resident workgroups per CU of the depth-1 / 2 / 4 shape (0: no such shape)
 };
 
 // Throws std::runtime_error (compile log included) on failure.

@@ -10,24 +10,30 @@
 #include "og_kernel_rt.hip.h"
 
 typedef void (*OgLaunchFn)(const OgBlockArgs& args, bool ramps, bool taps, hipStream_t stream);
+// workgroups of the depth-1 / 2 / 4 shape of the kernel a CU can hold at once (registers, LDS): what the engine's choice of
+// pipeline depth needs to know (hipOccupancyMaxActiveBlocksPerMultiprocessor); 0 = no such shape
+typedef int (*OgOccupancyFn)(int depth);
 
 struct OgKernelEntry {
     uint64_t hash;
     const char* name;
     OgLaunchFn launch;
+    OgOccupancyFn occupancy;
     OgKernelEntry* next;
 };
 
 OgKernelEntry*& og_kernel_registry_head();
 OgLaunchFn og_find_kernel(uint64_t hash);
+OgOccupancyFn og_find_occupancy(uint64_t hash);
 
 struct OgKernelRegistrar {
     OgKernelEntry entry;
-    OgKernelRegistrar(uint64_t hash, const char* name, OgLaunchFn fn)
+    OgKernelRegistrar(uint64_t hash, const char* name, OgLaunchFn fn, OgOccupancyFn occ = nullptr)
     {
         entry.hash = hash;
         entry.name = name;
         entry.launch = fn;
+        entry.occupancy = occ;
         entry.next = og_kernel_registry_head();
         og_kernel_registry_head() = &entry;
     }

@@ -226,6 +226,13 @@ hipError_t hipModuleLaunchKernel(hipFunction_t f, unsigned gx, unsigned gy, unsi
                                  hipStream_t s, void** params, void** extra);
 
 } // extern "C"
+// occupancy of an ahead-of-time kernel: what the round-5 fm kernels report on gfx950 for 64- / 128- / 256-thread workgroups
+template <class F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int block, size_t)
+{
+    *n = block >= 256 ? 6 : (block >= 128 ? 8 : 16);
+    return hipSuccess;
+}
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t n)
 {

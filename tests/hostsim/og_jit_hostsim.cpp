@@ -91,6 +91,8 @@ struct HostJit : OgJitKernel {
         const KernelFn f = K == 4 ? fn4[vi] : (K == 2 ? fn2[vi] : fn[vi]);
         simt::launch(dim3(grid), dim3(K * OG_WAVE), [&]() { f(a); });
     }
+    // (what the round-5 fm kernels report on gfx950: registers / LDS of the three shapes)
+    int occupancy(int depth) override { return depth == 4 ? (fn4[0] ? 6 : 0) : (depth == 2 ? (fn2[0] ? 8 : 0) : 16); }
 };
 
 } // namespace

@@ -132,3 +132,17 @@ def test_eight_rank_line_carries_config4_and_the_og_cluster_leg(hostsim_env, tmp
     assert "error" not in oc, oc
     assert oc["rccl_ranks"] == 8 and oc["cluster"]["devices"] == 8 and oc["cluster"]["rccl_reduces"] > 0 and oc["value"] > 0
     assert "configs" not in d and d["cpu_baseline"] is None       # N = 1 extras stay at N = 1
+
+
+def test_pipeline_depth_by_bank_size(hostsim_env):
+    """The engine's choice of kernel shape (og_engine.cpp, depth model; profiles/r05e_depth_sweep.md): the four-wave pipeline
+    for small banks, TWO waves at 131 072 voices (eight workgroups per CU, of which only six four-wave ones are resident: a
+    short second round costs almost a whole one), four again at 196 608 (two full rounds), the ordinary kernel from 262 144
+    on.  The simulator reports the occupancies the round-5 fm kernels have on gfx950 (16 / 8 / 6 workgroups per CU)."""
+    code = ("import sys; sys.path.insert(0, %r)\nimport oscen_amd\n"
+            "for V in (64, 16384, 65536, 98304, 131072, 196608, 262144, 1048576):\n"
+            "    e = oscen_amd.Engine('fm_voice', V, sample_rate=48000.0); print(V, e.pipeline_depth); e.close()\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=hostsim_env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = dict(tuple(int(x) for x in ln.split()) for ln in r.stdout.strip().splitlines())
+    assert got == {64: 4, 16384: 4, 65536: 4, 98304: 4, 131072: 2, 196608: 4, 262144: 1, 1048576: 1}, got
