@@ -1328,6 +1328,17 @@ void emit_tpt(NodeCtx& x)
         if (block_const(q)) iq = x.hoist("inv_q", "1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f)");
         else iq = "(1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f))";
         x.cg.os() << "        og::tpt_params_nomod_flat(" << cutoff.e << ", " << q.e << ", " << iq << ", " << tail;
+    } else if (nomod && x.n.domain != 1 && !(getenv("OGC_TPT_LAZY") && atoi(getenv("OGC_TPT_LAZY")) == 0)) {
+        // cutoff computed per frame: watch the raw input, run the reference's test only on frames whose input differs from
+        // the previous frame's (og::tpt_params_nomod_lazy).  q is watched too when it can change inside a launch: a ramped
+        // input (the RAMPS variants of the kernel) or a per-frame value.
+        const std::string li = x.p + "last_in", lq = x.p + "last_q";
+        x.cg.S().decl << "    float " << li << " = __uint_as_float(og::TPT_LAZY_SENTINEL), " << lq << " = __uint_as_float(og::TPT_LAZY_SENTINEL);\n";
+        // a per-voice value event may change a block-constant q: start over (the event path runs derive())
+        x.cg.S().derive << "        " << li << " = __uint_as_float(og::TPT_LAZY_SENTINEL);\n";
+        x.cg.any_derive = true;
+        const std::string qchk = block_const(q) ? "false" : (q.rate == Rate::UFrame ? "RAMPS" : "true");
+        x.cg.os() << "        og::tpt_params_nomod_lazy<" << qchk << ">(" << cutoff.e << ", " << q.e << ", " << li << ", " << lq << ", " << tail;
     } else if (nomod) {
         x.cg.os() << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << tail;
     } else {
@@ -3934,7 +3945,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // fully unrolled body; per-frame tests only exist on the (rare) event path
             auto call = [&](const std::string& flag) {
                 const std::string t = std::string("tick(f, ch, j, og::BoolC<") + flag + ">{})";
-                return last ? "og::bus_put<TAPS>(A, c, bus, f, f % OG_BUS_CHUNK, " + t + ");" : t + ";";
+                // row of the bus tile: f % OG_BUS_CHUNK = (base % OG_BUS_CHUNK) + j -- `base` is a multiple of XCH, which divides
+                // OG_BUS_CHUNK, so there is no carry; written this way the chunk-invariant part is formed once per chunk and the
+                // eight stores of the unrolled body take immediate offsets (one v_add + two SALU per frame less in the bus wave)
+                return last ? "og::bus_put<TAPS>(A, c, bus, f, (base & (OG_BUS_CHUNK - 1u)) + j, " + t + ");" : t + ";";
             };
             // node steady-state conditions of this wave's stages (Sect::fast_conds), as in the ordinary kernel
             std::string steady;

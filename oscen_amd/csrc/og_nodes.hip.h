@@ -323,6 +323,27 @@ OG_DEV void tpt_params_nomod(float cutoff_in, float q_in, float max_cutoff, floa
         tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
 }
 
+// apply_parameter_updates() for a cutoff that is computed every frame but mostly does NOT move (FMVoice: `env * amount +
+// cutoff` with amount 0, or an envelope that sits in Sustain): the reference runs its test on every frame; if this frame's
+// inputs are bit for bit the previous frame's, that test cannot fire -- the previous frame either updated to these very
+// values or found them within EPSILON of the current ones -- so one integer compare of the raw input against the last one
+// seen replaces clamp, two subtractions and two float compares.  `last_in` / `last_q` are per-lane registers, not state:
+// they start from a sentinel at every launch (and after a per-voice value event), so the first frame always runs the full
+// test.  QCHK: q can change inside a launch (a ramped or per-frame q); otherwise only the cutoff is watched.
+template <bool QCHK>
+OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float& last_in, float& last_q, float max_cutoff, float two_sr, float period,
+                                  float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
+{
+    bool moved = __float_as_uint(cutoff_in) != __float_as_uint(last_in);
+    if (QCHK) moved = moved || __float_as_uint(q_in) != __float_as_uint(last_q);
+    if (moved) {
+        last_in = cutoff_in;
+        if (QCHK) last_q = q_in;
+        tpt_params_nomod(cutoff_in, q_in, max_cutoff, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+    }
+}
+constexpr uint32_t TPT_LAZY_SENTINEL = 0x7fc0a5a5u; // a NaN payload no computation produces
+
 // The same update for a cutoff that moves every sample (an envelope on the cutoff, FMVoice): written
 // without a branch -- the new coefficients are computed on every tick and selected in.  A branch per
 // frame costs more than it saves here: it is taken on most frames anyway, and it cuts the unrolled
