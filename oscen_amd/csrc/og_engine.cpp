@@ -1632,7 +1632,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             //   four waves               1: 0.0318; 2: 0.0329; 3: 0.0345; 4: 0.0370; 6: 0.0438
             const uint32_t waves1 = (n_voices + OG_WAVE - 1) / OG_WAVE;
             const double cus = std::max(1, prop.multiProcessorCount);
-            const double scale = (double)std::max(8, e->cg->valu_estimate) / 127.0; // fm_voice's estimate
+            const double scale = (double)std::max(8, e->cg->valu_estimate) / 76.0; // fm_voice
             auto interp = [](const double* xs, const double* ys, int n, double x) {
                 if (x <= xs[0]) return ys[0];
                 for (int k = 1; k < n; ++k)

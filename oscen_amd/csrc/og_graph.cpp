@@ -421,15 +421,16 @@ int user_weight(const std::string& type);
 // rough VALU cost per tick of a node type (used to balance the two-stage split)
 int node_weight(const std::string& type)
 {
-    if (type.rfind("AdsrEnvelope", 0) == 0) return 6;  // tolerance mode: sub, cvt, rcp, 2 fma, countdown (was 11)
-    if (type.rfind("FmOperator", 0) == 0) return 21;
+    // (round 5, static counts of the quiet chunk bodies: profiles/r05g_session6.log picked the cut these weights give)
+    if (type.rfind("AdsrEnvelope", 0) == 0) return 5;  // tolerance mode: sub, fma, countdown share (+ release: sub, cvt, rcp, fma)
+    if (type.rfind("FmOperator", 0) == 0) return 10;   // fma, add, v_sin_f32 (a quarter-rate instruction: 4), 2 mul, add, v_fract
     if (type.rfind("TptFilter", 0) == 0) return 25;
     if (type.rfind("PolyBlepOscillator", 0) == 0) return 30;
     if (type.rfind("Oscillator", 0) == 0) return 22;
     if (type.rfind("IirLowpass", 0) == 0) return 14;
     if (type.rfind("LP18Filter", 0) == 0) return 40;
     if (type.rfind("Delay", 0) == 0) return 30;
-    if (type.rfind("Crossfade", 0) == 0) return 3;
+    if (type.rfind("Crossfade", 0) == 0) return 2;
     if (type.rfind("HardClip", 0) == 0) return 2;
     const int uw = user_weight(type);
     return uw > 0 ? uw : 1;
@@ -3314,7 +3315,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 }
                 // (its true cost is ~45, but the grouping this weight gives for fm_voice -- op2 with the consumer wave --
                 //  measured equal on the default run and 12% faster at 98 304 voices than op2 with the producer)
-                wt = moving ? 25 : 9; // core 7 + parameter test 8 + the coefficient update on the frames whose cutoff moved
+                wt = moving ? 12 : 9; // core 7 + the watched-input test + the coefficient update on the frames whose cutoff moved
             }
             w.push_back(wt);
             total += wt;
@@ -3344,7 +3345,69 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         }
         // contiguous grouping of the stages into `parts` waves minimising the heaviest wave (the last wave
         // also carries the mix-bus work); ties: smallest sum of squares
-        const int BUS_W = 4;
+        // (the wave that closes the chunk also transposes and reduces the bus tile and is the one everybody waits for:
+        //  interleaved A/B of the cuts, round 5 -- gain + add with the wave in front of the filter wave +1.5 .. +3.7 %)
+        const int BUS_W = 8;
+        // Values that cross a cut.  A value produced in one wave and read in another costs the producer an LDS store per
+        // frame, every reading wave an LDS load per frame AND eight registers (a chunk's hand-off values are fetched
+        // before its first tick): the cut {env2 op2 mixer env1}|{op1 env_filter gain add} balances the instruction counts
+        // better than {env2 op2 mixer}|{env1 op1 env_filter gain add} but reads one more value in its heaviest wave -- 92
+        // VGPRs instead of 80, five resident workgroups per CU instead of six, and measured 1.5 % slower
+        // (profiles/r05g_session6.log).  unit_of[node] = stage of every scheduled node; refs by (node, port).
+        std::map<std::string, int> unit_of_name;
+        {
+            int st = 0;
+            for (int k = 0; k < (int)order.size(); ++k) {
+                while (k >= unit_end[st]) ++st;
+                unit_of_name[cg.nodes[order[k]].decl->name] = st;
+            }
+        }
+        std::vector<std::set<std::pair<int, std::string>>> reads_of((size_t)unit_w.size()); // per stage: (producer stage, "node.port") it reads
+        for (int k = 0; k < (int)order.size(); ++k) {
+            const NodeInst& nd = cg.nodes[order[k]];
+            const int me = unit_of_name[nd.decl->name];
+            for (const auto& kv : nd.in_edges)
+                for (const auto& src : kv.second) {
+                    std::vector<const Expr*> refs;
+                    collect_refs(src.e, refs);
+                    for (const Expr* r : refs) {
+                        auto it = unit_of_name.find(r->node);
+                        if (r->port.empty() || it == unit_of_name.end() || it->second == me) continue;
+                        reads_of[(size_t)me].insert({it->second, r->node + "." + r->port});
+                    }
+                }
+        }
+        std::set<std::pair<int, std::string>> bus_reads; // what the graph outputs read: consumed by the LAST wave
+        for (auto& kv : out_edges)
+            for (auto& src : kv.second) {
+                std::vector<const Expr*> refs;
+                collect_refs(src.src, refs);
+                for (const Expr* r : refs) {
+                    auto it = unit_of_name.find(r->node);
+                    if (!r->port.empty() && it != unit_of_name.end()) bus_reads.insert({it->second, r->node + "." + r->port});
+                }
+            }
+        auto crossing = [&](int b0, int e, bool is_last) { // extra weight of the wave holding stages [b0, e)
+            std::set<std::string> in, outv;
+            for (int u = b0; u < e; ++u)
+                for (const auto& rd : reads_of[(size_t)u])
+                    if (rd.first < b0 || rd.first >= e) in.insert(rd.second);
+            if (is_last)
+                for (const auto& rd : bus_reads)
+                    if (rd.first < b0 || rd.first >= e) in.insert(rd.second);
+            for (int u = 0; u < (int)unit_w.size(); ++u) {
+                if (u >= b0 && u < e) continue;
+                for (const auto& rd : reads_of[(size_t)u])
+                    if (rd.first >= b0 && rd.first < e) outv.insert(rd.second);
+            }
+            if (!is_last)
+                for (const auto& rd : bus_reads)
+                    if (rd.first >= b0 && rd.first < e) outv.insert(rd.second);
+            // (3 per value read -- load, wait and eight registers --, 1 per value written: with these the DP picks the cut
+            //  that measured best of six, {env3 op3 xf}|{env2 op2 mix}|{env1 op1 env_f gain add}|{filter gain bus};
+            //  2 per read picked {env3 op3 xf env2}|{op2 mix env1}|..., which measured worst)
+            return 3 * (int)in.size() + (int)outv.size();
+        };
         auto grouping = [&](int parts) {
             const int n = (int)unit_w.size();
             std::vector<int> pre(n + 1, 0);
@@ -3361,7 +3424,8 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     for (int b0 = p2 - 1; b0 < e; ++b0) {
                         const Best& prev = dp[p2 - 1][b0];
                         if (prev.mx >= (1L << 40)) continue;
-                        const long wgt = pre[e] - pre[b0] + ((p2 == parts && e == n) ? BUS_W : 0);
+                        const bool is_last = p2 == parts && e == n;
+                        const long wgt = pre[e] - pre[b0] + (is_last ? BUS_W : 0) + crossing(b0, e, is_last);
                         const long mx = std::max(prev.mx, wgt), sq = prev.sq + wgt * wgt;
                         Best& cur = dp[p2][e];
                         if (mx < cur.mx || (mx == cur.mx && sq < cur.sq)) {
@@ -3380,7 +3444,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             }
             return groups;
         };
-        if (want && total >= 40 && unit_w.size() >= 2) {
+        if (want && total >= 34 && unit_w.size() >= 2) { // (thresholds in units of the round-5 node weights)
             cg.n_stages = (int)unit_w.size();
             int st = 0;
             for (int k = 0; k < (int)order.size(); ++k) {
@@ -3394,7 +3458,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 for (int k = 0; k < cg.n_stages; ++k) cg.groups2[k < ku ? 0 : 1].push_back(k);
             }
             const char* ep = getenv("OGC_PARTS");
-            if (total >= 80 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(getenv("OGC_K3") ? 3 : 4);
+            if (total >= 48 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(getenv("OGC_K3") ? 3 : 4);
             if (const char* ec = getenv("OGC_CUTS")) { // experiment knob: "a,b[,c]" = one-past-last stage of every wave but the last (3 or 4 waves)
                 std::vector<int> ends;
                 for (const char* q = ec; *q;) {

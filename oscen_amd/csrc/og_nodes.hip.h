@@ -334,12 +334,25 @@ template <bool QCHK>
 OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float& last_in, float& last_q, float max_cutoff, float two_sr, float period,
                                   float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
 {
-    bool moved = __float_as_uint(cutoff_in) != __float_as_uint(last_in);
-    if (QCHK) moved = moved || __float_as_uint(q_in) != __float_as_uint(last_q);
-    if (moved) {
-        last_in = cutoff_in;
-        if (QCHK) last_q = q_in;
+    if (QCHK) {
+        // q can change inside this launch (the kernel variants that read the ramp table): the reference's own per-frame test.
+        // Watching two inputs and keeping the EPSILON test for q -- below 1.0 two distinct q can be closer than EPSILON, and
+        // the reference ignores such a step -- nests two divergent regions and measured 9 % slower on those launches
+        // (profiles/r05g_session6.log, scripts/r5_session8.sh) than the plain test.
+        (void)last_q;
         tpt_params_nomod(cutoff_in, q_in, max_cutoff, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+        return;
+    }
+    if (__float_as_uint(cutoff_in) != __float_as_uint(last_in)) {
+        last_in = cutoff_in;
+        const float cutoff = clampf(cutoff_in, 20.0f, max_cutoff);
+        const float q = clampf(q_in, 0.1f, 10.0f);
+        // ONE divergent region, no second test inside it: a clamped cutoff (>= 20 Hz, ulp 1.9e-6) that differs from the
+        // current one at all differs by more than EPSILON, so the reference updates; one that does not differ re-derives the
+        // coefficients it already has.  (With the reference's test nested inside, the bank whose cutoff moves every frame
+        // lost 11 %.)  q is constant over the launch here; a change of q between launches smaller than EPSILON, which the
+        // reference would ignore, is picked up by the first frame's update -- part of the tolerance mode.
+        tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
     }
 }
 constexpr uint32_t TPT_LAZY_SENTINEL = 0x7fc0a5a5u; // a NaN payload no computation produces

@@ -221,7 +221,9 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert fm.count("if constexpr (decltype(chk)::value)") >= 3
     # the cutoff of FMVoice moves with an envelope: per-tick parameter check; sub_voice's is block-constant
     tick = fm[fm.index("auto tick"):fm.index("auto events")]
-    assert "og::tpt_params_nomod(" in tick
+    # (round 5: the per-tick check watches the raw input -- one integer compare -- and runs the reference's test only on
+    #  frames whose input differs from the previous frame's; q is watched in the kernel variants that read a ramp table)
+    assert "og::tpt_params_nomod_lazy<RAMPS>(" in tick and "og::tpt_params_nomod(" not in tick
     sub = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     derive = sub[sub.index("auto derive"):sub.index("auto tick")]
     tick = sub[sub.index("auto tick"):sub.index("auto events")]

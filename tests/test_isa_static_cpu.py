@@ -65,13 +65,14 @@ def test_sticky_chunk_loops_of_the_four_wave_kernel_carry_their_values_in_place(
     # the six sticky loops of the three envelope waves, as far as the layout keeps them contiguous (the unrolled 8-frame
     # body up to the first backward branch; the rest of the stay test and the barrier sit in a block placed elsewhere):
     # two branches (leave / repeat) -- and NO register shuffles
-    sticky = [c for c in loops if c["branch"] == 2 and c["n"] >= 100]
+    sticky = [c for c in loops if c["branch"] == 2 and c["n"] >= 90]
     assert len(sticky) == 6, [dict(c) for c in loops if c["n"] >= 80]
     for c in sticky:
         assert c["v_mov"] <= 2, dict(c)
-        # round 5 (the operators' sine is one v_sin_f32): 85 .. 133 VALU per 8 frames (release-free / release variant);
-        # round 4's polynomial sine: 181 .. 229
-        assert c["valu"] <= 140, dict(c)
+        # round 5 (the operators' sine is one v_sin_f32, the phase wrap one v_fract_f32; waves {env3 op3} | {xf env2 op2 mix} |
+        # {env1 op1 env_filter gain add}): 74 .. 141 VALU per 8 frames (release-free / release variant; the third wave holds
+        # two envelopes); round 4's polynomial sine: 181 .. 229
+        assert c["valu"] <= 146, dict(c)
     # all three waves' release-free variants together: < 13 VALU per frame and wave (round 4: < 25)
     assert sum(sorted(c["valu"] for c in sticky)[:3]) <= 3 * 8 * 13
     # and the sine really is the hardware's: 8 v_sin_f32 per unrolled chunk of every operator wave
