@@ -1090,6 +1090,7 @@ struct og_engine {
         A.frame0 = q_frame0;
         A.state = d_state;
         A.lane_state = d_lane_state;
+        A.lane_dump = d_lane_state ? d_lane_state + cg->lane_state.size() * (size_t)V * cg->lpv * cg->lane_width : nullptr;
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
@@ -1686,7 +1687,9 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         }
         HIPCK(hipMalloc(&e->d_state, std::max<size_t>(1, cg.state.size()) * (size_t)n_voices * 4));
         if (!cg.lane_state.empty())
-            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4));
+            // (+ one wave's worth of lane words behind the last plane: OgBlockArgs::lane_dump, where a lane beyond the last
+            //  voice writes what an event handler of an array-valued node writes through its state planes)
+            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4 + (size_t)OG_WAVE * 16 * 4));
         if (cg.bus_tremolo) HIPCK(hipMalloc(&e->d_bus_phase, 4));
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));

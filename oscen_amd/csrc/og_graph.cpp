@@ -1556,17 +1556,19 @@ void emit_ep_amp(NodeCtx& x)
     // (og_nodes.hip.h, EpAmp); the table the next ramp target uses sits in an LDS column
     std::string cur = x.state_lane_h("current_value", 0.0f), tgt = x.state_lane_h("target_value", 0.0f);
     const std::string dec = x.state_lane_plane("decay", 0.0f), rel = x.state_lane_plane("release", 0.0f);
+    auto writable = [](std::string e) { return e.replace(e.find("og::lane_plane<"), 15, "og::lane_plane_or_dump<"); }; // (handlers: see there)
+    const std::string dec_w = writable(dec), rel_w = writable(rel);
     std::string released = x.state_u("released", 0), step = x.state_u("interpolation_step", 64);
     std::string vel = x.state_f("velocity", [](const UEnv&) { return 0.0f; });
     x.cg.S().decl << "    og::EpAmp " << A << " = {};\n";
     x.cg.S().load << "        " << A << " = og::EpAmp{" << cur << ", " << tgt << ", " << released << ", " << step << ", " << vel
-              << ", nullptr, nullptr, nullptr};\n";
+              << "};\n";
     x.cg.S().pre << "    og::ep_amp_begin(" << A << ", " << dec << ", " << rel << ", c.valid);\n";
     // stores run before the generic store section reads the mirrors back
     x.cg.S().pre_store << "        " << cur << " = " << A << ".cur; " << tgt << " = " << A << ".tgt; " << released << " = " << A
                    << ".released; " << step << " = " << A << ".step; " << vel << " = " << A << ".velocity;\n";
     x.on_event("gate", [&](const std::string& val) {
-        return "                og::ep_amp_gate(" + A + ", c.h * OG_HPL, " + val + ", " + br.e + ", " + vs.e + ", " + dr.e + ", " + hd.e +
+        return "                og::ep_amp_gate(" + A + ", " + dec_w + ", " + rel_w + ", c.h * OG_HPL, " + val + ", " + br.e + ", " + vs.e + ", " + dr.e + ", " + hd.e +
                ", " + ks.e + ", " + rr.e + ");\n";
     });
     const std::string var = x.p + "amplitudes";

@@ -93,6 +93,7 @@ struct OgBlockArgs {
     // timed launches only (og_enable_kernel_timing), else null: workgroup 0 writes {shader cycles, 100 MHz ticks} at its first
     // and last instruction -- the shader clock the launch ran at UNDER ITS OWN LOAD (og_kernel_clock_ghz)
     unsigned long long* clock_out; // [4]
+    uint32_t* lane_dump;       // [OG_WAVE][16] words behind the last lane-state plane: the write target of lanes beyond the last voice
     float* rings[OG_MAX_RINGS];        // delay lines: [capacity][n_voices] each (slot-major, voices contiguous)
     uint32_t ring_cap[OG_MAX_RINGS];   // capacity in samples (a power of two, ring_buffer/mod.rs:35-41)
     uint32_t slots[OG_MAX_SLOTS]; // block-uniform values (f32 or u32 bits)
@@ -510,6 +511,16 @@ template <int LPV>
 __device__ __forceinline__ float* lane_plane(const OgBlockArgs& a, const VoiceCtx& c, int k)
 {
     return reinterpret_cast<float*>(a.lane_state) + (((size_t)k * a.n_voices + c.v) * LPV + c.h) * OG_HPL;
+}
+// ... or, for a lane beyond the bank's last voice, its slot of the dump area: every lane runs the tick, a node-to-node event
+// can reach the handler of such a lane, and what it writes must not land in another voice's planes.  A select, not a
+// branch: a guard around the handler's stores cost the e-piano kernel its scratch-free register allocation.
+template <int LPV>
+__device__ __forceinline__ float* lane_plane_or_dump(const OgBlockArgs& a, const VoiceCtx& c, int k)
+{
+    float* p = lane_plane<LPV>(a, c, k);
+    float* d = reinterpret_cast<float*>(a.lane_dump) + c.lane * 16;
+    return c.valid ? p : d;
 }
 template <int LPV>
 __device__ __forceinline__ void stl_h(const OgBlockArgs& a, const VoiceCtx& c, int k, const HarmV& x)

@@ -937,32 +937,40 @@ struct EpAmp {
     HarmV cur, tgt;          // this lane's harmonics
     uint32_t released, step; // per voice
     float velocity;
-    float4* mult;            // this lane's column of the wave's LDS copy of (released ? release : decay): element q at mult[q * OG_WAVE]
-    float* decay;            // this lane's OG_HPL words of the `decay` state plane
-    float* release;          // ... of the `release` state plane
 };
 
-OG_DEV void ep_mult_put(EpAmp& a, const HarmV& m)
+// the wave's LDS copy of (released ? release : decay), one column per lane (one-wave workgroups: column = lane).  Reached
+// through this accessor, not through a pointer in EpAmp: the compiler then knows the address space (ds_read_b128 /
+// ds_write_b128 with a 32-bit address) and no 64-bit generic pointer lives in registers across the frame loop.
+OG_DEV float4 (&ep_mult_lds())[OG_HPL >= 4 ? OG_HPL / 4 : 1][OG_WAVE]
 {
+    __shared__ float4 ep_mult[OG_HPL >= 4 ? OG_HPL / 4 : 1][OG_WAVE];
+    return ep_mult;
+}
+
+OG_DEV void ep_mult_put(const HarmV& m)
+{
+    const uint32_t lane = threadIdx.x % OG_WAVE;
 #if OG_HPL >= 4
 #pragma unroll
-    for (int q = 0; q < OG_HPL / 4; ++q) a.mult[q * OG_WAVE] = make_float4(m.p[2 * q].x, m.p[2 * q].y, m.p[2 * q + 1].x, m.p[2 * q + 1].y);
+    for (int q = 0; q < OG_HPL / 4; ++q) ep_mult_lds()[q][lane] = make_float4(m.p[2 * q].x, m.p[2 * q].y, m.p[2 * q + 1].x, m.p[2 * q + 1].y);
 #else
-    reinterpret_cast<float2*>(a.mult)[0] = make_float2(m.p[0].x, m.p[0].y);
+    ep_mult_lds()[0][lane] = make_float4(m.p[0].x, m.p[0].y, 0.0f, 0.0f);
 #endif
 }
-OG_DEV HarmV ep_mult_get(const EpAmp& a)
+OG_DEV HarmV ep_mult_get()
 {
+    const uint32_t lane = threadIdx.x % OG_WAVE;
     HarmV m;
 #if OG_HPL >= 4
 #pragma unroll
     for (int q = 0; q < OG_HPL / 4; ++q) {
-        const float4 v = a.mult[q * OG_WAVE];
+        const float4 v = ep_mult_lds()[q][lane];
         m.p[2 * q] = og_f2{v.x, v.y};
         m.p[2 * q + 1] = og_f2{v.z, v.w};
     }
 #else
-    const float2 v = reinterpret_cast<const float2*>(a.mult)[0];
+    const float4 v = ep_mult_lds()[0][lane];
     m.p[0] = og_f2{v.x, v.y};
 #endif
     return m;
@@ -994,23 +1002,21 @@ OG_DEV void ep_plane_put(float* p, const HarmV& x)
 }
 
 // block start: bind the lane's planes and its LDS column, bring the table the next target will be formed with
-OG_DEV void ep_amp_begin(EpAmp& a, float* decay_plane, float* release_plane, bool valid)
+OG_DEV void ep_amp_begin(EpAmp& a, const float* decay_plane, const float* release_plane, bool valid)
 {
-    __shared__ float4 ep_mult[OG_HPL >= 4 ? OG_HPL / 4 : 1][OG_WAVE]; // (one-wave workgroups: column = lane)
-    a.mult = &ep_mult[0][threadIdx.x % OG_WAVE];
-    // (a lane beyond the bank's last voice owns no planes: a node-to-node event can reach its handler -- every lane runs the
-    //  tick -- and must not write through these)
-    a.decay = valid ? decay_plane : nullptr;
-    a.release = valid ? release_plane : nullptr;
     HarmV m = harm_splat(0.0f);
     if (valid) m = ep_plane_get(a.released != 0u ? release_plane : decay_plane);
-    ep_mult_put(a, m);
+    ep_mult_put(m);
 }
 
 // on_gate :308-318 -> trigger_note :292-299 (get_decay :244-268, get_release :270-274,
 // get_initial_amplitudes :276-290; note_pitch stays 60.0) or release_note :301-304.   h0 = first harmonic of the lane
-OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float velocity_scaling, float decay_rate,
-                        float harmonic_decay, float key_scaling, float release_rate)
+// `decay` / `release`: this lane's OG_HPL words of the two state planes, formed by the caller where the event fires (no
+// pointer lives in registers across the frame loop).  A lane beyond the bank's last voice gets its slot of the dump area
+// instead (og::lane_plane_or_dump): a node-to-node event can reach its handler -- every lane runs the tick -- and it must
+// not write through planes that are not its own.
+OG_DEV void ep_amp_gate(EpAmp& a, float* decay_plane, float* release_plane, uint32_t h0, float v, float brightness, float velocity_scaling,
+                        float decay_rate, float harmonic_decay, float key_scaling, float release_rate)
 {
     if (v > 0.0f) {
         a.velocity = v;
@@ -1037,18 +1043,16 @@ OG_DEV void ep_amp_gate(EpAmp& a, uint32_t h0, float v, float brightness, float 
             cur[j] = amp;
         }
         const HarmV decay = harm_make(dec);
-        if (a.decay) { // self.decay = get_decay(..), self.release = get_release(..): the state planes
-            ep_plane_put(a.decay, decay);
-            ep_plane_put(a.release, harm_splat(rel));
-        }
-        ep_mult_put(a, decay);
+        ep_plane_put(decay_plane, decay); // self.decay = get_decay(..), self.release = get_release(..): the state planes
+        ep_plane_put(release_plane, harm_splat(rel));
+        ep_mult_put(decay);
         a.cur = harm_make(cur);
         a.released = 0u;
         a.step = 0u;
     } else {
         a.released = 1u;
         a.step = 0u;
-        if (a.release) ep_mult_put(a, ep_plane_get(a.release)); // (this lane's own earlier stores, if any, are visible to its loads)
+        ep_mult_put(ep_plane_get(release_plane)); // (this lane's own earlier stores, if any, are visible to its loads)
     }
 }
 
@@ -1072,7 +1076,7 @@ OG_DEV HarmV ep_amp_tick(EpAmp& a)
     // frames: one wave-uniform test skips the LDS reads, the products and the selects there (a per-lane `if` would cost
     // both sides).
     if (!OG_EP_FRESH_BRANCH || __any((int)fresh)) {
-        const HarmV mult = ep_mult_get(a);
+        const HarmV mult = ep_mult_get();
 #pragma unroll
         for (int i = 0; i < OG_HPAIRS; ++i) {
             const og_f2 tn = f2_mul(a.cur.p[i], mult.p[i]);

@@ -162,7 +162,7 @@ def test_frame2_voice_output_gives_a_stereo_bus():
         pans = ((np.arange(n) * 37 % 101) / 100.0).astype(np.float32)
         probe = np.unique(np.linspace(0, n - 1, 40).astype(np.uint32))
         eng = oscen_amd.Engine(g, n, sample_rate=SR)
-        assert eng.channels == 2 and eng.lib.og_voice_channels(eng.h) == 2 and eng.pipeline_depth == 1
+        assert eng.channels == 2 and eng.lib.og_voice_channels(eng.h) == 2  # (any kernel shape: the pipelined ones carry several bus channels since round 4)
         eng.set_voice_values("frequency", freqs)
         eng.set_voice_values("pan", pans)
         eng.schedule_voice_events("gate", np.arange(n), 3 + np.arange(n) % 50, np.full(n, 0.8, np.float32))

@@ -79,3 +79,23 @@ def test_sticky_chunk_loops_of_the_four_wave_kernel_carry_their_values_in_place(
     asm_text = asm.read_text()
     k0 = asm_text.index(kern + ":")
     assert asm_text[k0:asm_text.index(".Lfunc_end", k0)].count("v_sin_f32") >= 3 * 8
+
+
+@pytest.mark.timeout(600)
+def test_the_electric_piano_kernel_uses_no_scratch_at_three_waves_per_simd(tmp_path):
+    """168 VGPRs (three waves per SIMD), private segment 0 in all four variants: the read-mostly tables are not register
+    state (og_nodes.hip.h, EpAmp), and a lane beyond the last voice is redirected by a SELECT, not guarded by a branch --
+    a guard around the gate handler's stores brought 17 spills back."""
+    src = oscen_amd.Graph(builtin="epiano_voice").kernel_source()
+    hip, asm = tmp_path / "ep.hip", tmp_path / "ep.s"
+    hip.write_text(src)
+    r = subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-x", "hip", "-S", "--cuda-device-only", str(hip), "-o", str(asm)] + b.COMMON,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    text = asm.read_text()
+    kernels = re.findall(r"\.name:\s+(og_k_[0-9a-f]{16}_\d\d)\n(.*?)(?=\n  - |\Z)", text, flags=re.S)
+    assert len(kernels) == 4
+    for name, meta in kernels:
+        kv = dict(re.findall(r"\.(\w+):\s+(\S+)", meta))
+        assert kv["private_segment_fixed_size"] == "0" and kv["vgpr_spill_count"] == "0", (name, kv)
+        assert int(kv["vgpr_count"]) <= 170, (name, kv["vgpr_count"])
