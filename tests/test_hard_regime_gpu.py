@@ -63,7 +63,7 @@ def test_fm_voice_variant_one_second():
         scale = max(1.0, float(np.max(np.sum(np.abs(ref_taps), axis=0))))
         assert np.max(np.abs(bus[:, 0] - ref64)) <= TOL * scale
         f0 += frames
-    assert k == len(ev_f) and peak > 0.3  # every event was delivered; the voices sound
+    assert k == len(ev_f) and peak > 0.2  # every event was delivered; the voices sound (observed peak 0.308)
     observed.note(worst)
     path = os.environ.get("OSCEN_OBSERVED")
     if path:  # the error-vs-time curve for profiles/r05_observed_errors.md (max over 64 voices per block)
