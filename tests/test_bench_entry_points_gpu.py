@@ -83,3 +83,30 @@ def test_queued_blocks_into_a_device_buffer_equal_the_blocking_blocks_and_the_ti
     assert eng.event_stats["full_rebuilds"] >= 1
     with pytest.raises(oscen_amd.OscenError):
         eng.reserve_events(1 << 33)
+
+
+def test_the_kernel_reads_its_own_clock_and_the_probe_reads_the_idle_one():
+    """og_kernel_clock_ghz: workgroup 0 of every TIMED launch writes {shader cycles, 100 MHz ticks} at its first and last
+    instruction; og_shader_clock_ghz: a 20 us one-wave probe.  On the MI355X both land between the part's idle and boost
+    clocks; the host simulator has no such counters (0 / None).  Timing off: no marks are written, the getter says 0."""
+    n, frames = 4096, 256
+    eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    eng.set_voice_values("frequency", oscen_amd.note_plans(n)["frequency"])
+    eng.process_block(frames)
+    assert eng.kernel_clock_ghz == 0.0                      # nothing timed yet
+    eng.enable_kernel_timing(True)
+    for _ in range(6):
+        eng.process_block(frames)
+    ms, launches = eng.kernel_time_ms()
+    assert launches == 6 and ms > 0.0
+    k = eng.kernel_clock_ghz
+    p = eng.shader_clock_ghz()
+    if p is None:                                           # the simulator: no shader clock
+        assert k == 0.0
+    else:
+        assert 0.3 < k < 3.5 and 0.3 < p < 3.5, (k, p)
+        # cycles between the marks / launch duration agree with the clock (the marks bracket workgroup 0, the events the launch)
+        assert abs(k - p) < 1.5
+    eng.enable_kernel_timing(False)
+    eng.process_block(frames)
+    assert eng.kernel_time_ms()[0] < 0.0                    # timing off
