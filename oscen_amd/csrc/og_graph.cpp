@@ -4001,9 +4001,26 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (used_here && group_of(groups, xv.from) != gi) reads.push_back(k);
             }
             for (size_t k : reads) body << "    float xp" << k << "[XCH];\n";
+            // Ramp-table rows (ramped inputs: the RAMPS variants; stream inputs: every variant).  `RV(row, slot)` / `ST(row)`
+            // read A.ramp_table[row * stride + f] -- a scalar load behind a 64-bit address computation, per input and frame:
+            // the launches that read the table took 1.8x the time of the others (SALU 2.9x per block, round 5 counters).  In
+            // the unrolled chunk bodies the rows this wave reads are fetched for the WHOLE chunk at its top, next to the
+            // hand-off values (consecutive words from a uniform base: wide scalar loads); the rolled event path keeps the
+            // direct read.  RV -> RVP / ST -> STP in this wave's tick text.
+            std::string tick_text = group_tick(groups, gi);
+            std::set<int> rows;
+            for (const char* mac : {"RV(", "ST("}) {
+                const std::string pre_mac = std::string(mac, 2) + "P(";
+                for (size_t pos = tick_text.find(mac); pos != std::string::npos; pos = tick_text.find(mac, pos + 1)) {
+                    if (pos > 0 && (isalnum((unsigned char)tick_text[pos - 1]) || tick_text[pos - 1] == '_')) continue;
+                    rows.insert(atoi(tick_text.c_str() + pos + 3));
+                    tick_text.replace(pos, 3, pre_mac);
+                }
+            }
+            for (int r : rows) body << "    float rv_" << r << "[XCH];\n";
             body << "    auto tick = [&](const uint32_t f, const uint32_t ch, const uint32_t j, auto chk) __attribute__((always_inline))"
                  << (last ? (out.voice_channels > 1 ? " -> og::OutN<" + std::to_string(out.voice_channels) + ">" : std::string(" -> float")) : std::string()) << " {\n"
-                 << group_tick(groups, gi);
+                 << tick_text;
             if (last) body << "        return " << bus_expr << ";\n";
             body << "    };\n";
             body << events_code(st);
@@ -4051,13 +4068,25 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 sub("%N", n_expr);
                 return o;
             };
+            auto row_fetch = [&](const std::string& ind) { // the table rows of this chunk (`base` = its first frame within the launch)
+                std::ostringstream o;
+                if (rows.empty()) return std::string();
+                bool only_ramps = true; // (ST rows -- stream inputs -- are read in every variant, RV rows only under RAMPS)
+                for (size_t pos = tick_text.find("STP("); pos != std::string::npos; pos = std::string::npos) only_ramps = false;
+                o << ind << (only_ramps ? "if (RAMPS) {\n" : "{\n");
+                for (int r : rows)
+                    o << ind << "    og::row_fetch<XCH>(rv_" << r << ", A.ramp_table + (size_t)" << r << " * A.ramp_stride + base);\n";
+                o << ind << "}\n";
+                return o.str();
+            };
             auto quiet = [&](const char* chk_flag, const char* rel_flag, bool st_flag, const std::string& ind0, const std::string& stay = std::string()) {
-                const bool pre = !reads.empty();
+                const bool pre = !reads.empty() || !rows.empty();
                 const bool loop = sticky && !stay.empty();
                 const std::string ind = loop ? ind0 + "    " : ind0;
                 if (loop) body << ind0 << "for (;;) { // sticky: this variant again while its conditions hold\n";
                 if (std::string(rel_flag) == "true") body << fc_sync(st, ind);
                 if (pre) {
+                    body << row_fetch(ind);
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
@@ -4126,9 +4155,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: b | c | ev -- quiet chunks take the release-arithmetic / stage-end-check / event path (results stay valid)
             // the checked chunk: unrolled, stage-end checks and release arithmetic on, events applied on their frame
             auto checked = [&](const std::string& ind) {
-                const bool pre = !reads.empty();
+                const bool pre = !reads.empty() || !rows.empty();
                 body << fc_sync(st, ind);
                 if (pre) {
+                    body << row_fetch(ind);
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
@@ -4277,10 +4307,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         << "#if OG_NODE_EVENTS_PER_FRAME <= 4\n#define OG_EV_LOOP_PRAGMA _Pragma(\"unroll\")\n#else\n#define OG_EV_LOOP_PRAGMA _Pragma(\"unroll 1\")\n#endif\n"
         << "#define SF(i) og::slot_f(A, (i))\n#define SU(i) og::slot_u(A, (i))\n"
         << "#define RV(row, slot) (RAMPS ? A.ramp_table[(size_t)(row) * A.ramp_stride + f] : og::slot_f(A, (slot)))\n"
-        << "#define ST(row) A.ramp_table[(size_t)(row) * A.ramp_stride + f]\n\n"
+        << "#define ST(row) A.ramp_table[(size_t)(row) * A.ramp_stride + f]\n"
+        << "// the pipelined kernels: the chunk's rows are in rv_<row>[] when the chunk body is the unrolled one (BoolC::pre)\n"
+        << "#define RVP(row, slot) (RAMPS ? og::row_pick<decltype(chk)::pre>(rv_##row, j, A, (row), f) : og::slot_f(A, (slot)))\n"
+        << "#define STP(row) og::row_pick<decltype(chk)::pre>(rv_##row, j, A, (row), f)\n\n"
         << "namespace og_gen_" << hs << " {\n"
         << "constexpr int LPV = " << out.lpv << "; // lanes per voice\n"
-        << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n#undef ST\n\n";
+        << body_s << "} // namespace\n\n#undef SF\n#undef SU\n#undef RV\n#undef ST\n#undef RVP\n#undef STP\n\n";
     const char* variants[4][3] = {{"00", "false", "false"}, {"10", "true", "false"}, {"01", "false", "true"},
                                   {"11", "true", "true"}};
     // register budget of the ordinary kernel: 4 waves per SIMD = 128 VGPRs.  The 4-lanes-per-voice e-piano form

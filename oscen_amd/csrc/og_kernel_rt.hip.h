@@ -222,6 +222,32 @@ __device__ __forceinline__ void clock_mark(const OgBlockArgs& a, int which)
 #endif
 }
 
+// Ramp-table rows in the pipelined kernels: N consecutive words of a row from a UNIFORM address (one or two wide scalar
+// loads per row and chunk instead of a scalar load behind a 64-bit address computation per input and frame) ...
+template <uint32_t N>
+__device__ __forceinline__ void row_fetch(float (&dst)[N], const float* __restrict__ src)
+{
+#ifndef OG_HOSTSIM
+    // the table is written by the host before the launch and read-only for its whole duration: the CONSTANT address space,
+    // from which a uniform load is a scalar load whatever stores the kernel has issued (through a plain global pointer the
+    // compiler falls back to one vector load per lane once a store may alias)
+    typedef __attribute__((address_space(4))) const float cfloat;
+    const cfloat* s = (const cfloat*)(unsigned long long)src;
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) dst[j] = s[j];
+#else
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) dst[j] = src[j];
+#endif
+}
+// ... picked by the frame's position in the chunk where the chunk body is the unrolled one; read directly elsewhere
+template <bool PRE, uint32_t N>
+__device__ __forceinline__ float row_pick(const float (&pre)[N], uint32_t j, const OgBlockArgs& a, int row, uint32_t f)
+{
+    if constexpr (PRE) return pre[j];
+    else return a.ramp_table[(size_t)row * a.ramp_stride + f];
+}
+
 // u32::saturating_mul (the reference's outer -> inner rescale of an event's frame_offset)
 __device__ __forceinline__ uint32_t sat_mul_u32(uint32_t a, uint32_t b)
 {
