@@ -403,6 +403,7 @@ struct og_engine {
     uint32_t n_wg = 0;
     uint32_t lanes = OG_WAVE;
     uint32_t split = 0; // pipeline depth of the launched kernel variant: 0 (ordinary), 2 or 4 waves per 64 voices
+    bool wide = false;  // split == 4: the 16-frame hand-off form (og_k4w_*)
     uint32_t* d_state = nullptr;
     Bounce bounce; // pinned staging for transfers from / to memory that is not ours
     uint32_t* d_lane_state = nullptr;
@@ -1087,6 +1088,7 @@ struct og_engine {
         A.ramp_stride = (uint32_t)((size_t)OG_MAX_BLOCK * batch_cap);
         A.lanes = lanes;
         A.split = split;
+        A.wide = wide ? 1u : 0u;
         A.frame0 = q_frame0;
         A.state = d_state;
         A.lane_state = d_lane_state;
@@ -1673,6 +1675,16 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             }
             if (e->lanes != OG_WAVE) depth = 0; // the pipelined variants always run 64 voices per workgroup
             e->split = depth;
+            // the wide four-wave form (16-frame hand-offs: half the barriers, twice the LDS rings) where one round holds the
+            // whole bank: +2.4 .. +3.3 % at 65 536 voices (profiles/r05l_session11.log).  OSCEN_GPU_WIDE=0|1 pins it.
+            e->wide = false;
+            if (depth == 4 && e->cg->wide4) {
+                int cap = 0;
+                if (OgOccupancyFn occ = og_find_occupancy(e->cg->hash)) cap = occ(5);
+                else if (e->jit) cap = e->jit->occupancy(5);
+                e->wide = cap > 0 && std::ceil((double)waves1 / cus) <= (double)cap;
+                if (const char* ev = getenv("OSCEN_GPU_WIDE")) e->wide = atoi(ev) != 0 && cap > 0;
+            }
         }
         e->n_wg = (uint32_t)(((size_t)n_voices * e->cg->lpv + e->lanes - 1) / e->lanes);
         HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -2339,7 +2351,7 @@ const char* og_kernel_name(const og_engine* e)
 {
     static thread_local char buf[64];
     if (!e) return "";
-    snprintf(buf, sizeof buf, "og_k%s_%016llx", e->split == 4 ? "4" : (e->split == 2 ? "2" : ""), (unsigned long long)e->cg->hash);
+    snprintf(buf, sizeof buf, "og_k%s_%016llx", e->split == 4 ? (e->wide ? "4w" : "4") : (e->split == 2 ? "2" : ""), (unsigned long long)e->cg->hash);
     return buf;
 }
 int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* incremental_updates, uint64_t* resident_events)

@@ -3917,7 +3917,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (group_of(groups, cg.stage_of[ni]) == gi) body << " " << g.nodes[ni].name;
             body << (gi == K - 1 ? " + the mix bus\n" : "\n");
         }
-        body << "template <bool RAMPS, bool TAPS>\n"
+        body << "template <bool RAMPS, bool TAPS, uint32_t XCH_T = 0>\n"
              << "__device__ __forceinline__ void voice_block_p" << tag << "(const OgBlockArgs& A)\n{\n"
              << "    __shared__ og::" << (out.voice_channels > 1 ? "BusLdsN<" + std::to_string(out.voice_channels) + ">" : std::string("BusLds")) << " bus;\n";
         {
@@ -3940,7 +3940,13 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 const int want = atoi(ex);
                 if ((want == 4 || want == 8 || want == 16) && slots * (size_t)want * 64 * 4 <= 60 * 1024) xch = want;
             }
-            body << "    constexpr uint32_t XCH = " << xch << "; // frames per hand-off between the waves\n";
+            // Round 5: the four-wave kernel waits more than it issues (54 % of its wave cycles), and 16-frame hand-offs -- half
+            // the barriers -- measured +2.4 % at the driver's command and +3.3 % on 94-block regions at 65 536 voices; but
+            // their LDS rings (fm_voice: 36.9 KB per workgroup) fit only four workgroups per CU, so a bank of five or six per
+            // CU would run in two rounds.  Both exist: XCH_T = 16 instantiates the wide form (og_k4w_*), which the engine
+            // launches when every workgroup of the bank is resident at once (og_engine.cpp, depth model).
+            body << "    constexpr uint32_t XCH = XCH_T ? XCH_T : " << xch << "u; // frames per hand-off between the waves\n";
+            if (K == 4 && xch == 8 && slots * 16 * 64 * 4 + 4160 * (size_t)std::max(1u, out.voice_channels) <= 40 * 1024) out.wide4 = true;
         }
         for (size_t k = 0; k < cg.xvals.size(); ++k) {
             const auto& xv = cg.xvals[k];
@@ -4336,9 +4342,21 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         for (auto& v : variants)
             src << "extern \"C\" __global__ __launch_bounds__(" << 64 * W << ") void og_k" << K << "_" << hs << "_" << v[0]
                 << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p" << K << "<" << v[1] << ", " << v[2] << ">(A); }\n";
+    if (out.wide4)
+        for (auto& v : variants)
+            src << "extern \"C\" __global__ __launch_bounds__(" << 64 * (int)cg.groups4.size() << ") void og_k4w_" << hs << "_" << v[0]
+                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p4<" << v[1] << ", " << v[2] << ", 16>(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
         << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n";
+    if (out.wide4)
+        src << "    if (A.split == 4u && A.wide) { // four waves per 64 voices, 16-frame hand-offs\n"
+            << "        const dim3 gk((A.n_voices + OG_WAVE - 1) / OG_WAVE), bk(" << cg.groups4.size() << " * OG_WAVE);\n"
+            << "        if (!ramps && !taps) hipLaunchKernelGGL(og_k4w_" << hs << "_00, gk, bk, 0, s, A);\n"
+            << "        else if (ramps && !taps) hipLaunchKernelGGL(og_k4w_" << hs << "_10, gk, bk, 0, s, A);\n"
+            << "        else if (!ramps && taps) hipLaunchKernelGGL(og_k4w_" << hs << "_01, gk, bk, 0, s, A);\n"
+            << "        else hipLaunchKernelGGL(og_k4w_" << hs << "_11, gk, bk, 0, s, A);\n"
+            << "        return;\n    }\n";
     for (auto [K, W] : depths)
         src << "    if (A.split == " << K << "u) { // " << W << " waves per 64 voices\n"
             << "        const dim3 gk((A.n_voices + OG_WAVE - 1) / OG_WAVE), bk(" << W << " * OG_WAVE);\n"
@@ -4355,6 +4373,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     for (auto [K, W] : depths)
         src << "    if (depth == " << K << ") { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, og_k" << K << "_" << hs << "_00, " << 64 * W
             << ", 0); return n; }\n";
+    if (out.wide4)
+        src << "    if (depth == 5) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, og_k4w_" << hs << "_00, " << 64 * (int)cg.groups4.size()
+            << ", 0); return n; } // (5 = the wide four-wave form)\n";
     src << "    if (depth <= 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, og_k_" << hs << "_00, OG_WAVE, 0);\n    return n;\n}\n"
         << "static const OgKernelRegistrar og_reg_" << hs << "(0x" << hs << "ull, \"" << g.name << "\", &og_launch_"
         << hs << ", &og_occ_" << hs << ");\n#endif\n";

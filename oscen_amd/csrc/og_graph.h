@@ -145,6 +145,8 @@ struct CompiledGraph {
     int lane_width = 1;                // words a lane owns of every lane_state array (OG_HPL = 4 when lpv > 1)
     bool can_split = false;            // a two-wave pipeline variant of the kernel exists (og_k2_*)
     int max_pipeline = 1;              // deepest pipeline variant generated: 1, 2 (og_k2_*) or 4 (og_k4_*)
+    bool wide4 = false;                // the four-wave pipeline also exists with 16-frame hand-offs (og_k4w_*): fewer barriers, twice
+                                       // the LDS rings -- for banks whose workgroups all fit a CU at once
     int valu_estimate = 0;             // estimated VALU instructions per frame of one wave of the ordinary kernel (node weights)
     // post-mix stage (electric-piano/src/main.rs:88-96): Tremolo on the summed bus -> Frame<2>
     bool bus_tremolo = false;

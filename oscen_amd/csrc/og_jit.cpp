@@ -77,6 +77,7 @@ struct JitImpl : OgJitKernel {
     hipFunction_t fn[4] = {};
     hipFunction_t fn2[4] = {}; // two-wave pipeline variants (when the graph has them)
     hipFunction_t fn4[4] = {}; // four-wave pipeline variants
+    hipFunction_t fn4w[4] = {}; // ... with 16-frame hand-offs (when the graph has them)
     unsigned lpv = 1;
     ~JitImpl() override
     {
@@ -94,15 +95,17 @@ struct JitImpl : OgJitKernel {
         a.split = K > 1 ? K : 0;
         const unsigned grid = K > 1 ? (a.n_voices + OG_WAVE - 1) / OG_WAVE
                                     : (unsigned)(((size_t)a.n_voices * lpv + a.lanes - 1) / a.lanes);
-        hipError_t e = hipModuleLaunchKernel(K == 4 ? fn4[vi] : (K == 2 ? fn2[vi] : fn[vi]), grid, 1, 1, K * OG_WAVE, 1, 1, 0,
+        if (!(K == 4 && a.wide && fn4w[vi])) a.wide = 0;
+        hipError_t e = hipModuleLaunchKernel(K == 4 ? (a.wide ? fn4w[vi] : fn4[vi]) : (K == 2 ? fn2[vi] : fn[vi]), grid, 1, 1, K * OG_WAVE, 1, 1, 0,
                                              stream, nullptr, cfg);
         if (e != hipSuccess) throw std::runtime_error(std::string("oscen jit: launch failed: ") + hipGetErrorString(e));
     }
     int occupancy(int depth) override
     {
-        hipFunction_t f = depth == 4 ? fn4[0] : (depth == 2 ? fn2[0] : fn[0]);
+        hipFunction_t f = depth == 5 ? fn4w[0] : (depth == 4 ? fn4[0] : (depth == 2 ? fn2[0] : fn[0]));
         int n = 0;
-        if (!f || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, (depth >= 2 ? depth : 1) * OG_WAVE, 0) != hipSuccess) return 0;
+        const int waves = depth == 5 ? 4 : (depth >= 2 ? depth : 1);
+        if (!f || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, waves * OG_WAVE, 0) != hipSuccess) return 0;
         return n;
     }
 };
@@ -140,6 +143,11 @@ std::unique_ptr<OgJitKernel> og_jit_compile(const ogc::CompiledGraph& cg)
             const std::string name4 = std::string("og_k4_") + hs + "_" + var[i];
             if (hipModuleGetFunction(&k->fn4[i], k->mod, name4.c_str()) != hipSuccess)
                 throw std::runtime_error("oscen jit: kernel " + name4 + " not found in module");
+            if (cg.wide4) {
+                const std::string name4w = std::string("og_k4w_") + hs + "_" + var[i];
+                if (hipModuleGetFunction(&k->fn4w[i], k->mod, name4w.c_str()) != hipSuccess)
+                    throw std::runtime_error("oscen jit: kernel " + name4w + " not found in module");
+            }
         }
     }
     return k;

@@ -88,7 +88,7 @@ struct OgBlockArgs {
     uint32_t* out_ev_count;    // events logged so far (may run past out_ev_cap: the excess is counted as dropped)
     struct OgOutEvent* out_ev; // [out_ev_cap]
     uint32_t out_ev_cap;
-    uint32_t _pad0;
+    uint32_t wide;             // split == 4: launch the 16-frame hand-off form (og_k4w_*) -- every workgroup of the bank is resident at once
     uint32_t* ev_lost;         // pushes an in-voice event queue could not hold (OG_NODE_EVENTS_PER_FRAME per frame and output)
     // timed launches only (og_enable_kernel_timing), else null: workgroup 0 writes {shader cycles, 100 MHz ticks} at its first
     // and last instruction -- the shader clock the launch ran at UNDER ITS OWN LOAD (og_kernel_clock_ghz)

@@ -230,7 +230,7 @@ hipError_t hipModuleLaunchKernel(hipFunction_t f, unsigned gx, unsigned gy, unsi
 template <class F>
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int block, size_t)
 {
-    *n = block >= 256 ? 6 : (block >= 128 ? 8 : 16);
+    *n = block >= 256 ? 6 : (block >= 128 ? 8 : 16); // (the wide four-wave form reports 6 here, 4 on the hardware: results do not depend on it)
     return hipSuccess;
 }
 template <class T>

@@ -73,7 +73,7 @@ std::string compile_unit(const ogc::CompiledGraph& cg)
 
 struct HostJit : OgJitKernel {
     void* dl = nullptr;
-    KernelFn fn[4] = {}, fn2[4] = {}, fn4[4] = {};
+    KernelFn fn[4] = {}, fn2[4] = {}, fn4[4] = {}, fn4w[4] = {};
     unsigned lpv = 1;
     ~HostJit() override
     {
@@ -88,11 +88,12 @@ struct HostJit : OgJitKernel {
         else if (a.split >= 2 && fn2[vi]) K = 2;
         a.split = K > 1 ? K : 0;
         const unsigned grid = K > 1 ? (a.n_voices + OG_WAVE - 1) / OG_WAVE : (unsigned)(((size_t)a.n_voices * lpv + a.lanes - 1) / a.lanes);
-        const KernelFn f = K == 4 ? fn4[vi] : (K == 2 ? fn2[vi] : fn[vi]);
+        if (!(K == 4 && a.wide && fn4w[vi])) a.wide = 0;
+        const KernelFn f = K == 4 ? (a.wide ? fn4w[vi] : fn4[vi]) : (K == 2 ? fn2[vi] : fn[vi]);
         simt::launch(dim3(grid), dim3(K * OG_WAVE), [&]() { f(a); });
     }
     // (what the round-5 fm kernels report on gfx950: registers / LDS of the three shapes)
-    int occupancy(int depth) override { return depth == 4 ? (fn4[0] ? 6 : 0) : (depth == 2 ? (fn2[0] ? 8 : 0) : 16); }
+    int occupancy(int depth) override { return depth == 5 ? (fn4w[0] ? 4 : 0) : (depth == 4 ? (fn4[0] ? 6 : 0) : (depth == 2 ? (fn2[0] ? 8 : 0) : 16)); }
 };
 
 } // namespace
@@ -125,6 +126,7 @@ std::unique_ptr<OgJitKernel> og_jit_compile(const ogc::CompiledGraph& cg)
         k->fn[i] = sym("og_k_" + hs + "_" + var[i]);
         if (cg.max_pipeline >= 2) k->fn2[i] = sym("og_k2_" + hs + "_" + var[i]);
         if (cg.max_pipeline >= 4) k->fn4[i] = sym("og_k4_" + hs + "_" + var[i]);
+        if (cg.max_pipeline >= 4 && cg.wide4) k->fn4w[i] = sym("og_k4w_" + hs + "_" + var[i]);
     }
     return k;
 }

@@ -212,11 +212,15 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert p4.count("const uint32_t ch1 = ch + 1u, base1 = base + XCH;") == 7 and p4.count("__syncthreads();") == 4 + 7
     sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     assert "// Node order:" in sub_src
-    for k in ("og_k_", "og_k2_", "og_k4_"):
+    for k in ("og_k_", "og_k2_", "og_k4_", "og_k4w_"):  # (og_k4w_: the four-wave pipeline with 16-frame hand-offs, round 5)
         assert len(re.findall(r"__global__[^\n]*\b%s[0-9a-f]{16}_(00|10|01|11)\b" % k, fm)) == 4
+    assert "voice_block_p4<false, false, 16>" in fm and "constexpr uint32_t XCH = XCH_T ? XCH_T : 8u;" in fm
     # chunk variants: (stage-end checks, release arithmetic[, hand-off prefetch, node steady states])
     assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false, true>{}" in fm and "og::BoolC<true>{}" in fm
-    assert "og::BoolC<false, false, false, false>{}" in fm and "og::BoolC<true, true, true, false>{}" in fm
+    # (round 5: every wave of the pipelines prefetches something at the top of a chunk -- hand-off values or ramp-table rows --
+    #  so the third flag is set in all their unrolled bodies)
+    assert "og::BoolC<false, false, true, false>{}" in fm and "og::BoolC<true, true, true, false>{}" in fm
+    assert "og::row_fetch<XCH>(rv_0, A.ramp_table + (size_t)0 * A.ramp_stride + base);" in fm and "RVP(1, 2)" in fm
     assert "og::adsr_tick<decltype(chk)::release, true>" in fm and ".fc = (float)" in fm  # float countdown kept per chunk
     assert fm.count("if constexpr (decltype(chk)::value)") >= 3
     # the cutoff of FMVoice moves with an envelope: per-tick parameter check; sub_voice's is block-constant

@@ -128,15 +128,20 @@ def test_fm_bank_default_params_ragged_voice_count():
     assert worst <= TOL, worst
 
 
-@pytest.mark.parametrize("depth", [0, 2, 4])
+@pytest.mark.parametrize("depth", [0, 2, 4, "4w"])
 def test_fm_bank_every_pipeline_depth(depth, monkeypatch):
-    """The same bank through the ordinary kernel and the 2- and 4-wave pipelines (OSCEN_GPU_SPLIT pins the
-    variant the engine would otherwise pick from the bank size): ragged voice count, block lengths that are
-    not multiples of the 8-frame hand-off or the 16-frame bus tile, ramps, per-voice frequency events."""
+    """The same bank through the ordinary kernel, the 2-wave pipeline and both forms of the 4-wave pipeline -- 8-frame
+    hand-offs (og_k4_*) and 16-frame ones (og_k4w_*, round 5) -- (OSCEN_GPU_SPLIT / OSCEN_GPU_WIDE pin the variant the
+    engine would otherwise pick from the bank size): ragged voice count, block lengths that are not multiples of the
+    hand-off or the 16-frame bus tile, ramps, per-voice frequency events."""
+    wide = depth == "4w"
+    depth = 4 if wide else depth
     monkeypatch.setenv("OSCEN_GPU_SPLIT", str(depth))
+    monkeypatch.setenv("OSCEN_GPU_WIDE", "1" if wide else "0")
     n = 150
     p = Pair("fm_voice", ol.BANK_FM, n, ol.FM_PARAMS)
     assert p.eng.pipeline_depth == max(1, depth)
+    assert p.eng.kernel_variant.startswith({0: "og_k_", 2: "og_k2_", 4: "og_k4w_" if wide else "og_k4_"}[depth])
     for op in ("op3", "op2", "op1", "filter"):
         p.set_value(op + "_attack", 0.002)
         p.set_value(op + "_decay", 0.004)
