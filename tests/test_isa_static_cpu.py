@@ -99,3 +99,33 @@ def test_the_electric_piano_kernel_uses_no_scratch_at_three_waves_per_simd(tmp_p
         kv = dict(re.findall(r"\.(\w+):\s+(\S+)", meta))
         assert kv["private_segment_fixed_size"] == "0" and kv["vgpr_spill_count"] == "0", (name, kv)
         assert int(kv["vgpr_count"]) <= 170, (name, kv["vgpr_count"])
+
+
+def test_a_frame_valued_function_is_evaluated_once_per_frame_whatever_the_number_of_channels_read(tmp_path):
+    """A registered function that returns a Frame<N> reaches the kernel as one textual call per channel read
+    (og_graph.cpp, Codegen::call: the value is an expression the consumer places in its own scope).  The calls are
+    force-inlined and pure, so they must fold into ONE evaluation: the kernel that reads both channels holds exactly as
+    many v_exp_f32 as the kernel that reads one (VERDICT r4, item 11 asked for proof rather than reliance)."""
+    oscen_amd.register_node("IsaStereoVar::new", inputs=[], outputs=[("output", 2)], n_ctor_args=2,
+                            state=[("l", "f32", 0.0, 0), ("r", "f32", 0.0, 1)], process="    output.v[0] = l;\n    output.v[1] = r;\n    l += r;\n")
+    oscen_amd.register_function("isa_rot", [("v", 2)], result_channels=2,
+                                source="const float e = __expf(v.v[0]); og::Frame<2> o; o.v[0] = e * v.v[1]; o.v[1] = e + v.v[1]; return o;")
+    try:
+        counts = {}
+        for tag, decl, conn in [("both", "output out: stream: Frame<2>;", "isa_rot(s.output) -> out;"),
+                                ("both_by_index", "output a: stream; output b: stream;", "isa_rot(s.output)[0] -> a; isa_rot(s.output)[1] * 2.0 -> b;"),
+                                ("one", "output a: stream;", "isa_rot(s.output)[0] -> a;")]:
+            src = oscen_amd.Graph(dsl=f"name: IsaFn_{tag}; {decl} nodes {{ s = IsaStereoVar::new(0.1, 0.2); }} connections {{ {conn} }}").kernel_source()
+            hip, asm = tmp_path / f"{tag}.hip", tmp_path / f"{tag}.s"
+            hip.write_text(src)
+            r = subprocess.run([b.hipcc(), "--offload-arch=" + b.ARCH, "-x", "hip", "-S", "--cuda-device-only", str(hip), "-o", str(asm)] + b.COMMON,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            assert r.returncode == 0, r.stdout[-2000:]
+            text = asm.read_text()
+            m = re.search(r"^(og_k_[0-9a-f]{16}_00):.*?^\.Lfunc_end", text, flags=re.S | re.M)
+            assert m, tag
+            counts[tag] = len(re.findall(r"\bv_exp_f32", m.group(0)))
+        assert counts["one"] > 0 and counts["both"] == counts["one"] == counts["both_by_index"], counts
+    finally:
+        oscen_amd.unregister_function("isa_rot")
+        oscen_amd.unregister_node("IsaStereoVar::new")
