@@ -3782,6 +3782,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                                      "][OG_BUS_CHUNK][OG_WAVE];\n    uint32_t cbase = 0;\n")
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
+         << "    og::bus_init(c, bus);\n"
          << (getenv("OGC_PRIO_PARITY") ? "    if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_setprio(1); // experiment\n" : "")
          << cg.common_decl.str() << cat(all_stages, &Codegen::Sect::decl) << "    if (c.valid) {\n"
          << cg.common_load.str() << cat(all_stages, &Codegen::Sect::load) << "    }\n";
@@ -4208,6 +4209,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (rel_prio >= 0) body << ind0 << "    __builtin_amdgcn_s_setprio(" << base_prio << ");\n";
                 body << ind0 << "}\n";
             };
+            if (last) body << "    og::bus_init(c, bus); // (this wave owns the tile)\n";
             body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
                  << "        " << (sticky ? "" : "const ") << "uint32_t ch = t - " << gi << "u;\n"
                  << "        if (ch < n_chunks) {\n"

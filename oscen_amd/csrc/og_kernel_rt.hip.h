@@ -576,16 +576,31 @@ struct BusLds {
     float tile[OG_BUS_CHUNK][OG_WAVE + 1]; // +1 pad: conflict-free transposed read
 };
 
+// A lane that contributes nothing to the bus (beyond the last voice; not the lead lane of a multi-lane voice) is not masked
+// to 0.0 on every frame (one v_cndmask per frame): it writes into the pad column, which the transposed read never visits,
+// and its own column holds the zeros bus_init() put there.  The column is loop-invariant, so the store of a frame is one
+// ds_write_b32 with an immediate offset.
+// ALL_LANES: every lane of a multi-lane voice holds a share of the voice's output (see og::ep_bank_tick)
+template <bool ALL_LANES>
+__device__ __forceinline__ uint32_t bus_col(const VoiceCtx& c)
+{
+    return (c.valid && (ALL_LANES || c.lead)) ? c.lane : (uint32_t)OG_WAVE;
+}
+// once per launch, by the wave that owns the tile, before its first bus_put
+__device__ __forceinline__ void bus_init(const VoiceCtx& c, BusLds& lds)
+{
+#pragma unroll
+    for (int j = 0; j < OG_BUS_CHUNK; ++j) lds.tile[j][c.lane] = 0.0f;
+}
+
 // one sample of one voice into the wave's transpose tile (row j = frame within the chunk)
 template <bool TAPS, bool ALL_LANES = false>
 __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLds& lds, uint32_t f, uint32_t j,
                                         float out)
 {
-    // ALL_LANES: every lane of a multi-lane voice holds a share of the voice's output (see og::ep_bank_tick)
-    const float y = (c.valid && (ALL_LANES || c.lead)) ? out : 0.0f;
-    lds.tile[j][c.lane] = y;
+    lds.tile[j][bus_col<ALL_LANES>(c)] = out;
     if (TAPS) {
-        if (c.tap >= 0 && c.lead) a.taps[(size_t)c.tap * a.frames + f] = y;
+        if (c.tap >= 0 && c.lead) a.taps[(size_t)c.tap * a.frames + f] = out;
     }
 }
 
@@ -630,15 +645,20 @@ using BusLds2 = BusLdsN<2>;
 template <bool TAPS, bool ALL_LANES = false, int N = 2>
 __device__ __forceinline__ void bus_put(const OgBlockArgs& a, const VoiceCtx& c, BusLdsN<N>& lds, uint32_t f, uint32_t j, OutN<N> out)
 {
-    const bool on = c.valid && (ALL_LANES || c.lead);
+    const uint32_t col = bus_col<ALL_LANES>(c);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const float y = on ? out.v[k] : 0.0f;
-        lds.ch[k].tile[j][c.lane] = y;
+        lds.ch[k].tile[j][col] = out.v[k];
         if (TAPS) {
-            if (c.tap >= 0 && c.lead) a.taps[((size_t)c.tap * a.frames + f) * N + k] = y;
+            if (c.tap >= 0 && c.lead) a.taps[((size_t)c.tap * a.frames + f) * N + k] = out.v[k];
         }
     }
+}
+template <int N>
+__device__ __forceinline__ void bus_init(const VoiceCtx& c, BusLdsN<N>& lds)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) bus_init(c, lds.ch[k]);
 }
 template <int N>
 __device__ __forceinline__ void bus_chunk_reduce(const OgBlockArgs& a, const VoiceCtx& c, BusLdsN<N>& lds, uint32_t base, uint32_t n)

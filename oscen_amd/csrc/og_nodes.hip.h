@@ -343,8 +343,14 @@ OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float& last_in, f
         tpt_params_nomod(cutoff_in, q_in, max_cutoff, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
         return;
     }
-    if (__float_as_uint(cutoff_in) != __float_as_uint(last_in)) {
-        last_in = cutoff_in;
+    // Wave-uniform: if any lane's cutoff moved, every lane updates -- a lane whose input did not move re-derives the
+    // coefficients it already has from the very same input (the first frame of a launch moves every lane off the
+    // sentinel), so the result is the per-lane test's; the usual frame leaves on one scalar branch (v_cmp + s_cbranch_vccz)
+    // instead of entering and leaving an empty divergent region (two more SALU and a register copy per frame), and the
+    // frame that does update runs without an exec mask.
+    const bool moved = __float_as_uint(cutoff_in) != __float_as_uint(last_in);
+    last_in = cutoff_in; // (unconditional: where nothing moved it is the value it had -- no register to reconcile at the join)
+    if (__any((int)moved)) {
         const float cutoff = clampf(cutoff_in, 20.0f, max_cutoff);
         const float q = clampf(q_in, 0.1f, 10.0f);
         // ONE divergent region, no second test inside it: a clamped cutoff (>= 20 Hz, ulp 1.9e-6) that differs from the
