@@ -957,6 +957,31 @@ def cluster_record(args, N, V, K, W, R, graph=None):
     return line
 
 
+class Watchdog:
+    """Calls `on_timeout` from another thread unless cancel() comes within `seconds` (C calls release the GIL, so a leg that
+    hangs inside the library or inside RCCL does not block it)."""
+
+    def __init__(self, seconds, on_timeout):
+        import threading
+
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=lambda: None if self._done.wait(seconds) else on_timeout(), daemon=True)
+        self._thread.start()
+
+    def cancel(self):
+        self._done.set()
+
+
+def emit_line_and_exit(line, extra):
+    """The watchdog's exit: print the line as it stands (plus `extra`) as the LAST line of stdout and leave the process."""
+    import ctypes
+
+    line.update(extra)
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+    os._exit(0)
+
+
 def run_cluster(args):
     """--cluster: ONE process drives every GPU through the C-ABI cluster."""
     line = cluster_record(args, args.gpus, args.voices_per_gpu, args.steps, args.warmup, args.repeats if args.repeats > 0 else 5)
@@ -988,6 +1013,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` array (the other BASELINE configurations, measured after the headline at N = 1)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the blocking-path real-time latency record")
+    ap.add_argument("--cluster-timeout", type=int, default=300,
+                    help="N > 1: seconds the og_cluster sub-record may take before the line is printed without it")
     ap.add_argument("--rt-blocks", type=int, default=1000, help="blocks per bank size of the real-time record")
     ap.add_argument("--rt-paced-blocks", type=int, default=750,
                     help="blocks of the paced run (one call per 5.33 ms block period) on the largest bank of the real-time record")
@@ -1193,6 +1220,11 @@ def main():
             # library's ncclReduce (the ranks above used torch.distributed's communicator).  Rank 0 runs it after the
             # process group is gone; the other ranks have finished.
             eng.close()
+            # (the one leg of an N > 1 run that no rank-per-GPU phase above has exercised: if it does not come back, the
+            #  line -- headline and config4 complete -- is printed without it instead of being lost with the process)
+            guard = Watchdog(args.cluster_timeout, lambda: emit_line_and_exit(
+                line, {"og_cluster": {"error": "the og_cluster leg did not finish within %d s" % args.cluster_timeout},
+                       "realtime": None, "cpu_baseline": None}))
             try:
                 c = cluster_record(args, world_size, V, K, W, R)
                 line["og_cluster"] = {k: c[k] for k in ("value", "ms_per_step", "rccl_ranks", "cluster", "multi_gpu", "timing")}
@@ -1201,6 +1233,8 @@ def main():
                 line["og_cluster"]["kernel"], line["og_cluster"]["kernel_ms_per_block"] = rf["kernel_variant"], rf["kernel_ms_per_block"]
             except (Exception, SystemExit) as e:
                 line["og_cluster"] = {"error": str(e)[:300]}
+            finally:
+                guard.cancel()
         configs = None
         if world_size == 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant:
             eng.close()

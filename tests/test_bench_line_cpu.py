@@ -146,3 +146,26 @@ def test_pipeline_depth_by_bank_size(hostsim_env):
     assert r.returncode == 0, r.stderr[-2000:]
     got = dict(tuple(int(x) for x in ln.split()) for ln in r.stdout.strip().splitlines())
     assert got == {64: 4, 16384: 4, 65536: 4, 98304: 4, 131072: 2, 196608: 4, 262144: 1, 1048576: 1}, got
+
+
+def test_the_line_survives_a_leg_that_never_returns(tmp_path):
+    """bench.py's watchdog (N > 1: the og_cluster sub-record is the one leg no rank-per-GPU phase has exercised before it
+    runs): a leg that hangs -- here a sleep standing in for a collective that never completes -- costs its own sub-record,
+    not the line; a leg that returns in time cancels the watchdog."""
+    code = """
+import sys, time, json
+sys.path.insert(0, %r)
+import bench
+line = {"metric": "m", "value": 1.0}
+g = bench.Watchdog(60, lambda: bench.emit_line_and_exit(line, {"og_cluster": {"error": "fast leg timed out"}}))
+g.cancel()                                   # a leg that came back
+g = bench.Watchdog(1, lambda: bench.emit_line_and_exit(line, {"og_cluster": {"error": "timed out"}, "cpu_baseline": None}))
+print("noise before the line")
+time.sleep(30)                               # a leg that does not
+print(json.dumps({"never": "printed"}))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=25)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    assert d == {"metric": "m", "value": 1.0, "og_cluster": {"error": "timed out"}, "cpu_baseline": None}
