@@ -12,14 +12,23 @@
 #define ITERS 2048
 
 template <int OP>
-__device__ __forceinline__ void step(float (&x)[CH], float a, float b)
+__device__ __forceinline__ void step(float (&x)[CH], double (&xp)[CH], float a, float b, double ap, double bp)
 {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
         if (OP == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
         if (OP == 2) asm volatile("v_fract_f32 %0, %0" : "+v"(x[i]));
-        if (OP == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a) : );
+        if (OP == 3) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a) : );
+        if (OP == 13) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x[i]) : "v"(a) : );
+        if (OP == 14) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+        // compare + select pairs as the compiler writes them (it puts `s_nop 1` between a VALU write of the mask and the select)
+        if (OP == 18) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
+        if (OP == 19) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]" : "+v"(x[i]) : "v"(a), "v"(b) : "s20", "s21");
+        if (OP == 20) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
+        if (OP == 15) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+        if (OP == 16) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x[i]));
+        if (OP == 17) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
         if (OP == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
         if (OP == 5) asm volatile("v_sin_f32 %0, %0" : "+v"(x[i]));
         if (OP == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
@@ -35,7 +44,7 @@ __device__ __forceinline__ void step(float (&x)[CH], float a, float b)
             if (i == 7) asm volatile("v_sin_f32 %0, %0" : "+v"(x[i]));
             else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
         }
-        if (OP == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*(double*)&x[i & ~1]) : "v"(*(double*)&a), "v"(*(double*)&b));
+        if (OP == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(xp[i]) : "v"(ap), "v"(bp));
         if (OP == 11) asm volatile("s_mul_i32 s20, s20, s21" ::: "s20");
         if (OP == 12) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
     }
@@ -47,16 +56,19 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
     float x[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) x[i] = 0.5f + 0.01f * (float)(threadIdx.x + i);
-    float aa[2] = {a, a}, bb[2] = {b, b};
-    (void)aa; (void)bb;
+    double xp[CH]; // eight independent 64-bit register pairs for the packed form
+    union { float f[2]; double d; } ua = {{a, a}}, ub = {{b, b}};
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { union { float f[2]; double d; } u = {{x[i], x[i] * 0.5f}}; xp[i] = u.d; }
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555" ::: "vcc", "s20", "s21");
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < ITERS; ++it) step<OP>(x, a, b);
+    for (int it = 0; it < ITERS; ++it) step<OP>(x, xp, a, b, ua.d, ub.d);
     asm volatile("s_waitcnt lgkmcnt(0)");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) s += x[i];
+    for (int i = 0; i < CH; ++i) { union { double d; float f[2]; } u; u.d = xp[i]; s += x[i] + u.f[0] + u.f[1]; }
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -97,7 +109,15 @@ int main()
     run<1>("v_mul_f32", out, cyc, n_simd);
     run<12>("v_sub_f32", out, cyc, n_simd);
     run<2>("v_fract_f32", out, cyc, n_simd);
-    run<3>("v_cndmask_b32", out, cyc, n_simd);
+    run<3>("v_cndmask_b32 (vcc)", out, cyc, n_simd);
+    run<13>("v_cndmask_b32 (sgpr)", out, cyc, n_simd);
+    run<14>("v_max_f32", out, cyc, n_simd);
+    run<20>("v_cmp_gt_f32 -> vcc", out, cyc, n_simd);
+    run<18>("cmp+nop+cndmask vcc", out, cyc, n_simd);
+    run<19>("cmp+nop+cndmask sgpr", out, cyc, n_simd);
+    run<15>("v_med3_f32", out, cyc, n_simd);
+    run<16>("v_cvt_f32_u32", out, cyc, n_simd);
+    run<17>("v_add_u32", out, cyc, n_simd);
     run<10>("v_pk_fma_f32", out, cyc, n_simd);
     run<4>("v_rcp_f32", out, cyc, n_simd);
     run<5>("v_sin_f32", out, cyc, n_simd);
