@@ -715,6 +715,25 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
             else:
                 midi.process_block_async(block, base + i * block * ch * 4)
 
+    def steps(a, b):
+        """blocks a .. b-1.  Where nothing happens between blocks (no MIDI, no value change) they cross the boundary in ONE
+        call, og_process_blocks_async: same queue, same launches, same buses bit for bit -- what is left out is Python's
+        ~2 us per ctypes call, 40 us of a 600 us region at the driver's 20 steps, which a compiled host does not pay
+        (--per-block-calls keeps one call per block)."""
+        if midi is not None or args.per_block_calls:
+            for i in range(a, b):
+                step(i)
+            return
+        i = a
+        while i < b:
+            if i in ramp_blocks:
+                eng.set_value("filter_cutoff", ramp_blocks[i])
+            j = i + 1
+            while j < b and j not in ramp_blocks:
+                j += 1
+            eng.process_blocks_async(block, j - i, base + i * block * ch * 4, block * ch * 4)
+            i = j
+
     def reduce_bus(t):
         if args.backend == "gloo":  # CPU collective (plumbing check only)
             h = t.cpu()
@@ -734,8 +753,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
     # voice kernel after OTHER kernels (RCCL's, or any torch kernel) is ~35 % slower than in a steady stream of blocks
     # (same instruction count, +57 % instruction-fetch wait: its code has to come back from HBM), and with one launch per
     # 20-32 blocks that launch is the whole timed region -- a measurement artefact of the barrier, not of the path.
-    for i in range(max(0, W - 1)):
-        step(i)
+    steps(0, max(0, W - 1))
     eng.flush()
     if dist is not None:  # communicator set-up (lazy in RCCL) must not land in the timed region
         reduce_bus(bus[:max(1, W - 1)] if W > 1 else torch.zeros((1, block * ch), dtype=torch.float32, device="cuda"))
@@ -757,8 +775,7 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
             torch.cuda.synchronize()
         eng.enable_kernel_timing(True)  # (per region: the untimed block in front of it is not part of the launch average)
         t0 = time.perf_counter()
-        for i in range(first, first + K):
-            step(i)
+        steps(first, first + K)
         eng.flush()  # the reduces of the last (partial) batch of blocks: inside the timed region
         if dist is not None:
             # ONE RCCL reduce of the [K, block] mix bus over xGMI, bracketed by events on the stream it runs on (the
@@ -1013,6 +1030,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` array (the other BASELINE configurations, measured after the headline at N = 1)")
     ap.add_argument("--no-realtime", action="store_true", help="skip the blocking-path real-time latency record")
+    ap.add_argument("--per-block-calls", action="store_true",
+                    help="hand the blocks of a region to the engine one og_process_block_async call at a time (default: one "
+                         "og_process_blocks_async call per run of blocks with nothing in between)")
     ap.add_argument("--cluster-timeout", type=int, default=300,
                     help="N > 1: seconds the og_cluster sub-record may take before the line is printed without it")
     ap.add_argument("--rt-blocks", type=int, default=1000, help="blocks per bank size of the real-time record")
@@ -1177,6 +1197,8 @@ def main():
                 "events_in_timed_region": n_events_timed // R,
                 "note_plan_span_frames": span if span else 48000,
                 "blocks_per_launch_limit": args.bus_batch if args.bus_batch else "engine's choice (8..32 by bank size)",
+                "host_calls": "one og_process_block_async per block" if (midi is not None or args.per_block_calls)
+                              else "one og_process_blocks_async per run of blocks between value changes (K blocks per region)",
                 "voice_slots": ("grouped by first note-off (og_group_voices policy %d)" % args.group_voices) if (args.group_voices and midi is None) else "in voice order",
                 "event_path": ("midi-live (og_midi_send_batch + %s per block)" %
                                ("og_midi_process_block, blocking" if args.midi_blocking else "og_midi_process_block_async"))

@@ -40,6 +40,7 @@ extern "C" {
                                v: c_float) -> c_int;
     pub fn og_process_block(e: *mut og_engine, frames: u32, out_bus: *mut c_float) -> c_int;
     pub fn og_process_block_async(e: *mut og_engine, frames: u32, d_out_bus: *mut c_void) -> c_int;
+    pub fn og_process_blocks_async(e: *mut og_engine, frames: u32, n_blocks: u32, d_out_bus: *mut c_void, out_stride_bytes: usize) -> c_int;
     pub fn og_synchronize(e: *mut og_engine) -> c_int;
     pub fn og_render(e: *mut og_engine, total_frames: u64, block: u32, out: *mut c_float) -> c_int;
     pub fn og_latency_samples(e: *const og_engine) -> u32;

@@ -269,6 +269,12 @@ int og_process_block(og_engine* e, uint32_t frames, float* out_bus);
  * NULL to keep it in the engine's own buffer) and the call only enqueues work
  * on the engine's stream. */
 int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus);
+/* n_blocks consecutive og_process_block_async(frames) calls in one -- the reference's render loops call process_block
+ * back to back with nothing in between (BlockRender::render, oscen-lib/src/graph/offline.rs:46-90; the criterion loops,
+ * oscen-lib/benches/static_vs_runtime.rs:96-116) --: block b's bus goes to d_out_bus + b * out_stride_bytes (NULL keeps
+ * the buses in the engine's own buffer, where only the last one stays readable).  frames in 1..512.  Results are those
+ * of n_blocks separate calls, bit for bit; what it saves is n_blocks - 1 crossings of the boundary. */
+int og_process_blocks_async(og_engine* e, uint32_t frames, uint32_t n_blocks, float* d_out_bus, size_t out_stride_bytes);
 int og_synchronize(og_engine* e);
 /* Throughput option for streaming callers of og_process_block_async: up to `blocks` (1..32) consecutive async blocks
  * that nothing but event pushes separates (no value change, no taps) are rendered by ONE launch of the voice kernel over

@@ -1929,6 +1929,21 @@ int og_process_block_async(og_engine* e, uint32_t frames, float* d_out_bus)
     });
 }
 
+// n consecutive og_process_block_async calls in one: a render loop that has nothing to say between its blocks (offline
+// rendering, a streaming caller that queues a buffer's worth) crosses the boundary once.  Same queue, same results.
+int og_process_blocks_async(og_engine* e, uint32_t frames, uint32_t n_blocks, float* d_out_bus, size_t out_stride_bytes)
+{
+    if (!e) return set_err(OG_E_INVALID, "null engine");
+    if (!e->inited) return set_err(OG_E_STATE, "og_init must be called before processing");
+    if (frames == 0 || frames > OG_MAX_BLOCK_SIZE) return set_err(OG_E_INVALID, "frames must be in 1..512");
+    if (d_out_bus && out_stride_bytes % sizeof(float)) return set_err(OG_E_INVALID, "out_stride_bytes must be a multiple of 4");
+    return guard([&] {
+        for (uint32_t b = 0; b < n_blocks; ++b)
+            e->process_async(frames, d_out_bus ? d_out_bus + (size_t)b * (out_stride_bytes / sizeof(float)) : nullptr);
+        return OG_OK;
+    });
+}
+
 int og_synchronize(og_engine* e)
 {
     if (!e) return set_err(OG_E_INVALID, "null engine");

@@ -110,3 +110,44 @@ def test_the_kernel_reads_its_own_clock_and_the_probe_reads_the_idle_one():
     eng.enable_kernel_timing(False)
     eng.process_block(frames)
     assert eng.kernel_time_ms()[0] < 0.0                    # timing off
+
+
+@pytest.mark.parametrize("batch", [1, 0])
+def test_blocks_handed_over_in_one_call_equal_the_blocks_handed_over_one_by_one(batch):
+    """og_process_blocks_async (what bench.py's timed region calls where nothing happens between its blocks): n blocks in
+    one crossing of the boundary ≡ n og_process_block_async calls, bit for bit, buses at base + b * stride; a stride
+    wider than a block leaves the gap untouched; bad arguments are refused."""
+    n, block, nb = 200, 256, 9
+    total = block * nb
+    plans = oscen_amd.note_plans(n, span=total, fold="slice")
+
+    def run(one_call, stride_blocks=1):
+        eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+        oscen_amd.schedule_note_plans(eng, plans, total_frames=total)
+        if batch != 1:
+            eng.set_bus_batching(batch)
+        ch = eng.channels
+        stride = stride_blocks * block * ch * 4
+        buf = DeviceBuffer(nb * stride)
+        try:
+            if one_call:
+                eng.process_blocks_async(block, 4, buf.ptr.value, stride)            # two calls: 4 + 5 blocks
+                eng.process_blocks_async(block, nb - 4, buf.ptr.value + 4 * stride, stride)
+            else:
+                for i in range(nb):
+                    eng.process_block_async(block, buf.ptr.value + i * stride)
+            eng.synchronize()
+            return buf.to_host().reshape(nb, stride_blocks, block * ch), eng
+        finally:
+            buf.free()
+
+    a, _ = run(False)
+    b, eng = run(True)
+    assert np.array_equal(a, b) and np.abs(a).max() > 0.0
+    c, _ = run(True, stride_blocks=2)
+    assert np.array_equal(c[:, 0], a[:, 0]) and not c[:, 1].any()
+    with pytest.raises(oscen_amd.OscenError):
+        eng.process_blocks_async(0, 3)
+    with pytest.raises(oscen_amd.OscenError):
+        eng.process_blocks_async(513, 3)
+    eng.process_blocks_async(block, 0)  # nothing to do

@@ -192,8 +192,9 @@ class DeviceBuffer:
 
 
 def render_as_bench_does(graph, n, total, block, batch, env=None):
-    """bench.py:step/flush: async blocks into one device buffer, `batch` blocks per launch (0 = the engine's pick),
-    flushed once at the end"""
+    """bench.py:steps/flush: async blocks into one device buffer -- the first five one og_process_block_async call each
+    (`--per-block-calls`), the rest in ONE og_process_blocks_async call (the default) --, `batch` blocks per launch (0 = the
+    engine's pick), flushed once at the end"""
 
     old = {}
     for k, v in (env or {}).items():
@@ -215,8 +216,10 @@ def render_as_bench_does(graph, n, total, block, batch, env=None):
     nb = total // block
     bus = DeviceBuffer(nb * block * ch * 4)
     eng.enable_kernel_timing(True)
-    for i in range(nb):
+    single = min(5, nb)
+    for i in range(single):
         eng.process_block_async(block, bus.ptr.value + i * block * ch * 4)
+    eng.process_blocks_async(block, nb - single, bus.ptr.value + single * block * ch * 4, block * ch * 4)
     eng.flush()
     eng.synchronize()
     _, launches = eng.kernel_time_ms()
