@@ -54,6 +54,6 @@ def test_guard_maps_exception_types_to_codes_without_reading_messages():
 
 def test_environment_knobs_are_not_read_on_the_block_path():
     eng = open(os.path.join(CSRC, "og_engine.cpp")).read()
-    for fn in ("og_process_block", "og_process_block_async", "og_midi_process_block"):
+    for fn in ("og_process_block", "og_process_block_async", "og_process_blocks_async", "og_midi_process_block"):
         b = _body(eng, fn) or _body(open(os.path.join(CSRC, "og_midi.cpp")).read(), fn)
         assert b is not None and "getenv" not in b, fn
