@@ -468,7 +468,6 @@ def _realtime_record(graph, block, voices_list, n_blocks, midi_per_block, device
         # live MIDI only: at most a few 10^4 voices sound, the rest take the cheapest chunk variant
         "idle_bank": {"runs": out,
                       "realtime_voices_at_48k": max([r["voices"] for r in ok]) if ok else 0},
-        "runs": out,
         # the largest LOADED bank measured here whose EVERY block met the deadline (not an extrapolation)
         "realtime_voices_at_48k": best["voices"] if best else 0,
         "realtime_voices_at_48k_is": "loaded bank (resident score on every voice + live MIDI), back to back and paced",
@@ -989,23 +988,142 @@ class Watchdog:
         self._done.set()
 
 
-def emit_line_and_exit(line, extra):
-    """The watchdog's exit: print the line as it stands (plus `extra`) as the LAST line of stdout and leave the process."""
+def _sig(x, n=6):
+    """Floats to n significant digits (the line is read by people and by a tail-limited log), everything else as is."""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x)) if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d}
+
+
+LINE_LIMIT = 8000  # bytes: a log that keeps only its last 8 KB still holds the whole line (tests/test_bench_line_cpu.py)
+
+
+def compact_line(full):
+    """The ONE line of the contract, <= LINE_LIMIT bytes: the contract's keys, a trimmed `roofline` and `cpu_baseline`, the
+    compact `configs` array and one-number summaries of the other legs.  Everything else (every region's time, the real-time
+    runs, the CPU scaling probe, per-configuration roofline records) is in the detail record emit() writes beside it."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    if len(str(cfg.get("workload", ""))) > 420:
+        cfg["workload"] = cfg["workload"][:417] + "..."
+    out["config"] = cfg
+    rf = full.get("roofline")
+    if rf is not None:
+        r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "dram_gbs", "traffic_bytes_per_launch", "traffic_source",
+                       "stale_profile", "kernel_variant", "kernel_hash", "kernel_ms_avg", "kernel_launches", "blocks_per_launch",
+                       "kernel_ms_per_block", "algorithmic_bytes_per_launch", "bytes_per_voice_sample", "pipeline_waves_per_64_voices"))
+        r["achieved_is"] = "charged bytes (SURVEY 8d) / kernel time; DRAM bandwidth by counters = dram_gbs; the bound that applies = valu_issue"
+        r["valu_issue"] = _pick(rf.get("valu_issue"), ("achieved", "peak", "measured_ceiling", "unit", "frac", "frac_of_measured_ceiling",
+                                                       "valu_wave_inst_per_64_voices_per_frame", "cycles_per_valu_inst_per_simd"))
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "single_thread", "per_thread", "cpu_count"))
+        c["sample"] = str(cb.get("sample", ""))[:360]
+        cs = cb.get("criterion_shapes") or {}
+        c["criterion_shapes"] = {k: v for k, v in cs.items() if k != "source"}
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    tm = full.get("timing") or {}
+    out["timing"] = _pick(tm, ("repeats", "value_median", "value_min", "value_max", "value_first_region", "value_median_first5", "repeats_rule"))
+    if out["timing"] is not None:
+        k = [x for x in (tm.get("kernel_sclk_ghz") or []) if x]
+        out["timing"]["kernel_sclk_ghz_first_last"] = [k[0], k[-1]] if k else None
+        if len(str(out["timing"].get("repeats_rule", ""))) > 80:
+            out["timing"]["repeats_rule"] = out["timing"]["repeats_rule"][:77] + "..."
+    out["value_median_first5"] = tm.get("value_median_first5")
+    out["rccl_ranks"] = full.get("rccl_ranks")
+    mg = full.get("multi_gpu")
+    out["multi_gpu"] = None if mg is None else {k: v for k, v in mg.items() if not isinstance(v, (list, dict)) or len(json.dumps(v)) < 400}
+    for k in ("config4", "og_cluster"):
+        if full.get(k) is not None:
+            rec = full[k]
+            out[k] = {kk: vv for kk, vv in rec.items() if not isinstance(vv, (list, dict)) or len(json.dumps(vv)) < 300}
+    if full.get("event_stats") is not None:
+        out["event_stats"] = full["event_stats"]
+    rt = full.get("realtime")
+    if rt is not None:
+        def one(r):
+            lat = r.get("latency_ms") or {}
+            rec = {"voices": r.get("voices"), "loaded": bool(r.get("resident_score_events")), "p50_ms": lat.get("p50"), "p99_ms": lat.get("p99"),
+                   "max_ms": lat.get("max"), "misses": r.get("deadline_misses"), "blocks": r.get("blocks")}
+            if r.get("paced"):
+                rec["paced_p99_ms"], rec["paced_misses"] = (r["paced"].get("latency_ms") or {}).get("p99"), r["paced"].get("deadline_misses")
+            return rec
+        runs = list((rt.get("idle_bank") or {}).get("runs") or []) + list((rt.get("loaded") or {}).get("runs") or [])
+        runs = [r for r in runs if isinstance(r, dict) and "voices" in r][:8]
+        out["realtime"] = {"deadline_ms": runs[0].get("deadline_ms") if runs else None,
+                           "midi_messages_per_block": runs[0].get("midi_messages_per_block") if runs else None,
+                           "entry": "og_midi_send_batch + og_midi_process_block (blocking), one launch per block", "runs": [one(r) for r in runs]}
+        out["realtime_voices_at_48k"] = full.get("realtime_voices_at_48k")
+    else:
+        out["realtime"] = None
+    out["offline_voices_at_48k"] = full.get("offline_voices_at_48k")
+    if full.get("configs") is not None:
+        out["configs"], out["configs_keys"] = full["configs"], full["configs_keys"]
+    out["detail"] = full.get("detail")
+    # (the contract's own numbers -- value, ms_per_step -- stay at full precision: a reader may cross-check one against the other)
+    out = {k: (_sig(v, 17) if not isinstance(v, (dict, list)) else _sig(v)) for k, v in out.items()}
+    s = json.dumps(out, allow_nan=False)
+    for k in ("realtime", "og_cluster", "config4", "multi_gpu", "timing"):  # (never print a line a tail would cut)
+        if len(s) <= LINE_LIMIT:
+            break
+        out[k] = "dropped: the line would exceed %d bytes; see the detail record" % LINE_LIMIT
+        s = json.dumps(out, allow_nan=False)
+    return s
+
+
+def emit(full):
+    """Write the FULL record to a side file and to stdout as a `BENCH_DETAIL ` line, then the compact line of the contract as
+    the LAST line of stdout."""
     import ctypes
 
-    line.update(extra)
+    path = os.environ.get("OSCEN_BENCH_DETAIL")
+    if not path:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail_n%s.json" % full.get("n_gpus", 1))
+        except OSError:
+            path = None
+    detail = json.dumps(_sig(full, 9))
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(detail + "\n")
+            full["detail"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+        except OSError:
+            full["detail"] = "stdout: the BENCH_DETAIL line above"
+    # RCCL writes a version banner through C stdio: push it out first, so that the JSON is the LAST line of stdout
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(line), flush=True)
+    sys.stdout.write("BENCH_DETAIL " + detail + "\n")
+    sys.stdout.write(compact_line(full) + "\n")
+    sys.stdout.flush()
+
+
+def emit_line_and_exit(line, extra):
+    """The watchdog's exit: print the line as it stands (plus `extra`) as the LAST line of stdout and leave the process."""
+    line.update(extra)
+    emit(line)
     os._exit(0)
 
 
 def run_cluster(args):
     """--cluster: ONE process drives every GPU through the C-ABI cluster."""
     line = cluster_record(args, args.gpus, args.voices_per_gpu, args.steps, args.warmup, args.repeats if args.repeats > 0 else 5)
-    import ctypes
-
-    ctypes.CDLL(None).fflush(None)
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def main():
@@ -1262,7 +1380,7 @@ def main():
             eng.close()
             torch.cuda.synchronize()
             configs = config_records(args, local_rank)
-            line["roofline"]["configs"] = configs
+            line["configs_detail"] = configs
         if world_size == 1 and not args.no_realtime and has_gate and args.graph == "fm_voice":
             torch.cuda.synchronize()
             env = dict(os.environ)
@@ -1292,10 +1410,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(block, oscen_amd.SYNTH_SEED, K * block, span if span <= 48000 else 47999)
         else:
             line["cpu_baseline"] = None
-        # RCCL writes a version banner through C stdio: push it out first, so that the JSON is the LAST line of stdout
-        import ctypes
-
-        ctypes.CDLL(None).fflush(None)
         if configs is not None:
             # LAST key of the line, compact, so that the tail a log keeps still shows every configuration:
             # [name, voices, value, ms_per_step, kernel, roofline.frac, valu_issue.frac, dram GB/s, stale profile]
@@ -1306,7 +1420,7 @@ def main():
                                 sig(c.get("roofline_frac")), sig(c.get("valu_issue_frac")), sig(c.get("dram_gbs")), c.get("stale_profile"),
                                 c.get("error")] for c in configs]
             line["configs_keys"] = "name, voices, voices*samples/s, ms_per_step, kernel, roofline.frac (charged), valu_issue.frac, dram GB/s, stale_profile, error"
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ print("driver regions ms:", t.get("regions_ms"))
 rt = drv.get("realtime")
 if rt:
     print("realtime_voices_at_48k", rt["realtime_voices_at_48k"], "harness", rt.get("harness"))
-    for r in rt["runs"]:
+    for r in rt["idle_bank"]["runs"]:
         l = r["latency_ms"]
         p = r.get("paced")
         print("  %9d voices: p50 %.3f p99 %.3f p999 %.3f max %.3f ms, misses %d, marker timeouts %d%s" % (

@@ -56,7 +56,25 @@ def run_bench(env, argv):
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     assert r.stdout.rstrip().endswith(line)  # the JSON is the LAST line of stdout
-    return json.loads(line)
+    d = strict_line(line)
+    detail = [ln for ln in r.stdout.splitlines() if ln.startswith("BENCH_DETAIL ")]
+    assert len(detail) == 1 and r.stdout.index(detail[0]) < r.stdout.index(line)  # the full record comes BEFORE the line
+    d["_detail"] = json.loads(detail[0][len("BENCH_DETAIL "):])
+    return d
+
+
+def _no_constants(name):
+    raise ValueError("non-strict JSON constant %s in the bench line" % name)
+
+
+def strict_line(line):
+    """The line as the driver reads it: one line, < 8000 bytes (a log's 8 KB tail holds it whole), strict JSON (no NaN /
+    Infinity), the contract's keys."""
+    assert "\n" not in line and len(line.encode()) < 8000, len(line)
+    d = json.loads(line, parse_constant=_no_constants)
+    for k in CONTRACT:
+        assert k in d, k
+    return d
 
 
 CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
@@ -72,15 +90,17 @@ def test_default_line_carries_every_baseline_configuration(hostsim_env):
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert abs(d["value"] - 192 * 4 * 256 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_hash", "stale_profile"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_hash", "stale_profile", "dram_gbs", "kernel_variant",
+              "kernel_ms_per_block", "traffic_source", "valu_issue"):
         assert k in rf, k
-    assert list(d)[-2:] == ["configs", "configs_keys"]            # last keys of the line: they survive a log's tail
+    assert "value_median_first5" in d and d["detail"] and os.path.exists(os.path.join(ROOT, d["detail"]))
+    assert "regions_ms" not in d["timing"] and len(d["_detail"]["timing"]["regions_ms"]) == 2  # every region: the detail record
     names = [c[0] for c in d["configs"]]
     assert names == ["2-variant", "4-shard", "3a", "3b", "5"]
     for c in d["configs"]:
         assert c[-1] is None, c                                   # no error
         assert c[2] > 0 and c[3] > 0 and isinstance(c[4], str) and c[4].startswith("og_k")
-    full = rf["configs"]
+    full = d["_detail"]["configs_detail"]
     assert [c["graph"] for c in full] == ["fm_voice", "fm_voice", "epiano_voice", "sub_voice", "sat4x_voice"]
     assert full[0]["variant"] == "survey2" and full[0]["kernel"].endswith(("_10", "_11")) or "kernel" in full[0]
     assert full[2]["events_in_timed_region"] >= 0 and full[4]["events_in_timed_region"] == 0  # the saturator has no gate
@@ -120,14 +140,15 @@ def test_eight_rank_line_carries_config4_and_the_og_cluster_leg(hostsim_env, tmp
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                         # rank 0 prints ONE line
-    d = json.loads(lines[0])
+    d = strict_line(lines[0])
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 8 and d["config"]["total_voices"] == 8 * 64 and d["scaling"] == "weak"
     assert d["multi_gpu"]["rccl_ranks"] == 8 and len(d["multi_gpu"]["per_rank_kernel_ms_avg"]) == 8
     c4 = d["config4"]
     assert c4["voices_per_gpu"] == 128 and c4["total_voices"] == 8 * 128 and c4["rccl_ranks"] == 8 and c4["value"] > 0
-    assert len(c4["multi_gpu"]["per_rank_kernel_ms_avg"]) == 8
+    full = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("BENCH_DETAIL ")][0][len("BENCH_DETAIL "):])
+    assert len(full["config4"]["multi_gpu"]["per_rank_kernel_ms_avg"]) == 8
     oc = d["og_cluster"]
     assert "error" not in oc, oc
     assert oc["rccl_ranks"] == 8 and oc["cluster"]["devices"] == 8 and oc["cluster"]["rccl_reduces"] > 0 and oc["value"] > 0
@@ -168,4 +189,31 @@ print(json.dumps({"never": "printed"}))
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     d = json.loads(last)
-    assert d == {"metric": "m", "value": 1.0, "og_cluster": {"error": "timed out"}, "cpu_baseline": None}
+    assert d["metric"] == "m" and d["value"] == 1.0 and d["og_cluster"] == {"error": "timed out"} and d["cpu_baseline"] is None
+    assert "never" not in d
+
+
+def test_compact_line_of_a_full_driver_record_fits_a_log_tail():
+    """Round 5's driver record (profiles/bench_r05q_driver.json: 20 KB, every leg present -- 45 regions, six real-time banks, the
+    CPU scaling probe, five configurations) through compact_line(): under 8000 bytes, strict JSON, the keys VERDICT r5 item 1
+    lists.  A NaN anywhere in the record becomes null instead of a bare NaN token."""
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    full = json.load(open(os.path.join(ROOT, "profiles", "bench_r05q_driver.json")))
+    full["realtime"]["idle_bank"]["runs"] = full["realtime"]["runs"]
+    full["roofline"]["dram_frac"] = float("nan")
+    full["timing"]["value_max"] = float("inf")
+    line = bench.compact_line(full)
+    d = strict_line(line)
+    assert d["timing"]["value_max"] is None
+    assert d["value"] == full["value"] and d["value_median_first5"] and d["realtime_voices_at_48k"] == 8388608
+    assert len(d["realtime"]["runs"]) == 6 and d["realtime"]["runs"][-1]["loaded"] and d["realtime"]["deadline_ms"]
+    assert [c[0] for c in d["configs"]] == ["2-variant", "4-shard", "3a", "3b", "5"]
+    for k in ("value", "unit", "cores", "kind", "sample", "single_thread"):
+        assert k in d["cpu_baseline"], k
+    for k in ("frac", "achieved", "peak", "dram_gbs", "kernel_variant", "kernel_ms_per_block", "traffic_source", "stale_profile"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["valu_issue"]["frac"] > 0
