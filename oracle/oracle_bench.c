@@ -33,6 +33,29 @@ typedef struct {
 static int g_fold = 0;
 void oo_bench_set_fold(int fold) { g_fold = fold; }
 
+/* Scenario of the multi-threaded renders (full-size parity tests of SURVEY 8(d) config 2's VARIANT): broadcast
+ * parameters set immediately before the first frame, and setter calls `set_<n>(v)` (ramped inputs ramp over their
+ * declared length, examples/fm-synth/src/fm_voice.rs `[ramp: 2205]`) made right before frame `at_frame` -- the render
+ * cuts its block there, as a host calling the setter between two process_block calls does. */
+#define OO_SCN_MAX 16
+static struct { uint32_t param; float value; } g_scn_set[OO_SCN_MAX];
+static struct { uint32_t param; float value; uint32_t at_frame; } g_scn_ramp[OO_SCN_MAX];
+static uint32_t g_scn_nset = 0, g_scn_nramp = 0;
+void oo_bench_scenario_clear(void) { g_scn_nset = g_scn_nramp = 0; }
+int oo_bench_scenario_set(uint32_t param, float value)
+{
+    if (g_scn_nset >= OO_SCN_MAX) return -1;
+    g_scn_set[g_scn_nset].param = param, g_scn_set[g_scn_nset].value = value, ++g_scn_nset;
+    return 0;
+}
+int oo_bench_scenario_ramp(uint32_t param, float value, uint32_t at_frame)
+{
+    if (g_scn_nramp >= OO_SCN_MAX) return -1;
+    g_scn_ramp[g_scn_nramp].param = param, g_scn_ramp[g_scn_nramp].value = value, g_scn_ramp[g_scn_nramp].at_frame = at_frame;
+    ++g_scn_nramp;
+    return 0;
+}
+
 static double now_s(void)
 {
     struct timespec ts;
@@ -52,8 +75,13 @@ static void render_group(worker_arg *a, uint32_t lo, uint32_t hi, oo_note_events
     const int gated = a->kind != OO_BANK_SAT4X && a->kind != OO_BANK_SAT1X;
     float out[OO_MAX_BLOCK * 2];
     const uint32_t ch = oo_bank_channels(b);
-    for (uint32_t f0 = 0; f0 < a->frames_total; f0 += a->block) {
-        const uint32_t frames = a->frames_total - f0 < a->block ? a->frames_total - f0 : a->block;
+    for (uint32_t k = 0; k < g_scn_nset; ++k) oo_bank_set_value_immediate(b, g_scn_set[k].param, g_scn_set[k].value);
+    for (uint32_t f0 = 0, frames = 0; f0 < a->frames_total; f0 += frames) {
+        frames = a->frames_total - f0 < a->block ? a->frames_total - f0 : a->block;
+        for (uint32_t k = 0; k < g_scn_nramp; ++k) {
+            if (g_scn_ramp[k].at_frame == f0) oo_bank_set_value(b, g_scn_ramp[k].param, g_scn_ramp[k].value);
+            else if (g_scn_ramp[k].at_frame > f0 && g_scn_ramp[k].at_frame < f0 + frames) frames = g_scn_ramp[k].at_frame - f0;
+        }
         for (uint32_t i = 0; gated && i < n; ++i) {
             const oo_note_events *pl = &plans[i];
             for (uint32_t k = 0; k < pl->n; ++k)

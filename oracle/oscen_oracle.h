@@ -401,6 +401,10 @@ double oo_bank_render_mt(int kind, uint32_t first_voice, uint32_t n_voices, uint
                          double *abs64);
 /* note-plan fold mode of the three multi-threaded entry points (process-wide; 0 = scale, 1 = slice) */
 void oo_bench_set_fold(int fold);
+/* scenario of the multi-threaded renders: immediate parameter values before frame 0, setter calls before a frame */
+void oo_bench_scenario_clear(void);
+int oo_bench_scenario_set(uint32_t param, float value);
+int oo_bench_scenario_ramp(uint32_t param, float value, uint32_t at_frame);
 
 #ifdef __cplusplus
 }

@@ -222,6 +222,8 @@ def load():
     lib.oo_note_plan_scaled.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(NotePlan)]
     lib.oo_note_events_for_voice.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(NoteEvents)]
     lib.oo_bench_set_fold.argtypes = [C.c_int]
+    lib.oo_bench_scenario_set.argtypes = [C.c_uint32, C.c_float]
+    lib.oo_bench_scenario_ramp.argtypes = [C.c_uint32, C.c_float, C.c_uint32]
     lib.oo_tremolo_new.argtypes = [C.c_void_p]
     lib.oo_tremolo_process.argtypes = [C.c_void_p]
     lib.oo_midi_note_to_freq.restype = C.c_float
@@ -328,10 +330,17 @@ FOLD = {"scale": 0, "slice": 1}
 
 
 def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None, group=8, seed=0x05CE2026, span=0,
-              fold="scale"):
+              fold="scale", sets=(), ramps=()):
     """Multi-threaded oracle render of a voice range over its (scaled) note plans:
-    (mono f64 sum [frames], sum of |voice output| [frames], seconds)."""
+    (mono f64 sum [frames], sum of |voice output| [frames], seconds).
+    sets = [(param index, value)]: set_<n>_immediate before frame 0; ramps = [(param index, value, at_frame)]: set_<n>(value)
+    right before frame `at_frame` (the render cuts its block there)."""
     lib = load()
+    lib.oo_bench_scenario_clear()
+    for p, v in sets:
+        assert lib.oo_bench_scenario_set(p, v) == 0
+    for p, v, f in ramps:
+        assert lib.oo_bench_scenario_ramp(p, v, f) == 0
     threads = threads or (os.cpu_count() or 1)
     mono = np.zeros(frames_total, dtype=np.float64)
     ab = np.zeros(frames_total, dtype=np.float64)
@@ -339,6 +348,7 @@ def render_mt(kind, first_voice, n_voices, frames_total, block=256, threads=None
     lib.oo_bench_set_fold(FOLD[fold])
     t = lib.oo_bank_render_mt(kind, first_voice, n_voices, frames_total, block, threads, group, seed, span,
                               mono.ctypes.data_as(dp), ab.ctypes.data_as(dp))
+    lib.oo_bench_scenario_clear()
     return mono, ab, t
 
 
