@@ -90,6 +90,7 @@ def timed_run(plans, total, blocks, sets, ramp):
     eng = make_engine(plans, total, sets)
     ch = eng.channels
     dev = DeviceBuffer(total * ch * 4)
+    eng.set_bus_batching(0)  # queued blocks share a launch, the engine picks how many (bench.py's default)
     eng.enable_kernel_timing(True)
     i, f, calls = 0, 0, 0
     while i < len(blocks):
@@ -185,10 +186,6 @@ def test_the_timed_configuration_against_the_oracle_over_its_whole_horizon(name)
     assert info_t["launches"] < len(blocks) // 4, info_t  # queued: many blocks per launch
     assert np.array_equal(bus_t, bus_c), (info_t, float(np.abs(bus_t - bus_c).max()))
     assert np.array_equal(state_t, state_c), info_t
-    if ramp:
-        eng_value_after = 6000.0
-        assert abs(eng_value_after - ramp[1]) < 1e-6
-
     # the bus against the oracle's f64 sum over every voice (the reference's sequential f32 fold, emit_node.rs:463-466, and
     # the fixed tree differ by re-association only)
     threads = min(os.cpu_count() or 1, 32)
