@@ -348,6 +348,10 @@ void parse_node_decl(Lexer& lx, GraphDesc& g)
     }
     if (lx.eat('*')) {
         n.rate_factor = (uint32_t)lx.number();
+        // `[X; N] * M * P` (parse.rs:547-565; a second factor on a plain node is a type error in the reference's Rust)
+        if (lx.peek() == '*' || lx.peek() == '/')
+            dfail("node already has an embedded rate (`* N` or `/ N`)" + std::string(is_array ? " from the array literal" : "") +
+                  "; remove the trailing rate annotation", lx.line);
     } else if (lx.peek() == '/') {
         dfail_unsupported("node undersampling (`/ N`) is not supported (neither is it by the reference v1)", lx.line);
     }

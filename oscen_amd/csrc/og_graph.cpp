@@ -2733,6 +2733,7 @@ bool unregister_user_node(const std::string& type) { return user_registry().eras
 void register_graph_type(const std::string& name, const GraphDesc& g)
 {
     if (!is_ident(name)) fail("graph type name '" + name + "' is not an identifier");
+    check_reference_rules(g);
     graph_types()[name] = g;
 }
 bool unregister_graph_type(const std::string& name)
@@ -2746,8 +2747,257 @@ bool unregister_graph_type(const std::string& name)
     return true;
 }
 
+// ---- what the reference REFUSES, on the description as written (before arrays, nested graphs and poly wrappers are
+// expanded: the reference's macro sees one `graph!` body at a time) ---------------------------------------------------
+//  (1) kind compatibility of a connection statement (ir/lower.rs:459-490, types_compatible :1157-1165): endpoint kinds are
+//      known for typed graph inputs / outputs and for the two ends of a stream-only policy, and spread along connection
+//      statements to a fixpoint (infer_endpoint_types, ir/lower.rs:233-338); where BOTH ends of a statement are known
+//      the pair must be Stream->Stream, Value->Value, Event->Event or Value->Stream.
+//  (2) auto-summed fan-in (codegen/emit_node.rs:35-125 classify_stream_fanin): >= 2 edges into one destination slot that is
+//      not known to be a value / event are summed, and the sum is only defined for same-rate, simple (plain endpoint),
+//      scalar (neither end a node array) sources; anything else is a scoped compile error in the reference.
+// Diagnostics carry the reference's wording, so that a user sees the message rustc would have shown.
+namespace {
+enum class RK { Unknown = 0, Stream, Value, Event };
+const char* rk_name(RK k) { return k == RK::Stream ? "Stream" : (k == RK::Value ? "Value" : (k == RK::Event ? "Event" : "Unknown")); }
+struct RefEndpoint {
+    std::string node, endpoint;
+    long index = -1;
+    bool ok = false;
+};
+// `ident`, `ident.field`, `ident[k].field`, `ident.field[k]`, `ident[k]`, each optionally followed by `()`
+RefEndpoint ref_endpoint(const std::string& text)
+{
+    RefEndpoint r;
+    size_t i = 0;
+    auto ws = [&] {
+        while (i < text.size() && isspace((unsigned char)text[i])) ++i;
+    };
+    auto ident = [&] {
+        ws();
+        const size_t b = i;
+        if (i < text.size() && (isalpha((unsigned char)text[i]) || text[i] == '_'))
+            while (i < text.size() && (isalnum((unsigned char)text[i]) || text[i] == '_')) ++i;
+        return text.substr(b, i - b);
+    };
+    auto index = [&]() -> bool { // optional `[k]`
+        ws();
+        if (i >= text.size() || text[i] != '[') return true;
+        ++i;
+        ws();
+        std::string num;
+        while (i < text.size() && isdigit((unsigned char)text[i])) num.push_back(text[i++]);
+        ws();
+        if (num.empty() || i >= text.size() || text[i] != ']' || r.index >= 0) return false;
+        ++i;
+        r.index = strtol(num.c_str(), nullptr, 10);
+        return true;
+    };
+    r.node = ident();
+    if (r.node.empty() || !index()) return r;
+    ws();
+    if (i < text.size() && text[i] == '.') {
+        ++i;
+        r.endpoint = ident();
+        if (r.endpoint.empty() || !index()) return r;
+        ws();
+        if (i + 1 < text.size() && text[i] == '(' ) {
+            ++i;
+            ws();
+            if (i >= text.size() || text[i] != ')') return r;
+            ++i;
+        }
+    } else {
+        r.endpoint = r.node; // bare: the implicit endpoint of a graph input / output carries the declaration's name
+    }
+    ws();
+    r.ok = i == text.size();
+    return r;
+}
+// `voices[3].output` -> `voices.output` so that the expression parser (which runs after array expansion elsewhere) reads it
+std::string drop_node_indices(const std::string& t)
+{
+    std::string o;
+    for (size_t i = 0; i < t.size();) {
+        if (t[i] == '[' && !o.empty() && (isalnum((unsigned char)o.back()) || o.back() == '_')) {
+            size_t j = i + 1;
+            while (j < t.size() && (isdigit((unsigned char)t[j]) || isspace((unsigned char)t[j]))) ++j;
+            if (j < t.size() && t[j] == ']') {
+                size_t k = j + 1;
+                while (k < t.size() && isspace((unsigned char)t[k])) ++k;
+                if (k < t.size() && t[k] == '.' && k + 1 < t.size() && (isalpha((unsigned char)t[k + 1]) || t[k + 1] == '_')) {
+                    i = j + 1;
+                    continue;
+                }
+            }
+        }
+        o.push_back(t[i++]);
+    }
+    return o;
+}
+} // namespace
+
+void check_reference_rules(const GraphDesc& g)
+{
+    struct Named {
+        int what; // 0 graph input, 1 graph output, 2 node
+        uint32_t array_len = 0, rate = 1;
+    };
+    std::map<std::string, Named> names;
+    std::map<std::pair<std::string, std::string>, RK> kinds;
+    auto decl = [](Kind k) { return k == Kind::Stream ? RK::Stream : (k == Kind::Value ? RK::Value : RK::Event); };
+    for (const GInput& in : g.inputs) {
+        names[in.name] = {0, 0, 1};
+        kinds[{in.name, in.name}] = decl(in.kind);
+    }
+    for (const GOutput& o : g.outputs) {
+        names[o.name] = {1, 0, 1};
+        kinds[{o.name, o.name}] = decl(o.kind);
+    }
+    for (const GNode& n : g.nodes) {
+        if (n.bus) return; // (a lowered wrapper with its post-mix stage: checked when it was written as a wrapper)
+        names[n.name] = {2, n.array_len, n.rate_factor ? n.rate_factor : 1u};
+        if (n.name.rfind("__inline_delay_", 0) == 0) { // `-> [N] ->`: synth_delay_endpoints (ir/lower.rs:186-206)
+            kinds[{n.name, "input"}] = kinds[{n.name, "output"}] = RK::Stream;
+            kinds[{n.name, "delay_samples"}] = kinds[{n.name, "feedback"}] = RK::Value;
+        }
+    }
+    auto lookup = [&](const std::string& node, const std::string& ep) {
+        auto it = kinds.find({node, ep});
+        return it == kinds.end() ? RK::Unknown : it->second;
+    };
+    // endpoint_kind_of (ir/lower.rs:937-959)
+    std::function<RK(const ExprP&)> kind_of = [&](const ExprP& e) -> RK {
+        if (!e) return RK::Unknown;
+        switch (e->t) {
+        case Expr::Num: return RK::Value;
+        case Expr::Ref: return names.count(e->node) ? lookup(e->node, e->port.empty() ? e->node : e->port) : RK::Unknown;
+        case Expr::Chan: return e->a && e->a->t == Expr::Ref ? kind_of(e->a) : RK::Unknown;
+        case Expr::Bin: {
+            const RK l = kind_of(e->a), r = kind_of(e->b);
+            if (l == RK::Unknown || r == RK::Unknown || l == RK::Event || r == RK::Event) return RK::Unknown;
+            return (l == RK::Stream || r == RK::Stream) ? RK::Stream : RK::Value;
+        }
+        default: return RK::Unknown; // calls, methods, negation: no inference
+        }
+    };
+    struct Stmt {
+        std::string src_text, dst_text, policy;
+        ExprP src;
+        RefEndpoint src_ep, dst_ep; // src_ep.ok: the source is a plain endpoint
+    };
+    std::vector<Stmt> stmts;
+    for (size_t i = 0; i < g.edges.size(); ++i) {
+        const GEdge& e = g.edges[i];
+        if (e.feedback) continue; // (second leg of `src -> [via] -> dst`: folded into its statement below)
+        Stmt st;
+        st.src_text = e.src;
+        st.dst_text = e.dst;
+        st.policy = e.policy;
+        if (i + 1 < g.edges.size() && g.edges[i + 1].feedback) st.dst_text = g.edges[i + 1].dst; // the statement's ends (ir/lower.rs:459-490)
+        try {
+            st.src = Parser(drop_node_indices(e.src)).parse();
+        } catch (const std::exception&) {
+            continue; // (malformed expressions are reported where the graph is lowered)
+        }
+        st.src_ep = ref_endpoint(st.src_text);
+        st.dst_ep = ref_endpoint(st.dst_text);
+        if (!st.dst_ep.ok || !names.count(st.dst_ep.node)) continue;
+        if (st.src_ep.ok && !names.count(st.src_ep.node)) st.src_ep.ok = false;
+        stmts.push_back(st);
+    }
+    for (const Stmt& st : stmts) // stream-only policies type both of their ends (only vacant entries)
+        if (st.policy == "linear" || st.policy == "sinc" || st.policy == "sinc_iir") {
+            kinds.emplace(std::make_pair(st.dst_ep.node, st.dst_ep.endpoint), RK::Stream);
+            if (st.src_ep.ok) kinds.emplace(std::make_pair(st.src_ep.node, st.src_ep.endpoint), RK::Stream);
+        }
+    for (size_t round = 0; round <= stmts.size(); ++round) {
+        bool changed = false;
+        for (const Stmt& st : stmts) {
+            const RK sk = kind_of(st.src);
+            if (sk != RK::Unknown && kinds.emplace(std::make_pair(st.dst_ep.node, st.dst_ep.endpoint), sk).second) changed = true;
+            const RK dk = lookup(st.dst_ep.node, st.dst_ep.endpoint);
+            if (dk != RK::Unknown && st.src_ep.ok && kinds.emplace(std::make_pair(st.src_ep.node, st.src_ep.endpoint), dk).second) changed = true;
+        }
+        if (!changed) break;
+    }
+    // (1) kind compatibility, statement by statement
+    for (const Stmt& st : stmts) {
+        const RK sk = kind_of(st.src), dk = lookup(st.dst_ep.node, st.dst_ep.endpoint);
+        if (sk == RK::Unknown || dk == RK::Unknown) continue;
+        const bool ok = sk == dk || (sk == RK::Value && dk == RK::Stream);
+        if (!ok)
+            fail(std::string("Type mismatch in connection: source is ") + rk_name(sk) + " but destination expects " + rk_name(dk) + " ('" +
+                 st.src_text + " -> " + st.dst_text + "')");
+    }
+    // (2) fan-in: the edges (both legs of a `[via]` statement are edges of their own) by destination slot, in edge order
+    struct Edge {
+        const GEdge* e;
+        RefEndpoint dst;
+    };
+    std::map<std::string, std::vector<Edge>> buckets;
+    std::vector<std::string> bucket_order;
+    for (const GEdge& e : g.edges) {
+        RefEndpoint d = ref_endpoint(e.dst);
+        if (!d.ok || !names.count(d.node)) continue;
+        const std::string key = d.node + "." + d.endpoint + "#" + std::to_string(d.index);
+        if (!buckets.count(key)) bucket_order.push_back(key);
+        buckets[key].push_back({&e, d});
+    }
+    for (const std::string& key : bucket_order) {
+        const std::vector<Edge>& b = buckets[key];
+        if (b.size() < 2) continue;
+        const RefEndpoint& d = b[0].dst;
+        const RK dk = lookup(d.node, d.endpoint);
+        if (dk == RK::Value || dk == RK::Event) continue; // per-edge path: last write wins / event queues
+        struct Src {
+            ExprP x;
+            RefEndpoint ep;
+            std::string primary;
+        };
+        std::vector<Src> srcs;
+        bool any_event = false, parsed = true;
+        for (const Edge& ed : b) {
+            Src s;
+            try {
+                s.x = Parser(drop_node_indices(ed.e->src)).parse();
+            } catch (const std::exception&) {
+                parsed = false;
+                break;
+            }
+            s.ep = ref_endpoint(ed.e->src);
+            std::vector<const Expr*> refs;
+            collect_refs(s.x, refs);
+            for (const Expr* r : refs)
+                if (names.count(r->node)) {
+                    s.primary = r->node;
+                    break;
+                }
+            if (kind_of(s.x) == RK::Event) any_event = true;
+            srcs.push_back(s);
+        }
+        if (!parsed || any_event) continue;
+        const std::string dest_desc = d.endpoint == d.node ? d.node : d.node + "." + d.endpoint;
+        for (size_t k = 0; k < b.size(); ++k) {
+            const Src& s = srcs[k];
+            const char* what = nullptr;
+            const Named* sn = s.primary.empty() ? nullptr : &names[s.primary];
+            const Named& dn = names[d.node];
+            if (sn && sn->rate != dn.rate) what = "a cross-rate edge";
+            else if (!(s.ep.ok && names.count(s.ep.node)) || !sn) what = "a compound (non-endpoint) source";
+            else if (sn->array_len && dn.array_len) what = "an array (parallel) source";
+            else if (!sn->array_len && dn.array_len) what = "a broadcast source";
+            else if (sn->array_len && !dn.array_len) what = "an array fan-in source";
+            if (what)
+                fail(std::string("fan-in summing supports only same-rate scalar/frame stream sources; saw ") + what + " into `" + dest_desc +
+                     "` ('" + b[k].e->src + " -> " + b[k].e->dst + "')");
+        }
+    }
+}
+
 std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
 {
+    check_reference_rules(g_in);
     const GraphDesc g = expand(g_in);
     auto cgp = std::make_unique<CompiledGraph>();
     CompiledGraph& out = *cgp;
@@ -2801,9 +3051,10 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             fail("node '" + nd.name + "': " + nd.type + " takes " + std::to_string(nti->nargs) + " arguments");
         if (nd.rate_factor != 1) { // `* N`, N in {2,4,8} (parse.rs:460-488)
             if (nd.rate_factor != 2 && nd.rate_factor != 4 && nd.rate_factor != 8)
-                fail("node '" + nd.name + "': oversampling factor must be 1, 2, 4 or 8");
+                fail("node '" + nd.name + "': rate factor must be 1, 2, 4, or 8");
             if (cg.N != 1 && cg.N != (int)nd.rate_factor)
-                fail_unsupported("all oversampled nodes of a graph must share one factor in this version (node '" + nd.name + "')");
+                fail_unsupported("all oversampled nodes of a graph must share one factor in this version (node '" + nd.name +
+                                 "'); the reference: v1 does not support connections between two differently-rated non-default-rate nodes");
             cg.N = (int)nd.rate_factor;
         }
         cg.node_by_name[nd.name] = (int)i;

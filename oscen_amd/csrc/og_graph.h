@@ -176,6 +176,10 @@ struct CompiledGraph {
 
 // Throws std::runtime_error with a diagnostic on malformed/unsupported graphs.
 std::unique_ptr<CompiledGraph> compile(const GraphDesc& g);
+// The connections the reference's macro refuses (kind mismatch between typed ends, ir/lower.rs:459-490; a summed fan-in with a
+// compound / cross-rate / array source, codegen/emit_node.rs:35-125), checked on the description as written.  compile() and
+// register_graph_type() call it; throws with the reference's wording.
+void check_reference_rules(const GraphDesc& g);
 
 // ---- user node types: the `#[derive(Node)]` plug-in surface (oscen-macros/src/lib.rs:7-327) -----------------
 // A node type = its endpoints (`#[input(stream|value|event)]`, `#[output(stream)]` fields), its private fields

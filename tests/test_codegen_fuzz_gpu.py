@@ -189,14 +189,12 @@ def random_expression_graph(seed):
     nodes = " ".join("o%d = PolyBlepOscillator::%s(220.0, 0.6);" % (i, w) for i, w in enumerate(waves)) + " g = Gain::new(0.75);"
     conns = " ".join("frequency * %r -> o%d.frequency;" % (r, i) for i, r in enumerate(ratios)) + " %s -> g.input;" % _text(gain_in)
     decl = ""
+    # the node's output joins the last scalar output INSIDE its expression: a summed fan-in takes plain endpoints only (the
+    # reference refuses a compound source there, codegen/emit_node.rs:90-93 -- and so does og_graph.cpp)
+    last = max(i for i, (_, w) in enumerate(outs) if w == 1) if any(w == 1 for _, w in outs) else None
     for i, (e, w) in enumerate(outs):
         decl += "output out%d: stream%s; " % (i, ": Frame<2>" if w == 2 else "")
-        conns += " %s -> out%d;" % (_text(e), i)
-    if any(w == 1 for _, w in outs):
-        last = max(i for i, (_, w) in enumerate(outs) if w == 1)
-        conns += " g.output -> out%d;" % last  # fan-in: the expression edge + the node edge sum in edge order
-    else:
-        last = None
+        conns += (" (%s) + g.output -> out%d;" if i == last else " %s -> out%d;") % (_text(e), i)
     text = "name: Fx%d; input frequency: value = 220.0; %s nodes { %s } connections { %s }" % (seed, decl, nodes, conns)
     return text, dict(waves=waves, ratios=ratios, outs=outs, gain_in=gain_in, last=last)
 

@@ -70,7 +70,7 @@ def graph_bodies():
     for dp, _, fn in os.walk(REF):
         rel = os.path.relpath(dp, REF)
         if rel.startswith("target") or "/target" in rel or rel.startswith("oscen-macros/tests/ui") or rel.startswith("oscen-macros/src"):
-            continue  # ui/: compile-FAIL fixtures (every body there is wrong on purpose); src/: macro documentation
+            continue  # ui/: compile-FAIL fixtures (every body there is wrong on purpose: tests/test_dsl_negative_corpus_cpu.py); src/: macro documentation
         for f in sorted(fn):
             if not f.endswith(".rs"):
                 continue

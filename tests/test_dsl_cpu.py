@@ -385,11 +385,19 @@ def test_several_edges_into_a_value_destination_follow_the_reference_kind_propag
     # is a stream, so g.gain is a stream destination and `amount` joins the sum instead of replacing it
     def src3(gain_conns):
         g = oscen_amd.Graph(dsl="""name: DxK2; input amount: value = 0.5; output out: stream; output aux: stream;
-            nodes { a = PolyBlepOscillator::saw(220.0, 0.5) * 2; c = HardClip::new() * 2; g = Gain::new(1.0) * 2; }
-            connections { a.output -> c.input; [sinc] c.output -> aux; a.output -> g.input; [sinc] g.output -> out; """ + gain_conns + " }")
+            nodes { a = PolyBlepOscillator::saw(220.0, 0.5); c = HardClip::new(); g = Gain::new(1.0); up = HardClip::new() * 2; }
+            connections { a.output -> c.input; [linear] c.output -> up.input; [sinc] up.output -> aux; a.output -> g.input; g.output -> out; """
+                            + gain_conns + " }")
         return g.kernel_source()
 
     assert src3("c.output -> g.gain; amount -> g.gain;") == src3("c.output + amount -> g.gain;")
+    # ... but only same-rate sources can be summed: the same fan-in into an OVERSAMPLED node takes `amount` across a rate
+    # boundary, which the reference refuses (codegen/emit_node.rs:87-89 "a cross-rate edge") -- and so does this compiler
+    with pytest.raises(oscen_amd.OscenError, match="fan-in summing supports only same-rate scalar/frame stream sources; saw a cross-rate edge into `g.gain`"):
+        oscen_amd.Graph(dsl="""name: DxK2x; input amount: value = 0.5; output out: stream; output aux: stream;
+            nodes { a = PolyBlepOscillator::saw(220.0, 0.5) * 2; c = HardClip::new() * 2; g = Gain::new(1.0) * 2; }
+            connections { a.output -> c.input; [sinc] c.output -> aux; a.output -> g.input; [sinc] g.output -> out;
+                          c.output -> g.gain; amount -> g.gain; }""").kernel_source()
     # one kind per (ROOT node, field): a typed value input wired to ONE element of an array makes the port a value endpoint
     # of every element (the reference infers kinds before it unrolls the array) -- two edges into another element: last wins
     def src4(conns):

@@ -36,8 +36,7 @@ connections {
     cutoff -> filt.cutoff;
     osc.output -> a.input;
     osc.output * env.output -> b.input;
-    a.output * env.output -> filt.input;
-    b.output - a.output -> filt.input;
+    a.output * env.output + (b.output - a.output) -> filt.input;
     filt.output -> mix.input;
     mix.output -> out;
 }

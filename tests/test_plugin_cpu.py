@@ -226,8 +226,7 @@ def test_frame_ports_lower_to_channel_values():
     g.node("f", "TptFilter::<Frame<2>>::new", 900.0, 0.7)
     g.node("n", "Narrow::new")
     g.connect("osc.output", "w.input")
-    g.connect("w.output * osc.output", "f.input")
-    g.connect("-w.output", "f.input")
+    g.connect("w.output * osc.output + -w.output", "f.input")  # (ONE compound source: the reference refuses compound sources in a summed fan-in)
     g.connect("f.output", "n.input")
     g.connect("n.output", "out")
     assert "TptFilter::<Frame<2>>::new(900.0" in g.to_dsl()
