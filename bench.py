@@ -736,10 +736,10 @@ def timed_bank(args, graph, V, K, W, R, rank, local_rank, world_size, dist, vari
     def reduce_bus(t):
         if args.backend == "gloo":  # CPU collective (plumbing check only)
             h = t.cpu()
-            ogd.reduce_bus(h)
+            ogd.reduce_bus(h, engine=eng)
             t.copy_(h)
         else:
-            ogd.reduce_bus(t)
+            ogd.reduce_bus(t, engine=eng)
 
     def barrier():
         if args.backend == "gloo":

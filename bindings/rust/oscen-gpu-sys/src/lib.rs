@@ -44,6 +44,7 @@ extern "C" {
     pub fn og_synchronize(e: *mut og_engine) -> c_int;
     pub fn og_render(e: *mut og_engine, total_frames: u64, block: u32, out: *mut c_float) -> c_int;
     pub fn og_latency_samples(e: *const og_engine) -> u32;
+    pub fn og_post_mix_kind(e: *const og_engine) -> c_int;
     pub fn og_last_error() -> *const c_char;
 }
 

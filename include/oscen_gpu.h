@@ -334,6 +334,11 @@ uint32_t og_voice_channels(const og_engine* e);
 int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, uint32_t* width);
 uint32_t og_num_voices(const og_engine* e);
 uint32_t og_latency_samples(const og_engine* e); /* emit_struct.rs:534-570 */
+/* The post-mix node of a wrapper graph (`voices.output -> tremolo.input`, electric-piano/src/main.rs:88-96): 0 = none,
+ * 1 = a node that is LINEAR in its input (Tremolo: out = in * pan, tremolo.rs:40-62), 2 = any other.  A host that sums the
+ * buses of several engines itself (oscen_amd/distributed.py) may sum AFTER a linear post-mix stage; for kind 2 it must sum
+ * the voice sums first and run the node once, as og_cluster_* does. */
+int og_post_mix_kind(const og_engine* e);
 uint64_t og_frames_processed(const og_engine* e);
 /* layout facts used by the roofline accounting */
 uint32_t og_state_words_per_voice(const og_engine* e);

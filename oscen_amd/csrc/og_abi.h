@@ -3,6 +3,7 @@
 // guard every entry point that can allocate, compile or touch the device runs under -- nothing may unwind across
 // the C ABI ("never throws across the ABI", include/oscen_gpu.h:13).
 #pragma once
+#include <cstdlib>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -56,5 +57,24 @@ T guard_value(T fallback, F&& f) noexcept
     (void)rc;
     return fallback;
 }
+
+// ---- environment knobs -----------------------------------------------------------------------------------------------
+// SETTINGS are part of the product and read as they are: OSCEN_GPU_SPLIT (pin the kernel shape: 0 ordinary, 2 / 4 waves per
+// 64 voices), OSCEN_GPU_WIDE (16-frame hand-offs of the four-wave shape on / off), OSCEN_GPU_RCCL_LIB (path of the librccl to
+// bind), OSCEN_GPU_CSRC (where the JIT finds the device headers).  Everything else is an EXPERIMENT knob of the A/B scripts
+// (scripts/build_variant.py, scripts/ab_bench.sh) and of a few tests: read through experiment_knob(), which IGNORES the
+// environment unless OSCEN_GPU_EXPERIMENTAL=1 -- a stray variable cannot change what a product build generates or runs.
+// og_version() lists both sets; tests/test_abi_guard_cpu.py checks that no translation unit reads any other variable.
+#define OG_SETTINGS "OSCEN_GPU_SPLIT OSCEN_GPU_WIDE OSCEN_GPU_RCCL_LIB OSCEN_GPU_CSRC OSCEN_GPU_EXPERIMENTAL"
+#define OG_EXPERIMENT_KNOBS                                                                                                      \
+    "OSCEN_GPU_HOST_PROF OSCEN_GPU_BLOCKING_MEMCPY OSCEN_GPU_EV_HEADROOM OSCEN_GPU_LANES OSCEN_GPU_OUT_EVENTS OSCEN_GPU_FORCE_RCCL "  \
+    "OGC_TPT_FLAT OGC_TPT_LAZY OGC_HPL OGC_ALAP OGC_SPLIT OGC_CUT2 OGC_PARTS OGC_K3 OGC_CUTS OGC_UNROLL OGC_PRIO_PARITY OGC_CHUNK_CHK "  \
+    "OGC_STICKY1 OGC_XCH16 OGC_XCH OGC_ROT OGC_PRIO OGC_STICKY OGC_FORCE_PATH OGC_EVSKIP OGC_EVUNROLL OGC_RELPRIO OGC_SLOWPRIO OGC_WAVES_EU"
+inline bool experiments_enabled()
+{
+    const char* e = getenv("OSCEN_GPU_EXPERIMENTAL");
+    return e && atoi(e) != 0;
+}
+inline const char* experiment_knob(const char* name) { return experiments_enabled() ? getenv(name) : nullptr; }
 
 } // namespace ogabi

@@ -529,7 +529,7 @@ int og_cluster_create(const og_graph_desc* g, uint64_t n_voices_total, const int
             HIPCK(hipMalloc(&c->d_phase, 4));
             HIPCK(hipMemset(c->d_phase, 0, 4));
         }
-        const char* force = getenv("OSCEN_GPU_FORCE_RCCL"); // exercise the RCCL leg on a one-device cluster (tests)
+        const char* force = ogabi::experiment_knob("OSCEN_GPU_FORCE_RCCL"); // exercise the RCCL leg on a one-device cluster (tests)
         if (nd > 1 || (force && atoi(force) != 0)) {
             Rccl& R = rccl();
             R.load();

@@ -359,7 +359,7 @@ struct HostProf {
     enum { SYNC_EVENTS, INCREMENTAL, REBUILD, LAUNCH, RAMPS, EV_WAIT, EV_COMMIT, N };
     double t[N] = {};
     uint64_t n[N] = {};
-    bool on = getenv("OSCEN_GPU_HOST_PROF") != nullptr;
+    bool on = ogabi::experiment_knob("OSCEN_GPU_HOST_PROF") != nullptr;
     struct Scope {
         HostProf& p;
         int k;
@@ -1263,7 +1263,10 @@ int push_event(og_engine* e, uint32_t input, uint32_t voice, uint64_t frame, flo
 extern "C" {
 
 const char* og_last_error(void) { return g_err.c_str(); }
-const char* og_version(void) { return "oscen_amd 0.1 (gfx950)"; }
+const char* og_version(void)
+{
+    return "oscen_amd 0.1 (gfx950); settings: " OG_SETTINGS "; experiment knobs (read only when OSCEN_GPU_EXPERIMENTAL=1): " OG_EXPERIMENT_KNOBS;
+}
 
 int og_graph_new(const char* name, og_graph_desc** out)
 {
@@ -1599,10 +1602,10 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
             // Measured on MI355X (65 536 fm voices): 64 lanes 0.129 ms, 32 lanes 0.185 ms, 16 lanes
             // 0.325 ms per block -- a wave-instruction costs the same issue time however many of its
             // lanes are active, so narrowing only multiplies instructions.  Kept as an experiment knob.
-            e->blocking_memcpy = getenv("OSCEN_GPU_BLOCKING_MEMCPY") != nullptr; // (environment knobs are read HERE, once)
-            if (const char* hv = getenv("OSCEN_GPU_EV_HEADROOM")) e->ev_headroom_env = std::max<size_t>(64, (size_t)atoll(hv));
+            e->blocking_memcpy = ogabi::experiment_knob("OSCEN_GPU_BLOCKING_MEMCPY") != nullptr; // (environment knobs are read HERE, once)
+            if (const char* hv = ogabi::experiment_knob("OSCEN_GPU_EV_HEADROOM")) e->ev_headroom_env = std::max<size_t>(64, (size_t)atoll(hv));
             uint32_t lanes = OG_WAVE;
-            if (const char* ev = getenv("OSCEN_GPU_LANES")) {
+            if (const char* ev = ogabi::experiment_knob("OSCEN_GPU_LANES")) {
                 const int l = atoi(ev);
                 if (l == 16 || l == 32 || l == 64) lanes = (uint32_t)l;
             }
@@ -1717,7 +1720,7 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         }
         if (!cg.event_outputs.empty()) { // room for four events per voice between two reads (OSCEN_GPU_OUT_EVENTS overrides)
             size_t cap = std::max<size_t>(65536, (size_t)n_voices * 4);
-            if (const char* ev = getenv("OSCEN_GPU_OUT_EVENTS")) cap = std::max<size_t>(16, (size_t)atoll(ev));
+            if (const char* ev = ogabi::experiment_knob("OSCEN_GPU_OUT_EVENTS")) cap = std::max<size_t>(16, (size_t)atoll(ev));
             e->out_ev_cap = (uint32_t)std::min<size_t>(cap, 0x7FFFFFFFu);
             HIPCK(hipMalloc(&e->d_out_ev, (size_t)e->out_ev_cap * sizeof(OgOutEvent)));
         }
@@ -2250,6 +2253,8 @@ int og_output_channel(const og_engine* e, const char* name, uint32_t* offset, ui
 }
 uint32_t og_num_voices(const og_engine* e) { return e ? e->V : 0; }
 uint32_t og_latency_samples(const og_engine* e) { return e ? e->cg->latency_samples : 0; }
+// (Tremolo is the only post-mix node type the compiler takes -- og_graph.cpp, bus nodes -- and it is linear in its input)
+int og_post_mix_kind(const og_engine* e) { return (e && e->cg->bus_tremolo) ? 1 : 0; }
 uint64_t og_frames_processed(const og_engine* e) { return e ? e->frame_now : 0; }
 uint32_t og_state_words_per_voice(const og_engine* e)
 {

@@ -1320,7 +1320,7 @@ void emit_tpt(NodeCtx& x)
         // first frame of the block, so it runs in derive() (block start and after per-voice value events)
         x.cg.S().derive << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << tail;
         x.cg.any_derive = true;
-    } else if (nomod && getenv("OGC_TPT_FLAT") && atoi(getenv("OGC_TPT_FLAT")) != 0) {
+    } else if (nomod && ogabi::experiment_knob("OGC_TPT_FLAT") && atoi(ogabi::experiment_knob("OGC_TPT_FLAT")) != 0) {
         // experiment: branch-free update (see og::tpt_params_nomod_flat); measured slower on MI355X for
         // fm_voice (65 536 voices 0.098 ms against 0.087 ms; 262 144 voices 0.293 against 0.234): the
         // branch is wave-uniformly skipped whenever no lane's envelope moves
@@ -1329,7 +1329,7 @@ void emit_tpt(NodeCtx& x)
         if (block_const(q)) iq = x.hoist("inv_q", "1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f)");
         else iq = "(1.0f / og::clampf(" + q.e + ", 0.1f, 10.0f))";
         x.cg.os() << "        og::tpt_params_nomod_flat(" << cutoff.e << ", " << q.e << ", " << iq << ", " << tail;
-    } else if (nomod && x.n.domain != 1 && !(getenv("OGC_TPT_LAZY") && atoi(getenv("OGC_TPT_LAZY")) == 0)) {
+    } else if (nomod && x.n.domain != 1 && !(ogabi::experiment_knob("OGC_TPT_LAZY") && atoi(ogabi::experiment_knob("OGC_TPT_LAZY")) == 0)) {
         // cutoff computed per frame: watch the raw input, run the reference's test only on frames whose input differs from
         // the previous frame's (og::tpt_params_nomod_lazy).  q is watched too when it can change inside a launch: a ramped
         // input (the RAMPS variants of the kernel) or a per-frame value.
@@ -3375,7 +3375,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     // per voice amortise it over more harmonics; 156 VGPRs still leave three waves per SIMD.  OGC_HPL=2|4|8 overrides;
     // the state layout [voice][32] does not depend on it.
     int hpl = 8;
-    if (const char* eh = getenv("OGC_HPL")) {
+    if (const char* eh = ogabi::experiment_knob("OGC_HPL")) {
         const int h = atoi(eh);
         if (h == 2 || h == 4 || h == 8) hpl = h;
     }
@@ -3436,7 +3436,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         for (int ni : order) any_delay_node = any_delay_node || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
         bool any_rate = false;
         for (int ni : order) any_rate = any_rate || cg.nodes[ni].decl->rate_factor != 1;
-        const bool reorder = !(getenv("OGC_ALAP") && atoi(getenv("OGC_ALAP")) == 0) && !any_feedback && !cg.dynamic_events && !any_delay_node &&
+        const bool reorder = !(ogabi::experiment_knob("OGC_ALAP") && atoi(ogabi::experiment_knob("OGC_ALAP")) == 0) && !any_feedback && !cg.dynamic_events && !any_delay_node &&
                              !any_rate && out.lpv == 1 && order.size() >= 3;
         if (reorder) {
             std::vector<int> pos(g.nodes.size(), -1);
@@ -3509,7 +3509,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     cg.n_stages = 1;
     bool stereo_out = false;
     {
-        const char* env_split = getenv("OGC_SPLIT");
+        const char* env_split = ogabi::experiment_knob("OGC_SPLIT");
         bool any_delay = false; // delay lines are staged per chunk by the ordinary kernel only
         for (int ni : order) any_delay = any_delay || cg.nodes[ni].decl->type.rfind("Delay::", 0) == 0;
         // a Frame<2> voice output (two bus tiles) is summed by the ordinary kernel only
@@ -3705,14 +3705,14 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 cg.stage_of[order[k]] = st;
             }
             cg.groups2 = grouping(2);
-            if (const char* ec = getenv("OGC_CUT2")) { // experiment knob: first wave = the first k stages
+            if (const char* ec = ogabi::experiment_knob("OGC_CUT2")) { // experiment knob: first wave = the first k stages
                 const int ku = std::max(1, std::min(cg.n_stages - 1, atoi(ec)));
                 cg.groups2 = {{}, {}};
                 for (int k = 0; k < cg.n_stages; ++k) cg.groups2[k < ku ? 0 : 1].push_back(k);
             }
-            const char* ep = getenv("OGC_PARTS");
-            if (total >= 48 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(getenv("OGC_K3") ? 3 : 4);
-            if (const char* ec = getenv("OGC_CUTS")) { // experiment knob: "a,b[,c]" = one-past-last stage of every wave but the last (3 or 4 waves)
+            const char* ep = ogabi::experiment_knob("OGC_PARTS");
+            if (total >= 48 && unit_w.size() >= 4 && !(ep && atoi(ep) < 4)) cg.groups4 = grouping(ogabi::experiment_knob("OGC_K3") ? 3 : 4);
+            if (const char* ec = ogabi::experiment_knob("OGC_CUTS")) { // experiment knob: "a,b[,c]" = one-past-last stage of every wave but the last (3 or 4 waves)
                 std::vector<int> ends;
                 for (const char* q = ec; *q;) {
                     ends.push_back(atoi(q));
@@ -3977,7 +3977,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     }
     out.valu_estimate = graph_weight + 8; // + the mix bus
     int unroll = (has_env && graph_weight >= 100) ? 1 : 2;
-    if (const char* u = getenv("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
+    if (const char* u = ogabi::experiment_knob("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
     // A kernel is assembled from GROUPS of consecutive stages, one wave per group: the ordinary kernel
     // has the single group {0..n-1}, the pipelined ones two or four groups.
@@ -4034,7 +4034,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
          << "    og::VoiceCtx c;\n"
          << "    og::voice_begin<TAPS, LPV>(A, c);\n"
          << "    og::bus_init(c, bus);\n"
-         << (getenv("OGC_PRIO_PARITY") ? "    if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_setprio(1); // experiment\n" : "")
+         << (ogabi::experiment_knob("OGC_PRIO_PARITY") ? "    if ((blockIdx.x >> 3) & 1u) __builtin_amdgcn_s_setprio(1); // experiment\n" : "")
          << cg.common_decl.str() << cat(all_stages, &Codegen::Sect::decl) << "    if (c.valid) {\n"
          << cg.common_load.str() << cat(all_stages, &Codegen::Sect::load) << "    }\n";
     body << "    auto derive = [&]() __attribute__((always_inline)) {\n" << cat(all_stages, &Codegen::Sect::derive) << "    };\n";
@@ -4045,7 +4045,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     // one frame of the voice graph (nodes in topological order); returns the voice's output sample
     // min over the countdowns of a group's envelopes, or "" when it has none
     // (dynamic_events: a gate from another node can start a Release or a new stage on any frame)
-    const bool chunk_chk = !(getenv("OGC_CHUNK_CHK") && atoi(getenv("OGC_CHUNK_CHK")) == 0) && !cg.dynamic_events;
+    const bool chunk_chk = !(ogabi::experiment_knob("OGC_CHUNK_CHK") && atoi(ogabi::experiment_knob("OGC_CHUNK_CHK")) == 0) && !cg.dynamic_events;
     auto min_cnt = [&](const std::vector<int>& st) {
         std::string m;
         if (!chunk_chk) return m;
@@ -4091,7 +4091,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         // Sticky chunks in the ordinary kernel (OGC_STICKY1=0 turns them off): as in the pipelined kernels (emit_pipeline below), a wave stays in the quiet variant it is in while that
         // variant's conditions hold on the next chunk, instead of going back through the chunk loop's head, where the
         // compiler reconciles the register assignments of the four chunk bodies (fm_voice: 57 v_mov per 16-frame chunk).
-        const bool sticky1 = !(getenv("OGC_STICKY1") && atoi(getenv("OGC_STICKY1")) == 0); // round 5: on (+4.5 % at 262 144 voices, +6 % at 1 M, +3.4 % saturator; profiles/r05a_session1.md)
+        const bool sticky1 = !(ogabi::experiment_knob("OGC_STICKY1") && atoi(ogabi::experiment_knob("OGC_STICKY1")) == 0); // round 5: on (+4.5 % at 262 144 voices, +6 % at 1 M, +3.4 % saturator; profiles/r05a_session1.md)
         std::string stay_path1;
         auto variants = [&](const std::string& tail, const std::string& ind0) {
             auto quiet = [&](const std::string& flag, const std::string& ind1, const std::string& stay = std::string()) {
@@ -4183,12 +4183,12 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 const int depth = far - group_of(groups, xv.from) + 1;
                 if (depth > 1) slots += (size_t)depth;
             }
-            const bool wide = K == 2 && slots * 16 * 64 * 4 <= 36 * 1024 && getenv("OGC_XCH16");
+            const bool wide = K == 2 && slots * 16 * 64 * 4 <= 36 * 1024 && ogabi::experiment_knob("OGC_XCH16");
             int xch = wide ? 16 : 8;
             // OGC_XCH=4|16: experiment for the next round -- with the sticky chunk loops a hand-off costs ~9 VALU + ~17 SALU
             // and a barrier instead of ~45 + ~40, so the trade between hand-off overhead (longer chunks) and lock-step wait /
             // LDS footprint (shorter ones) has moved since the measurements above.  OG_BUS_CHUNK (16) must stay a multiple.
-            if (const char* ex = getenv("OGC_XCH")) {
+            if (const char* ex = ogabi::experiment_knob("OGC_XCH")) {
                 const int want = atoi(ex);
                 if ((want == 4 || want == 8 || want == 16) && slots * (size_t)want * 64 * 4 <= 60 * 1024) xch = want;
             }
@@ -4210,7 +4210,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
         }
         const char* rot_expr[5] = {"0u", "blockIdx.x", "(blockIdx.x >> 3)", "(blockIdx.x >> 5)", "(blockIdx.x >> 8)"};
         int rot = 1;
-        if (const char* er = getenv("OGC_ROT")) rot = std::max(0, std::min(4, atoi(er)));
+        if (const char* er = ogabi::experiment_knob("OGC_ROT")) rot = std::max(0, std::min(4, atoi(er)));
         body << "    const uint32_t stage = (threadIdx.x / OG_WAVE + " << rot_expr[rot] << ") % " << K << "u;\n"
              << "    og::VoiceCtx c;\n"
              << "    og::voice_begin_split<TAPS>(A, c);\n"
@@ -4238,7 +4238,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     pr.front() = 2;
                     pr.back() = 0;
                 }
-                if (const char* ep = getenv("OGC_PRIO")) {
+                if (const char* ep = ogabi::experiment_knob("OGC_PRIO")) {
                     pr.clear();
                     for (const char* q = ep; *q; ++q)
                         if (isdigit((unsigned char)*q)) pr.push_back(*q - '0');
@@ -4306,10 +4306,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // VALU per 8 frames; rocprofv3 SQ_INSTS_VALU per 64-voice frame at the driver's command 120.7 -> 107.4.  Interleaved A/B on one MI355X, 65 536 voices: 94-block
             // runs 3.73e11 -> 4.01e11, the driver's command 3.29e11 -> 3.54e11, 131 072 voices 3.90e11 -> 4.20e11 (+7.5 % each);
             // parity subset of the GPU suite green with the variant before it became the default.  OGC_STICKY=0 turns it off.
-            const bool sticky = !(getenv("OGC_STICKY") && atoi(getenv("OGC_STICKY")) == 0) && !getenv("OGC_FORCE_PATH");
+            const bool sticky = !(ogabi::experiment_knob("OGC_STICKY") && atoi(ogabi::experiment_knob("OGC_STICKY")) == 0) && !ogabi::experiment_knob("OGC_FORCE_PATH");
             std::string stay_path; // conditions of the enclosing branches, on the next chunk
-            const std::string sync_line = getenv("OGC_NOSYNC") ? "// (experiment: hand-off barrier removed -- results are wrong, timing only)"
-                                                               : "__syncthreads(); // hand-off: every wave stays one chunk ahead of the next one";
+            const std::string sync_line = "OG_HANDOFF_BARRIER(); // hand-off: every wave stays one chunk ahead of the next one";
             const std::string bus_tail_fmt = // %B = first frame of the finished chunk, %N = its length
                 "{ // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / XCH hand-offs\n"
                 "%I    const uint32_t lastf = %B + %N - 1;\n"
@@ -4383,11 +4382,11 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // checked body (two-wave kernel 26.8 -> 35.9 KB) and the QUIET path pays for it: idle bank 0.0514 -> 0.0528,
             // sustaining 0.0536 -> 0.0553.  At the benchmark's event density the two cancel (2.73e11 either way), so
             // (1) was on and (2) off through round 3: OGC_EVSKIP=0 turns (1) off.
-            const bool ev_skip = !(getenv("OGC_EVSKIP") && atoi(getenv("OGC_EVSKIP")) == 0);
+            const bool ev_skip = !(ogabi::experiment_knob("OGC_EVSKIP") && atoi(ogabi::experiment_knob("OGC_EVSKIP")) == 0);
             // (round 4: (2) is ON -- with the event records prefetched into registers (og::VoiceCtx::nx_*) the handlers inlined
             //  into the checked body no longer carry loads and waits; four-wave kernel at 65 536 voices, interleaved A/B:
             //  3.07e11 either way at the driver's command, 3.57e11 against 3.44e11 on the 188-block run; OGC_EVUNROLL=0 turns it off)
-            const bool ev_unroll = !(getenv("OGC_EVUNROLL") && atoi(getenv("OGC_EVUNROLL")) == 0);
+            const bool ev_unroll = !(ogabi::experiment_knob("OGC_EVUNROLL") && atoi(ogabi::experiment_knob("OGC_EVUNROLL")) == 0);
             std::string relevant; // condition on `tgt`: this wave has a handler for the event
             {
                 const std::string code = cat(st, &Codegen::Sect::derive) + group_tick(groups, gi) + cat(st, &Codegen::Sect::decl);
@@ -4410,7 +4409,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 for (int h : handled) relevant += (relevant.empty() ? "" : " || ") + ("tgt == " + std::to_string(h) + "u");
                 if (relevant.empty()) relevant = "false";
             }
-            const char* force = getenv("OGC_FORCE_PATH"); // experiment knob: b | c | ev -- quiet chunks take the release-arithmetic / stage-end-check / event path (results stay valid)
+            const char* force = ogabi::experiment_knob("OGC_FORCE_PATH"); // experiment knob: b | c | ev -- quiet chunks take the release-arithmetic / stage-end-check / event path (results stay valid)
             // the checked chunk: unrolled, stage-end checks and release arithmetic on, events applied on their frame
             auto checked = [&](const std::string& ind) {
                 const bool pre = !reads.empty() || !rows.empty();
@@ -4447,7 +4446,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 }
             };
             // the two straight-line variants only (the caller has established that no countdown ends in the chunk)
-            const int rel_prio = getenv("OGC_RELPRIO") ? atoi(getenv("OGC_RELPRIO")) : -1;
+            const int rel_prio = ogabi::experiment_knob("OGC_RELPRIO") ? atoi(ogabi::experiment_knob("OGC_RELPRIO")) : -1;
             auto fast_variants = [&](bool st_flag, const std::string& ind0) {
                 const std::string no_rel = "__all((int)(" + rs_sum(st) + " == 0.0f))";
                 body << ind0 << "if (" << no_rel << ") { // no lane is in Release\n";
@@ -4482,7 +4481,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // the gain.  (The two-wave kernel carries it too although it does nothing for it -- forced with
             // OSCEN_GPU_SPLIT=2 at 65 536 voices: 3.16e11 with, 3.19e11 without; the engine does not pick that kernel at
             // any bank size of the bench.)  OGC_SLOWPRIO=-1 turns it off.
-            const int slow_prio = getenv("OGC_SLOWPRIO") ? atoi(getenv("OGC_SLOWPRIO")) : 3;
+            const int slow_prio = ogabi::experiment_knob("OGC_SLOWPRIO") ? atoi(ogabi::experiment_knob("OGC_SLOWPRIO")) : 3;
             const bool one_checked = ev_unroll && !mc.empty() && !force; // events and stage ends share ONE unrolled, checked body
             if (one_checked)
                 body << "        if (n == XCH && __all((int)(c.next_ev >= base + XCH)) && __all((int)(" << mc
@@ -4584,7 +4583,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     // and is 3.3 % faster in an interleaved A/B (1.57e11 -> 1.62e11 at 262 144 voices): taken.  Four waves (128 VGPRs)
     // spill inside the frame loop.
     int waves_eu = (out.lpv > 1 && out.lane_width == 8) ? 3 : 4;
-    if (const char* ew = getenv("OGC_WAVES_EU")) waves_eu = std::max(1, std::min(8, atoi(ew)));
+    if (const char* ew = ogabi::experiment_knob("OGC_WAVES_EU")) waves_eu = std::max(1, std::min(8, atoi(ew)));
     for (auto& v : variants)
         src << "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(" << waves_eu << "))) void og_k_" << hs << "_" << v[0]
             << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block<" << v[1] << ", " << v[2] << ">(A); }\n";

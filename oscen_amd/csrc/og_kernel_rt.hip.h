@@ -47,6 +47,13 @@ using __hip_internal::uint64_t;
 #define OG_MAX_LAUNCH_FRAMES (OG_MAX_BLOCK * OG_MAX_LAUNCH_BLOCKS)
 #define OG_MAX_SLOTS 160
 #define OG_BUS_CHUNK 16
+// the hand-off of the pipelined shapes: one workgroup barrier per chunk.  -DOG_EXPERIMENT_NOSYNC (scripts/build_variant.py
+// <tag> -- -DOG_EXPERIMENT_NOSYNC; never a product build) removes it to time an upper bound: the results are then WRONG.
+#ifdef OG_EXPERIMENT_NOSYNC
+#define OG_HANDOFF_BARRIER() ((void)0)
+#else
+#define OG_HANDOFF_BARRIER() __syncthreads()
+#endif
 #define OG_NO_EVENT 0xFFFFFFFFu
 #define OG_EV_SETVALUE 0x80000000u
 

@@ -267,7 +267,7 @@ struct og_midi {
     // reaches the parser (the generated loop only visits frames < frames and the queue is cleared with the
     // block, codegen/mod.rs:782-871), so it must not touch the allocator either.
     // OSCEN_GPU_HOST_PROF=1: time spent parsing / allocating / pushing (printed by og_midi_destroy)
-    bool prof_on = getenv("OSCEN_GPU_HOST_PROF") != nullptr;
+    bool prof_on = ogabi::experiment_knob("OSCEN_GPU_HOST_PROF") != nullptr;
     double prof_t = 0.0;
     uint64_t prof_msgs = 0, prof_calls = 0;
     void flush(uint32_t frames = 0xFFFFFFFFu)

@@ -9,8 +9,9 @@ blocks are combined by ONE reduce (RCCL over xGMI when the backend is "nccl";
 a [blocks x frames] f32 message is latency-bound, so it is batched rather than
 issued per 1 KB block).  The fm-synth bus is mono and the hosts duplicate it
 to L/R after the sum (examples/fm-synth/src/lib.rs:269-274).  In this torch-level path an engine with a post-mix
-node (the e-piano's stereo Tremolo) applies it per rank before the reduce -- the node is linear in its input, so the
-reduced bus is the same; the C-ABI cluster (og_cluster_*) reduces the mono sums and runs it once on the root.
+node applies it per rank BEFORE the reduce, which is only the same bus when the node is linear in its input (the e-piano's
+stereo Tremolo: out = in * pan): reduce_bus() checks that (`engine=`, og_post_mix_kind) and refuses any other node -- the
+C-ABI cluster (og_cluster_*) is the general path: it reduces the voice sums and runs the node once on the root.
 """
 import os
 
@@ -28,14 +29,20 @@ def shard_range(rank, world_size, total_voices):
     return lo, hi
 
 
-def reduce_bus(bus, dst=0, group=None):
+def reduce_bus(bus, dst=0, group=None, engine=None):
     """Sum the per-rank partial mix buses onto `dst` with a single collective.
 
     `bus` is a torch tensor [blocks, frames(, channels)] on the rank's device
     (CUDA tensor -> RCCL, CPU tensor -> gloo).  In place; only `dst` holds the
-    full mix afterwards.
+    full mix afterwards.  `engine` (the Engine that rendered `bus`): its post-mix
+    node, if any, has already run on this rank's partial bus -- summing after it is
+    only right for a node that is linear in its input; anything else is refused.
     """
     import torch.distributed as dist
+
+    if engine is not None and engine.post_mix_kind not in (0, 1):
+        raise ValueError("reduce_bus: the engine's post-mix node is not linear in its input: sum the voice sums first and run the "
+                         "node once on the destination (og_cluster_* does that)")
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)

@@ -1,5 +1,6 @@
 """Build an A/B variant of liboscen_gpu.so: python scripts/build_variant.py <tag> [ENV=VAL ...] [-- extra hipcc flags]
-Output: oscen_amd/_build/liboscen_gpu_<tag>.so (select it with OSCEN_GPU_LIB=...)."""
+Output: oscen_amd/_build/liboscen_gpu_<tag>.so (select it with OSCEN_GPU_LIB=...).
+The hand-off barrier experiment is a compile-time flag: python scripts/build_variant.py nosync -- -DOG_EXPERIMENT_NOSYNC (results are wrong, timing only)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,6 +8,7 @@ from oscen_amd import build as b
 
 tag = sys.argv[1]
 env = dict(os.environ)
+env["OSCEN_GPU_EXPERIMENTAL"] = "1"  # the OGC_* knobs are ignored without it (og_abi.h)
 flags = []
 rest = sys.argv[2:]
 if "--" in rest:

@@ -23,3 +23,19 @@ if os.path.exists(curve_path):
     print("|---|" + "---|" * len(win))
     print("| max error | " + " | ".join("%.2e" % v for v in win.values()) + " |")
     print("\nworst block: %.3g -- the error does not grow with time (the loop gain of the operators' self-feedback is 0.94)." % d["worst"])
+
+# the error-vs-time curves of tests/test_timed_config_gpu.py (the configuration bench.py times, whole horizon), if written
+import glob
+for path in sorted(glob.glob(sys.argv[1] + ".timed_*.json")):
+    d = json.load(open(path))
+    name = os.path.basename(path)[len(os.path.basename(sys.argv[1])) + len(".timed_"):-len(".json")]
+    win = collections.OrderedDict()
+    for f0, e in d["curve"]:
+        win[f0 // 4800] = max(win.get(f0 // 4800, 0.0), e)
+    print("\n## The timed configuration, %s (%d voices grouped, %s, 20-block queued runs; %d sampled voices, %d frames)\n"
+          % (name, d["voices"], d["kernel"], d["sampled"], d["frames"]))
+    print("max error over the sampled voices per 0.1 s window (reference peak %.3f); the timed path's bus and final state equal the checked run's bit for bit:\n" % d["ref_peak"])
+    print("| window start (s) | " + " | ".join("%.1f" % (k * 0.1) for k in win) + " |")
+    print("|---|" + "---|" * len(win))
+    print("| max error | " + " | ".join("%.2e" % v for v in win.values()) + " |")
+    print("\nworst block: %.3g" % d["worst"])

@@ -57,3 +57,29 @@ def test_environment_knobs_are_not_read_on_the_block_path():
     for fn in ("og_process_block", "og_process_block_async", "og_process_blocks_async", "og_midi_process_block"):
         b = _body(eng, fn) or _body(open(os.path.join(CSRC, "og_midi.cpp")).read(), fn)
         assert b is not None and "getenv" not in b, fn
+
+
+def test_only_listed_environment_variables_are_read_and_experiment_knobs_are_gated():
+    """og_abi.h: SETTINGS are read as they are; every other variable is an experiment knob, read through
+    ogabi::experiment_knob() (nullptr unless OSCEN_GPU_EXPERIMENTAL=1).  No source reads a variable that og_version() does not
+    list, no experiment knob is read with a bare getenv, and the one knob whose effect was WRONG RESULTS (the hand-off barrier
+    experiment) is not a run-time knob at all: it is a compile-time flag of scripts/build_variant.py."""
+    import re
+
+    abi = open(os.path.join(CSRC, "og_abi.h")).read()
+    settings = set(re.search(r'#define OG_SETTINGS "([^"]+)"', abi).group(1).split())
+    knobs = set(" ".join(re.findall(r'"([A-Z0-9_ ]+)"', abi[abi.index("#define OG_EXPERIMENT_KNOBS"):abi.index("inline bool experiments_enabled")])).split())
+    assert settings and knobs and not (settings & knobs)
+    raw, gated = set(), set()
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith((".cpp", ".h", ".inl")):
+            continue
+        t = open(os.path.join(CSRC, f)).read()
+        raw |= set(re.findall(r'(?<![\w:])getenv\("([A-Z0-9_]+)"\)', t))
+        gated |= set(re.findall(r'experiment_knob\("([A-Z0-9_]+)"\)', t))
+    assert raw <= settings, sorted(raw - settings)
+    assert gated <= knobs, sorted(gated - knobs)
+    assert "OGC_NOSYNC" not in knobs | settings | raw | gated
+    assert "OG_EXPERIMENT_NOSYNC" in open(os.path.join(CSRC, "og_kernel_rt.hip.h")).read()
+    eng = open(os.path.join(CSRC, "og_engine.cpp")).read()
+    assert "OG_SETTINGS" in _body(eng, "og_version") and "OG_EXPERIMENT_KNOBS" in _body(eng, "og_version")

@@ -209,7 +209,7 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     # sticky chunks: every quiet variant of every wave is a loop of its own around its body (hand-off barrier inside), left
     # only when its conditions fail on the next chunk -- three envelope waves x {release-free, release} + the filter wave
     assert p4.count("for (;;) { // sticky: this variant again while its conditions hold") == 7
-    assert p4.count("const uint32_t ch1 = ch + 1u, base1 = base + XCH;") == 7 and p4.count("__syncthreads();") == 4 + 7
+    assert p4.count("const uint32_t ch1 = ch + 1u, base1 = base + XCH;") == 7 and p4.count("OG_HANDOFF_BARRIER();") == 4 + 7
     sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     assert "// Node order:" in sub_src
     for k in ("og_k_", "og_k2_", "og_k4_", "og_k4w_"):  # (og_k4w_: the four-wave pipeline with 16-frame hand-offs, round 5)

@@ -40,6 +40,7 @@ def cluster(graph, n, total, block, shards, per_block=False):
 
 @pytest.mark.parametrize("graph,n", [("fm_voice", 3000), ("epiano_voice", 300), ("sat4x_voice", 1000)])
 def test_two_shard_cluster_matches_the_single_engine_bus(graph, n, monkeypatch):
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")  # (OSCEN_GPU_FORCE_RCCL is an experiment knob: ignored without it)
     monkeypatch.setenv("OSCEN_GPU_FORCE_RCCL", "1")
     total, block = 1024, 256
     want = single(graph, n, total, block)
@@ -157,6 +158,7 @@ def test_multi_device_cluster_at_the_config4_shard_size(graph):
 def test_stereo_voice_outputs_through_the_cluster(monkeypatch):
     """a graph whose stream output is fed a Frame<2> (per-voice pan): the shards hand over interleaved L R sums, the
     reduce covers both channels"""
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")  # (OSCEN_GPU_FORCE_RCCL is an experiment knob: ignored without it)
     monkeypatch.setenv("OSCEN_GPU_FORCE_RCCL", "1")
     n, total, block = 1500, 768, 256
     oscen_amd.register_node(
@@ -206,6 +208,7 @@ def test_eight_shard_cluster_on_one_device_matches_the_single_engine(monkeypatch
     """the shape of BASELINE config 4 (eight shards, one reduce per batch) at a small size with all shards on the one
     device there is: global voice ranges, per-shard note streams, the per-device accumulation of eight buffers, the RCCL
     leg with a one-rank communicator; render (threaded, batched) and the per-block real-time entry (thread-free)"""
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")  # (OSCEN_GPU_FORCE_RCCL is an experiment knob: ignored without it)
     monkeypatch.setenv("OSCEN_GPU_FORCE_RCCL", "1")
     n, total, block = 8 * 640 + 37, 1280, 256   # (a ragged total: the shards differ in size)
     want = single("fm_voice", n, total, block)

@@ -44,6 +44,23 @@ def _rank_main(rank, world, total_voices, blocks, frames, port, out_path):
     dist.destroy_process_group()
 
 
+def test_reduce_bus_refuses_a_post_mix_node_that_is_not_linear():
+    """the torch-level path sums AFTER each rank's post-mix stage: right for Tremolo (out = in * pan), wrong for anything
+    else -- refused (og_cluster_* reduces the voice sums and runs the node once on the root)"""
+    import types
+
+    import pytest
+    import torch
+
+    from oscen_amd import distributed as ogd
+
+    bus = torch.zeros((2, 8))
+    for kind in (0, 1):
+        assert ogd.reduce_bus(bus, engine=types.SimpleNamespace(post_mix_kind=kind)) is bus
+    with pytest.raises(ValueError, match="not linear"):
+        ogd.reduce_bus(bus, engine=types.SimpleNamespace(post_mix_kind=2))
+
+
 def test_shard_ranges_partition_the_bank():
     from oscen_amd import distributed as ogd
 

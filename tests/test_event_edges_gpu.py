@@ -241,11 +241,13 @@ def test_graph_event_outputs_reach_the_host_in_frame_voice_push_order():
         assert eng.events_dropped == lost and lost > 50
         # a log too small for what arrives between two reads: the excess is counted, not lost silently
         import os
+        os.environ["OSCEN_GPU_EXPERIMENTAL"] = "1"
         os.environ["OSCEN_GPU_OUT_EVENTS"] = "64"
         try:
             small = oscen_amd.Engine(g, n, sample_rate=SR)
         finally:
             del os.environ["OSCEN_GPU_OUT_EVENTS"]
+            del os.environ["OSCEN_GPU_EXPERIMENTAL"]
         small.set_voice_values("period", periods)
         small.set_voice_values("pushes", np.ones(n, dtype=np.float32))
         small.process_block(512)

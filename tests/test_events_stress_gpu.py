@@ -82,6 +82,7 @@ def test_bulk_incremental_and_queued_event_paths_agree(n, monkeypatch):
                 e.process_block(block)
         return e.process_block(64), e.save_state()
 
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")
     monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "4096")  # a small ring: many wraps (and merges of old + new events)
     bmode = engine()
     bus_b, state_b = live(bmode, queued=False)
