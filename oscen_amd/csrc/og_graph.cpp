@@ -1339,7 +1339,16 @@ void emit_tpt(NodeCtx& x)
         x.cg.S().derive << "        " << li << " = __uint_as_float(og::TPT_LAZY_SENTINEL);\n";
         x.cg.any_derive = true;
         const std::string qchk = block_const(q) ? "false" : (q.rate == Rate::UFrame ? "RAMPS" : "true");
-        x.cg.os() << "        og::tpt_params_nomod_lazy<" << qchk << ">(" << cutoff.e << ", " << q.e << ", " << li << ", " << lq << ", " << tail;
+        // 1 / q once per launch where q cannot change inside it: a block-constant q, or a rampable graph input in the kernel
+        // variants that do not read the ramp table (`RV(row, slot)` is the slot there)
+        std::string q_launch = block_const(q) ? q.e : std::string();
+        if (q_launch.empty() && q.rate == Rate::UFrame && q.e.compare(0, 3, "RV(") == 0 && q.e.find(')') == q.e.size() - 1) {
+            const size_t comma = q.e.find(", ");
+            if (comma != std::string::npos) q_launch = "SF(" + q.e.substr(comma + 2);
+        }
+        const std::string iq = q_launch.empty() ? std::string("0.0f") : x.hoist("inv_q", "1.0f / og::clampf(" + q_launch + ", 0.1f, 10.0f)");
+        x.cg.os() << "        og::tpt_params_nomod_lazy<" << qchk << ", " << (q_launch.empty() ? "false" : "true") << ">(" << cutoff.e << ", " << q.e << ", "
+                  << iq << ", " << li << ", " << lq << ", " << tail;
     } else if (nomod) {
         x.cg.os() << "        og::tpt_params_nomod(" << cutoff.e << ", " << q.e << ", " << tail;
     } else {
@@ -4169,7 +4178,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 if (group_of(groups, cg.stage_of[ni]) == gi) body << " " << g.nodes[ni].name;
             body << (gi == K - 1 ? " + the mix bus\n" : "\n");
         }
-        body << "template <bool RAMPS, bool TAPS, uint32_t XCH_T = 0>\n"
+        // FD_T = 0: one workgroup barrier per hand-off (every wave one chunk behind its predecessor); FD_T >= 2: flag
+        // hand-off (og_kernel_rt.hip.h, handoff_wait / handoff_publish) over rings of FD_T chunks per crossing value
+        body << "template <bool RAMPS, bool TAPS, uint32_t XCH_T = 0, uint32_t FD_T = 0>\n"
              << "__device__ __forceinline__ void voice_block_p" << tag << "(const OgBlockArgs& A)\n{\n"
              << "    __shared__ og::" << (out.voice_channels > 1 ? "BusLdsN<" + std::to_string(out.voice_channels) + ">" : std::string("BusLds")) << " bus;\n";
         {
@@ -4205,9 +4216,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             int far = group_of(groups, xv.from);
             for (int u : xv.users) far = std::max(far, group_of(groups, u));
             const int depth = far - group_of(groups, xv.from) + 1;
-            body << "    constexpr uint32_t XD" << k << " = " << depth << ";\n";
+            body << "    constexpr uint32_t XD" << k << " = " << (depth > 1 ? "FD_T ? FD_T : " : "") << depth << ";\n";
             if (depth > 1) body << "    __shared__ float chan" << k << "[XD" << k << "][XCH][OG_WAVE];\n";
         }
+        body << "    __shared__ uint32_t prog[" << K << "]; // flag hand-off: chunks completed, per stage\n"
+             << "    __shared__ uint32_t cons[" << K << "]; // ... and chunks whose inputs this stage has taken out of the rings\n"
+             << "    if constexpr (FD_T != 0) {\n"
+             << "        if (threadIdx.x < " << K << "u) prog[threadIdx.x] = cons[threadIdx.x] = 0u;\n"
+             << "        __syncthreads();\n"
+             << "    }\n";
         const char* rot_expr[5] = {"0u", "blockIdx.x", "(blockIdx.x >> 3)", "(blockIdx.x >> 5)", "(blockIdx.x >> 8)"};
         int rot = 1;
         if (const char* er = ogabi::experiment_knob("OGC_ROT")) rot = std::max(0, std::min(4, atoi(er)));
@@ -4243,8 +4260,17 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     for (const char* q = ep; *q; ++q)
                         if (isdigit((unsigned char)*q)) pr.push_back(*q - '0');
                 }
-                if (gi < (int)pr.size() && pr[gi] > 0) body << "    __builtin_amdgcn_s_setprio(" << pr[gi] << ");\n";
                 base_prio = gi < (int)pr.size() ? pr[gi] : 0;
+                // Round 6, flag hand-off (FD_T != 0): the order turns round -- 0,1,2,3, downstream first.  Without the barrier a
+                // consumer that has its inputs runs them down at once and the producers fill in behind it; the rings stay near
+                // empty and no wave sits blocked on a full one.  Interleaved A/B, 65 536 voices, 16-frame chunks, rings of 2
+                // (profiles/r06_handoff_ab.md): barrier 2,1,1,0 (round 5) 5.45e11 at the driver's command; flags 2,1,1,0
+                // 5.56e11; flags 0,0,0,0 5.40e11; flags 0,1,1,2 5.65e11; 0,0,1,2 5.74e11; 0,1,2,2 5.57e11; 1,1,2,3 5.38e11;
+                // 0,0,2,3 5.32e11; flags 0,1,2,3 5.93e11 -- and the barrier with 0,1,2,3 4.89e11: the order only works without
+                // the lock step.  Moving-cutoff variant 3.95e11 -> 4.37e11; 188-block regions 6.42e11 -> 6.2e11 (-3 %).
+                const int flag_prio = ogabi::experiment_knob("OGC_PRIO") ? base_prio : std::min(gi, 3);
+                body << "    constexpr int BASE_PRIO = FD_T != 0 ? " << flag_prio << " : " << base_prio << ";\n"
+                     << "    og::set_prio<BASE_PRIO>();\n";
             }
             body << cat(st, &Codegen::Sect::decl) << "    if (c.valid) {\n" << cat(st, &Codegen::Sect::load) << "    }\n";
             body << "    auto derive = [&]() __attribute__((always_inline)) {\n" << cat(st, &Codegen::Sect::derive) << "    };\n";
@@ -4308,7 +4334,31 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
             // parity subset of the GPU suite green with the variant before it became the default.  OGC_STICKY=0 turns it off.
             const bool sticky = !(ogabi::experiment_knob("OGC_STICKY") && atoi(ogabi::experiment_knob("OGC_STICKY")) == 0) && !ogabi::experiment_knob("OGC_FORCE_PATH");
             std::string stay_path; // conditions of the enclosing branches, on the next chunk
-            const std::string sync_line = "OG_HANDOFF_BARRIER(); // hand-off: every wave stays one chunk ahead of the next one";
+            // hand-off partners of this wave: the stages whose values it reads (producers) and the stages that read its values
+            std::set<int> producers, consumers;
+            for (const auto& xv : cg.xvals) {
+                const int from = group_of(groups, xv.from);
+                for (int u : xv.users) {
+                    const int to = group_of(groups, u);
+                    if (to == from) continue;
+                    if (to == gi) producers.insert(from);
+                    if (from == gi) consumers.insert(to);
+                }
+            }
+            for (int q : producers) body << "    uint32_t seen_p" << q << " = 0u;\n";
+            for (int q : consumers) body << "    uint32_t seen_c" << q << " = 0u;\n";
+            // flags: before chunk `ch` -- its inputs are complete, and the ring slots it writes have been read
+            std::string wait_all = "if constexpr (FD_T != 0) {";
+            for (int q : producers) wait_all += " og::handoff_wait(&prog[" + std::to_string(q) + "], seen_p" + std::to_string(q) + ", ch + 1u);";
+            for (int q : consumers) wait_all += " og::handoff_wait(&cons[" + std::to_string(q) + "], seen_c" + std::to_string(q) + ", ch + 1u - FD_T);";
+            wait_all += " }";
+            // (a stage that reads hand-off values gives their ring slots back as soon as the chunk's values sit in its registers --
+            //  `taken`, after the prefetch of the unrolled bodies -- or, on the rolled path, with the chunk)
+            const std::string taken = producers.empty() ? std::string()
+                                                        : "if constexpr (FD_T != 0) og::handoff_publish(&cons[" + std::to_string(gi) + "], ch + 1u);";
+            const std::string sync_line = "if constexpr (FD_T != 0) { og::handoff_publish(&prog[" + std::to_string(gi) + "], ch + 1u);" +
+                                          (producers.empty() ? std::string() : " __hip_atomic_store(&cons[" + std::to_string(gi) + "], ch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);") +
+                                          " } else OG_HANDOFF_BARRIER(); // hand-off: chunk `ch` of this stage is complete";
             const std::string bus_tail_fmt = // %B = first frame of the finished chunk, %N = its length
                 "{ // the bus tile holds OG_BUS_CHUNK frames = OG_BUS_CHUNK / XCH hand-offs\n"
                 "%I    const uint32_t lastf = %B + %N - 1;\n"
@@ -4347,6 +4397,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
+                    if (!reads.empty() && !taken.empty()) body << ind << taken << "\n";
                 }
                 const std::string flag = std::string(chk_flag) + ", " + rel_flag + ", " + (pre ? "true" : "false") + ", " +
                                          (st_flag ? "true" : "false");
@@ -4361,8 +4412,9 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                          << ")) break;\n";
                     if (last) body << bus_tail(ind, "XCH");
                     body << ind << sync_line << "\n"
-                         << ind << "++t;\n" << ind << "ch = ch1;\n" << ind << "base = base1;\n"
-                         << ind0 << "}\n";
+                         << ind << "++t;\n" << ind << "ch = ch1;\n" << ind << "base = base1;\n";
+                    if (!wait_all.empty()) body << ind << wait_all << "\n";
+                    body << ind0 << "}\n";
                 }
             };
             const std::string mc = min_cnt(st);
@@ -4419,6 +4471,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                     body << ind << "#pragma unroll\n" << ind << "for (uint32_t j = 0; j < XCH; ++j) {\n";
                     for (size_t k : reads) body << ind << "    xp" << k << "[j] = chan" << k << "[ch % XD" << k << "][j][c.lane];\n";
                     body << ind << "}\n";
+                    if (!reads.empty() && !taken.empty()) body << ind << taken << "\n";
                 }
                 const std::string flag = std::string("true, true, ") + (pre ? "true" : "false") + ", false";
                 body << ind << "#pragma unroll\n"
@@ -4456,13 +4509,15 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 // whole, and their workgroups are the ones a launch waits for; measured WITHOUT grouping in round 4: loses)
                 if (rel_prio >= 0) body << ind0 << "    __builtin_amdgcn_s_setprio(" << rel_prio << ");\n";
                 quiet("false", "true", st_flag, ind0 + "    ", "!" + no_rel);
-                if (rel_prio >= 0) body << ind0 << "    __builtin_amdgcn_s_setprio(" << base_prio << ");\n";
+                if (rel_prio >= 0) body << ind0 << "    og::set_prio<BASE_PRIO>();\n";
                 body << ind0 << "}\n";
             };
             if (last) body << "    og::bus_init(c, bus); // (this wave owns the tile)\n";
-            body << "    for (uint32_t t = 0; t < n_chunks + " << (K - 1) << "u; ++t) {\n"
-                 << "        " << (sticky ? "" : "const ") << "uint32_t ch = t - " << gi << "u;\n"
-                 << "        if (ch < n_chunks) {\n"
+            body << "    for (uint32_t t = 0; t < n_chunks + (FD_T ? 0u : " << (K - 1) << "u); ++t) {\n"
+                 << "        " << (sticky ? "" : "const ") << "uint32_t ch = t - (FD_T ? 0u : " << gi << "u);\n"
+                 << "        if (ch < n_chunks) {\n";
+            if (!wait_all.empty()) body << "        " << wait_all << "\n";
+            body
                  << "        " << (sticky ? "" : "const ") << "uint32_t base = ch * XCH;\n"
                  << "        const uint32_t n = min((uint32_t)XCH, A.frames - base);\n";
             if (ev_skip && relevant != "true")
@@ -4512,7 +4567,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 body << "        } else if (n == XCH) { // an event or a stage end in this chunk: the checked, unrolled body\n";
                 if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << slow_prio << "); // the wave on the slow path is the straggler\n";
                 checked("            ");
-                if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << base_prio << ");\n";
+                if (slow_prio >= 0) body << "            og::set_prio<BASE_PRIO>();\n";
             }
             body << "        } else {\n"
                  << fc_sync(st, "            ")
@@ -4539,8 +4594,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::string user_src;
     for (const auto& kv : cg.user_fns) user_src += kv.second;
     const std::string body_s = user_src + body.str();
+    // the wide four-wave form: 16-frame chunks, flag hand-off over rings of two chunks (round 6; round 5: one barrier per chunk).
+    // OGC_FLAGS="xch,depth" (experiment): `xch` frames per chunk, rings of `depth` chunks, depth 0 = the barrier
+    std::string wide_args = "16, 2";
+    if (const char* ef = ogabi::experiment_knob("OGC_FLAGS")) {
+        int xch = 0, fd = 0;
+        if (sscanf(ef, "%d,%d", &xch, &fd) == 2 && (xch == 4 || xch == 8 || xch == 16) && (fd == 0 || (fd >= 2 && fd <= 8)))
+            wide_args = std::to_string(xch) + ", " + std::to_string(fd);
+    }
     out.hash = fnv1a(body_s + "|lpv" + std::to_string(out.lpv) + (cg.ev_capacity != 2 ? "|evq" + std::to_string(cg.ev_capacity) : std::string()) +
-                     "|rt" + OG_RT_DIGEST);
+                     "|wide" + wide_args + "|rt" + OG_RT_DIGEST);
     char hs[32];
     snprintf(hs, sizeof hs, "%016llx", (unsigned long long)out.hash);
 
@@ -4597,7 +4660,7 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     if (out.wide4)
         for (auto& v : variants)
             src << "extern \"C\" __global__ __launch_bounds__(" << 64 * (int)cg.groups4.size() << ") void og_k4w_" << hs << "_" << v[0]
-                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p4<" << v[1] << ", " << v[2] << ", 16>(A); }\n";
+                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p4<" << v[1] << ", " << v[2] << ", " << wide_args << ">(A); }\n";
     src << "\n#ifndef OG_JIT\n#include \"og_registry.h\"\n"
         << "static void og_launch_" << hs << "(const OgBlockArgs& A, bool ramps, bool taps, hipStream_t s)\n{\n"
         << "    const dim3 grid(((size_t)A.n_voices * " << out.lpv << " + A.lanes - 1) / A.lanes), block(OG_WAVE);\n";

@@ -54,6 +54,44 @@ using __hip_internal::uint64_t;
 #else
 #define OG_HANDOFF_BARRIER() __syncthreads()
 #endif
+
+// ---- flag hand-off (pipelined shapes instantiated with FD_T >= 2) ---------------------------------------------------------
+// Instead of one workgroup barrier per chunk -- every wave waits for the slowest of the four at every step -- each stage
+// publishes its progress in an LDS word (`prog[stage]` = chunks completed) and waits only for what it needs: its producers
+// to have completed the chunk it is about to read, its consumers to have left the ring slot it is about to overwrite
+// (FD_T slots per crossing value: a producer may run FD_T chunks ahead).  LDS operations of one wave complete in issue
+// order, so data written before the progress word is visible to whoever reads the word first and the data after it; the
+// fences keep the COMPILER from moving accesses across (workgroup scope, LDS only: `s_waitcnt lgkmcnt(0)`, no vmcnt).
+// `seen` caches the last value read (wave-uniform, an SGPR): a stage that is already known to be far enough ahead costs a
+// scalar compare and no LDS read.  All four waves of a workgroup are resident together, so polling cannot starve a producer.
+namespace og {
+// returns whether the wave had to poll (the value was not there yet)
+__device__ __forceinline__ bool handoff_wait(uint32_t* word, uint32_t& seen, const uint32_t need)
+{
+    if ((int)(seen - need) >= 0) return false;
+    bool polled = false;
+    for (;;) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(seen - need) >= 0) break;
+        polled = true;
+#if defined(OG_HOSTSIM) || (defined(OG_HANDOFF_SLEEP) && OG_HANDOFF_SLEEP > 0)
+        __builtin_amdgcn_s_sleep(1); // (measured: a tight poll beats a sleeping one by 1-2 %; the host simulator yields here)
+#endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return polled;
+}
+template <int P>
+__device__ __forceinline__ void set_prio()
+{
+    __builtin_amdgcn_s_setprio(P);
+}
+__device__ __forceinline__ void handoff_publish(uint32_t* word, const uint32_t done)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_store(word, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+} // namespace og
 #define OG_NO_EVENT 0xFFFFFFFFu
 #define OG_EV_SETVALUE 0x80000000u
 

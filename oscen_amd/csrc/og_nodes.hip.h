@@ -330,9 +330,31 @@ OG_DEV void tpt_params_nomod(float cutoff_in, float q_in, float max_cutoff, floa
 // seen replaces clamp, two subtractions and two float compares.  `last_in` / `last_q` are per-lane registers, not state:
 // they start from a sentinel at every launch (and after a per-voice value event), so the first frame always runs the full
 // test.  QCHK: q can change inside a launch (a ramped or per-frame q); otherwise only the cutoff is watched.
-template <bool QCHK>
-OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float& last_in, float& last_q, float max_cutoff, float two_sr, float period,
-                                  float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
+// update_coefficients for the lazy form below: the same operations as tpt_update_coefficients, arranged for a wave that
+// updates on (nearly) every frame -- `inv_q` = 1.0f / q comes from the caller when q cannot change inside the launch (an IEEE
+// division, ten instructions, formed once per launch instead of once per frame: the compiler cannot hoist it itself, the
+// slot it derives from is pinned to a scalar register by a convergent readfirstlane), and og_tanf_q1's `x > pi/4` arm
+// (cutoff above a quarter of the sample rate) sits behind ONE wave-uniform test instead of a divergent region per frame.
+OG_DEV void tpt_update_coefficients_iq(float cutoff, float q, float inv_q, float two_sr, float period, float nyquist, float& cur_c,
+                                       float& cur_q, float& h, float& g, float& k)
+{
+    const float freq = clampf(cutoff, 20.0f, nyquist);
+    const float x = F32_TAU * freq * period;
+    float t;
+    if (__any((int)(x > 0x1.921fb6p-1f))) t = og_tanf_q1(x);
+    else t = og_tan_poly(x);
+    const float f = two_sr * t * period;
+    h = div_near(1.0f, OG_FMA(f, f, OG_FMA(inv_q, f, 1.0f))); // 1 / (1 + inv_q * f + f * f)
+    g = f;
+    k = f + inv_q;
+    cur_c = cutoff;
+    cur_q = q;
+}
+
+// IQ: `inv_q_in` = 1.0f / clamp(q) was formed by the caller (q is constant over the launch)
+template <bool QCHK, bool IQ>
+OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float inv_q_in, float& last_in, float& last_q, float max_cutoff, float two_sr,
+                                  float period, float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
 {
     if (QCHK) {
         // q can change inside this launch (the kernel variants that read the ramp table): the reference's own per-frame test.
@@ -358,7 +380,11 @@ OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float& last_in, f
         // coefficients it already has.  (With the reference's test nested inside, the bank whose cutoff moves every frame
         // lost 11 %.)  q is constant over the launch here; a change of q between launches smaller than EPSILON, which the
         // reference would ignore, is picked up by the first frame's update -- part of the tolerance mode.
+#ifdef OG_TPT_OLD_UPDATE // (A/B: round 5's update path)
         tpt_update_coefficients(cutoff, q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+#else
+        tpt_update_coefficients_iq(cutoff, q, IQ ? inv_q_in : 1.0f / q, two_sr, period, nyquist, cur_c, cur_q, h, g, k);
+#endif
     }
 }
 constexpr uint32_t TPT_LAZY_SENTINEL = 0x7fc0a5a5u; // a NaN payload no computation produces

@@ -84,6 +84,7 @@ struct Api {
     void (*wave_sync)();
     void (*syncthreads)();
     void (*launch)(dim3, dim3, const std::function<void()>&);
+    void (*yield)(); // a lane that polls shared memory (the flag hand-off of the pipelined kernels) lets the others run
 };
 Api* default_api(); // simt.cpp (library only)
 inline Api*& api_slot()
@@ -144,7 +145,10 @@ static inline void __threadfence_system() {}
 // the amdgcn builtins the device headers call by name
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) (simt::api()->yield())
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
 #define __builtin_amdgcn_wave_barrier() (simt::api()->wave_sync())
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 // (the kernels call it on wave-uniform values only -- kernel-argument slots, to pin them to a scalar register -- and from

@@ -277,8 +277,17 @@ uint32_t api_shfl_xor(uint32_t v, int m) { return block_on(OP_SHFL_XOR, v, (uint
 uint32_t api_first(uint32_t v) { return block_on(OP_FIRST, v, 0); }
 void api_wave_sync() { (void)block_on(OP_WAVE_SYNC, 0, 0); }
 void api_syncthreads() { (void)block_on(OP_BARRIER, 0, 0); }
+// a polling lane: stays READY, runs again on the scheduler's next pass (after every other ready lane has had its turn).  A poll
+// whose condition can never come true spins for ever -- the tests run under a timeout -- instead of being reported as a deadlock.
+void api_yield()
+{
+    Sched* s = g_sched;
+    if (!s || !s->cur) return;
+    Lane* me = s->cur;
+    og_simt_switch(&me->sp, s->main_sp);
+}
 
-Api g_api = {api_cur, api_all, api_any, api_shfl_xor, api_first, api_wave_sync, api_syncthreads, do_launch};
+Api g_api = {api_cur, api_all, api_any, api_shfl_xor, api_first, api_wave_sync, api_syncthreads, do_launch, api_yield};
 
 // x86 traps on an integer division by zero; the GPU does not (the quotient is garbage, typically in a lane whose result is
 // never used).  Say where it happened -- object + offset, for llvm-symbolizer on a unit compiled with OG_HOSTSIM_DEBUG=1 --

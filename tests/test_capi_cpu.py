@@ -199,22 +199,26 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     assert re.search(r"// Node order: env3 env2 env1 env_filter op3_osc", fm)  # the reference's Kahn order, for the record
     assert re.search(r"// Schedule \([^)]*\): env3 op3_osc op3_route env2 op2_osc op1_mod_mixer env1 op1_osc env_filter filter_env_gain cutoff_mod filter output_gain", fm)
     assert re.search(r"//   wave 0: env3 op3_osc op3_route env2 op2_osc\b", fm) and re.search(r"//   wave 1: [a-z0-9_ ]*op1_osc env_filter", fm)
-    # wave priorities of the four-wave workgroup: first wave 2, middle waves 1, the wave that closes the chunk 0
+    # wave priorities of the four-wave workgroup: behind the hand-off barrier (og_k4_*) first wave 2, middle waves 1, the wave
+    # that closes the chunk 0; with the flag hand-off (og_k4w_*, round 6) the other way round, 0 1 2 3
     p4 = fm[fm.index("voice_block_p4"):]
-    assert p4.count("\n    __builtin_amdgcn_s_setprio(2);") == 1 and p4.count("\n    __builtin_amdgcn_s_setprio(1);") == 2
+    assert [m for m in re.findall(r"constexpr int BASE_PRIO = FD_T != 0 \? (\d) : (\d);", p4)] == [("0", "2"), ("1", "1"), ("2", "1"), ("3", "0")]
     # ... and a wave runs a chunk that holds an event or a stage end (the checked body) at priority 3, then drops back
     # (three of the four waves hold an envelope; the last one -- filter and bus -- has no checked body)
     assert p4.count("__builtin_amdgcn_s_setprio(3); // the wave on the slow path") == 3
-    assert len(re.findall(r"\n {8,}__builtin_amdgcn_s_setprio\([012]\);", p4)) == 3
+    assert len(re.findall(r"\n {8,}og::set_prio<BASE_PRIO>\(\);", p4)) == 3
     # sticky chunks: every quiet variant of every wave is a loop of its own around its body (hand-off barrier inside), left
     # only when its conditions fail on the next chunk -- three envelope waves x {release-free, release} + the filter wave
     assert p4.count("for (;;) { // sticky: this variant again while its conditions hold") == 7
     assert p4.count("const uint32_t ch1 = ch + 1u, base1 = base + XCH;") == 7 and p4.count("OG_HANDOFF_BARRIER();") == 4 + 7
+    # round 6: every hand-off is `flags or barrier` by instantiation; the flag form publishes the stage's progress word and waits
+    # for its producers' words and its consumers' release words only
+    assert p4.count("if constexpr (FD_T != 0) { og::handoff_publish(&prog[") == 4 + 7 and "og::handoff_wait(&cons[1], seen_c1, ch + 1u - FD_T);" in p4
     sub_src = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     assert "// Node order:" in sub_src
     for k in ("og_k_", "og_k2_", "og_k4_", "og_k4w_"):  # (og_k4w_: the four-wave pipeline with 16-frame hand-offs, round 5)
         assert len(re.findall(r"__global__[^\n]*\b%s[0-9a-f]{16}_(00|10|01|11)\b" % k, fm)) == 4
-    assert "voice_block_p4<false, false, 16>" in fm and "constexpr uint32_t XCH = XCH_T ? XCH_T : 8u;" in fm
+    assert "voice_block_p4<false, false, 16, 2>" in fm and "constexpr uint32_t XCH = XCH_T ? XCH_T : 8u;" in fm
     # chunk variants: (stage-end checks, release arithmetic[, hand-off prefetch, node steady states])
     assert "og::BoolC<false, false>{}" in fm and "og::BoolC<false, true>{}" in fm and "og::BoolC<true>{}" in fm
     # (round 5: every wave of the pipelines prefetches something at the top of a chunk -- hand-off values or ramp-table rows --
@@ -227,7 +231,9 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     tick = fm[fm.index("auto tick"):fm.index("auto events")]
     # (round 5: the per-tick check watches the raw input -- one integer compare -- and runs the reference's test only on
     #  frames whose input differs from the previous frame's; q is watched in the kernel variants that read a ramp table)
-    assert "og::tpt_params_nomod_lazy<RAMPS>(" in tick and "og::tpt_params_nomod(" not in tick
+    # (round 6: 1 / q is formed once per launch -- `inv_q` in derive() -- where q cannot change inside it)
+    assert "og::tpt_params_nomod_lazy<RAMPS, true>(" in tick and "og::tpt_params_nomod(" not in tick
+    assert "inv_q = 1.0f / og::clampf(SF(" in fm[fm.index("auto derive"):fm.index("auto tick")]
     sub = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     derive = sub[sub.index("auto derive"):sub.index("auto tick")]
     tick = sub[sub.index("auto tick"):sub.index("auto events")]
