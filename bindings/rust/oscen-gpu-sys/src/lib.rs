@@ -130,6 +130,7 @@ extern "C" {
                                   out: *mut *mut og_midi) -> c_int;
     pub fn og_blocking_stats(e: *const og_engine, calls: *mut u64, marker_timeouts: *mut u64) -> c_int;
     pub fn og_event_ring_wraps(e: *const og_engine) -> u64;
+    pub fn og_events_copied(e: *const og_engine) -> u64;
     pub fn og_reserve_events(e: *mut og_engine, n_events: u64) -> c_int;
     pub fn og_group_voices(e: *mut og_engine, policy: u32) -> c_int;
     pub fn og_voice_slot(e: *const og_engine, voice: u32, slot: *mut u32) -> c_int;

@@ -85,7 +85,8 @@ int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type
  * `<event_output>.push_at(frame_offset, value)`, plain `push(value)` = offset 0 -- multiplied (saturating) by N on an
  * outer -> inner edge and divided by N on an inner -> outer edge, codegen/emit_edge.rs:86-99) -- but only the VALUE inputs
  * (streams do not exist yet when an event fires).  og_math.h / og_nodes.hip.h helpers (og_sin_turns, og_sinf, og::clampf,
- * ...) are in scope.  The bodies are compiled into
+ * ...) are in scope; og_sin_turns -- sin of an argument in TURNS -- is the hardware sine and is defined for |t| <= 256
+ * turns only (0 beyond): a body whose argument is not bounded calls og_sin_turns_wide instead.  The bodies are compiled into
  * the fused voice kernel by hiprtc when an engine is created for a graph that uses the type.  Process-wide registry. */
 typedef struct {
     const char* name;
@@ -388,6 +389,12 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 /* times the live path's append pointer wrapped around the device event buffer (a ring: the space of consumed /
  * superseded segments is reused, so steady live playing never needs the O(V) timeline rebuild) */
 uint64_t og_event_ring_wraps(const og_engine* e);
+/* events the incremental path has written to the ring so far: the pushes themselves plus whatever it carried over of the
+ * voice's waiting events.  A live message on a voice with a long resident score ahead of it carries over only what is due
+ * up to the message's frame -- the rest of the score stays in place as the voice's continuation segment and the kernel
+ * moves on to it by itself (the reference merges staged events into the block by frame_offset per block,
+ * oscen-graph-compiler/src/codegen/mod.rs:782-871; here the merge is by absolute frame and costs O(1) per message) */
+uint64_t og_events_copied(const og_engine* e);
 /* room, in events, the device timeline keeps BEHIND a bulk score for live pushes (default: half the score + 2 M).
  * A live push re-writes the touched voice's remaining events as a fresh segment at the tail; a voice that still has a
  * long resident score ahead of it costs that many events per push, and once the tail meets the (still live) score the

@@ -134,17 +134,20 @@ __global__ __launch_bounds__(512) void og_bus_tremolo(const float* __restrict__ 
 // Incremental event path: append the staged segments to the timeline and point the listed voices at them.
 // `staged` and `upd` are PINNED HOST buffers read by the kernel itself: a kernel launch never waits for the stream,
 // whereas hipMemcpyAsync of a small pinned buffer was measured to block until the stream had drained (~290 us with a
-// batch of blocks in flight), which serialised the host's event preparation with the GPU.  upd = n x {voice, cursor, end}
+// batch of blocks in flight), which serialised the host's event preparation with the GPU.
+// upd = n x {voice, cursor, end, continuation cursor, continuation end} (OgBlockArgs::ev_cont)
+constexpr size_t EV_UPD_WORDS = 5;
 __global__ void og_apply_event_updates(const uint4* __restrict__ staged, uint32_t n_ev, uint4* __restrict__ timeline_tail,
                                        const uint32_t* __restrict__ upd, uint32_t n, uint32_t* __restrict__ cursor,
-                                       uint32_t* __restrict__ end)
+                                       uint32_t* __restrict__ end, uint2* __restrict__ cont)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ev) timeline_tail[i] = staged[i]; // (OgEvent = 16 bytes)
     if (i < n) {
-        const uint32_t v = upd[3 * i];
-        cursor[v] = upd[3 * i + 1];
-        end[v] = upd[3 * i + 2];
+        const uint32_t v = upd[EV_UPD_WORDS * i];
+        cursor[v] = upd[EV_UPD_WORDS * i + 1];
+        end[v] = upd[EV_UPD_WORDS * i + 2];
+        cont[v] = uint2{upd[EV_UPD_WORDS * i + 3], upd[EV_UPD_WORDS * i + 4]};
     }
 }
 
@@ -417,6 +420,7 @@ struct og_engine {
     size_t ev_reserve = 0; // og_reserve_events: room kept behind a bulk score for live segments
     uint32_t* d_ev_end = nullptr;
     uint32_t* d_ev_cursor = nullptr;
+    uint2* d_ev_cont = nullptr; // [V] continuation segment of every voice (OgBlockArgs::ev_cont)
     float* d_partials = nullptr;
     float* d_partials2 = nullptr; // group sums of the multi-pass bus reduce
     // Block queue (og_set_bus_batching): up to `bus_batch` consecutive async blocks that nothing separates (no value
@@ -471,6 +475,56 @@ struct og_engine {
     std::vector<OgEvent> h_events;       // host mirror of d_events (the whole ring)
     std::vector<uint32_t> seg_begin, seg_end; // per voice: its current segment (empty vectors = all segments empty)
     std::vector<uint64_t> seg_last;           // per voice: frame of the segment's last event (< frame_now: all consumed)
+    // Continuation (round 6): a voice's timeline is its segment [seg_begin, seg_end) followed by [cont_begin, cont_end) -- the
+    // tail of an EARLIER segment left where it lies.  A live push onto a voice with a long score ahead of it writes a new
+    // segment {what is due up to the last pushed frame, merged with the pushes} and points its continuation at the rest;
+    // every frame in the segment is <= every frame in the continuation.  Vectors are empty until a continuation exists.
+    std::vector<uint32_t> cont_begin, cont_end;
+    std::vector<uint64_t> cont_last;
+    uint64_t n_events_copied = 0; // events written to the ring by incremental updates (old ones carried over + new ones)
+    static constexpr uint32_t CONT_MIN = 8; // a tail shorter than this is carried over with the merge
+    bool has_cont(uint32_t v) const { return !cont_begin.empty() && cont_begin[v] != cont_end[v]; }
+    void ensure_cont()
+    {
+        if (cont_begin.empty()) {
+            cont_begin.assign(V, 0);
+            cont_end.assign(V, 0);
+            cont_last.assign(V, 0);
+        }
+    }
+    // events of one segment are sorted by frame: first index in [b, e) whose frame is >= fr / > fr
+    uint32_t lower_frame(uint32_t b, uint32_t e, uint64_t fr) const
+    {
+        while (b < e) {
+            const uint32_t m = b + (e - b) / 2;
+            if (h_events[m].frame < fr) b = m + 1;
+            else e = m;
+        }
+        return b;
+    }
+    uint32_t upper_frame(uint32_t b, uint32_t e, uint64_t fr) const
+    {
+        while (b < e) {
+            const uint32_t m = b + (e - b) / 2;
+            if (h_events[m].frame <= fr) b = m + 1;
+            else e = m;
+        }
+        return b;
+    }
+    // the unconsumed part of the voice's segment / of its continuation, as index ranges of h_events
+    void unconsumed_ranges(uint32_t v, uint64_t hz, uint32_t& hb, uint32_t& he, uint32_t& cb, uint32_t& ce) const
+    {
+        hb = he = cb = ce = 0;
+        if (seg_begin.empty()) return;
+        if (seg_begin[v] != seg_end[v] && seg_last[v] >= hz) {
+            hb = lower_frame(seg_begin[v], seg_end[v], hz);
+            he = seg_end[v];
+        }
+        if (has_cont(v) && cont_last[v] >= hz) {
+            cb = lower_frame(cont_begin[v], cont_end[v], hz);
+            ce = cont_end[v];
+        }
+    }
     std::vector<uint32_t> grp_head, grp_tail, grp_next, grp_voices; // incremental path: pending events chained per voice
     std::vector<uint8_t> local_cnt;      // [voice * n_event_inputs + event input]: try_push'ed events queued for the next block
     std::vector<uint32_t> local_touched; // entries of local_cnt to clear when the block starts
@@ -502,7 +556,10 @@ struct og_engine {
         const uint64_t hz = consumed_horizon();
         while (!ring_live.empty() && sweep-- > 0) {
             const RingSeg& f = ring_live.front();
-            const bool dead = seg_begin[f.voice] != f.begin || seg_end[f.voice] != f.end || seg_last[f.voice] < hz;
+            // alive: the voice's current segment, or the segment its continuation lies in, with something left to play
+            const bool is_head = seg_begin[f.voice] == f.begin && seg_end[f.voice] == f.end && seg_last[f.voice] >= hz;
+            const bool holds_cont = has_cont(f.voice) && cont_begin[f.voice] >= f.begin && cont_end[f.voice] <= f.end && cont_last[f.voice] >= hz;
+            const bool dead = !is_head && !holds_cont;
             if (!dead) break;
             ring_live.pop_front();
         }
@@ -600,6 +657,7 @@ struct og_engine {
         (void)hipFree(d_events);
         (void)hipFree(d_ev_end);
         (void)hipFree(d_ev_cursor);
+        (void)hipFree(d_ev_cont);
         (void)hipFree(d_partials);
         (void)hipFree(d_partials2);
         (void)hipFree(d_stage_bus);
@@ -675,6 +733,9 @@ struct og_engine {
         seg_begin.clear();
         seg_end.clear();
         seg_last.clear();
+        cont_begin.clear();
+        cont_end.clear();
+        cont_last.clear();
         ev_tail = 0;
         ring_live.clear();
         ev_rebuild = false;
@@ -682,6 +743,7 @@ struct og_engine {
         clear_local_counts();
         HIPCK(hipMemsetAsync(d_ev_cursor, 0, (size_t)V * 4, stream));
         HIPCK(hipMemsetAsync(d_ev_end, 0, (size_t)V * 4, stream));
+        HIPCK(hipMemsetAsync(d_ev_cont, 0, (size_t)V * sizeof(uint2), stream));
     }
 
     void clear_local_counts()
@@ -704,13 +766,23 @@ struct og_engine {
     }
     uint64_t consumed_horizon() const { return queue.empty() ? frame_now : q_frame0; }
     // unconsumed events of voice v on the device timeline (a block consumes everything before its end)
-    bool has_old_events(uint32_t v) const { return !seg_begin.empty() && seg_begin[v] != seg_end[v] && seg_last[v] >= consumed_horizon(); }
+    bool has_old_events(uint32_t v) const
+    {
+        if (seg_begin.empty()) return false;
+        const uint64_t hz = consumed_horizon();
+        return (seg_begin[v] != seg_end[v] && seg_last[v] >= hz) || (has_cont(v) && cont_last[v] >= hz);
+    }
+    void old_events(uint32_t v, std::vector<OgEvent>& out, uint64_t hz) const
+    {
+        uint32_t hb, he, cb, ce;
+        unconsumed_ranges(v, hz, hb, he, cb, ce); // (binary search for the horizon: no walk over what has been played)
+        out.insert(out.end(), h_events.begin() + hb, h_events.begin() + he);
+        out.insert(out.end(), h_events.begin() + cb, h_events.begin() + ce);
+    }
     void old_events(uint32_t v, std::vector<OgEvent>& out) const
     {
         if (!has_old_events(v)) return; // (no look at h_events: cold memory)
-        const uint64_t hz = consumed_horizon();
-        for (uint32_t i = seg_begin[v]; i < seg_end[v]; ++i)
-            if (h_events[i].frame >= hz) out.push_back(h_events[i]);
+        old_events(v, out, consumed_horizon());
     }
 
     static bool push_order(const HostEvent& a, const HostEvent& b)
@@ -751,7 +823,7 @@ struct og_engine {
             cursor[v] = (uint32_t)evs.size();
             size_t q = p;
             while (q < np && pending[q].voice == v) ++q;
-            if (had && seg_begin[v] != seg_end[v]) {
+            if (had && (seg_begin[v] != seg_end[v] || has_cont(v))) {
                 old.clear();
                 old_events(v, old);
                 merge_by_frame(old, pending.data() + p, pending.data() + q, evs);
@@ -780,6 +852,10 @@ struct og_engine {
         if (n) bounce.h2d(d_events, evs.data(), n * sizeof(OgEvent), stream);
         bounce.h2d(d_ev_cursor, cursor.data(), (size_t)V * 4, stream);
         bounce.h2d(d_ev_end, end.data(), (size_t)V * 4, stream);
+        if (!cont_begin.empty()) HIPCK(hipMemsetAsync(d_ev_cont, 0, (size_t)V * sizeof(uint2), stream)); // (everything is in the segments now)
+        cont_begin.clear();
+        cont_end.clear();
+        cont_last.clear();
         HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
         h_events.swap(evs);
         // mirror of the whole ring, reserved up front so that the live path never reallocates while playing (grown on demand:
@@ -808,7 +884,7 @@ struct og_engine {
         if (!h_stage_ev[0]) {
             for (int i = 0; i < EV_RING; ++i) {
                 HIPCK(hipHostMalloc((void**)&h_stage_ev[i], EV_STAGE_EVENTS * sizeof(OgEvent), hipHostMallocDefault));
-                HIPCK(hipHostMalloc((void**)&h_stage_upd[i], EV_STAGE_EVENTS * 3 * 4, hipHostMallocDefault));
+                HIPCK(hipHostMalloc((void**)&h_stage_upd[i], EV_STAGE_EVENTS * EV_UPD_WORDS * 4, hipHostMallocDefault));
             }
         }
         if (seg_begin.empty()) {
@@ -862,9 +938,10 @@ struct og_engine {
                 }
                 if (ordered && n_ev + k <= EV_STAGE_EVENTS) {
                     grp_head[v] = NONE;
-                    upd[3 * n_upd] = v; // (cursor, end) relative to the batch: its place in the ring is chosen below
-                    upd[3 * n_upd + 1] = (uint32_t)n_ev;
-                    upd[3 * n_upd + 2] = (uint32_t)(n_ev + k);
+                    upd[EV_UPD_WORDS * n_upd] = v; // (cursor, end) relative to the batch: its place in the ring is chosen below
+                    upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
+                    upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + k);
+                    upd[EV_UPD_WORDS * n_upd + 3] = upd[EV_UPD_WORDS * n_upd + 4] = 0u; // (no continuation: nothing of this voice is waiting)
                     n_ev += k;
                     n_upd += 1;
                     continue;
@@ -883,18 +960,48 @@ struct og_engine {
                 }
                 mine[j] = k;
             }
+            // What of this voice is still to be played and due up to the last pushed frame is merged with the pushes into
+            // the new segment; what lies BEHIND that frame stays where it is and becomes (or remains) the continuation --
+            // the rest of a long score is never copied.  A short rest is carried over instead (one segment, no hop).
             old.clear();
             merged.clear();
-            old_events(v, old);
+            uint32_t keep_b = 0, keep_e = 0;
+            {
+                const uint64_t last_new = mine.back().frame;
+                uint32_t hb, he, cb, ce;
+                unconsumed_ranges(v, consumed_horizon(), hb, he, cb, ce);
+                if (cb != ce) { // (every frame of the segment is <= every frame of the continuation)
+                    const uint32_t split = upper_frame(cb, ce, last_new);
+                    old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
+                    old.insert(old.end(), h_events.begin() + cb, h_events.begin() + split);
+                    if (ce - split >= CONT_MIN) {
+                        keep_b = split;
+                        keep_e = ce;
+                    } else {
+                        old.insert(old.end(), h_events.begin() + split, h_events.begin() + ce);
+                    }
+                } else {
+                    const uint32_t split = upper_frame(hb, he, last_new);
+                    if (he - split >= CONT_MIN) {
+                        old.insert(old.end(), h_events.begin() + hb, h_events.begin() + split);
+                        keep_b = split;
+                        keep_e = he;
+                    } else {
+                        old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
+                    }
+                }
+            }
             merge_by_frame(old, mine.data(), mine.data() + mine.size(), merged);
             if (n_ev + merged.size() > EV_STAGE_EVENTS) {
                 fits = false;
                 continue;
             }
             memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
-            upd[3 * n_upd] = v;
-            upd[3 * n_upd + 1] = (uint32_t)n_ev;
-            upd[3 * n_upd + 2] = (uint32_t)(n_ev + merged.size());
+            upd[EV_UPD_WORDS * n_upd] = v;
+            upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
+            upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
+            upd[EV_UPD_WORDS * n_upd + 3] = keep_b; // (absolute ring positions: the rest stays where it is)
+            upd[EV_UPD_WORDS * n_upd + 4] = keep_e;
             n_ev += merged.size();
             n_upd += 1;
         }
@@ -908,19 +1015,29 @@ struct og_engine {
         if (h_events.size() < base + n_ev) h_events.resize(base + n_ev); // (capacity ev_cap is reserved: no reallocation, no fill of the unused room)
         memcpy(h_events.data() + base, sev, n_ev * sizeof(OgEvent));
         for (size_t i = 0; i < n_upd; ++i) {
-            const uint32_t v = upd[3 * i];
-            seg_last[v] = sev[upd[3 * i + 2] - 1].frame;
-            upd[3 * i + 1] += (uint32_t)base;
-            upd[3 * i + 2] += (uint32_t)base;
-            seg_begin[v] = upd[3 * i + 1];
-            seg_end[v] = upd[3 * i + 2];
-            ring_live.push_back(RingSeg{v, upd[3 * i + 1], upd[3 * i + 2]});
+            uint32_t* u = upd + EV_UPD_WORDS * i;
+            const uint32_t v = u[0];
+            seg_last[v] = sev[u[2] - 1].frame;
+            u[1] += (uint32_t)base;
+            u[2] += (uint32_t)base;
+            seg_begin[v] = u[1];
+            seg_end[v] = u[2];
+            if (u[3] != u[4]) {
+                ensure_cont();
+                cont_begin[v] = u[3];
+                cont_end[v] = u[4];
+                cont_last[v] = h_events[u[4] - 1].frame;
+            } else if (!cont_begin.empty()) {
+                cont_begin[v] = cont_end[v] = 0;
+            }
+            ring_live.push_back(RingSeg{v, u[1], u[2]});
         }
+        n_events_copied += n_ev;
         ev_tail = base;
         static_assert(sizeof(OgEvent) == sizeof(uint4), "og_apply_event_updates copies events as 16-byte words");
         const uint32_t n_wg_upd = (uint32_t)((std::max(n_upd, n_ev) + 255) / 256);
         hipLaunchKernelGGL(og_apply_event_updates, dim3(n_wg_upd), dim3(256), 0, stream, (const uint4*)sev, (uint32_t)n_ev,
-                           (uint4*)(d_events + ev_tail), (const uint32_t*)upd, (uint32_t)n_upd, d_ev_cursor, d_ev_end);
+                           (uint4*)(d_events + ev_tail), (const uint32_t*)upd, (uint32_t)n_upd, d_ev_cursor, d_ev_end, d_ev_cont);
         HIPCK(hipGetLastError());
         stage_seq[r] = flush_seq + 1; // read in stream order before the batch that is about to be launched
         batch_staged = true;
@@ -1096,6 +1213,7 @@ struct og_engine {
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
+        A.ev_cont = d_ev_cont;
         A.partials = d_partials;
         const uint32_t n_chunks16 = (q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES;
         A.partial_plane = (uint32_t)((size_t)n_chunks16 * n_wg * OG_RED_FRAMES);
@@ -1704,12 +1822,14 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         if (!cg.lane_state.empty())
             // (+ one wave's worth of lane words behind the last plane: OgBlockArgs::lane_dump, where a lane beyond the last
             //  voice writes what an event handler of an array-valued node writes through its state planes)
-            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4 + (size_t)OG_WAVE * 16 * 4));
+            HIPCK(hipMalloc(&e->d_lane_state, cg.lane_state.size() * (size_t)n_voices * cg.lpv * cg.lane_width * 4 + (size_t)OG_WAVE * OG_LANE_DUMP_WORDS * 4));
         if (cg.bus_tremolo) HIPCK(hipMalloc(&e->d_bus_phase, 4));
         HIPCK(hipMalloc(&e->d_ev_end, (size_t)n_voices * 4));
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
+        HIPCK(hipMalloc(&e->d_ev_cont, (size_t)n_voices * sizeof(uint2)));
+        HIPCK(hipMemset(e->d_ev_cont, 0, (size_t)n_voices * sizeof(uint2)));
         e->alloc_bus_buffers(1);
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * OG_MAX_BUS_CHANNELS * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));
@@ -2384,6 +2504,7 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 }
 
 uint64_t og_event_ring_wraps(const og_engine* e) { return e ? e->n_ring_wraps : 0; }
+uint64_t og_events_copied(const og_engine* e) { return e ? e->n_events_copied : 0; }
 
 int og_reserve_events(og_engine* e, uint64_t n_events)
 {
@@ -2611,14 +2732,14 @@ size_t dsp_bytes(const og_engine* e)
 void collect_unconsumed(const og_engine* e, std::vector<SnapEvent>& out)
 {
     const uint64_t hz = e->frame_now;
-    if (!e->seg_begin.empty())
+    if (!e->seg_begin.empty()) {
+        std::vector<OgEvent> old;
         for (uint32_t v = 0; v < e->V; ++v) {
-            if (e->seg_begin[v] == e->seg_end[v] || e->seg_last[v] < hz) continue;
-            for (uint32_t i = e->seg_begin[v]; i < e->seg_end[v]; ++i) {
-                const OgEvent& ev = e->h_events[i];
-                if (ev.frame >= hz) out.push_back(SnapEvent{v, ev.target, ev.frame, ev.value, 0u});
-            }
+            old.clear();
+            e->old_events(v, old, hz); // the voice's segment, then its continuation
+            for (const OgEvent& ev : old) out.push_back(SnapEvent{v, ev.target, ev.frame, ev.value, 0u});
         }
+    }
     for (const HostEvent& h : e->pending)
         if (h.frame >= hz) out.push_back(SnapEvent{h.voice, h.target, h.frame, h.value, h.block_local ? 1u : 0u});
 }

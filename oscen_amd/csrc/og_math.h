@@ -138,8 +138,13 @@ OG_HD float og_sin_turns_poly(float t)
 }
 
 // OG_SIN_TURNS: how an FM operator takes its sine.  0 = og_sinf((phase + mod) * TAU) -- follows the reference's f32
-// product; 1 = og_sin_turns_poly(phase + mod); 2 = the hardware's v_sin_f32 (argument in turns, valid for |t| <= 256),
+// product; 1 = og_sin_turns_poly(phase + mod); 2 = the hardware's v_sin_f32 (argument in turns),
 // host builds (tests/test_og_math.py, the host simulator) take the polynomial.
+// DOMAIN of form 2: |t| <= 256 turns -- beyond it v_sin_f32 returns 0 where `(t * TAU).sin()` still returns a number.  An
+// FM operator gets there only with a modulation index above 256 turns (1 608 rad); at that size ulp(t) = 3e-5 turns, i.e.
+// the reference's own f32 argument is already coarser than the 1e-5 contract and no form but -DOG_STRICT follows it
+// (measured against the reference's f32 form: 4.6e-7 / 7.6e-7 / 1.5e-6 / 3.4e-6 at 0 / 1 / 4 / 16 turns of modulation,
+// scripts/ubench/vsin.hip).  A node body whose argument is not bounded like that calls og_sin_turns_wide().
 #ifndef OG_SIN_TURNS
 #ifdef OG_STRICT
 #define OG_SIN_TURNS 0
@@ -155,6 +160,15 @@ OG_HD float og_sin_turns(float t)
     return og_sin_turns_poly(t);
 #else
     return og_sinf(t * 6.28318548202514648f);
+#endif
+}
+// sin(2 pi t) for an argument of any size: the sine has period 1, so the fractional part (exact: v_fract_f32) goes in
+OG_HD float og_sin_turns_wide(float t)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return og_sin_turns(__builtin_amdgcn_fractf(t));
+#else
+    return og_sin_turns(t - floorf(t));
 #endif
 }
 

@@ -356,7 +356,12 @@ template <bool QCHK, bool IQ>
 OG_DEV void tpt_params_nomod_lazy(float cutoff_in, float q_in, float inv_q_in, float& last_in, float& last_q, float max_cutoff, float two_sr,
                                   float period, float nyquist, float& cur_c, float& cur_q, float& h, float& g, float& k)
 {
-    if (QCHK) {
+#ifdef OG_STRICT // the reference's test on every frame (the lazy form picks up a q step below EPSILON between launches)
+    constexpr bool strict = true;
+#else
+    constexpr bool strict = false;
+#endif
+    if (QCHK || strict) {
         // q can change inside this launch (the kernel variants that read the ramp table): the reference's own per-frame test.
         // Watching two inputs and keeping the EPSILON test for q -- below 1.0 two distinct q can be closer than EPSILON, and
         // the reference ignores such a step -- nests two divergent regions and measured 9 % slower on those launches
@@ -446,9 +451,20 @@ enum : uint32_t { PB_SINE = 0, PB_SAW = 1, PB_SQUARE = 2, PB_TRIANGLE = 3 };
 // x % 1.0 (Rust `%` = C fmod): x - trunc(x) is that value exactly (the subtraction is exact: both
 // operands share the exponent range of x and the result has fewer significant bits).  Two VALU ops
 // instead of the general fmod loop.  (Differs from fmod only in the sign of a zero result for -0.0.)
+// -DOG_STRICT keeps the reference's own operations in both: x - trunc(x), and for rem_euclid the `r + 1.0` that
+// can round up to 1.0 where v_fract clamps to 0.99999994.
+#ifdef OG_STRICT
+OG_DEV float fmod1(float x) { return x - truncf(x); }
+OG_DEV float wrap_phase(float p) // rem_euclid(1.0) :171-173
+{
+    const float r = p - truncf(p);
+    return (r < 0.0f) ? r + 1.0f : r;
+}
+#else
 OG_DEV float fmod1(float x) { return fract_keep_sign(x); }
 
 OG_DEV float wrap_phase(float p) { return fract_floor(p); } // rem_euclid(1.0) :171-173
+#endif
 
 // poly_blep :139-153 and poly_blamp :155-169, written without branches: in a bank some lane is next to
 // a discontinuity on almost every sample, so both sides are evaluated and selected.  rdt = rcp(dt) is

@@ -41,6 +41,9 @@ struct dim3 {
     unsigned x, y, z;
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct uint2 {
+    unsigned x, y;
+};
 struct uint4 {
     unsigned x, y, z, w;
 };

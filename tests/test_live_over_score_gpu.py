@@ -1,0 +1,151 @@
+"""Live messages on top of a long RESIDENT score.
+
+The reference merges the events staged for a block into it by `frame_offset`, block after block
+(oscen-graph-compiler/src/codegen/mod.rs:782-871) -- a MIDI note-off costs the same whatever is going to be played later.
+Here a whole score can be resident on the device (`og_schedule_*`); until round 6 a live push re-wrote the voice's remaining
+score.  Now the push becomes a short segment {what is due up to the pushed frame, the push} in front of the rest of the
+score, which stays where it lies (the voice's continuation segment, OgBlockArgs::ev_cont) and which the kernel moves on
+to by itself.  Checked: the samples against the oracle fed the merged event list, the same engine with the whole list
+scheduled up front bit for bit, and `og_events_copied` -- the cost of the live messages does not grow with the score."""
+import numpy as np
+import pytest
+
+import oscen_amd
+from tests import observed
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def resident_score(n, total, rng, every):
+    """per voice: gate on / off pairs all the way through `total` frames, `every` frames apart on average"""
+    ev = []
+    for v in range(n):
+        t = int(rng.integers(0, every))
+        on = True
+        while t < total:
+            ev.append((t, v, float(np.float32(0.4 + 0.5 * rng.random())) if on else 0.0))
+            on = not on
+            t += int(rng.integers(every // 2, every * 3 // 2))
+    return ev
+
+
+def live_messages(n, blocks, block, rng, per_block):
+    """(block, frame offset, voice, value): note-offs that cut a resident note short, and retriggers"""
+    out = []
+    for b in range(2, blocks - 1):
+        for _ in range(per_block):
+            out.append((b, int(rng.integers(0, block)), int(rng.integers(0, n)), 0.0 if rng.random() < 0.6 else 0.8))
+    return out
+
+
+def run(n, blocks, block, score, live, *, live_as_pushes, split=None, monkeypatch=None, queued=False):
+    if split is not None:
+        monkeypatch.setenv("OSCEN_GPU_SPLIT", str(split))
+    e = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    if split is not None:
+        monkeypatch.delenv("OSCEN_GPU_SPLIT")
+    freqs = oscen_amd.midi_note_to_freq(np.random.default_rng(5).integers(40, 90, n)).astype(np.float32)
+    e.set_voice_values("frequency", freqs)
+    allev = list(score)
+    if not live_as_pushes:
+        allev += [(b * block + off, v, x) for b, off, v, x in live]
+    # (equal frames: the resident event was there first -- it fires first; a stable sort by frame keeps that)
+    allev.sort(key=lambda t: t[0])
+    e.schedule_voice_events("gate", [v for _, v, _ in allev], [f for f, _, _ in allev], [x for _, _, x in allev])
+    e.set_voice_taps(np.arange(n, dtype=np.uint32))
+    if queued:
+        e.set_bus_batching(4)
+    by_block = [[] for _ in range(blocks)]
+    for b, off, v, x in live:
+        by_block[b].append((off, v, x))
+    taps = []
+    for b in range(blocks):
+        if live_as_pushes:
+            for off, v, x in by_block[b]:
+                assert e.push_voice_event("gate", v, off, x) == 0
+        if queued:
+            e.process_block_async(block)
+            if b % 4 == 3:
+                e.flush()
+                e.synchronize()
+        else:
+            e.process_block(block)
+            taps.append(e.read_voice_taps(block))
+    if queued:
+        e.flush()
+        e.synchronize()
+    state = e.save_state()
+    return e, (np.concatenate(taps, axis=1) if taps else None), state, freqs
+
+
+@pytest.mark.parametrize("split", [None, 0])
+def test_live_messages_cut_into_a_resident_score_without_rewriting_it(split, monkeypatch):
+    n, blocks, block = 96, 24, 128
+    total = blocks * block
+    rng = np.random.default_rng(2026)
+    score = resident_score(n, total + 40 * block, rng, every=48)  # ~64 events per voice within the run, as many beyond it
+    live = live_messages(n, blocks, block, rng, per_block=6)
+    per_voice = len(score) / n
+    assert per_voice > 100
+
+    e_live, taps_live, state_live, freqs = run(n, blocks, block, score, live, live_as_pushes=True, split=split, monkeypatch=monkeypatch)
+    st = e_live.event_stats
+    assert st["full_rebuilds"] == 1 and st["incremental_updates"] >= blocks - 4, st
+    # the cost of the live path: every message carries over at most what was due in its own block plus a short rest --
+    # not the ~100 events its voice still has to play
+    assert st["events_copied"] <= len(live) * 12, (st, len(live), per_voice)
+
+    # the same timeline scheduled up front, one segment per voice, no continuation anywhere: bit for bit
+    e_all, taps_all, state_all, _ = run(n, blocks, block, score, live, live_as_pushes=False, split=split, monkeypatch=monkeypatch)
+    assert e_all.event_stats["incremental_updates"] == 0
+    assert np.array_equal(taps_live, taps_all)
+    dsp = e_all.state_words_per_voice * n * 4
+    assert np.array_equal(state_live[:dsp], state_all[:dsp])
+
+    # a snapshot of the live engine holds segment + continuation: a fresh engine that loads it plays on identically
+    e2 = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    e2.load_state(state_live)
+    e2.set_voice_taps(np.arange(n, dtype=np.uint32))
+    e_live.process_block(block)
+    e2.process_block(block)
+    assert np.array_equal(e_live.read_voice_taps(block), e2.read_voice_taps(block))
+
+    # against the oracle
+    probe = list(range(0, n, 7))
+    bank = ol.Bank(ol.BANK_FM, len(probe), SR)
+    idx = {v: i for i, v in enumerate(probe)}
+    for v, i in idx.items():
+        bank.set_voice_frequency(i, float(freqs[v]))
+    merged = list(score) + [(b * block + off, v, x) for b, off, v, x in live]
+    merged.sort(key=lambda t: t[0])
+    ref = []
+    for b in range(blocks):
+        for f, v, x in merged:
+            if v in idx and b * block <= f < (b + 1) * block:
+                bank.push_event(idx[v], f - b * block, ol.EV_GATE, x)
+        _, t = bank.process_block(block, taps=list(range(len(probe))))
+        ref.append(t)
+    ref = np.concatenate(ref, axis=1)
+    err = float(np.max(np.abs(taps_live[probe] - ref) / np.maximum(1.0, np.abs(ref))))
+    observed.note(err)
+    assert err <= 1e-5 and np.abs(ref).max() > 1e-2, err
+
+
+def test_live_messages_over_a_score_on_the_queued_entry_and_through_ring_wraps(monkeypatch):
+    """the asynchronous entry with the block queue on, and a ring so small that the live segments wrap around the resident
+    score's continuation segments several times: same state as the all-up-front engine"""
+    n, blocks, block = 200, 32, 96
+    total = blocks * block
+    rng = np.random.default_rng(77)
+    score = resident_score(n, total + 10 * block, rng, every=40)
+    live = live_messages(n, blocks, block, rng, per_block=10)
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")
+    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "512")
+    e_live, _, state_live, _ = run(n, blocks, block, score, live, live_as_pushes=True, queued=True)
+    monkeypatch.delenv("OSCEN_GPU_EV_HEADROOM")
+    e_all, _, state_all, _ = run(n, blocks, block, score, live, live_as_pushes=False, queued=True)
+    dsp = e_all.state_words_per_voice * n * 4
+    assert np.array_equal(state_live[:dsp], state_all[:dsp])
+    assert e_live.event_stats["incremental_updates"] > 0

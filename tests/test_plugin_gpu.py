@@ -100,6 +100,45 @@ def test_user_node_with_event_handler_and_integer_state():
     assert np.array_equal(got, ref)
 
 
+def test_sine_helpers_domain_of_the_hardware_sine_and_the_wide_form():
+    """og_sin_turns is v_sin_f32 on the device: defined for |t| <= 256 turns, 0 beyond (og_math.h, ADVICE r5);
+    og_sin_turns_wide takes the fractional part first and is a sine at any argument size."""
+    oscen_amd.register_node(
+        "SineProbe::new", inputs=[("frequency", "value", 1.0, -1)], outputs=["narrow", "wide"],
+        state=[("k", "f32", 0.0, -1)],
+        process="""
+    const float t = frequency * (k + 1.0f) * 0.001f + 0.125f;
+    narrow = og_sin_turns(t);
+    wide = og_sin_turns_wide(t);
+    k += 1.0f;
+""")
+    outs = {}
+    n, frames = 64, 256
+    scale = np.geomspace(1.0, 4.0e6, n).astype(np.float32)  # arguments up to ~1e6 turns
+    for port in ("narrow", "wide"):
+        g = oscen_amd.Graph("sine_probe_" + port)
+        g.input_value("frequency", 1.0, per_voice=True)
+        g.output_stream("out")
+        g.node("p", "SineProbe::new")
+        g.connect("frequency", "p.frequency")
+        g.connect("p." + port, "out")
+        eng = oscen_amd.Engine(g, n, sample_rate=SR)
+        eng.set_voice_values("frequency", scale)
+        eng.set_voice_taps(np.arange(n, dtype=np.uint32))
+        eng.process_block(frames)
+        outs[port] = eng.read_voice_taps(frames)
+    k = np.arange(1, frames + 1, dtype=np.float32)[None, :]
+    t = ((scale[:, None] * k).astype(np.float32) * np.float32(0.001)).astype(np.float32)
+    t = (t + np.float32(0.125)).astype(np.float32)
+    t64 = t.astype(np.float64)
+    ref = np.sin(2.0 * np.pi * (t64 - np.floor(t64)))
+    assert np.max(np.abs(t)) > 1.0e5
+    assert np.max(np.abs(outs["wide"] - ref)) < 2e-6  # the hardware sine on an exact fractional part
+    inside = np.abs(t) <= 256.0
+    assert np.max(np.abs(outs["narrow"][inside] - ref[inside])) < 2e-6
+    assert np.all(outs["narrow"][np.abs(t) > 257.0] == 0.0)  # the documented behaviour beyond the domain
+
+
 def test_node_arrays_match_the_hand_expanded_graph_and_the_interpreter():
     n, frames, blocks = 6, 192, 4
     freqs = np.array([55.0, 110.0, 164.81, 220.0, 440.0, 659.25], dtype=np.float32)
