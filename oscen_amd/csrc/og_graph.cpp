@@ -1346,7 +1346,10 @@ void emit_tpt(NodeCtx& x)
             const size_t comma = q.e.find(", ");
             if (comma != std::string::npos) q_launch = "SF(" + q.e.substr(comma + 2);
         }
-        const std::string iq = q_launch.empty() ? std::string("0.0f") : x.hoist("inv_q", "1.0f / og::clampf(" + q_launch + ", 0.1f, 10.0f)");
+        // (a voice-uniform q -- a graph input that is not per-voice -- gives a wave-uniform quotient: kept in a scalar register)
+        const bool q_uniform = q.rate <= Rate::UBlock || q.rate == Rate::UFrame;
+        const std::string iq_expr = "1.0f / og::clampf(" + q_launch + ", 0.1f, 10.0f)";
+        const std::string iq = q_launch.empty() ? std::string("0.0f") : x.hoist("inv_q", q_uniform ? "og::uniform_f(" + iq_expr + ")" : iq_expr);
         x.cg.os() << "        og::tpt_params_nomod_lazy<" << qchk << ", " << (q_launch.empty() ? "false" : "true") << ">(" << cutoff.e << ", " << q.e << ", "
                   << iq << ", " << li << ", " << lq << ", " << tail;
     } else if (nomod) {

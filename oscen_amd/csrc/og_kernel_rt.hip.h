@@ -160,6 +160,13 @@ __device__ __forceinline__ uint32_t scalar_u(const OgBlockArgs& a, int i)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)a.slots[i]);
 }
 
+// a value every lane computes alike (it derives from kernel-argument slots only), pinned to a scalar register: it then
+// costs no VGPR for the length of the launch (the ordinary kernels sit at the 128-VGPR cap of four waves per SIMD)
+__device__ __forceinline__ float uniform_f(const float x)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)));
+}
+
 // compile-time flags passed to the generated tick lambdas: `value` = envelope stage-end checks on,
 // `release` = envelope release arithmetic on (off in chunks where no lane of the wave is releasing),
 // `pre` = the chunk's hand-off values were read from LDS into registers at the top of the chunk,
