@@ -391,9 +391,10 @@ int og_event_stats(const og_engine* e, uint64_t* full_rebuilds, uint64_t* increm
 uint64_t og_event_ring_wraps(const og_engine* e);
 /* events the incremental path has written to the ring so far: the pushes themselves plus whatever it carried over of the
  * voice's waiting events.  A live message on a voice with a long resident score ahead of it carries over only what is due
- * up to the message's frame -- the rest of the score stays in place as the voice's continuation segment and the kernel
- * moves on to it by itself (the reference merges staged events into the block by frame_offset per block,
- * oscen-graph-compiler/src/codegen/mod.rs:782-871; here the merge is by absolute frame and costs O(1) per message) */
+ * up to the end of the launch being prepared -- the rest of the score stays in place as the voice's continuation, and the
+ * engine points the voice at it before the launch in which its first event is due (the reference merges staged events into
+ * the block by frame_offset per block, oscen-graph-compiler/src/codegen/mod.rs:782-871; here the merge is by absolute
+ * frame and a message costs its own records whatever the score's length) */
 uint64_t og_events_copied(const og_engine* e);
 /* room, in events, the device timeline keeps BEHIND a bulk score for live pushes (default: half the score + 2 M).
  * A live push re-writes the touched voice's remaining events as a fresh segment at the tail; a voice that still has a

@@ -135,11 +135,11 @@ __global__ __launch_bounds__(512) void og_bus_tremolo(const float* __restrict__ 
 // `staged` and `upd` are PINNED HOST buffers read by the kernel itself: a kernel launch never waits for the stream,
 // whereas hipMemcpyAsync of a small pinned buffer was measured to block until the stream had drained (~290 us with a
 // batch of blocks in flight), which serialised the host's event preparation with the GPU.
-// upd = n x {voice, cursor, end, continuation cursor, continuation end} (OgBlockArgs::ev_cont)
-constexpr size_t EV_UPD_WORDS = 5;
+// upd = n x {voice, cursor, end}
+constexpr size_t EV_UPD_WORDS = 3;
 __global__ void og_apply_event_updates(const uint4* __restrict__ staged, uint32_t n_ev, uint4* __restrict__ timeline_tail,
                                        const uint32_t* __restrict__ upd, uint32_t n, uint32_t* __restrict__ cursor,
-                                       uint32_t* __restrict__ end, uint2* __restrict__ cont)
+                                       uint32_t* __restrict__ end)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ev) timeline_tail[i] = staged[i]; // (OgEvent = 16 bytes)
@@ -147,7 +147,6 @@ __global__ void og_apply_event_updates(const uint4* __restrict__ staged, uint32_
         const uint32_t v = upd[EV_UPD_WORDS * i];
         cursor[v] = upd[EV_UPD_WORDS * i + 1];
         end[v] = upd[EV_UPD_WORDS * i + 2];
-        cont[v] = uint2{upd[EV_UPD_WORDS * i + 3], upd[EV_UPD_WORDS * i + 4]};
     }
 }
 
@@ -420,7 +419,6 @@ struct og_engine {
     size_t ev_reserve = 0; // og_reserve_events: room kept behind a bulk score for live segments
     uint32_t* d_ev_end = nullptr;
     uint32_t* d_ev_cursor = nullptr;
-    uint2* d_ev_cont = nullptr; // [V] continuation segment of every voice (OgBlockArgs::ev_cont)
     float* d_partials = nullptr;
     float* d_partials2 = nullptr; // group sums of the multi-pass bus reduce
     // Block queue (og_set_bus_batching): up to `bus_batch` consecutive async blocks that nothing separates (no value
@@ -475,16 +473,34 @@ struct og_engine {
     std::vector<OgEvent> h_events;       // host mirror of d_events (the whole ring)
     std::vector<uint32_t> seg_begin, seg_end; // per voice: its current segment (empty vectors = all segments empty)
     std::vector<uint64_t> seg_last;           // per voice: frame of the segment's last event (< frame_now: all consumed)
-    // Continuation (round 6): a voice's timeline is its segment [seg_begin, seg_end) followed by [cont_begin, cont_end) -- the
-    // tail of an EARLIER segment left where it lies.  A live push onto a voice with a long score ahead of it writes a new
-    // segment {what is due up to the last pushed frame, merged with the pushes} and points its continuation at the rest;
-    // every frame in the segment is <= every frame in the continuation.  Vectors are empty until a continuation exists.
+    // Continuation (round 6): on the HOST a voice's timeline is its segment [seg_begin, seg_end) followed by
+    // [cont_begin, cont_end) -- the tail of an EARLIER segment left where it lies in the ring.  A live push onto a voice with
+    // a long score ahead of it writes a new segment {what is due up to the end of the launch being prepared, merged with the
+    // pushes} and remembers the rest as the continuation; every frame in the segment is < every frame in the continuation.
+    // The device knows nothing of this (one segment per voice, as ever -- a first form that taught the kernels to hop cost
+    // the four-wave kernel 4 % and the ordinary one 30 spills): before the launch in which a continuation's first event is
+    // due the host points the voice at it -- a 12-byte cursor update when the segment in front has been played, which is
+    // the usual case (resolve_due_continuations).  Cost of a message: its own records, whatever the score's length.
+    // Vectors are empty until a continuation exists; `cont_due` orders the voices by their continuation's first frame.
     std::vector<uint32_t> cont_begin, cont_end;
     std::vector<uint64_t> cont_last;
     uint64_t n_events_copied = 0; // events written to the ring by incremental updates (old ones carried over + new ones)
-    static constexpr uint32_t CONT_MIN = 8; // a tail shorter than this is carried over with the merge
+    std::vector<std::pair<uint64_t, uint32_t>> cont_due; // min-heap of {first frame of the continuation, voice}; stale entries are skipped
+    void cont_due_push(uint32_t v)
+    {
+        cont_due.emplace_back(h_events[cont_begin[v]].frame, v);
+        std::push_heap(cont_due.begin(), cont_due.end(), std::greater<std::pair<uint64_t, uint32_t>>());
+    }
+    // end of the launch that is being prepared: everything before it must be in the voices' segments
+    uint64_t launch_end() const { return queue.empty() ? frame_now : q_frame0 + q_frames; }
+    bool continuation_due() const { return !cont_due.empty() && cont_due.front().first < launch_end(); }
+    // A rest shorter than this is carried over with the merge: copying a kilobyte costs less than the bookkeeping of a
+    // continuation (a heap entry, a second cursor update, two more looks into the cold host mirror) -- measured on the loaded
+    // real-time banks, whose 1 s scores leave ~14 events per voice: with continuations for those p99 rose from 2.29 to
+    // 2.69 ms at 4 194 304 voices (gpurun r06q).
+    static constexpr uint32_t CONT_MIN = 64;
     bool has_cont(uint32_t v) const { return !cont_begin.empty() && cont_begin[v] != cont_end[v]; }
-    void ensure_cont()
+    void ensure_cont() // (sized with the segment arrays, outside the real-time path: 16 bytes per voice of zero-fill)
     {
         if (cont_begin.empty()) {
             cont_begin.assign(V, 0);
@@ -557,7 +573,8 @@ struct og_engine {
         while (!ring_live.empty() && sweep-- > 0) {
             const RingSeg& f = ring_live.front();
             // alive: the voice's current segment, or the segment its continuation lies in, with something left to play
-            const bool is_head = seg_begin[f.voice] == f.begin && seg_end[f.voice] == f.end && seg_last[f.voice] >= hz;
+            // (a voice that was pointed at its continuation plays a sub-range of the older segment the continuation lay in)
+            const bool is_head = seg_begin[f.voice] != seg_end[f.voice] && seg_begin[f.voice] >= f.begin && seg_end[f.voice] <= f.end && seg_last[f.voice] >= hz;
             const bool holds_cont = has_cont(f.voice) && cont_begin[f.voice] >= f.begin && cont_end[f.voice] <= f.end && cont_last[f.voice] >= hz;
             const bool dead = !is_head && !holds_cont;
             if (!dead) break;
@@ -657,7 +674,6 @@ struct og_engine {
         (void)hipFree(d_events);
         (void)hipFree(d_ev_end);
         (void)hipFree(d_ev_cursor);
-        (void)hipFree(d_ev_cont);
         (void)hipFree(d_partials);
         (void)hipFree(d_partials2);
         (void)hipFree(d_stage_bus);
@@ -736,6 +752,7 @@ struct og_engine {
         cont_begin.clear();
         cont_end.clear();
         cont_last.clear();
+        cont_due.clear();
         ev_tail = 0;
         ring_live.clear();
         ev_rebuild = false;
@@ -743,7 +760,6 @@ struct og_engine {
         clear_local_counts();
         HIPCK(hipMemsetAsync(d_ev_cursor, 0, (size_t)V * 4, stream));
         HIPCK(hipMemsetAsync(d_ev_end, 0, (size_t)V * 4, stream));
-        HIPCK(hipMemsetAsync(d_ev_cont, 0, (size_t)V * sizeof(uint2), stream));
     }
 
     void clear_local_counts()
@@ -852,10 +868,7 @@ struct og_engine {
         if (n) bounce.h2d(d_events, evs.data(), n * sizeof(OgEvent), stream);
         bounce.h2d(d_ev_cursor, cursor.data(), (size_t)V * 4, stream);
         bounce.h2d(d_ev_end, end.data(), (size_t)V * 4, stream);
-        if (!cont_begin.empty()) HIPCK(hipMemsetAsync(d_ev_cont, 0, (size_t)V * sizeof(uint2), stream)); // (everything is in the segments now)
-        cont_begin.clear();
-        cont_end.clear();
-        cont_last.clear();
+        cont_due.clear();
         HIPCK(hipStreamSynchronize(stream)); // the staging vectors die here
         h_events.swap(evs);
         // mirror of the whole ring, reserved up front so that the live path never reallocates while playing (grown on demand:
@@ -865,6 +878,9 @@ struct og_engine {
         seg_begin.swap(cursor);
         seg_end.swap(end);
         seg_last.swap(last);
+        cont_begin.assign(V, 0); // (everything is in the segments now; the arrays are sized here, not on the live path)
+        cont_end.assign(V, 0);
+        cont_last.assign(V, 0);
         ev_tail = n;
         ring_live.clear();
         for (uint32_t v = 0; v < V; ++v)
@@ -873,6 +889,74 @@ struct og_engine {
         local_from = 0;
         ev_rebuild = false;
         n_full_rebuilds += 1;
+    }
+
+    // One voice of an incremental batch: its pushes `mine` (sorted; may be empty: a voice whose continuation falls due) merged
+    // with what it still has to play UP TO `bound` = the later of the last pushed frame and the end of the launch being
+    // prepared; what lies behind stays where it is and becomes (or remains) the continuation -- the rest of a long score is
+    // never copied.  A short rest is carried over instead.  A voice without pushes whose segment has been played is simply
+    // pointed at its continuation: no record is written at all.  false: the batch does not fit the staging buffer.
+    bool merge_voice(uint32_t v, const std::vector<HostEvent>& mine, uint64_t lend, OgEvent* sev, uint32_t* upd, size_t& n_ev, size_t& n_upd,
+                     std::vector<uint32_t>& kept, std::vector<OgEvent>& old, std::vector<OgEvent>& merged)
+    {
+        old.clear();
+        merged.clear();
+        uint32_t keep_b = 0, keep_e = 0;
+        const uint64_t bound = std::max<uint64_t>(mine.empty() ? 0 : mine.back().frame, lend ? lend - 1 : 0);
+        uint32_t hb, he, cb, ce;
+        unconsumed_ranges(v, consumed_horizon(), hb, he, cb, ce);
+        if (mine.empty()) {
+            if (cb == ce) return true; // (nothing left behind after all)
+            if (hb == he) { // the segment in front has been played: the continuation IS the voice's segment from here on
+                if (n_upd >= EV_STAGE_EVENTS) return false;
+                upd[EV_UPD_WORDS * n_upd] = v;
+                upd[EV_UPD_WORDS * n_upd + 1] = cb; // (absolute ring positions)
+                upd[EV_UPD_WORDS * n_upd + 2] = ce;
+                kept.insert(kept.end(), {0u, 0u, 1u});
+                n_upd += 1;
+                return true;
+            }
+        }
+        if (cb != ce) { // (every frame of the segment is <= every frame of the continuation)
+            const uint32_t split = upper_frame(cb, ce, bound);
+            old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
+            old.insert(old.end(), h_events.begin() + cb, h_events.begin() + split);
+            if (ce - split >= CONT_MIN) {
+                keep_b = split;
+                keep_e = ce;
+            } else {
+                old.insert(old.end(), h_events.begin() + split, h_events.begin() + ce);
+            }
+        } else {
+            const uint32_t split = upper_frame(hb, he, bound);
+            if (he - split >= CONT_MIN) {
+                old.insert(old.end(), h_events.begin() + hb, h_events.begin() + split);
+                keep_b = split;
+                keep_e = he;
+            } else {
+                old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
+            }
+        }
+        merge_by_frame(old, mine.data(), mine.data() + mine.size(), merged);
+        if (merged.empty()) { // (only a rest behind the launch: point the voice at it, as above)
+            if (keep_b == keep_e) return true;
+            if (n_upd >= EV_STAGE_EVENTS) return false;
+            upd[EV_UPD_WORDS * n_upd] = v;
+            upd[EV_UPD_WORDS * n_upd + 1] = keep_b;
+            upd[EV_UPD_WORDS * n_upd + 2] = keep_e;
+            kept.insert(kept.end(), {0u, 0u, 1u});
+            n_upd += 1;
+            return true;
+        }
+        if (n_ev + merged.size() > EV_STAGE_EVENTS || n_upd >= EV_STAGE_EVENTS) return false;
+        memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
+        upd[EV_UPD_WORDS * n_upd] = v;
+        upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev; // (relative to the batch: its place in the ring is chosen at the commit)
+        upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
+        kept.insert(kept.end(), {keep_b, keep_e, 0u});
+        n_ev += merged.size();
+        n_upd += 1;
+        return true;
     }
 
     // live pushes: O(#pushes) host work, asynchronous upload.  Returns false when the batch does not fit
@@ -891,6 +975,7 @@ struct og_engine {
             seg_begin.assign(V, 0);
             seg_end.assign(V, 0);
             seg_last.assign(V, 0);
+            ensure_cont();
         }
         // group the pending pushes per voice without sorting the batch: chain them in arrival order (O(n)), then put
         // every (short) chain into (frame, push order)
@@ -912,6 +997,21 @@ struct og_engine {
             }
             grp_tail[v] = (uint32_t)i;
         }
+        // voices whose continuation has its first event inside the launch being prepared (and no push in this batch: a
+        // pushed voice is brought up to the end of the launch anyway)
+        const uint64_t lend = launch_end();
+        std::vector<uint32_t> due;
+        while (!cont_due.empty() && cont_due.front().first < lend) {
+            const std::pair<uint64_t, uint32_t> top = cont_due.front();
+            std::pop_heap(cont_due.begin(), cont_due.end(), std::greater<std::pair<uint64_t, uint32_t>>());
+            cont_due.pop_back();
+            const uint32_t v = top.second;
+            if (!has_cont(v) || h_events[cont_begin[v]].frame != top.first) continue; // (stale: the voice was merged or re-pointed since)
+            if (grp_head[v] != NONE) continue;
+            due.push_back(v);
+        }
+        std::sort(due.begin(), due.end());
+        due.erase(std::unique(due.begin(), due.end()), due.end());
         const int r = stage_head;
         {
             HostProf::Scope pw(prof, HostProf::EV_WAIT);
@@ -921,6 +1021,7 @@ struct og_engine {
         uint32_t* upd = h_stage_upd[r];
         std::vector<OgEvent> old, merged;
         std::vector<HostEvent> mine;
+        std::vector<uint32_t> kept; // per update: {begin, end} of the continuation the voice keeps (equal: none), absolute-positions flag
         size_t n_ev = 0, n_upd = 0;
         bool fits = true;
         for (const uint32_t v : grp_voices) {
@@ -941,7 +1042,7 @@ struct og_engine {
                     upd[EV_UPD_WORDS * n_upd] = v; // (cursor, end) relative to the batch: its place in the ring is chosen below
                     upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
                     upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + k);
-                    upd[EV_UPD_WORDS * n_upd + 3] = upd[EV_UPD_WORDS * n_upd + 4] = 0u; // (no continuation: nothing of this voice is waiting)
+                    kept.insert(kept.end(), {0u, 0u, 0u});
                     n_ev += k;
                     n_upd += 1;
                     continue;
@@ -960,50 +1061,14 @@ struct og_engine {
                 }
                 mine[j] = k;
             }
-            // What of this voice is still to be played and due up to the last pushed frame is merged with the pushes into
-            // the new segment; what lies BEHIND that frame stays where it is and becomes (or remains) the continuation --
-            // the rest of a long score is never copied.  A short rest is carried over instead (one segment, no hop).
-            old.clear();
-            merged.clear();
-            uint32_t keep_b = 0, keep_e = 0;
-            {
-                const uint64_t last_new = mine.back().frame;
-                uint32_t hb, he, cb, ce;
-                unconsumed_ranges(v, consumed_horizon(), hb, he, cb, ce);
-                if (cb != ce) { // (every frame of the segment is <= every frame of the continuation)
-                    const uint32_t split = upper_frame(cb, ce, last_new);
-                    old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
-                    old.insert(old.end(), h_events.begin() + cb, h_events.begin() + split);
-                    if (ce - split >= CONT_MIN) {
-                        keep_b = split;
-                        keep_e = ce;
-                    } else {
-                        old.insert(old.end(), h_events.begin() + split, h_events.begin() + ce);
-                    }
-                } else {
-                    const uint32_t split = upper_frame(hb, he, last_new);
-                    if (he - split >= CONT_MIN) {
-                        old.insert(old.end(), h_events.begin() + hb, h_events.begin() + split);
-                        keep_b = split;
-                        keep_e = he;
-                    } else {
-                        old.insert(old.end(), h_events.begin() + hb, h_events.begin() + he);
-                    }
-                }
+            if (!merge_voice(v, mine, lend, sev, upd, n_ev, n_upd, kept, old, merged)) fits = false;
+        }
+        for (const uint32_t v : due) { // (after the pushed voices: `due` holds none of them)
+            if (!fits) { // (the batch goes to full_rebuild, which merges every continuation)
+                break;
             }
-            merge_by_frame(old, mine.data(), mine.data() + mine.size(), merged);
-            if (n_ev + merged.size() > EV_STAGE_EVENTS) {
-                fits = false;
-                continue;
-            }
-            memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
-            upd[EV_UPD_WORDS * n_upd] = v;
-            upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
-            upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
-            upd[EV_UPD_WORDS * n_upd + 3] = keep_b; // (absolute ring positions: the rest stays where it is)
-            upd[EV_UPD_WORDS * n_upd + 4] = keep_e;
-            n_ev += merged.size();
-            n_upd += 1;
+            mine.clear();
+            if (!merge_voice(v, mine, lend, sev, upd, n_ev, n_upd, kept, old, merged)) fits = false;
         }
         if (!fits) return false;
         // a place in the ring for the whole batch (the segments touched above count as superseded only after the commit,
@@ -1017,16 +1082,25 @@ struct og_engine {
         for (size_t i = 0; i < n_upd; ++i) {
             uint32_t* u = upd + EV_UPD_WORDS * i;
             const uint32_t v = u[0];
+            const uint32_t kb = kept[3 * i], ke = kept[3 * i + 1];
+            if (kept[3 * i + 2]) { // pointed at records that are in the ring already (the segment they lie in stays alive: ring_alloc)
+                seg_begin[v] = u[1];
+                seg_end[v] = u[2];
+                seg_last[v] = h_events[u[2] - 1].frame;
+                if (!cont_begin.empty()) cont_begin[v] = cont_end[v] = 0;
+                continue;
+            }
             seg_last[v] = sev[u[2] - 1].frame;
             u[1] += (uint32_t)base;
             u[2] += (uint32_t)base;
             seg_begin[v] = u[1];
             seg_end[v] = u[2];
-            if (u[3] != u[4]) {
+            if (kb != ke) {
                 ensure_cont();
-                cont_begin[v] = u[3];
-                cont_end[v] = u[4];
-                cont_last[v] = h_events[u[4] - 1].frame;
+                cont_begin[v] = kb;
+                cont_end[v] = ke;
+                cont_last[v] = h_events[ke - 1].frame;
+                cont_due_push(v);
             } else if (!cont_begin.empty()) {
                 cont_begin[v] = cont_end[v] = 0;
             }
@@ -1037,7 +1111,7 @@ struct og_engine {
         static_assert(sizeof(OgEvent) == sizeof(uint4), "og_apply_event_updates copies events as 16-byte words");
         const uint32_t n_wg_upd = (uint32_t)((std::max(n_upd, n_ev) + 255) / 256);
         hipLaunchKernelGGL(og_apply_event_updates, dim3(n_wg_upd), dim3(256), 0, stream, (const uint4*)sev, (uint32_t)n_ev,
-                           (uint4*)(d_events + ev_tail), (const uint32_t*)upd, (uint32_t)n_upd, d_ev_cursor, d_ev_end, d_ev_cont);
+                           (uint4*)(d_events + ev_tail), (const uint32_t*)upd, (uint32_t)n_upd, d_ev_cursor, d_ev_end);
         HIPCK(hipGetLastError());
         stage_seq[r] = flush_seq + 1; // read in stream order before the batch that is about to be launched
         batch_staged = true;
@@ -1071,7 +1145,7 @@ struct og_engine {
     // over several blocks: one staging copy and one cursor update for all of them)
     void upload_events()
     {
-        if (pending.empty() && !ev_rebuild) return;
+        if (pending.empty() && !ev_rebuild && !continuation_due()) return;
         // try_push'ed events of the block that is still being assembled (pushed since the last block was queued) stay
         // on the host: drop_late_local() has not judged them against that block's length yet.  A flush in between --
         // og_process_block launches earlier async blocks, the setters launch the queue -- must not turn an event whose
@@ -1093,7 +1167,7 @@ struct og_engine {
                 e->pending.insert(e->pending.end(), held.begin(), held.end());
             }
         } put_back{this, held};
-        if (pending.empty() && !ev_rebuild) return;
+        if (pending.empty() && !ev_rebuild && !continuation_due()) return;
         HostProf::Scope ps(prof, HostProf::SYNC_EVENTS);
         // many voices touched at once (bulk scheduling): one compact CSR rebuild beats per-voice segments
         const bool bulk = ev_rebuild || pending.size() > EV_STAGE_EVENTS || pending.size() > (size_t)V / 2 + 64 || !d_events;
@@ -1213,7 +1287,6 @@ struct og_engine {
         A.events = d_events;
         A.ev_end = d_ev_end;
         A.ev_cursor = d_ev_cursor;
-        A.ev_cont = d_ev_cont;
         A.partials = d_partials;
         const uint32_t n_chunks16 = (q_frames + OG_RED_FRAMES - 1) / OG_RED_FRAMES;
         A.partial_plane = (uint32_t)((size_t)n_chunks16 * n_wg * OG_RED_FRAMES);
@@ -1828,8 +1901,6 @@ int og_create(const og_graph_desc* g, uint32_t n_voices, int device_id, og_engin
         HIPCK(hipMalloc(&e->d_ev_cursor, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_end, 0, (size_t)n_voices * 4));
         HIPCK(hipMemset(e->d_ev_cursor, 0, (size_t)n_voices * 4));
-        HIPCK(hipMalloc(&e->d_ev_cont, (size_t)n_voices * sizeof(uint2)));
-        HIPCK(hipMemset(e->d_ev_cont, 0, (size_t)n_voices * sizeof(uint2)));
         e->alloc_bus_buffers(1);
         HIPCK(hipMalloc(&e->d_bus, (size_t)OG_MAX_BLOCK * OG_MAX_BUS_CHANNELS * 4));
         HIPCK(hipMalloc(&e->d_tap_slot, (size_t)n_voices * 4));

@@ -123,13 +123,8 @@ struct OgBlockArgs {
     uint32_t* state;           // [n_state_words][n_voices], raw 32-bit words
     uint32_t* lane_state;      // [n_lane_words][n_voices][LPV]: words of voices that span LPV lanes
     const OgEvent* events;     // sorted by (voice, frame, push order)
-    uint32_t* ev_end;          // [n_voices] one past the last event of the voice's current segment
+    const uint32_t* ev_end;    // [n_voices] one past the last event of the voice's current segment
     uint32_t* ev_cursor;       // [n_voices] next unconsumed event
-    // [n_voices] {cursor, end} of the segment that CONTINUES the voice's timeline when the current one runs out, x == y: none.
-    // A live message on top of a long resident score becomes a short segment {what is due up to the message, the message}
-    // in front of the rest of the score, which stays where it is (og_engine.cpp, incremental_update): the voice's cost of a
-    // message does not depend on how much score it still has to play.
-    const uint2* ev_cont;
     float* partials;           // [ceil(frames / 16)][n_workgroups][16]: per-workgroup partial sums of the mix bus
                                // (a Frame<2> voice output: two such planes, `partial_plane` floats apart)
     const float* ramp_table;   // [n_ramps + n_streams][ramp_stride] per-frame values of ramped / stream inputs
@@ -426,10 +421,7 @@ __device__ __forceinline__ void voice_begin_split(const OgBlockArgs& a, VoiceCtx
 
 __device__ __forceinline__ void voice_end(const OgBlockArgs& a, const VoiceCtx& c)
 {
-    if (c.valid && c.lead && c.ev_cur != c.ev_cur0) {
-        a.ev_cursor[c.v] = c.ev_cur;
-        a.ev_end[c.v] = c.ev_end; // (ev_continue may have moved the voice on to its continuation segment)
-    }
+    if (c.valid && c.lead && c.ev_cur != c.ev_cur0) a.ev_cursor[c.v] = c.ev_cur;
     clock_mark(a, 1);
 }
 
@@ -458,21 +450,6 @@ __device__ __forceinline__ void ev_out_log(const OgBlockArgs& a, const VoiceCtx&
 #endif
 }
 
-// the current segment has run out: go on with the voice's continuation segment, if it has one and is not in it already
-// (OgBlockArgs::ev_cont).  Rare -- once per live message on a voice that still has score to play -- and every wave of a
-// pipelined workgroup takes the step by itself, from the same words: nothing is written before voice_end.
-template <bool PRE>
-__device__ __forceinline__ void ev_continue(const OgBlockArgs& a, VoiceCtx& c)
-{
-    if (!a.ev_cont || !c.valid) return;
-    const uint2 k = a.ev_cont[c.v];
-    if (k.x < k.y && k.y != c.ev_end) {
-        c.ev_cur = k.x;
-        c.ev_end = k.y;
-        ev_arm<PRE>(a, c);
-    }
-}
-
 // pop the current event: the next one's frame is already known (next2); its payload and the frame of the one behind it
 // are requested here and only waited for when they are used
 template <bool PRE = true>
@@ -480,12 +457,7 @@ __device__ __forceinline__ void ev_advance(const OgBlockArgs& a, VoiceCtx& c)
 {
     c.ev_cur += 1;
     if (!PRE) {
-        if (c.ev_cur < c.ev_end) {
-            c.next_ev = ev_rel_frame(a, c.ev_cur);
-        } else {
-            c.next_ev = OG_NO_EVENT;
-            ev_continue<false>(a, c);
-        }
+        c.next_ev = (c.ev_cur < c.ev_end) ? ev_rel_frame(a, c.ev_cur) : OG_NO_EVENT;
         return;
     }
     c.next_ev = ev_rel_of(a, c.n2_frame); // (~0: far beyond the launch -> OG_NO_EVENT)
@@ -495,8 +467,6 @@ __device__ __forceinline__ void ev_advance(const OgBlockArgs& a, VoiceCtx& c)
         c.nx_target = ev.target;
         c.nx_value = ev.value;
         if (c.ev_cur + 1u < c.ev_end) c.n2_frame = a.events[c.ev_cur + 1u].frame;
-    } else {
-        ev_continue<true>(a, c);
     }
 }
 

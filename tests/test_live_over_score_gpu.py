@@ -3,9 +3,9 @@
 The reference merges the events staged for a block into it by `frame_offset`, block after block
 (oscen-graph-compiler/src/codegen/mod.rs:782-871) -- a MIDI note-off costs the same whatever is going to be played later.
 Here a whole score can be resident on the device (`og_schedule_*`); until round 6 a live push re-wrote the voice's remaining
-score.  Now the push becomes a short segment {what is due up to the pushed frame, the push} in front of the rest of the
-score, which stays where it lies (the voice's continuation segment, OgBlockArgs::ev_cont) and which the kernel moves on
-to by itself.  Checked: the samples against the oracle fed the merged event list, the same engine with the whole list
+score.  Now the push becomes a short segment {what is due up to the end of the launch being prepared, the push}; the
+rest of the score stays where it lies as the voice's continuation, and the engine points the voice at it -- a cursor
+update -- before the launch in which its first event is due (og_engine.cpp, merge_voice).  Checked: the samples against the oracle fed the merged event list, the same engine with the whole list
 scheduled up front bit for bit, and `og_events_copied` -- the cost of the live messages does not grow with the score."""
 import numpy as np
 import pytest
@@ -85,16 +85,16 @@ def test_live_messages_cut_into_a_resident_score_without_rewriting_it(split, mon
     n, blocks, block = 96, 24, 128
     total = blocks * block
     rng = np.random.default_rng(2026)
-    score = resident_score(n, total + 40 * block, rng, every=48)  # ~64 events per voice within the run, as many beyond it
+    score = resident_score(n, total + 200 * block, rng, every=48)  # ~64 events per voice within the run, ~530 beyond it
     live = live_messages(n, blocks, block, rng, per_block=6)
     per_voice = len(score) / n
-    assert per_voice > 100
+    assert per_voice > 400
 
     e_live, taps_live, state_live, freqs = run(n, blocks, block, score, live, live_as_pushes=True, split=split, monkeypatch=monkeypatch)
     st = e_live.event_stats
     assert st["full_rebuilds"] == 1 and st["incremental_updates"] >= blocks - 4, st
-    # the cost of the live path: every message carries over at most what was due in its own block plus a short rest --
-    # not the ~100 events its voice still has to play
+    # the cost of the live path: every message carries over at most what was due in its own block --
+    # not the ~500 events its voice still has to play (a rest below 64 events would be carried over: og_engine.cpp, CONT_MIN)
     assert st["events_copied"] <= len(live) * 12, (st, len(live), per_voice)
 
     # the same timeline scheduled up front, one segment per voice, no continuation anywhere: bit for bit
@@ -139,10 +139,10 @@ def test_live_messages_over_a_score_on_the_queued_entry_and_through_ring_wraps(m
     n, blocks, block = 200, 32, 96
     total = blocks * block
     rng = np.random.default_rng(77)
-    score = resident_score(n, total + 10 * block, rng, every=40)
+    score = resident_score(n, total + 120 * block, rng, every=40)
     live = live_messages(n, blocks, block, rng, per_block=10)
     monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")
-    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "512")
+    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "1024")
     e_live, _, state_live, _ = run(n, blocks, block, score, live, live_as_pushes=True, queued=True)
     monkeypatch.delenv("OSCEN_GPU_EV_HEADROOM")
     e_all, _, state_all, _ = run(n, blocks, block, score, live, live_as_pushes=False, queued=True)
