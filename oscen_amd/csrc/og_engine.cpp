@@ -902,6 +902,26 @@ struct og_engine {
         old.clear();
         merged.clear();
         uint32_t keep_b = 0, keep_e = 0;
+        if (!mine.empty() && !has_cont(v) && seg_end[v] - seg_begin[v] < CONT_MIN) {
+            // the usual loaded voice: a handful of waiting events, no continuation, nothing worth leaving behind -- one pass
+            // over the segment, as before round 6 (the real-time banks: ~1000 of these per block)
+            const uint64_t hz = consumed_horizon();
+            if (seg_last[v] >= hz)
+                for (uint32_t i = seg_begin[v]; i < seg_end[v]; ++i)
+                    if (h_events[i].frame >= hz) old.push_back(h_events[i]);
+            merge_by_frame(old, mine.data(), mine.data() + mine.size(), merged);
+            if (n_ev + merged.size() > EV_STAGE_EVENTS || n_upd >= EV_STAGE_EVENTS) return false;
+            memcpy(sev + n_ev, merged.data(), merged.size() * sizeof(OgEvent));
+            upd[EV_UPD_WORDS * n_upd] = v;
+            upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
+            upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
+            kept.push_back(0u);
+            kept.push_back(0u);
+            kept.push_back(0u);
+            n_ev += merged.size();
+            n_upd += 1;
+            return true;
+        }
         const uint64_t bound = std::max<uint64_t>(mine.empty() ? 0 : mine.back().frame, lend ? lend - 1 : 0);
         uint32_t hb, he, cb, ce;
         unconsumed_ranges(v, consumed_horizon(), hb, he, cb, ce);
@@ -1022,6 +1042,7 @@ struct og_engine {
         std::vector<OgEvent> old, merged;
         std::vector<HostEvent> mine;
         std::vector<uint32_t> kept; // per update: {begin, end} of the continuation the voice keeps (equal: none), absolute-positions flag
+        kept.reserve(3 * (grp_voices.size() + due.size()));
         size_t n_ev = 0, n_upd = 0;
         bool fits = true;
         for (const uint32_t v : grp_voices) {
