@@ -499,7 +499,17 @@ struct og_engine {
     // real-time banks, whose 1 s scores leave ~14 events per voice: with continuations for those p99 rose from 2.29 to
     // 2.69 ms at 4 194 304 voices (gpurun r06q).
     static constexpr uint32_t CONT_MIN = 64;
-    bool has_cont(uint32_t v) const { return !cont_begin.empty() && cont_begin[v] != cont_end[v]; }
+    size_t n_conts = 0; // voices that have a continuation right now (0: nobody looks at the cont_* arrays -- cold memory)
+    bool has_cont(uint32_t v) const { return n_conts != 0 && cont_begin[v] != cont_end[v]; }
+    void set_cont(uint32_t v, uint32_t b, uint32_t e)
+    {
+        const bool had = cont_begin[v] != cont_end[v];
+        cont_begin[v] = b;
+        cont_end[v] = e;
+        if (b != e) cont_last[v] = h_events[e - 1].frame;
+        n_conts += (b != e ? 1 : 0);
+        n_conts -= (had ? 1 : 0);
+    }
     void ensure_cont() // (sized with the segment arrays, outside the real-time path: 16 bytes per voice of zero-fill)
     {
         if (cont_begin.empty()) {
@@ -574,7 +584,9 @@ struct og_engine {
             const RingSeg& f = ring_live.front();
             // alive: the voice's current segment, or the segment its continuation lies in, with something left to play
             // (a voice that was pointed at its continuation plays a sub-range of the older segment the continuation lay in)
-            const bool is_head = seg_begin[f.voice] != seg_end[f.voice] && seg_begin[f.voice] >= f.begin && seg_end[f.voice] <= f.end && seg_last[f.voice] >= hz;
+            // (seg_begin first: a superseded segment -- the usual one at the front -- is settled by that one cold word, as ever)
+            const uint32_t sb = seg_begin[f.voice];
+            const bool is_head = sb >= f.begin && sb < f.end && seg_end[f.voice] <= f.end && sb != seg_end[f.voice] && seg_last[f.voice] >= hz;
             const bool holds_cont = has_cont(f.voice) && cont_begin[f.voice] >= f.begin && cont_end[f.voice] <= f.end && cont_last[f.voice] >= hz;
             const bool dead = !is_head && !holds_cont;
             if (!dead) break;
@@ -753,6 +765,7 @@ struct og_engine {
         cont_end.clear();
         cont_last.clear();
         cont_due.clear();
+        n_conts = 0;
         ev_tail = 0;
         ring_live.clear();
         ev_rebuild = false;
@@ -878,6 +891,7 @@ struct og_engine {
         seg_begin.swap(cursor);
         seg_end.swap(end);
         seg_last.swap(last);
+        n_conts = 0;
         cont_begin.assign(V, 0); // (everything is in the segments now; the arrays are sized here, not on the live path)
         cont_end.assign(V, 0);
         cont_last.assign(V, 0);
@@ -1108,7 +1122,7 @@ struct og_engine {
                 seg_begin[v] = u[1];
                 seg_end[v] = u[2];
                 seg_last[v] = h_events[u[2] - 1].frame;
-                if (!cont_begin.empty()) cont_begin[v] = cont_end[v] = 0;
+                if (n_conts) set_cont(v, 0u, 0u);
                 continue;
             }
             seg_last[v] = sev[u[2] - 1].frame;
@@ -1118,12 +1132,10 @@ struct og_engine {
             seg_end[v] = u[2];
             if (kb != ke) {
                 ensure_cont();
-                cont_begin[v] = kb;
-                cont_end[v] = ke;
-                cont_last[v] = h_events[ke - 1].frame;
+                set_cont(v, kb, ke);
                 cont_due_push(v);
-            } else if (!cont_begin.empty()) {
-                cont_begin[v] = cont_end[v] = 0;
+            } else if (n_conts) {
+                set_cont(v, 0u, 0u);
             }
             ring_live.push_back(RingSeg{v, u[1], u[2]});
         }
