@@ -85,8 +85,9 @@ int og_graph_add_node_array(og_graph_desc* g, const char* name, const char* type
  * `<event_output>.push_at(frame_offset, value)`, plain `push(value)` = offset 0 -- multiplied (saturating) by N on an
  * outer -> inner edge and divided by N on an inner -> outer edge, codegen/emit_edge.rs:86-99) -- but only the VALUE inputs
  * (streams do not exist yet when an event fires).  og_math.h / og_nodes.hip.h helpers (og_sin_turns, og_sinf, og::clampf,
- * ...) are in scope; og_sin_turns -- sin of an argument in TURNS -- is the hardware sine and is defined for |t| <= 256
- * turns only (0 beyond): a body whose argument is not bounded calls og_sin_turns_wide instead.  The bodies are compiled into
+ * ...) are in scope; og_sin_turns -- sin of an argument in TURNS -- is the hardware sine, documented for |t| <= 256 turns
+ * (gfx950 reduces larger arguments itself, measured; og_sin_turns_wide takes the fractional part first and does not rely on
+ * that).  The bodies are compiled into
  * the fused voice kernel by hiprtc when an engine is created for a graph that uses the type.  Process-wide registry. */
 typedef struct {
     const char* name;

@@ -140,11 +140,13 @@ OG_HD float og_sin_turns_poly(float t)
 // OG_SIN_TURNS: how an FM operator takes its sine.  0 = og_sinf((phase + mod) * TAU) -- follows the reference's f32
 // product; 1 = og_sin_turns_poly(phase + mod); 2 = the hardware's v_sin_f32 (argument in turns),
 // host builds (tests/test_og_math.py, the host simulator) take the polynomial.
-// DOMAIN of form 2: |t| <= 256 turns -- beyond it v_sin_f32 returns 0 where `(t * TAU).sin()` still returns a number.  An
-// FM operator gets there only with a modulation index above 256 turns (1 608 rad); at that size ulp(t) = 3e-5 turns, i.e.
-// the reference's own f32 argument is already coarser than the 1e-5 contract and no form but -DOG_STRICT follows it
-// (measured against the reference's f32 form: 4.6e-7 / 7.6e-7 / 1.5e-6 / 3.4e-6 at 0 / 1 / 4 / 16 turns of modulation,
-// scripts/ubench/vsin.hip).  A node body whose argument is not bounded like that calls og_sin_turns_wide().
+// DOMAIN of form 2: the ISA documents v_sin_f32 for |t| <= 256 turns.  Measured on gfx950 (scripts/dbg_sin_domain.py, round 6;
+// tests/test_plugin_gpu.py holds it): the instruction reduces its argument itself -- 1.1e-7 from sin(2 pi frac(t)) at every
+// size tried, up to 1e6 turns, no zeros beyond 256 -- so og_sin_turns follows `(t * TAU).sin()` as far as the f32 argument
+// means anything (ulp(t) > 1e-5 turns from t = 128 on: at such modulation depths no form but -DOG_STRICT reproduces the
+// reference's rounding of the product).  Against the reference's f32 form: 4.6e-7 / 7.6e-7 / 1.5e-6 / 3.4e-6 at 0 / 1 / 4 /
+// 16 turns of modulation (scripts/ubench/vsin.hip).  og_sin_turns_wide() takes the fractional part first and does not
+// lean on that behaviour: the form for node bodies meant to run on other parts as well.
 #ifndef OG_SIN_TURNS
 #ifdef OG_STRICT
 #define OG_SIN_TURNS 0

@@ -101,8 +101,9 @@ def test_user_node_with_event_handler_and_integer_state():
 
 
 def test_sine_helpers_domain_of_the_hardware_sine_and_the_wide_form():
-    """og_sin_turns is v_sin_f32 on the device: defined for |t| <= 256 turns, 0 beyond (og_math.h, ADVICE r5);
-    og_sin_turns_wide takes the fractional part first and is a sine at any argument size."""
+    """og_sin_turns is v_sin_f32 on the device.  The ISA documents it for |t| <= 256 turns (a deep modulation
+    would silently give zeros); measured, gfx950 reduces any argument itself -- this test holds that.  og_sin_turns_wide
+    takes the fractional part first and is a sine at any argument size whatever the part does."""
     oscen_amd.register_node(
         "SineProbe::new", inputs=[("frequency", "value", 1.0, -1)], outputs=["narrow", "wide"],
         state=[("k", "f32", 0.0, -1)],
@@ -134,9 +135,7 @@ def test_sine_helpers_domain_of_the_hardware_sine_and_the_wide_form():
     ref = np.sin(2.0 * np.pi * (t64 - np.floor(t64)))
     assert np.max(np.abs(t)) > 1.0e5
     assert np.max(np.abs(outs["wide"] - ref)) < 2e-6  # the hardware sine on an exact fractional part
-    inside = np.abs(t) <= 256.0
-    assert np.max(np.abs(outs["narrow"][inside] - ref[inside])) < 2e-6
-    assert np.all(outs["narrow"][np.abs(t) > 257.0] == 0.0)  # the documented behaviour beyond the domain
+    assert np.max(np.abs(outs["narrow"] - ref)) < 2e-6  # ... and so is the bare instruction on this part, far beyond 256 turns
 
 
 def test_node_arrays_match_the_hand_expanded_graph_and_the_interpreter():
