@@ -13,6 +13,7 @@
 #pragma once
 #ifndef __HIPCC_RTC__
 #include <math.h>
+#include <string.h>
 #include <stdint.h>
 #else
 using __hip_internal::int32_t;
@@ -158,6 +159,23 @@ OG_HD float og_sin_turns(float t)
 {
 #if OG_SIN_TURNS == 2 && defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sinf(t);
+#elif OG_SIN_TURNS == 2 && defined(OG_HOSTSIM)
+    // The host simulator's stand-in for v_sin_f32 (test infrastructure, VERDICT r5: the CPU suite should run the shipped
+    // numerics, not a better sine): the exact sine of the exact fractional part plus an error of the size MEASURED on the
+    // part -- up to 1.1e-7 absolute (scripts/dbg_sin_domain.py, scripts/ubench/vsin.hip), taken from a hash of the argument's
+    // bits so that it is a function of the argument, like the instruction (bit-for-bit invariants between kernel shapes
+    // keep holding).  The polynomial the plain host build takes is twice as close to the true sine as the hardware.
+    {
+        const double f = (double)t - floor((double)t);
+        uint32_t h;
+        memcpy(&h, &t, 4);
+        h *= 2654435761u;
+        h ^= h >> 15;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        const double e = ((double)(h & 0xFFFFu) / 32767.5 - 1.0) * 1.1e-7;
+        return (float)(sin(6.283185307179586476925 * f) + e);
+    }
 #elif OG_SIN_TURNS >= 1
     return og_sin_turns_poly(t);
 #else
