@@ -31,6 +31,8 @@ import subprocess
 import sys
 import time
 
+T_START = time.time()  # (wall-clock budget of the run: line["wall_s"])
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -1044,6 +1046,7 @@ def compact_line(full):
         if len(str(out["timing"].get("repeats_rule", ""))) > 80:
             out["timing"]["repeats_rule"] = out["timing"]["repeats_rule"][:77] + "..."
     out["value_median_first5"] = tm.get("value_median_first5")
+    out["wall_s"] = full.get("wall_s")
     out["rccl_ranks"] = full.get("rccl_ranks")
     mg = full.get("multi_gpu")
     out["multi_gpu"] = None if mg is None else {k: v for k, v in mg.items() if not isinstance(v, (list, dict)) or len(json.dumps(v)) < 400}
@@ -1250,7 +1253,11 @@ def main():
         est_region_ms = max(1e-3, K * 0.045 * V / 65536.0)  # ~0.045 ms per 256-frame block of 65 536 fm voices
         R = int(max(5, min(48, -(-40.0 // est_region_ms))))
         repeats_rule = "auto: ~40 ms of timed work (5..48 regions) so that the clock governor has settled by the median region"
+    # wall-clock budget of the run, leg by leg (N > 1: the driver's 8-GPU command = headline + config4 + og_cluster; the line
+    # carries it so that the run can be seen to fit a timeout before one is hit -- VERDICT r5, item 8)
+    t_legs, t_leg0 = {}, time.time()
     m = timed_bank(args, args.graph, V, K, W, R, rank, local_rank, world_size, dist, args.variant)
+    t_legs["headline"] = time.time() - t_leg0
     eng, times, kern_ms, n_launch, n_blocks_timed, multi_gpu = m.eng, m.times, m.kern_ms, m.n_launch, m.n_blocks_timed, m.multi_gpu
     rccl_ranks, timed_blocks, bus, host_bus, midi = m.rccl_ranks, m.timed_blocks, m.bus, m.host_bus, m.midi
     n_events_timed, span, total_voices, block = m.n_events_timed, m.span, m.total_voices, m.block
@@ -1261,7 +1268,9 @@ def main():
     V4 = max(64, 262144 // args.test_scale)
     if world_size > 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant and V4 != V:
         K4, W4, R4 = (188, 8, 3) if args.test_scale == 1 else (4, 2, 2)
+        t_leg0 = time.time()
         m4 = timed_bank(args, "fm_voice", V4, K4, W4, R4, rank, local_rank, world_size, dist, None)
+        t_legs["config4"] = time.time() - t_leg0
         if rank == 0:
             e4, _ = region_stats(m4.times, m4.total_voices, K4, block)
             rf4 = roofline_record(m4.eng, V4, block, "fm_voice", m4.kern_ms, m4.n_launch, m4.n_blocks_timed)
@@ -1351,6 +1360,20 @@ def main():
         else:
             dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+    # N > 1: rank 0 goes on to drive ALL N devices from one process (the og_cluster leg).  The other ranks give their device
+    # back first -- engine closed, allocator emptied -- and say so through a file; rank 0 waits for every such file before it
+    # touches their devices (torchrun gives no "the others are done" signal once the process group is gone).
+    release_dir = None
+    if world_size > 1:
+        import tempfile
+        release_dir = os.path.join(tempfile.gettempdir(), "oscen_bench_release_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        os.makedirs(release_dir, exist_ok=True)
+        if rank != 0:
+            eng.close()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            with open(os.path.join(release_dir, "rank%d.released" % rank), "w") as f:
+                f.write("%f\n" % time.time())
     if line is not None:
         has_gate = "gate" in eng.input_names
         if config4 is not None:
@@ -1360,6 +1383,22 @@ def main():
             # library's ncclReduce (the ranks above used torch.distributed's communicator).  Rank 0 runs it after the
             # process group is gone; the other ranks have finished.
             eng.close()
+            t_leg0 = time.time()
+            want = [os.path.join(release_dir, "rank%d.released" % r) for r in range(1, world_size)]
+            while not all(os.path.exists(w) for w in want) and time.time() - t_leg0 < 60.0:
+                time.sleep(0.02)
+            released = all(os.path.exists(w) for w in want)
+            t_legs["wait_for_ranks_to_release_devices"] = time.time() - t_leg0
+            for w in want:
+                try:
+                    os.remove(w)
+                except OSError:
+                    pass
+            try:
+                os.rmdir(release_dir)
+            except OSError:
+                pass
+            t_leg0 = time.time()
             # (the one leg of an N > 1 run that no rank-per-GPU phase above has exercised: if it does not come back, the
             #  line -- headline and config4 complete -- is printed without it instead of being lost with the process)
             guard = Watchdog(args.cluster_timeout, lambda: emit_line_and_exit(
@@ -1375,6 +1414,9 @@ def main():
                 line["og_cluster"] = {"error": str(e)[:300]}
             finally:
                 guard.cancel()
+            if isinstance(line.get("og_cluster"), dict):
+                line["og_cluster"]["ranks_released_devices_first"] = released
+            t_legs["og_cluster"] = time.time() - t_leg0
         configs = None
         if world_size == 1 and not args.no_configs and args.graph == "fm_voice" and not args.midi_live and not args.variant:
             eng.close()
@@ -1420,6 +1462,8 @@ def main():
                                 sig(c.get("roofline_frac")), sig(c.get("valu_issue_frac")), sig(c.get("dram_gbs")), c.get("stale_profile"),
                                 c.get("error")] for c in configs]
             line["configs_keys"] = "name, voices, voices*samples/s, ms_per_step, kernel, roofline.frac (charged), valu_issue.frac, dram GB/s, stale_profile, error"
+        t_legs["total_since_start"] = time.time() - T_START
+        line["wall_s"] = {k: round(v, 2) for k, v in t_legs.items()}
         emit(line)
 
 

@@ -152,6 +152,10 @@ def test_eight_rank_line_carries_config4_and_the_og_cluster_leg(hostsim_env, tmp
     oc = d["og_cluster"]
     assert "error" not in oc, oc
     assert oc["rccl_ranks"] == 8 and oc["cluster"]["devices"] == 8 and oc["cluster"]["rccl_reduces"] > 0 and oc["value"] > 0
+    # round 6: the run's wall clock leg by leg (so that an 8-GPU run can be seen to fit a timeout), and the og_cluster leg
+    # started only after the other seven ranks had released their devices (a file each; rank 0 waits for all of them)
+    assert set(d["wall_s"]) >= {"headline", "config4", "wait_for_ranks_to_release_devices", "og_cluster", "total_since_start"}, d["wall_s"]
+    assert oc.get("ranks_released_devices_first") is True, oc
     assert "configs" not in d and d["cpu_baseline"] is None       # N = 1 extras stay at N = 1
 
 
