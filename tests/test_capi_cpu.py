@@ -233,7 +233,7 @@ def test_kernel_structure_chunk_variants_and_pipelines():
     #  frames whose input differs from the previous frame's; q is watched in the kernel variants that read a ramp table)
     # (round 6: 1 / q is formed once per launch -- `inv_q` in derive() -- where q cannot change inside it)
     assert "og::tpt_params_nomod_lazy<RAMPS, true>(" in tick and "og::tpt_params_nomod(" not in tick
-    assert "inv_q = 1.0f / og::clampf(SF(" in fm[fm.index("auto derive"):fm.index("auto tick")]
+    assert "inv_q = og::uniform_f(1.0f / og::clampf(SF(" in fm[fm.index("auto derive"):fm.index("auto tick")]  # (kept in a scalar register)
     sub = oscen_amd.Graph(builtin="sub_voice").kernel_source()
     derive = sub[sub.index("auto derive"):sub.index("auto tick")]
     tick = sub[sub.index("auto tick"):sub.index("auto events")]
