@@ -4656,10 +4656,16 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     std::vector<std::pair<int, int>> depths; // (tag: what OgBlockArgs::split selects, waves per workgroup)
     if (!cg.groups2.empty()) depths.push_back({2, (int)cg.groups2.size()});
     if (!cg.groups4.empty()) depths.push_back({4, (int)cg.groups4.size()});
+    // OGC_NARROW_FD=<depth> (experiment): the 8-frame shapes with the flag hand-off as well, rings of `depth` chunks
+    std::string narrow_args;
+    if (const char* en = ogabi::experiment_knob("OGC_NARROW_FD")) {
+        const int fd = atoi(en);
+        if (fd >= 2 && fd <= 8) narrow_args = ", 8, " + std::to_string(fd);
+    }
     for (auto [K, W] : depths)
         for (auto& v : variants)
             src << "extern \"C\" __global__ __launch_bounds__(" << 64 * W << ") void og_k" << K << "_" << hs << "_" << v[0]
-                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p" << K << "<" << v[1] << ", " << v[2] << ">(A); }\n";
+                << "(OgBlockArgs A) { og_gen_" << hs << "::voice_block_p" << K << "<" << v[1] << ", " << v[2] << narrow_args << ">(A); }\n";
     if (out.wide4)
         for (auto& v : variants)
             src << "extern \"C\" __global__ __launch_bounds__(" << 64 * (int)cg.groups4.size() << ") void og_k4w_" << hs << "_" << v[0]
