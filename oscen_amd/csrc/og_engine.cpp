@@ -1295,7 +1295,12 @@ struct og_engine {
         q_frames += frames;
         frame_now += frames;
         last_frames = frames;
-        if (queue.size() >= bus_batch || n_taps > 0) flush_bus();
+        // The last ramp ended inside this block: launch what is queued, so that the blocks that follow -- nothing moves in
+        // them -- start a queue of their own on the kernel variant that does not read the table.  (Round 6, the moving-cutoff
+        // variant of the bench: the launch that held the 2 205-frame cutoff ramp also held the ~20 quiet blocks queued behind
+        // it and ran them 35 % slower -- per-frame parameter tests, table reads -- than the `_00` variant; a launch costs 25 us.)
+        const bool ramps_done = ramping && active_ramps == 0 && cg->n_streams == 0;
+        if (queue.size() >= bus_batch || n_taps > 0 || ramps_done) flush_bus();
     }
 
     // launch the queued blocks: voice kernel over their frames, bus reduce (fixed-association tree: groups of 1024
