@@ -1364,7 +1364,8 @@ def main():
     # back first -- engine closed, allocator emptied -- and say so through a file; rank 0 waits for every such file before it
     # touches their devices (torchrun gives no "the others are done" signal once the process group is gone).
     release_dir = None
-    if world_size > 1:
+    cluster_leg = world_size > 1 and not args.no_configs and not args.midi_live and not args.variant
+    if cluster_leg:
         import tempfile
         release_dir = os.path.join(tempfile.gettempdir(), "oscen_bench_release_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
         os.makedirs(release_dir, exist_ok=True)
@@ -1378,7 +1379,7 @@ def main():
         has_gate = "gate" in eng.input_names
         if config4 is not None:
             line["config4"] = config4
-        if world_size > 1 and not args.no_configs and not args.midi_live and not args.variant:
+        if cluster_leg:
             # the SAME workload through the product's own multi-GPU leg: one process, og_cluster_* over all N devices, the
             # library's ncclReduce (the ranks above used torch.distributed's communicator).  Rank 0 runs it after the
             # process group is gone; the other ranks have finished.

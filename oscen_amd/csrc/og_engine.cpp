@@ -480,7 +480,7 @@ struct og_engine {
     // The device knows nothing of this (one segment per voice, as ever -- a first form that taught the kernels to hop cost
     // the four-wave kernel 4 % and the ordinary one 30 spills): before the launch in which a continuation's first event is
     // due the host points the voice at it -- a 12-byte cursor update when the segment in front has been played, which is
-    // the usual case (resolve_due_continuations).  Cost of a message: its own records, whatever the score's length.
+    // the usual case (incremental_update / merge_voice).  Cost of a message: its own records, whatever the score's length.
     // Vectors are empty until a continuation exists; `cont_due` orders the voices by their continuation's first frame.
     std::vector<uint32_t> cont_begin, cont_end;
     std::vector<uint64_t> cont_last;
@@ -1106,6 +1106,11 @@ struct og_engine {
             if (!merge_voice(v, mine, lend, sev, upd, n_ev, n_upd, kept, old, merged)) fits = false;
         }
         if (!fits) return false;
+        if (n_upd == 0) { // (every due entry was stale, nothing was pushed: no kernel to launch)
+            pending.clear();
+            local_from = 0;
+            return true;
+        }
         // a place in the ring for the whole batch (the segments touched above count as superseded only after the commit,
         // so the batch never lands on the old events it was merged from)
         const size_t base = ring_alloc(n_ev);
