@@ -149,3 +149,96 @@ def test_live_messages_over_a_score_on_the_queued_entry_and_through_ring_wraps(m
     dsp = e_all.state_words_per_voice * n * 4
     assert np.array_equal(state_live[:dsp], state_all[:dsp])
     assert e_live.event_stats["incremental_updates"] > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_mix_of_resident_scheduled_ahead_and_live_events_equals_the_timeline_scheduled_up_front(seed, monkeypatch):
+    """Differential: one engine is given the whole timeline up front; the other gets the long-range part as a resident score
+    and the rest the way a player would -- block-local pushes, events scheduled a few blocks ahead (they land between
+    resident ones and split continuations), a snapshot taken and loaded back half way, blocking and queued blocks mixed, a
+    small ring.  No two events of a voice share a frame, so the order is the frame order in both.  Same DSP state at the end."""
+    rng = np.random.default_rng(1000 + seed)
+    n, blocks, block = 64, 40, 64
+    total = blocks * block
+    used = [set() for _ in range(n)]
+
+    def fresh_frame(v, lo, hi):
+        for _ in range(100):
+            f = int(rng.integers(lo, hi))
+            if f not in used[v]:
+                used[v].add(f)
+                return f
+        return None
+
+    resident = []
+    for v in range(n):
+        for _ in range(int(rng.integers(120, 200))):  # long scores: most of it lies beyond the run
+            f = fresh_frame(v, 0, total * 4)
+            if f is not None:
+                resident.append((f, v, float(np.float32(rng.random())) if rng.random() < 0.5 else 0.0))
+    local, ahead = [], []  # (push block, frame, voice, value)
+    for b in range(1, blocks):
+        for _ in range(int(rng.integers(0, 8))):
+            v = int(rng.integers(0, n))
+            f = fresh_frame(v, b * block, (b + 1) * block)
+            if f is not None:
+                local.append((b, f, v, 0.0 if rng.random() < 0.5 else 0.7))
+        for _ in range(int(rng.integers(0, 4))):
+            v = int(rng.integers(0, n))
+            f = fresh_frame(v, (b + 1) * block, min(total * 2, (b + 1 + int(rng.integers(1, 12))) * block))
+            if f is not None:
+                ahead.append((b, f, v, 0.0 if rng.random() < 0.5 else 0.9))
+    freqs = oscen_amd.midi_note_to_freq(rng.integers(40, 90, n)).astype(np.float32)
+
+    def schedule(e, evs):
+        evs = sorted(evs, key=lambda t: t[0])
+        e.schedule_voice_events("gate", [v for _, v, _ in evs], [f for f, _, _ in evs], [x for _, _, x in evs])
+
+    a = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    a.set_voice_values("frequency", freqs)
+    schedule(a, resident + [(f, v, x) for _, f, v, x in local] + [(f, v, x) for _, f, v, x in ahead])
+    for _ in range(blocks):
+        a.process_block(block)
+    state_a = a.save_state()
+
+    monkeypatch.setenv("OSCEN_GPU_EXPERIMENTAL", "1")
+    monkeypatch.setenv("OSCEN_GPU_EV_HEADROOM", "2048")
+    b_eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+    monkeypatch.delenv("OSCEN_GPU_EV_HEADROOM")
+    b_eng.set_voice_values("frequency", freqs)
+    schedule(b_eng, resident)
+    queued = False
+    for blk in range(blocks):
+        if blk == blocks // 2:  # a snapshot holds segment + continuation of every voice; a fresh engine plays on from it
+            if queued:
+                b_eng.flush()
+                b_eng.synchronize()
+            blob = b_eng.save_state()
+            b_eng = oscen_amd.Engine("fm_voice", n, sample_rate=SR)
+            b_eng.load_state(blob)
+            queued = False
+        for pb, f, v, x in ahead:
+            if pb == blk:
+                b_eng.schedule_voice_event("gate", v, f, x)
+        for pb, f, v, x in local:
+            if pb == blk:
+                assert b_eng.push_voice_event("gate", v, f - blk * block, x) == 0
+        if blk % 7 == 3:
+            b_eng.set_bus_batching(4)
+            queued = True
+        if blk % 7 == 6 and queued:
+            b_eng.flush()
+            b_eng.synchronize()
+            b_eng.set_bus_batching(1)
+            queued = False
+        if queued:
+            b_eng.process_block_async(block)
+        else:
+            b_eng.process_block(block)
+    if queued:
+        b_eng.flush()
+        b_eng.synchronize()
+    state_b = b_eng.save_state()
+    dsp = a.state_words_per_voice * n * 4
+    assert np.array_equal(state_a[:dsp], state_b[:dsp])
+    assert b_eng.event_stats["incremental_updates"] > 0
