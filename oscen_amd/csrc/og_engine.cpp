@@ -929,9 +929,6 @@ struct og_engine {
             upd[EV_UPD_WORDS * n_upd] = v;
             upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
             upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
-            kept.push_back(0u);
-            kept.push_back(0u);
-            kept.push_back(0u);
             n_ev += merged.size();
             n_upd += 1;
             return true;
@@ -946,7 +943,7 @@ struct og_engine {
                 upd[EV_UPD_WORDS * n_upd] = v;
                 upd[EV_UPD_WORDS * n_upd + 1] = cb; // (absolute ring positions)
                 upd[EV_UPD_WORDS * n_upd + 2] = ce;
-                kept.insert(kept.end(), {0u, 0u, 1u});
+                kept.insert(kept.end(), {(uint32_t)n_upd, 0u, 0u, 1u});
                 n_upd += 1;
                 return true;
             }
@@ -978,7 +975,7 @@ struct og_engine {
             upd[EV_UPD_WORDS * n_upd] = v;
             upd[EV_UPD_WORDS * n_upd + 1] = keep_b;
             upd[EV_UPD_WORDS * n_upd + 2] = keep_e;
-            kept.insert(kept.end(), {0u, 0u, 1u});
+            kept.insert(kept.end(), {(uint32_t)n_upd, 0u, 0u, 1u});
             n_upd += 1;
             return true;
         }
@@ -987,7 +984,7 @@ struct og_engine {
         upd[EV_UPD_WORDS * n_upd] = v;
         upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev; // (relative to the batch: its place in the ring is chosen at the commit)
         upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + merged.size());
-        kept.insert(kept.end(), {keep_b, keep_e, 0u});
+        if (keep_b != keep_e) kept.insert(kept.end(), {(uint32_t)n_upd, keep_b, keep_e, 0u});
         n_ev += merged.size();
         n_upd += 1;
         return true;
@@ -1055,8 +1052,9 @@ struct og_engine {
         uint32_t* upd = h_stage_upd[r];
         std::vector<OgEvent> old, merged;
         std::vector<HostEvent> mine;
-        std::vector<uint32_t> kept; // per update: {begin, end} of the continuation the voice keeps (equal: none), absolute-positions flag
-        kept.reserve(3 * (grp_voices.size() + due.size()));
+        // the updates that are not plain "new segment, no continuation" (few): {update index, begin and end of the continuation
+        // the voice keeps, 1 = the update's positions are absolute ring positions (the voice is pointed at records in place)}
+        std::vector<uint32_t> kept;
         size_t n_ev = 0, n_upd = 0;
         bool fits = true;
         for (const uint32_t v : grp_voices) {
@@ -1077,7 +1075,6 @@ struct og_engine {
                     upd[EV_UPD_WORDS * n_upd] = v; // (cursor, end) relative to the batch: its place in the ring is chosen below
                     upd[EV_UPD_WORDS * n_upd + 1] = (uint32_t)n_ev;
                     upd[EV_UPD_WORDS * n_upd + 2] = (uint32_t)(n_ev + k);
-                    kept.insert(kept.end(), {0u, 0u, 0u});
                     n_ev += k;
                     n_upd += 1;
                     continue;
@@ -1119,11 +1116,18 @@ struct og_engine {
         HostProf::Scope pc(prof, HostProf::EV_COMMIT);
         if (h_events.size() < base + n_ev) h_events.resize(base + n_ev); // (capacity ev_cap is reserved: no reallocation, no fill of the unused room)
         memcpy(h_events.data() + base, sev, n_ev * sizeof(OgEvent));
+        size_t kq = 0; // (next entry of `kept`: they are in update order)
         for (size_t i = 0; i < n_upd; ++i) {
             uint32_t* u = upd + EV_UPD_WORDS * i;
             const uint32_t v = u[0];
-            const uint32_t kb = kept[3 * i], ke = kept[3 * i + 1];
-            if (kept[3 * i + 2]) { // pointed at records that are in the ring already (the segment they lie in stays alive: ring_alloc)
+            uint32_t kb = 0, ke = 0, in_place = 0;
+            if (kq < kept.size() && kept[kq] == (uint32_t)i) {
+                kb = kept[kq + 1];
+                ke = kept[kq + 2];
+                in_place = kept[kq + 3];
+                kq += 4;
+            }
+            if (in_place) { // pointed at records that are in the ring already (the segment they lie in stays alive: ring_alloc)
                 seg_begin[v] = u[1];
                 seg_end[v] = u[2];
                 seg_last[v] = h_events[u[2] - 1].frame;
