@@ -1,8 +1,8 @@
-"""profiles/r06_handoff_ab.md from the A/B logs of scripts/r6_ab.sh (gpurun_out/<tag>/ab.log): one table per session."""
+"""profiles/r06_handoff_ab.md from the A/B logs of docs/history/scripts/r6_ab.sh (gpurun_out/<tag>/ab.log): one table per session."""
 import collections, os, re, statistics, sys
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 out = ['# Round 6: hand-off of the four-wave kernel -- barrier vs flags, wave priorities, cuts (interleaved A/B on one MI355X per session)', '',
-       '`scripts/r6_ab.sh <tag> "<variants>" <rounds> [bench args]`: every variant is a whole `liboscen_gpu_<tag>.so` (`scripts/build_variant.py`), runs are interleaved',
+       '`docs/history/scripts/r6_ab.sh <tag> "<variants>" <rounds> [bench args]`: every variant is a whole `liboscen_gpu_<tag>.so` (`scripts/build_variant.py`), runs are interleaved',
        'round by round on the same box; `value` = `bench.py --steps 20 --warmup 5` (median region), `first5` = what five cold regions report, kernel ms per 256-frame block',
        'from the in-kernel clock.  Sessions ran on different boxes: compare within a session only.  65 536 voices, fm_voice, unless the tag names a bank size.', '',
        'Variant names: `base` = the library of the tree at that time (barrier, priorities 2,1,1,0 until session r06l; flags 16x2 + 0,1,2,3 from r06m on); `nosync` = no hand-off at all',

@@ -2,7 +2,7 @@
 PMC figures (`roofline.traffic`, `valu_issue`) up by kernel hash and reports `stale_profile` when the newest summary of a
 configuration was taken on another build -- VERDICT r4 asked for `stale_profile: null` in the driver's line.  This test
 fails the moment a change to the generator or the device headers renames the kernels without the profiles being re-taken
-(docs/history/scripts/r5_final.sh <tag> prof)."""
+(docs/history/scripts/r6_final.sh <tag> prof)."""
 import os
 import re
 import sys
