@@ -3989,6 +3989,22 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
     }
     out.valu_estimate = graph_weight + 8; // + the mix bus
     int unroll = (has_env && graph_weight >= 100) ? 1 : 2;
+    // Round 6: the whole 16-frame bus chunk as ONE straight-line region wherever registers allow.  A value that lives across
+    // frames -- the saturator's four half-band histories (62 live samples that shift every frame), phases, filter states --
+    // crosses the loop's back edge once per trip and has to sit where the loop head expects it: with two frames per trip the
+    // histories were copied on every trip (20 v_mov per frame of 162 VALU); with sixteen a sample is written straight into the
+    // register it will be read from a chunk later.  Interleaved A/B on one MI355X (profiles/r06_handoff_ab.md, r07f / r07g):
+    // SatGraph_4x 131 072 voices 3.33e11 -> 3.50 / 3.61 / 3.71e11 at 4 / 8 / 16; fm_voice 262 144 6.88e11 -> 6.97 / 6.92 /
+    // 7.02e11, 1 048 576 8.06e11 -> 8.17 / 8.06 / 8.17e11; osc+env+TPT 1.125e12 -> 1.157 / 1.161 / 1.153e12; the delay-line
+    // voice 5.21e11 -> 5.32 / 5.28 / 5.17e11 (its chunk is bracketed by the ring staging: four frames per trip); the
+    // electric piano does not move (its harmonics are not shifted) and keeps its two.  (The pipelined shapes always
+    // unrolled their chunks.)
+    if (unroll > 1) {
+        if (out.lpv > 1) unroll = 2;
+        else if (!out.rings.empty()) unroll = 4;
+        else if (cg.N > 1) unroll = 16;
+        else unroll = (has_env && graph_weight >= 70) ? 4 : 8; // (fm_voice: sixteen is worth +0.7 % over four and brings spills into the tapped variants' chunk bodies)
+    }
     if (const char* u = ogabi::experiment_knob("OGC_UNROLL")) unroll = std::max(1, std::min(16, atoi(u)));
 
     // A kernel is assembled from GROUPS of consecutive stages, one wave per group: the ordinary kernel

@@ -102,7 +102,7 @@ def test_the_ordinary_fm_kernel_spills_nothing_inside_a_chunk_body(tmp_path):
         assert int(kv["vgpr_count"]) <= 128 and int(kv["private_segment_fixed_size"]) <= 64, (name, kv)
         loops = _innermost_loops(text, name)
         bodies = [c for c in loops if c["valu"] >= 100]  # the unrolled 16-frame chunk bodies (sticky loops, checked body)
-        assert len(bodies) >= 3, (name, [c["n"] for c in loops])
+        assert len(bodies) >= 2, (name, [c["n"] for c in loops])  # (round 6: whole 16-frame chunks as one region)
         assert all(c["scratch"] == 0 for c in bodies), (name, [(c["n"], c["valu"], c["scratch"]) for c in loops])
         # (the only loops that touch the private segment at all are the event walks of the tapped ramp variant: cold code,
         #  ~45 VALU among 250 instructions, one reload each)
