@@ -888,6 +888,15 @@ struct og_engine {
         // no zero-fill of the room here) -- up to 2^28 events (4 GB of host memory); a ring larger than that mirrors what is
         // resident plus the promised reserve and grows on demand beyond it
         h_events.reserve(ev_cap <= ((size_t)1 << 28) ? ev_cap : std::min(ev_cap, h_events.size() + std::max<size_t>(ev_reserve, (size_t)1 << 28)));
+        // ... and the first half gigabyte of that room is touched HERE, while the score is being laid out: the live path appends
+        // ~150 KB of segments per block at 8 M voices, i.e. it enters a fresh 2 MB region of this mapping every dozen blocks,
+        // and a first touch that has to wait for the kernel to find (compact) a huge page is a stall of milliseconds on the
+        // real-time path (one 12.5 ms block in five driver-command runs of round 6, one 6.4 ms block in round 5's -- neither
+        // reproduced on demand).  Half a gigabyte covers ~3 000 blocks of live playing at that size; costs ~0.1 s here.
+        {
+            const size_t room = (h_events.capacity() - h_events.size()) * sizeof(OgEvent);
+            if (room) memset(reinterpret_cast<char*>(h_events.data()) + h_events.size() * sizeof(OgEvent), 0, std::min<size_t>(room, (size_t)512 << 20));
+        }
         seg_begin.swap(cursor);
         seg_end.swap(end);
         seg_last.swap(last);
