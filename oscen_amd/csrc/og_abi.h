@@ -69,7 +69,7 @@ T guard_value(T fallback, F&& f) noexcept
 #define OG_EXPERIMENT_KNOBS                                                                                                      \
     "OSCEN_GPU_HOST_PROF OSCEN_GPU_BLOCKING_MEMCPY OSCEN_GPU_EV_HEADROOM OSCEN_GPU_LANES OSCEN_GPU_OUT_EVENTS OSCEN_GPU_FORCE_RCCL "  \
     "OGC_TPT_FLAT OGC_TPT_LAZY OGC_HPL OGC_ALAP OGC_SPLIT OGC_CUT2 OGC_PARTS OGC_K3 OGC_CUTS OGC_UNROLL OGC_PRIO_PARITY OGC_CHUNK_CHK "  \
-    "OGC_STICKY1 OGC_XCH16 OGC_XCH OGC_ROT OGC_PRIO OGC_STICKY OGC_FORCE_PATH OGC_EVSKIP OGC_EVUNROLL OGC_RELPRIO OGC_SLOWPRIO OGC_WAVES_EU OGC_FLAGS OGC_NARROW_FD"
+    "OGC_STICKY1 OGC_XCH16 OGC_XCH OGC_ROT OGC_PRIO OGC_STICKY OGC_FORCE_PATH OGC_EVSKIP OGC_EVUNROLL OGC_RELPRIO OGC_SLOWPRIO OGC_WAVES_EU OGC_FLAGS OGC_NARROW_FD OGC_STAGEEND_BODY"
 inline bool experiments_enabled()
 {
     const char* e = getenv("OSCEN_GPU_EXPERIMENTAL");

@@ -4582,6 +4582,14 @@ std::unique_ptr<CompiledGraph> compile(const GraphDesc& g_in)
                 pick(false, "                ");
                 body << "            }\n";
             }
+            if (one_checked && ogabi::experiment_knob("OGC_STAGEEND_BODY") && atoi(ogabi::experiment_knob("OGC_STAGEEND_BODY")) != 0) {
+                // experiment (round 6): a chunk with a stage end but NO event takes a body with the stage-end checks and without
+                // the per-frame event tests and the inlined handlers
+                body << "        } else if (n == XCH && __all((int)(c.next_ev >= base + XCH))) { // a stage end, no event\n";
+                if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << slow_prio << ");\n";
+                quiet("true", "true", false, "            ");
+                if (slow_prio >= 0) body << "            og::set_prio<BASE_PRIO>();\n";
+            }
             if (one_checked) {
                 body << "        } else if (n == XCH) { // an event or a stage end in this chunk: the checked, unrolled body\n";
                 if (slow_prio >= 0) body << "            __builtin_amdgcn_s_setprio(" << slow_prio << "); // the wave on the slow path is the straggler\n";
