@@ -212,7 +212,7 @@ def test_every_graph_body_of_the_reference_parses_and_lowers():
                             src = g.kernel_source()
                             assert "og_k_" in src or "voice_block" in src
                             n_lowered[0] += 1
-                            if n_lowered[0] % 3 == 0 or reg_fns:  # every third body (and every one that calls a function) is
+                            if n_lowered[0] % 4 == 0 or reg_fns:  # every fourth body (and every one that calls a function) is
                                 assert g.jit_check() > 0, key     # also COMPILED for gfx950; all 117 do (158 s when all are)
                                 n_compiled[0] += 1
                             if reg_nodes or reg_fns:
@@ -281,7 +281,7 @@ def test_every_graph_body_of_the_reference_parses_and_lowers():
                            ("oscen-lib/tests/stereo_render.rs", "StereoGainGraph")]:
             assert (path, name) in stubbed or (path, name) not in parsed, (path, name)
         assert len(lowered) >= 70 and len(lowered) + len(stubbed) + len(other) == len(parsed), (len(lowered), len(stubbed), len(other))
-        assert n_compiled[0] >= 39
+        assert n_compiled[0] >= 29
         print("\n%d bodies: %d parse (+%d external), %d lower as written, %d lower with stub node types read off the Rust structs, "
               "%d allow-listed; %d of the lowered bodies also compiled for gfx950"
               % (len(bodies), len(parsed), len(external), len(lowered), len(stubbed), len(other), n_compiled[0]))
