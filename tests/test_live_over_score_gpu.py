@@ -151,7 +151,13 @@ def test_live_messages_over_a_score_on_the_queued_entry_and_through_ring_wraps(m
     assert e_live.event_stats["incremental_updates"] > 0
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+import os  # noqa: E402
+
+# (soak runs: OSCEN_SOAK_SEEDS="4 5 6 ..." adds seeds; hostsim_asan.sh and a GPU session of round 6 ran 40 of them)
+SEEDS = [1, 2, 3] + [int(x) for x in os.environ.get("OSCEN_SOAK_SEEDS", "").split()]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_mix_of_resident_scheduled_ahead_and_live_events_equals_the_timeline_scheduled_up_front(seed, monkeypatch):
     """Differential: one engine is given the whole timeline up front; the other gets the long-range part as a resident score
     and the rest the way a player would -- block-local pushes, events scheduled a few blocks ahead (they land between
@@ -159,6 +165,8 @@ def test_random_mix_of_resident_scheduled_ahead_and_live_events_equals_the_timel
     small ring.  No two events of a voice share a frame, so the order is the frame order in both.  Same DSP state at the end."""
     rng = np.random.default_rng(1000 + seed)
     n, blocks, block = 64, 40, 64
+    if os.environ.get("OSCEN_SOAK_SCALE"):  # (soak runs: more voices, twice the blocks)
+        n, blocks = 64 * int(os.environ["OSCEN_SOAK_SCALE"]), 80
     total = blocks * block
     used = [set() for _ in range(n)]
 
